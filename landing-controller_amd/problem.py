@@ -1,0 +1,176 @@
+"""Host-side mirror of how the reference's callers build the inputs of the landing solver function.
+
+The unit of work is one call of the 21-input solver function
+``landingCtrller_IPOPT(Xref, Uref, dt, q_min, q_max, qd_min, qd_max, q_init, qd_init, q_term_min,
+q_term_max, qd_term_min, qd_term_max, QN, x0, mu, l_leg_max, f_max, mass, Ib, Ib_inv) -> (x*, f*)``
+(generate_landingCtrller_IPOPT.m:323-327).  Everything here is numpy; a batch simply carries a
+leading member dimension.
+
+Layouts:
+  x = [X(:); U(:)], X 12x(N+1) column-major = [pos rpy omega_body v_world], U 24xN = [c(12) f(12)]
+  p = [Xref(:) (12(N+1)); dt (N); q_min q_max qd_min qd_max q_init qd_init q_term_min q_term_max
+       qd_term_min qd_term_max (6 each); QN (12); mu; l_leg_max; f_max; mass; Ib(3); Ib_inv(3)]
+      (Uref is an inactive Opti parameter and is not part of p.)
+"""
+from dataclasses import dataclass
+
+import numpy as np
+
+from .constants import HIP_SRBM, robot_constants
+
+
+def nx(N):
+    return 36 * N + 12
+
+
+def ng(N):
+    return 104 * N + 12
+
+
+def n_p(N):
+    return 13 * N + 94
+
+
+def nnz_jac(N):
+    return 36 + 385 * (N - 1) + 313
+
+
+def nnz_hess(N):
+    return 177 * N + 12 * (N - 1) + 12
+
+
+def param_offsets(N):
+    b = 12 * (N + 1) + N
+    names = ["q_min", "q_max", "qd_min", "qd_max", "q_init", "qd_init", "q_term_min", "q_term_max",
+             "qd_term_min", "qd_term_max"]
+    o = {"Xref": 0, "dt": 12 * (N + 1)}
+    for i, n in enumerate(names):
+        o[n] = b + 6 * i
+    o.update(QN=b + 60, mu=b + 72, l_leg_max=b + 73, f_max=b + 74, mass=b + 75, Ib=b + 76, Ib_inv=b + 79,
+             np=b + 82)
+    return o
+
+
+def rpy_to_rot_xyz(rpy):
+    """rpyToRotMat_xyz.m: rx(r)' * ry(p)' * rz(y)' (used by the callers for sampling/refs only)."""
+    r, p, y = rpy
+    cx, sx, cy, sy, cz, sz = np.cos(r), np.sin(r), np.cos(p), np.sin(p), np.cos(y), np.sin(y)
+    Rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
+    Ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+    Rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
+    return Rx @ Ry @ Rz
+
+
+def rpy_to_rot(rpy):
+    """rpyToRotMat.m:2: rz(y)' * ry(p)' * rx(r)' (the rotation used inside the NLP)."""
+    r, p, y = rpy
+    cx, sx, cy, sy, cz, sz = np.cos(r), np.sin(r), np.cos(p), np.sin(p), np.cos(y), np.sin(y)
+    Rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
+    Ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+    Rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
+    return Rz @ Ry @ Rx
+
+
+SIDE_SIGN = np.array([1, -1, 1, 1, 1, 1, -1, -1, 1, -1, 1, 1], float)
+
+
+@dataclass
+class CallerConstants:
+    """Fixed arguments of the batch callers (generate_training_data_automated.m:62-102,
+    main_scripts/landing_optimization.m:219-258)."""
+    q_min: tuple = (-10, -10, 0.075, -10, -10, -10)
+    q_max: tuple = (10, 10, 1.0, 10, 10, 10)
+    qd_min: tuple = (-10, -10, -10, -40, -40, -40)
+    qd_max: tuple = (10, 10, 10, 40, 40, 40)
+    q_term_min: tuple = (-10, -10, 0.15, -0.1, -0.1, -10)
+    q_term_max: tuple = (10, 10, 5, 0.1, 0.1, 10)
+    qd_term_min: tuple = (-10, -10, -10, -0.5, -0.5, -0.5)
+    qd_term_max: tuple = (10, 10, 10, 0.5, 0.5, 0.5)
+    q_term_ref: tuple = (0, 0, 0.25, 0, 0, 0)
+    qd_term_ref: tuple = (0, 0, 0, 0, 0, 0)
+    c_ref: tuple = (0.2, 0.2, -0.3)
+    QN: tuple = (0, 0, 100, 10, 10, 0, 10, 10, 10, 10, 10, 10)
+    mu: float = 0.75
+    l_leg_max: float = 0.4
+    f_max: float = 500.0
+    td_nom: float = 0.35
+
+
+def sample_drop_states(B, seed, dt1, consts=None):
+    """Random drop states, main_scripts/landing_optimization.m:207-218 (the reference never seeds
+    ``rand``; the seed is ours).  Returns q_init[B,6], qd_init[B,6]."""
+    c = consts or CallerConstants()
+    rng = np.random.default_rng(seed)
+    u = rng.random((B, 9))
+    q = np.zeros((B, 6))
+    qd = np.zeros((B, 6))
+    q[:, 3] = 0.25 * (2 * u[:, 0] - 1)
+    q[:, 4] = (np.pi / 3) * (2 * u[:, 1] - 1)
+    q[:, 5] = 0.25 * (2 * u[:, 2] - 1)
+    qd[:, 0:3] = 0.5 * (2 * u[:, 3:6] - 1)
+    qd[:, 3:5] = 1.0 * (2 * u[:, 6:8] - 1)
+    qd[:, 5] = -4.5 * u[:, 8] - 0.5
+    for b in range(B):
+        R = rpy_to_rot_xyz(q[b, 3:6])
+        hip_z = (R @ HIP_SRBM.T)[2, :]
+        q[b, 2] = c.td_nom + abs(hip_z.min()) + abs(dt1 * qd[b, 5])
+    return q, qd
+
+
+def reference_trajectories(N, q_init, qd_init, consts=None):
+    """Xref[12,N+1], Uref[24,N] of one member (generate_training_data_automated.m:105-119)."""
+    c = consts or CallerConstants()
+    Xref = np.zeros((12, N + 1))
+    for i in range(6):
+        Xref[i] = np.linspace(q_init[i], c.q_term_ref[i], N + 1)
+        Xref[6 + i] = np.linspace(qd_init[i], c.qd_term_ref[i], N + 1)
+    c_ref = SIDE_SIGN * np.tile(np.asarray(c.c_ref, float), 4)
+    Uref = np.zeros((24, N))
+    for k in range(N):
+        R = rpy_to_rot_xyz(Xref[3:6, k])
+        for leg in range(4):
+            Uref[3 * leg:3 * leg + 3, k] = Xref[0:3, k] + R @ c_ref[3 * leg:3 * leg + 3]
+    return Xref, Uref
+
+
+def pack_params(N, Xref, dt, q_min, q_max, qd_min, qd_max, q_init, qd_init, q_term_min, q_term_max,
+                qd_term_min, qd_term_max, QN, mu, l_leg_max, f_max, mass, Ib, Ib_inv):
+    """p vector in Opti's parameter order (generate_landingCtrller_IPOPT.m:51-75)."""
+    parts = [np.asarray(Xref, float).reshape(12, N + 1).flatten(order="F"), np.asarray(dt, float).reshape(N)]
+    for v in (q_min, q_max, qd_min, qd_max, q_init, qd_init, q_term_min, q_term_max, qd_term_min, qd_term_max):
+        parts.append(np.asarray(v, float).reshape(6))
+    parts.append(np.asarray(QN, float).reshape(12))
+    parts.append(np.array([mu, l_leg_max, f_max, mass], float))
+    parts.append(np.asarray(Ib, float).reshape(3))
+    parts.append(np.asarray(Ib_inv, float).reshape(3))
+    p = np.concatenate(parts)
+    assert p.size == n_p(N)
+    return p
+
+
+def make_member(N, T, q_init, qd_init, consts=None):
+    """(p, x0, Xref, Uref) for one drop state with the callers' fixed arguments; x0=[Xref(:);Uref(:)]."""
+    c = consts or CallerConstants()
+    mass, Ib, Ib_inv = robot_constants()
+    dt = np.full(N, T / N)
+    Xref, Uref = reference_trajectories(N, q_init, qd_init, c)
+    p = pack_params(N, Xref, dt, c.q_min, c.q_max, c.qd_min, c.qd_max, q_init, qd_init, c.q_term_min,
+                    c.q_term_max, c.qd_term_min, c.qd_term_max, c.QN, c.mu, c.l_leg_max, c.f_max, mass, Ib, Ib_inv)
+    x0 = np.concatenate([Xref.flatten(order="F"), Uref.flatten(order="F")])
+    return p, x0, Xref, Uref
+
+
+def make_batch(B, N=40, T=0.6, seed=20211, consts=None):
+    """Synthetic drop-state batch of SURVEY 8(d): returns P[B,np], X0[B,nx], q_init, qd_init."""
+    q, qd = sample_drop_states(B, seed, T / N, consts)
+    P = np.zeros((B, n_p(N)))
+    X0 = np.zeros((B, nx(N)))
+    for b in range(B):
+        P[b], X0[b], _, _ = make_member(N, T, q[b], qd[b], consts)
+    return P, X0, q, qd
+
+
+def split_solution(N, x):
+    """X*[12,N+1], U*[24,N] (generate_training_data_automated.m:139-141)."""
+    x = np.asarray(x)
+    return x[:12 * (N + 1)].reshape(12, N + 1, order="F"), x[12 * (N + 1):].reshape(24, N, order="F")
