@@ -1,0 +1,132 @@
+/*
+ * landing_nlp.h -- C ABI of the MI355X-native batched SRBM landing-NLP library
+ * (liblanding_mi355x.so).  Plain pointers and sizes only; no torch / C++ types.
+ *
+ * Two boundaries of the reference are covered:
+ *
+ *  (1) the batched forms of the CasADi external functions the reference's generated library
+ *      exports (optimizations/landing/codegen_casadi/landingCtrller_IPOPT.c):
+ *        nlp_f       :10995  -> f
+ *        nlp_g       :11161  -> g
+ *        nlp_grad_f  :52602  -> f, grad_f_x
+ *        nlp_jac_g   :94014  -> g, jac_g_x (CCS nonzeros, pattern casadi_s5 :64)
+ *        nlp_hess_l  :53527  -> hess_gamma_x_x (upper-triangular CCS nonzeros, casadi_s4 :63)
+ *        nlp_grad    :22015  -> f, g, grad_gamma_x, grad_gamma_p
+ *      landing_eval_batch() evaluates any subset of these for B independent (x,p[,lam]) in one
+ *      launch; the single-problem CasADi ABI itself (same symbol names, `int F(const double**
+ *      arg, double** res, long long* iw, double* w, int mem)` plus the 15 metadata functions per
+ *      symbol, landingCtrller_IPOPT.c:10916-10993) is exported by the drop-in library
+ *      landingCtrller_IPOPT_mi355x.so (include/landing_casadi_abi.h), which forwards to this one.
+ *
+ *  (2) the solver function the MATLAB callers invoke,
+ *        [x*, f*] = landingCtrller_IPOPT(Xref, Uref, dt, q_min, q_max, qd_min, qd_max, q_init,
+ *                     qd_init, q_term_min, q_term_max, qd_term_min, qd_term_max, QN, x0, mu,
+ *                     l_leg_max, f_max, mass, Ib, Ib_inv)
+ *      (generate_solver/generate_landingCtrller_IPOPT.m:323-327; call sites
+ *      main_scripts/landing_optimization.m:305-311, generate_data/generate_training_data_automated.m:130-136),
+ *      as landing_solve_batch(): B drop states at once, each argument with a leading batch
+ *      dimension, the active parameters packed into p exactly as CasADi packs them.
+ *
+ * Layouts (all fp64, member-major, C order):
+ *   x   [B][nx]   nx = 36N+12 : [X(:) ; U(:)], X 12x(N+1) column-major, U 24xN column-major
+ *   p   [B][np]   np = 13N+94 : [Xref(:) ; dt ; q_min q_max qd_min qd_max q_init qd_init q_term_min
+ *                               q_term_max qd_term_min qd_term_max ; QN ; mu l_leg_max f_max mass ; Ib ; Ib_inv]
+ *   g, lam_g [B][ng]  ng = 104N+12 ;  jac [B][nnz_jac] ; hess [B][nnz_hess]
+ * "d_" arguments are DEVICE pointers (HBM resident); `stream` is a hipStream_t passed as void*
+ * (NULL = default stream).  Every function returns 0 on success, a negative LANDING_E_* code on
+ * error; no function falls back to a CPU path.
+ */
+#ifndef LANDING_NLP_H
+#define LANDING_NLP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct landing_ctx landing_ctx;
+
+#define LANDING_E_ARG (-1)     /* bad argument */
+#define LANDING_E_HIP (-2)     /* HIP runtime error (see landing_last_error) */
+#define LANDING_E_NODEV (-3)   /* no usable gfx950 device */
+
+/* Formulation constants that are literals in the reference scripts (not parameters). */
+typedef struct {
+  double kin_box[3];  /* generate_landingCtrller_IPOPT.m:149-151 (.15,.15,.30); CCC variant .05,.05,.27 */
+  double kin_z_off;   /* :155  0.05 */
+  double comp_eps;    /* :140  1e-3 */
+  double slip_eps;    /* :143-144  1e-2 */
+} landing_form;
+
+/* Options of the interior-point solver; names follow the IPOPT options the reference sets
+ * (generate_landingCtrller_IPOPT.m:231-264) where the meaning is the same. */
+typedef struct {
+  double tol;            /* unscaled KKT tolerance on pr/du/compl (default 1e-6)   */
+  int max_iter;          /* default 3000 (:232)                                    */
+  double mu_init;        /* 0.1 (:247)                                             */
+  double bound_push;     /* 0.5 (:242)                                             */
+  double bound_frac;     /* 0.5 (:241)                                             */
+  double kappa_eps;      /* barrier-subproblem tolerance factor (IPOPT default 10) */
+  double kappa_mu;       /* 0.2                                                    */
+  double theta_mu;       /* 1.5                                                    */
+  int max_soc;           /* reserved                                               */
+  int reserved[7];
+} landing_solver_opts;
+
+/* status codes written per batch member by landing_solve_batch */
+#define LANDING_CONVERGED 0
+#define LANDING_MAX_ITER 1
+#define LANDING_NUMERICAL 2     /* NaN/Inf or regularisation blow-up; other members unaffected */
+
+void landing_form_default(landing_form* f);
+void landing_solver_opts_default(landing_solver_opts* o);
+
+/* sizes for N intervals */
+long long landing_nx(int N);
+long long landing_ng(int N);
+long long landing_np(int N);
+long long landing_nnz_jac(int N);
+long long landing_nnz_hess(int N);
+/* CCS patterns (colind[nx+1], row[nnz]); equal to casadi_s5 / casadi_s4 for N=20. Host arrays. */
+int landing_pattern_jac(int N, long long* colind, long long* row);
+int landing_pattern_hess(int N, long long* colind, long long* row);
+
+/* context: device selection, pattern tables, solver workspace (grown on demand) */
+landing_ctx* landing_create(int N, int device, const landing_form* form /* NULL = default */);
+void landing_destroy(landing_ctx* ctx);
+const char* landing_last_error(void);
+int landing_device_count(void);
+
+/* Batched function layer.  Any output pointer may be NULL (skipped), as with CasADi's res[i]==0.
+ * d_lam_f: [B] or NULL (=1.0); d_lam_g: [B][ng], required for d_hess / d_grad_gamma_*.        */
+int landing_eval_batch(landing_ctx* ctx, int B, const double* d_x, const double* d_p,
+                       const double* d_lam_f, const double* d_lam_g,
+                       double* d_f, double* d_g, double* d_grad_f, double* d_jac, double* d_hess,
+                       double* d_grad_gamma_x, double* d_grad_gamma_p, void* stream);
+/* same, host pointers (copies in and out; used by the CasADi drop-in library) */
+int landing_eval_batch_host(landing_ctx* ctx, int B, const double* x, const double* p,
+                            const double* lam_f, const double* lam_g,
+                            double* f, double* g, double* grad_f, double* jac, double* hess,
+                            double* grad_gamma_x, double* grad_gamma_p);
+/* lbg/ubg of every member from p (Opti canonicalisation, optistack_internal.cpp:742-856);
+ * infinite bounds are +-INFINITY.  d_lbg/d_ubg: [B][ng]. */
+int landing_bounds_batch(landing_ctx* ctx, int B, const double* d_p, double* d_lbg, double* d_ubg, void* stream);
+
+/* Batched solver: B independent NLPs.  Outputs (device, any may be NULL except d_x):
+ *   d_x [B][nx] solution, d_f [B] objective, d_lam_g [B][ng] multipliers (CasADi sign: >0 at upper
+ *   bounds), d_status [B] (LANDING_*), d_iters [B], d_kkt [B][3] = pr_inf, du_inf, compl (unscaled). */
+int landing_solve_batch(landing_ctx* ctx, int B, const double* d_p, const double* d_x0,
+                        const landing_solver_opts* opts,
+                        double* d_x, double* d_f, double* d_lam_g, int* d_status, int* d_iters,
+                        double* d_kkt, void* stream);
+int landing_solve_batch_host(landing_ctx* ctx, int B, const double* p, const double* x0,
+                             const landing_solver_opts* opts,
+                             double* x, double* f, double* lam_g, int* status, int* iters, double* kkt);
+
+/* name of the dominant kernels (for profilers) and per-launch algorithmic bytes of the sweep */
+const char* landing_kernel_name_sweep(void);
+long long landing_sweep_bytes_per_member(int N);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,152 @@
+"""ctypes binding of the C ABI (include/landing_nlp.h) of liblanding_mi355x.so.
+
+The library is the product: HIP kernels for gfx950 behind plain-C entry points.  This module fails
+loudly (ImportError / RuntimeError) when the library is missing or no GPU is usable -- there is no
+CPU fallback.  ``load(path)`` lets the CPU test-suite bind the host-emulated build of the same
+sources (tests/emu) for logic tests; product code never passes a path.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_NAME = "liblanding_mi355x.so"
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+_llp = C.POINTER(C.c_longlong)
+
+
+class LandingForm(C.Structure):
+    _fields_ = [("kin_box", C.c_double * 3), ("kin_z_off", C.c_double), ("comp_eps", C.c_double), ("slip_eps", C.c_double)]
+
+
+class SolverOpts(C.Structure):
+    _fields_ = [("tol", C.c_double), ("max_iter", C.c_int), ("mu_init", C.c_double), ("bound_push", C.c_double),
+                ("bound_frac", C.c_double), ("kappa_eps", C.c_double), ("kappa_mu", C.c_double), ("theta_mu", C.c_double),
+                ("max_soc", C.c_int), ("reserved", C.c_int * 7)]
+
+
+EXPORTS = ["landing_last_error", "landing_form_default", "landing_solver_opts_default", "landing_nx", "landing_ng",
+           "landing_np", "landing_nnz_jac", "landing_nnz_hess", "landing_pattern_jac", "landing_pattern_hess",
+           "landing_create", "landing_destroy", "landing_device_count", "landing_eval_batch", "landing_eval_batch_host",
+           "landing_bounds_batch", "landing_solve_batch", "landing_solve_batch_host", "landing_kernel_name_sweep",
+           "landing_sweep_bytes_per_member"]
+
+
+def load(path=None):
+    path = path or os.path.join(HERE, LIB_NAME)
+    if not os.path.exists(path):
+        raise ImportError(f"{path} not found: build it with __graft_entry__.build() (hipcc, gfx950). No CPU fallback exists.")
+    lib = C.CDLL(path)
+    lib.landing_last_error.restype = C.c_char_p
+    lib.landing_kernel_name_sweep.restype = C.c_char_p
+    for n in ("landing_nx", "landing_ng", "landing_np", "landing_nnz_jac", "landing_nnz_hess", "landing_sweep_bytes_per_member"):
+        getattr(lib, n).restype = C.c_longlong
+        getattr(lib, n).argtypes = [C.c_int]
+    lib.landing_pattern_jac.argtypes = [C.c_int, _llp, _llp]
+    lib.landing_pattern_hess.argtypes = [C.c_int, _llp, _llp]
+    lib.landing_create.restype = C.c_void_p
+    lib.landing_create.argtypes = [C.c_int, C.c_int, C.POINTER(LandingForm)]
+    lib.landing_destroy.argtypes = [C.c_void_p]
+    vp = C.c_void_p
+    lib.landing_eval_batch.argtypes = [vp, C.c_int] + [vp] * 11 + [vp]
+    lib.landing_eval_batch_host.argtypes = [vp, C.c_int] + [_dp] * 11
+    lib.landing_bounds_batch.argtypes = [vp, C.c_int, vp, vp, vp, vp]
+    lib.landing_solve_batch.argtypes = [vp, C.c_int, vp, vp, C.POINTER(SolverOpts), vp, vp, vp, vp, vp, vp, vp]
+    lib.landing_solve_batch_host.argtypes = [vp, C.c_int, _dp, _dp, C.POINTER(SolverOpts), _dp, _dp, _dp, _ip, _ip, _dp]
+    return lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(_dp)
+
+
+class LandingLib:
+    """Thin object wrapper: one context per (N, device)."""
+
+    def __init__(self, N, device=0, kin_box=None, lib_path=None):
+        self.lib = load(lib_path)
+        self.N = N
+        form = LandingForm()
+        self.lib.landing_form_default(C.byref(form))
+        if kin_box is not None:
+            for i in range(3):
+                form.kin_box[i] = kin_box[i]
+        self.ctx = self.lib.landing_create(N, device, C.byref(form))
+        if not self.ctx:
+            raise RuntimeError("landing_create failed: " + self.lib.landing_last_error().decode())
+        self.nx, self.ng, self.np_ = self.lib.landing_nx(N), self.lib.landing_ng(N), self.lib.landing_np(N)
+        self.nnz_jac, self.nnz_hess = self.lib.landing_nnz_jac(N), self.lib.landing_nnz_hess(N)
+
+    def close(self):
+        if self.ctx:
+            self.lib.landing_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError(f"{what} failed ({rc}): {self.lib.landing_last_error().decode()}")
+
+    def default_opts(self):
+        o = SolverOpts()
+        self.lib.landing_solver_opts_default(C.byref(o))
+        return o
+
+    def pattern_jac(self):
+        ci = np.zeros(self.nx + 1, np.int64); r = np.zeros(self.nnz_jac, np.int64)
+        self._check(self.lib.landing_pattern_jac(self.N, ci.ctypes.data_as(_llp), r.ctypes.data_as(_llp)), "pattern_jac")
+        return ci, r
+
+    def pattern_hess(self):
+        ci = np.zeros(self.nx + 1, np.int64); r = np.zeros(self.nnz_hess, np.int64)
+        self._check(self.lib.landing_pattern_hess(self.N, ci.ctypes.data_as(_llp), r.ctypes.data_as(_llp)), "pattern_hess")
+        return ci, r
+
+    # ---- host-pointer entry points (numpy in / numpy out) --------------------------------------
+    def eval_host(self, x, p, lam_f=None, lam_g=None, want=("f", "g", "grad_f", "jac", "hess", "grad_gamma_x", "grad_gamma_p")):
+        x = np.ascontiguousarray(np.atleast_2d(x), float); p = np.ascontiguousarray(np.atleast_2d(p), float)
+        B = x.shape[0]
+        if lam_g is not None:
+            lam_g = np.ascontiguousarray(np.atleast_2d(lam_g), float)
+        if lam_f is not None:
+            lam_f = np.ascontiguousarray(np.atleast_1d(lam_f), float)
+        shapes = dict(f=(B,), g=(B, self.ng), grad_f=(B, self.nx), jac=(B, self.nnz_jac), hess=(B, self.nnz_hess),
+                      grad_gamma_x=(B, self.nx), grad_gamma_p=(B, self.np_))
+        out = {k: (np.full(shapes[k], np.nan) if k in want else None) for k in shapes}
+        rc = self.lib.landing_eval_batch_host(self.ctx, B, _p(x), _p(p), _p(lam_f), _p(lam_g), _p(out["f"]), _p(out["g"]),
+                                              _p(out["grad_f"]), _p(out["jac"]), _p(out["hess"]), _p(out["grad_gamma_x"]),
+                                              _p(out["grad_gamma_p"]))
+        self._check(rc, "landing_eval_batch_host")
+        return {k: v for k, v in out.items() if v is not None}
+
+    def solve_host(self, p, x0, opts=None):
+        p = np.ascontiguousarray(np.atleast_2d(p), float); x0 = np.ascontiguousarray(np.atleast_2d(x0), float)
+        B = p.shape[0]
+        opts = opts or self.default_opts()
+        x = np.zeros((B, self.nx)); f = np.zeros(B); lam = np.zeros((B, self.ng))
+        status = np.zeros(B, np.int32); iters = np.zeros(B, np.int32); kkt = np.zeros((B, 3))
+        rc = self.lib.landing_solve_batch_host(self.ctx, B, _p(p), _p(x0), C.byref(opts), _p(x), _p(f), _p(lam),
+                                               status.ctypes.data_as(_ip), iters.ctypes.data_as(_ip), _p(kkt))
+        self._check(rc, "landing_solve_batch_host")
+        return dict(x=x, f=f, lam_g=lam, status=status, iters=iters, kkt=kkt)
+
+    # ---- device-pointer entry points (integers = device addresses, e.g. torch tensor.data_ptr()) --
+    def eval_device(self, B, d_x, d_p, d_lam_f=0, d_lam_g=0, d_f=0, d_g=0, d_grad_f=0, d_jac=0, d_hess=0, d_ggx=0, d_ggp=0, stream=0):
+        rc = self.lib.landing_eval_batch(self.ctx, B, d_x, d_p, d_lam_f or None, d_lam_g or None, d_f or None, d_g or None,
+                                         d_grad_f or None, d_jac or None, d_hess or None, d_ggx or None, d_ggp or None, stream or None)
+        self._check(rc, "landing_eval_batch")
+
+    def bounds_device(self, B, d_p, d_lbg, d_ubg, stream=0):
+        self._check(self.lib.landing_bounds_batch(self.ctx, B, d_p, d_lbg, d_ubg, stream or None), "landing_bounds_batch")
+
+    def solve_device(self, B, d_p, d_x0, opts, d_x, d_f=0, d_lam_g=0, d_status=0, d_iters=0, d_kkt=0, stream=0):
+        rc = self.lib.landing_solve_batch(self.ctx, B, d_p, d_x0, C.byref(opts), d_x, d_f or None, d_lam_g or None,
+                                          d_status or None, d_iters or None, d_kkt or None, stream or None)
+        self._check(rc, "landing_solve_batch")

@@ -1,0 +1,237 @@
+// capi.hip -- C ABI of liblanding_mi355x.so (include/landing_nlp.h): context, launches, host copies.
+// There is no CPU fallback anywhere in this file: every entry point either runs the HIP kernels on
+// the selected gfx950 device or returns an error code.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "../../include/landing_nlp.h"
+#include "layout.hpp"
+#include "srbm_stage.hpp"
+#include "eval_kernels.hip"
+#include "solver_kernels.hip"
+
+using landing::Layout;
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) { g_err = msg; return code; }
+#define HIP_TRY(expr)                                                                      \
+  do {                                                                                     \
+    hipError_t e_ = (expr);                                                                \
+    if (e_ != hipSuccess) return fail(LANDING_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+
+struct landing_ctx {
+  Layout L;
+  int device;
+  landing::SolverWorkspace ws;
+};
+
+extern "C" {
+
+const char* landing_last_error(void) { return g_err.c_str(); }
+
+void landing_form_default(landing_form* f) {
+  f->kin_box[0] = 0.15; f->kin_box[1] = 0.15; f->kin_box[2] = 0.30;
+  f->kin_z_off = 0.05; f->comp_eps = 1e-3; f->slip_eps = 1e-2;
+}
+
+void landing_solver_opts_default(landing_solver_opts* o) {
+  memset(o, 0, sizeof(*o));
+  o->tol = 1e-6; o->max_iter = 3000; o->mu_init = 0.1; o->bound_push = 0.5; o->bound_frac = 0.5;
+  o->kappa_eps = 10.0; o->kappa_mu = 0.2; o->theta_mu = 1.5; o->max_soc = 0;
+}
+
+long long landing_nx(int N) { return 36LL * N + 12; }
+long long landing_ng(int N) { return 104LL * N + 12; }
+long long landing_np(int N) { return 13LL * N + 94; }
+long long landing_nnz_jac(int N) { return 36 + 385LL * (N - 1) + 313; }
+long long landing_nnz_hess(int N) { return 177LL * N + 12LL * (N - 1) + 12; }
+long long landing_sweep_bytes_per_member(int N) {
+  // read x,p,lam_g ; write g, grad_f, jac nz, hess nz
+  return 8 * (landing_nx(N) + landing_np(N) + landing_ng(N) + landing_ng(N) + landing_nx(N) + landing_nnz_jac(N) + landing_nnz_hess(N));
+}
+const char* landing_kernel_name_sweep(void) { return "landing_sweep_kernel"; }
+
+int landing_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+// ---- CCS patterns: recorded from the very emission order the kernels use -----------------------
+namespace {
+struct RecJ {
+  std::vector<long long>* rows; std::vector<long long>* colind; long long base_own, base_prev; bool first;
+  void col() { colind->push_back((long long)rows->size()); }
+  void put(int r, double) {
+    long long g;
+    if (r >= 0) g = base_own + r;
+    else if (r > -100) { const int i = -1 - r; g = first ? i : base_prev + landing::dyn_row_of_state(i); }
+    else { const int c = -100 - r; g = base_prev + 16 + 12 * (c / 6) + 2 + (c % 6); }
+    rows->push_back(g);
+  }
+};
+}  // namespace
+
+int landing_pattern_jac(int N, long long* colind, long long* row) {
+  if (N < 2 || !colind || !row) return fail(LANDING_E_ARG, "landing_pattern_jac: bad argument");
+  const Layout L = landing::make_layout(N);
+  std::vector<long long> rx, cx, ru, cu;
+  srbm::StageVars z; srbm::StageParams P;
+  memset(&z, 0, sizeof(z)); memset(&P, 0, sizeof(P));
+  P.mass = 1.0;
+  const double fzp[4] = {0, 0, 0, 0};
+  for (int k = 0; k < N; ++k) {
+    RecJ ex{&rx, &cx, L.g_stage(k), k ? L.g_stage(k - 1) : 0, k == 0};
+    RecJ eu{&ru, &cu, L.g_stage(k), k ? L.g_stage(k - 1) : 0, k == 0};
+    srbm::stage_jac(z, P, k == 0, k == N - 1, fzp, ex, eu);
+  }
+  // X_N columns: terminal rows then the identity of stage N-1
+  for (int i = 0; i < 12; ++i) {
+    cx.push_back((long long)rx.size());
+    if (i < 6) { rx.push_back(12 + i); rx.push_back(18 + i); } else { rx.push_back(24 + i - 6); rx.push_back(30 + i - 6); }
+    rx.push_back(L.g_stage(N - 1) + landing::dyn_row_of_state(i));
+  }
+  if ((long long)(rx.size() + ru.size()) != L.nnz_jac) return fail(LANDING_E_ARG, "internal: jac pattern size");
+  long long n = 0;
+  for (size_t c = 0; c < cx.size(); ++c) colind[n++] = cx[c];
+  for (size_t c = 0; c < cu.size(); ++c) colind[n++] = (long long)rx.size() + cu[c];
+  colind[n] = L.nnz_jac;
+  std::copy(rx.begin(), rx.end(), row);
+  std::copy(ru.begin(), ru.end(), row + rx.size());
+  return 0;
+}
+
+int landing_pattern_hess(int N, long long* colind, long long* row) {
+  if (N < 2 || !colind || !row) return fail(LANDING_E_ARG, "landing_pattern_hess: bad argument");
+  const Layout L = landing::make_layout(N);
+  long long n = 0, c = 0;
+  // X columns (order of srbm::stage_hess: pos diag; (pos,e),(e,e); (e,omega),(omega,omega))
+  for (int k = 0; k <= N; ++k) {
+    const long long X = L.x_X(k);
+    if (k == N) { for (int i = 0; i < 12; ++i) { colind[c++] = n; row[n++] = X + i; } break; }
+    for (int j = 0; j < 3; ++j) { colind[c++] = n; row[n++] = X + j; }
+    for (int a = 0; a < 3; ++a) { colind[c++] = n; for (int i = 0; i < 3; ++i) row[n++] = X + i; for (int b = 0; b <= a; ++b) row[n++] = X + 3 + b; }
+    colind[c++] = n; row[n++] = X + 4; row[n++] = X + 5;
+    colind[c++] = n; row[n++] = X + 3; row[n++] = X + 4; row[n++] = X + 5; row[n++] = X + 6;
+    colind[c++] = n; row[n++] = X + 3; row[n++] = X + 4; row[n++] = X + 5; row[n++] = X + 6; row[n++] = X + 7;
+    for (int j = 0; j < 3; ++j) colind[c++] = n;   // v columns: empty
+  }
+  for (int k = 0; k < N; ++k) {
+    const long long X = L.x_X(k), U = L.x_U(k);
+    for (int l = 0; l < 4; ++l) for (int j = 0; j < 3; ++j) {
+      colind[c++] = n;
+      row[n++] = X + j; row[n++] = X + 3; row[n++] = X + 4; row[n++] = X + 5;
+      if (k > 0) row[n++] = L.x_U(k - 1) + 12 + 3 * l + 2;
+      row[n++] = U + 3 * l + j;
+    }
+    for (int l = 0; l < 4; ++l) for (int j = 0; j < 3; ++j) {
+      colind[c++] = n;
+      for (int i = 0; i < 3; ++i) if (i != j) row[n++] = X + i;
+      row[n++] = X + 3; row[n++] = X + 4; row[n++] = X + 5;
+      for (int i = 0; i < 3; ++i) if (i != j || j == 2) row[n++] = U + 3 * l + i;
+    }
+  }
+  colind[c] = n;
+  if (n != L.nnz_hess || c != L.nx) return fail(LANDING_E_ARG, "internal: hess pattern size");
+  return 0;
+}
+
+// ---- context ----------------------------------------------------------------------------------
+landing_ctx* landing_create(int N, int device, const landing_form* form) {
+  if (N < 2 || N > 256) { fail(LANDING_E_ARG, "landing_create: N must be in [2,256]"); return nullptr; }
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { fail(LANDING_E_NODEV, "landing_create: no HIP device (this library has no CPU path)"); return nullptr; }
+  if (device < 0 || device >= n) { fail(LANDING_E_ARG, "landing_create: bad device index"); return nullptr; }
+  if (hipSetDevice(device) != hipSuccess) { fail(LANDING_E_HIP, "hipSetDevice failed"); return nullptr; }
+  landing_ctx* c = new landing_ctx();
+  c->L = landing::make_layout(N);
+  c->device = device;
+  if (form) {
+    for (int i = 0; i < 3; ++i) c->L.kin_box[i] = form->kin_box[i];
+    c->L.kin_z_off = form->kin_z_off; c->L.comp_eps = form->comp_eps; c->L.slip_eps = form->slip_eps;
+  }
+  return c;
+}
+
+void landing_destroy(landing_ctx* ctx) {
+  if (!ctx) return;
+  hipSetDevice(ctx->device);
+  ctx->ws.release();
+  delete ctx;
+}
+
+// ---- function layer -----------------------------------------------------------------------------
+int landing_eval_batch(landing_ctx* ctx, int B, const double* d_x, const double* d_p, const double* d_lam_f,
+                       const double* d_lam_g, double* d_f, double* d_g, double* d_grad_f, double* d_jac,
+                       double* d_hess, double* d_ggx, double* d_ggp, void* stream) {
+  if (!ctx || B < 0 || !d_x || !d_p) return fail(LANDING_E_ARG, "landing_eval_batch: bad argument");
+  if ((d_hess || d_ggx || d_ggp) && !d_lam_g) return fail(LANDING_E_ARG, "landing_eval_batch: lam_g required for hess/grad_gamma");
+  if (B == 0) return 0;
+  HIP_TRY(hipSetDevice(ctx->device));
+  landing::EvalArgs A{d_x, d_p, d_lam_f, d_lam_g, d_f, d_g, d_grad_f, d_jac, d_hess, d_ggx, d_ggp};
+  hipLaunchKernelGGL(landing::landing_sweep_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, ctx->L, B, A);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+namespace {
+struct DevBuf {
+  double* p = nullptr;
+  ~DevBuf() { if (p) hipFree(p); }
+  hipError_t alloc(size_t n) { return hipMalloc((void**)&p, n * sizeof(double)); }
+};
+}  // namespace
+
+int landing_eval_batch_host(landing_ctx* ctx, int B, const double* x, const double* p, const double* lam_f,
+                            const double* lam_g, double* f, double* g, double* grad_f, double* jac, double* hess,
+                            double* ggx, double* ggp) {
+  if (!ctx || B <= 0 || !x || !p) return fail(LANDING_E_ARG, "landing_eval_batch_host: bad argument");
+  const Layout& L = ctx->L;
+  HIP_TRY(hipSetDevice(ctx->device));
+  DevBuf dx, dp, dlf, dlg, df, dg, dgf, dj, dh, dgx, dgp;
+  const size_t b = (size_t)B;
+  HIP_TRY(dx.alloc(b * L.nx)); HIP_TRY(dp.alloc(b * L.np));
+  HIP_TRY(hipMemcpy(dx.p, x, b * L.nx * 8, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(dp.p, p, b * L.np * 8, hipMemcpyHostToDevice));
+  if (lam_f) { HIP_TRY(dlf.alloc(b)); HIP_TRY(hipMemcpy(dlf.p, lam_f, b * 8, hipMemcpyHostToDevice)); }
+  if (lam_g) { HIP_TRY(dlg.alloc(b * L.ng)); HIP_TRY(hipMemcpy(dlg.p, lam_g, b * L.ng * 8, hipMemcpyHostToDevice)); }
+  if (f) HIP_TRY(df.alloc(b));
+  if (g) HIP_TRY(dg.alloc(b * L.ng));
+  if (grad_f) HIP_TRY(dgf.alloc(b * L.nx));
+  if (jac) HIP_TRY(dj.alloc(b * L.nnz_jac));
+  if (hess) HIP_TRY(dh.alloc(b * L.nnz_hess));
+  if (ggx) HIP_TRY(dgx.alloc(b * L.nx));
+  if (ggp) HIP_TRY(dgp.alloc(b * L.np));
+  int rc = landing_eval_batch(ctx, B, dx.p, dp.p, dlf.p, dlg.p, df.p, dg.p, dgf.p, dj.p, dh.p, dgx.p, dgp.p, nullptr);
+  if (rc) return rc;
+  HIP_TRY(hipDeviceSynchronize());
+  if (f) HIP_TRY(hipMemcpy(f, df.p, b * 8, hipMemcpyDeviceToHost));
+  if (g) HIP_TRY(hipMemcpy(g, dg.p, b * L.ng * 8, hipMemcpyDeviceToHost));
+  if (grad_f) HIP_TRY(hipMemcpy(grad_f, dgf.p, b * L.nx * 8, hipMemcpyDeviceToHost));
+  if (jac) HIP_TRY(hipMemcpy(jac, dj.p, b * L.nnz_jac * 8, hipMemcpyDeviceToHost));
+  if (hess) HIP_TRY(hipMemcpy(hess, dh.p, b * L.nnz_hess * 8, hipMemcpyDeviceToHost));
+  if (ggx) HIP_TRY(hipMemcpy(ggx, dgx.p, b * L.nx * 8, hipMemcpyDeviceToHost));
+  if (ggp) HIP_TRY(hipMemcpy(ggp, dgp.p, b * L.np * 8, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int landing_bounds_batch(landing_ctx* ctx, int B, const double* d_p, double* d_lbg, double* d_ubg, void* stream) {
+  if (!ctx || B < 0 || !d_p || !d_lbg || !d_ubg) return fail(LANDING_E_ARG, "landing_bounds_batch: bad argument");
+  if (B == 0) return 0;
+  HIP_TRY(hipSetDevice(ctx->device));
+  const size_t n = (size_t)B * ctx->L.ng;
+  hipLaunchKernelGGL(landing::landing_bounds_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ctx->L, B, d_p, d_lbg, d_ubg);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+}  // extern "C"
+
+#include "solver_capi.inc"

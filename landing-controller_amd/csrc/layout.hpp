@@ -1,0 +1,44 @@
+// layout.hpp -- sizes and offsets of the reference's vectors for N intervals (host + device POD).
+//   x, p, g: generate_landingCtrller_IPOPT.m:41-75, SURVEY rows a1/a2/App. A
+//   CCS segments of casadi_s5 / casadi_s4 (landingCtrller_IPOPT.c:63-64): see DESIGN.md
+#pragma once
+
+namespace landing {
+
+struct Layout {
+  int N;
+  int nx, ng, np, nnz_jac, nnz_hess;
+  // offsets into p
+  int o_dt, o_q_min, o_q_max, o_qd_min, o_qd_max, o_q_init, o_qd_init, o_q_term_min, o_q_term_max,
+      o_qd_term_min, o_qd_term_max, o_QN, o_mu, o_l_leg_max, o_f_max, o_mass, o_Ib, o_Ib_inv;
+  // formulation constants
+  double kin_box[3], kin_z_off, comp_eps, slip_eps;
+
+  __host__ __device__ int x_X(int k) const { return 12 * k; }
+  __host__ __device__ int x_U(int k) const { return 12 * (N + 1) + 24 * k; }
+  __host__ __device__ int g_stage(int k) const { return 36 + 104 * k; }
+  __host__ __device__ int rows(int k) const { return k == N - 1 ? 80 : 104; }
+  // Jacobian CCS: [X_0..X_{N-1} (157 each) | X_N (36) | U_0 (204) | U_1..U_{N-2} (228 each) | U_{N-1} (180)]
+  __host__ __device__ int jx(int k) const { return 157 * k; }
+  __host__ __device__ int ju(int k) const { return 157 * N + 36 + (k == 0 ? 0 : 204 + 228 * (k - 1)); }
+  __host__ __device__ int ju_len(int k) const { return k == 0 ? (N == 1 ? 156 : 204) : (k == N - 1 ? 180 : 228); }
+  // Hessian CCS: [X_0..X_{N-1} (29 each) | X_N (12) | U_0 (148) | U_k (160 each)]
+  __host__ __device__ int hx(int k) const { return 29 * k; }
+  __host__ __device__ int hu(int k) const { return 29 * N + 12 + (k == 0 ? 0 : 148 + 160 * (k - 1)); }
+};
+
+inline Layout make_layout(int N) {
+  Layout L;
+  L.N = N;
+  L.nx = 36 * N + 12; L.ng = 104 * N + 12; L.np = 13 * N + 94;
+  L.nnz_jac = 36 + 385 * (N - 1) + 313; L.nnz_hess = 177 * N + 12 * (N - 1) + 12;
+  L.o_dt = 12 * (N + 1);
+  const int b = L.o_dt + N;
+  L.o_q_min = b; L.o_q_max = b + 6; L.o_qd_min = b + 12; L.o_qd_max = b + 18; L.o_q_init = b + 24; L.o_qd_init = b + 30;
+  L.o_q_term_min = b + 36; L.o_q_term_max = b + 42; L.o_qd_term_min = b + 48; L.o_qd_term_max = b + 54;
+  L.o_QN = b + 60; L.o_mu = b + 72; L.o_l_leg_max = b + 73; L.o_f_max = b + 74; L.o_mass = b + 75; L.o_Ib = b + 76; L.o_Ib_inv = b + 79;
+  L.kin_box[0] = 0.15; L.kin_box[1] = 0.15; L.kin_box[2] = 0.30; L.kin_z_off = 0.05; L.comp_eps = 1e-3; L.slip_eps = 1e-2;
+  return L;
+}
+
+}  // namespace landing

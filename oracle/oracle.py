@@ -110,6 +110,13 @@ class Oracle:
         self.lib.lo_bounds(self._F, _p(p), _p(lb), _p(ub))
         return lb, ub
 
+    def stage_eval(self, k, x, p, lam=None, want_J=True):
+        """dense per-stage blocks: g[104], J[104,60], H[60,60] (locals: X_k,U_k,X_{k+1},c_{k+1})."""
+        g = np.zeros(104); J = np.zeros((104, 60)) if want_J else None
+        H = np.zeros((60, 60)) if lam is not None else None
+        self.lib.lo_stage_eval(self._F, C.c_int(k), _p(x), _p(p), _p(lam), _p(g), _p(J), _p(H))
+        return g, J, H
+
     def kkt(self, x, p, lam_g):
         out = np.zeros(3)
         self.lib.lo_kkt(self._F, _p(x), _p(p), _p(lam_g), _p(out))

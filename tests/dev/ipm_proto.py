@@ -1,0 +1,340 @@
+#!/usr/bin/env python3
+"""Development prototype (numpy) of the batched interior-point algorithm: used to pick the
+algorithm that the HIP solver and oracle/landing_solver_cpu.c implement.  Not a test, not product.
+
+Primal-dual interior point with slacks on every inequality row of the reference NLP (what IPOPT
+sees through the CasADi boundary: all bounds live in g, lbx/ubx = +-inf), filter line search,
+stage-wise Riccati solve of the condensed KKT system with (X_k,c_k) as state and (f_k,c_{k+1}) as
+control.
+"""
+import sys, os, time
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import importlib
+from oracle.oracle import Oracle
+
+P = importlib.import_module("landing-controller_amd.problem")
+
+# local index sets of a stage: X_k 0..11, c_k 12..23, f_k 24..35, X+ 36..47, c+ 48..59
+IX = np.arange(0, 12); IC = np.arange(12, 24); IF = np.arange(24, 36); IXN = np.arange(36, 48); ICN = np.arange(48, 60)
+SIG = np.concatenate([IX, IC])            # state  (X_k, c_k)
+CTL = np.concatenate([IF, ICN])           # control (f_k, c_{k+1})
+W48 = np.concatenate([SIG, CTL])
+# dyn rows are ordered pos,rpy,v,omega ; state order is pos,rpy,omega,v
+ROW2STATE = np.array([0, 1, 2, 3, 4, 5, 9, 10, 11, 6, 7, 8])
+
+
+class Problem:
+    def __init__(self, O, p, x0):
+        self.O, self.p = O, p
+        self.N = N = O.N
+        self.lb, self.ub = O.bounds(p)
+        self.nr = [104] * (N - 1) + [80]
+        self.x0 = x0.copy()
+        o = O.param_offsets()
+        self.o = o
+        self.x_init = np.concatenate([p[o["q_init"]:o["q_init"] + 6], p[o["qd_init"]:o["qd_init"] + 6]])
+        # inequality row mask
+        self.ineq = self.lb != self.ub
+        self.ineq[:12] = False
+
+    def eval(self, x, y=None, want_J=True):
+        N = self.N
+        g = np.zeros(self.O.ng)
+        g[:12] = x[:12]
+        XN = x[12 * N:12 * N + 12]
+        g[12:18] = XN[:6]; g[18:24] = XN[:6]; g[24:30] = XN[6:]; g[30:36] = XN[6:]
+        J = np.zeros((N, 104, 60)) if want_J else None
+        H = np.zeros((N, 60, 60)) if y is not None else None
+        for k in range(N):
+            lam = None
+            if y is not None:
+                lam = np.zeros(104); lam[:self.nr[k]] = y[36 + 104 * k:36 + 104 * k + self.nr[k]]
+            gk, Jk, Hk = self.O.stage_eval(k, x, self.p, lam, want_J)
+            g[36 + 104 * k:36 + 104 * k + self.nr[k]] = gk[:self.nr[k]]
+            if want_J: J[k] = Jk
+            if y is not None: H[k] = Hk
+        f, gf = self.O.grad_f(x, self.p)
+        return f, gf, g, J, H
+
+
+def riccati(prob, M, m, A_rows, c_dyn, MN, mN, dX0, delta):
+    """Solve min sum_k 1/2 w_k' M_k w_k + m_k' w_k  s.t. J_dyn w + dX+ + c = 0.
+    M[k]: 60x60 (X+ cols zero), m[k]: 60; A_rows[k] = J_dyn (12x60, rows permuted to state order);
+    MN (12x12), mN(12) terminal. Returns dx stage-wise, costates, ok flag."""
+    N = prob.N
+    Pm = MN + delta * np.eye(12); pv = mN.copy()       # cost-to-go on sigma_{N}=X_N
+    K = [None] * N; kap = [None] * N
+    Tl = [None] * N; tl = [None] * N
+    for k in range(N - 1, -1, -1):
+        last = (k == N - 1)
+        ctl = IF if last else CTL
+        nw = 24 + len(ctl)
+        widx = np.concatenate([SIG, ctl])
+        G = M[k][np.ix_(widx, widx)].copy()
+        gam = m[k][widx].copy()
+        G[np.arange(nw), np.arange(nw)] += delta
+        # sigma+ = T w + t
+        Jd = A_rows[k]
+        nsn = 12 if last else 24
+        T = np.zeros((nsn, nw)); t = np.zeros(nsn)
+        T[:12, :] = -Jd[:, widx]; t[:12] = -c_dyn[k]
+        if not last:
+            T[12:24, 24 + 12:24 + 24] = np.eye(12)
+        PT = Pm @ T
+        G += T.T @ PT
+        gam += T.T @ (Pm @ t + pv)
+        Guu = G[24:, 24:]; Gus = G[24:, :24]; Gss = G[:24, :24]
+        try:
+            L = np.linalg.cholesky(Guu)
+        except np.linalg.LinAlgError:
+            return None
+        Kk = np.linalg.solve(L.T, np.linalg.solve(L, Gus))
+        kk = np.linalg.solve(L.T, np.linalg.solve(L, gam[24:]))
+        Pm = Gss - Gus.T @ Kk
+        Pm = 0.5 * (Pm + Pm.T)
+        pv = gam[:24] - Gus.T @ kk
+        K[k] = Kk; kap[k] = kk; Tl[k] = T; tl[k] = t
+    # stage 0: X_0 fixed (dX0), c_0 free
+    Pcc = Pm[12:, 12:]
+    try:
+        L = np.linalg.cholesky(Pcc)
+    except np.linalg.LinAlgError:
+        return None
+    dc0 = -np.linalg.solve(L.T, np.linalg.solve(L, pv[12:] + Pm[12:, :12] @ dX0))
+    sig = np.concatenate([dX0, dc0])
+    V0grad = Pm @ sig + pv
+    dw = []
+    for k in range(N):
+        u = -K[k] @ sig - kap[k]
+        w = np.concatenate([sig, u])
+        dw.append(w)
+        sig = Tl[k] @ w + tl[k]
+    return dw, sig, V0grad
+
+
+def solve(prob, opts=None, verbose=True):
+    o = dict(tol=1e-6, max_iter=500, mu_init=0.1, bound_push=0.5, bound_frac=0.5, kappa_eps=10.0,
+             kappa_mu=0.2, theta_mu=1.5, tau_min=0.99, gamma_theta=1e-5, gamma_phi=1e-8, eta_phi=1e-8,
+             delta_sw=1.0, s_theta=1.1, s_phi=2.3, max_soc=4, kappa_soc=0.99)
+    if opts: o.update(opts)
+    N = prob.N; O = prob.O
+    lb, ub, ineq = prob.lb, prob.ub, prob.ineq
+    x = prob.x0.copy()
+    x[:12] = prob.x_init
+    hasL = ineq & np.isfinite(lb); hasU = ineq & np.isfinite(ub)
+    f, gf, g, J, _ = prob.eval(x)
+    # slack init (IPOPT push into interior)
+    s = g.copy()
+    pl = np.where(hasL & hasU, np.minimum(o["bound_push"] * np.maximum(1, np.abs(lb)), o["bound_frac"] * (ub - lb)),
+                  o["bound_push"] * np.maximum(1, np.abs(np.where(hasL, lb, 0))))
+    pu = np.where(hasL & hasU, np.minimum(o["bound_push"] * np.maximum(1, np.abs(ub)), o["bound_frac"] * (ub - lb)),
+                  o["bound_push"] * np.maximum(1, np.abs(np.where(hasU, ub, 0))))
+    s = np.where(hasL, np.maximum(s, lb + pl), s)
+    s = np.where(hasU, np.minimum(s, ub - pu), s)
+    zL = np.where(hasL, 1.0, 0.0); zU = np.where(hasU, 1.0, 0.0)
+    y = np.zeros(O.ng)
+    y[ineq] = zU[ineq] - zL[ineq]
+    mu = o["mu_init"]
+    filt = []
+    delta_last = 0.0
+    hist = []
+
+    def barrier(f, s, mu):
+        return f - mu * np.sum(np.log(s[hasL] - lb[hasL])) - mu * np.sum(np.log(ub[hasU] - s[hasU]))
+
+    def theta_of(g, s):
+        eqr = ~ineq
+        r = np.where(ineq, g - s, g - lb)
+        r[:12] = 0
+        return np.sum(np.abs(r))
+
+    def kkt_error(gf, g, J, s, y, zL, zU, mu):
+        # stationarity
+        gx = gf.copy()
+        XN0 = 12 * N
+        gx[:12] += y[:12]
+        gx[XN0:XN0 + 6] += y[12:18] + y[18:24]; gx[XN0 + 6:XN0 + 12] += y[24:30] + y[30:36]
+        for k in range(N):
+            nr = prob.nr[k]
+            v = J[k][:nr].T @ y[36 + 104 * k:36 + 104 * k + nr]
+            nloc = 60 if k < N - 1 else 48
+            for a, idxs in ((0, IX), (1, np.concatenate([IC, IF])), (2, IXN), (3, ICN)):
+                pass
+            gx[12 * k:12 * k + 12] += v[0:12]
+            u0 = 12 * (N + 1) + 24 * k
+            gx[u0:u0 + 24] += v[12:36]
+            gx[12 * (k + 1):12 * (k + 1) + 12] += v[36:48]
+            if k < N - 1: gx[u0 + 24:u0 + 36] += v[48:60]
+        gx_free = gx.copy(); gx_free[:12] = 0    # X_0 multipliers absorb these
+        du = np.max(np.abs(gx_free))
+        rs = np.where(ineq, zU - zL - y, 0.0)
+        du = max(du, np.max(np.abs(rs)))
+        pr = np.where(ineq, g - s, g - lb); pr[:12] = x[:12] - prob.x_init
+        prn = np.max(np.abs(pr))
+        cL = np.where(hasL, (s - lb) * zL - mu, 0.0); cU = np.where(hasU, (ub - s) * zU - mu, 0.0)
+        co = max(np.max(np.abs(cL)), np.max(np.abs(cU)))
+        return du, prn, co, gx
+
+    it = 0
+    t0 = time.time()
+    status = "max_iter"
+    while it < o["max_iter"]:
+        f, gf, g, J, H = prob.eval(x, y)
+        du, prn, co0, gx = kkt_error(gf, g, J, s, y, zL, zU, 0.0)
+        # true (mu=0) error for termination, unscaled
+        if verbose and (it % 10 == 0 or it < 10):
+            print(f"it {it:4d} f {f:10.4e} pr {prn:8.2e} du {du:8.2e} co {co0:8.2e} mu {mu:8.2e} dw {delta_last:7.1e} |filt| {len(filt)}")
+        hist.append((f, prn, du, co0, mu))
+        if max(du, prn, co0) <= o["tol"]:
+            status = "converged"; break
+        # barrier subproblem error
+        du_m, pr_m, co_m, _ = kkt_error(gf, g, J, s, y, zL, zU, mu)
+        while max(du_m, pr_m, co_m) <= o["kappa_eps"] * mu and mu > o["tol"] / 10:
+            mu = max(o["tol"] / 10, min(o["kappa_mu"] * mu, mu ** o["theta_mu"]))
+            filt = []
+            du_m, pr_m, co_m, _ = kkt_error(gf, g, J, s, y, zL, zU, mu)
+        tau = max(o["tau_min"], 1 - mu)
+        # ---- condensed stage blocks
+        dL = np.where(hasL, s - lb, 1.0); dU = np.where(hasU, ub - s, 1.0)
+        Sig = np.where(hasL, zL / dL, 0.0) + np.where(hasU, zU / dU, 0.0)
+        rho = Sig * (g - s) + np.where(hasU, mu / dU, 0.0) - np.where(hasL, mu / dL, 0.0)
+        rho = np.where(ineq, rho, 0.0); Sig = np.where(ineq, Sig, 0.0)
+        M = []; m = []; Arows = []; cdyn = []
+        for k in range(N):
+            nr = prob.nr[k]; r0 = 36 + 104 * k
+            Jk = J[k][:nr]
+            Jd = Jk[12:]; Sg = Sig[r0 + 12:r0 + nr]; rh = rho[r0 + 12:r0 + nr]
+            Mk = H[k] + Jd.T @ (Sg[:, None] * Jd)
+            mk = Jd.T @ rh
+            M.append(Mk); m.append(mk)
+            Ar = np.zeros((12, 60)); Ar[ROW2STATE] = Jk[:12]
+            cd = np.zeros(12); cd[ROW2STATE] = g[r0:r0 + 12]
+            Arows.append(Ar); cdyn.append(cd)
+        QN2 = 2 * prob.p[prob.o["QN"]:prob.o["QN"] + 12]
+        MN = np.diag(QN2) + np.diag(np.concatenate([Sig[12:18] + Sig[18:24], Sig[24:30] + Sig[30:36]]))
+        mN = gf[12 * N:12 * N + 12] + np.concatenate([rho[12:18] + rho[18:24], rho[24:30] + rho[30:36]])
+        dX0 = prob.x_init - x[:12]
+        # ---- inertia-corrected Riccati
+        delta = 0.0; res = riccati(prob, M, m, Arows, cdyn, MN, mN, dX0, delta)
+        ntry = 0
+        while res is None:
+            if delta == 0.0:
+                delta = 1e-4 if delta_last == 0 else max(1e-20, delta_last / 3)
+            else:
+                delta *= (100 if delta_last == 0 else 8)
+            res = riccati(prob, M, m, Arows, cdyn, MN, mN, dX0, delta)
+            ntry += 1
+            if delta > 1e40: raise RuntimeError("delta blowup")
+        if delta > 0: delta_last = delta
+        dw, sigN, V0g = res
+        dx = np.zeros_like(x)
+        for k in range(N):
+            w = dw[k]
+            dx[12 * k:12 * k + 12] = w[0:12]
+            u0 = 12 * (N + 1) + 24 * k
+            dx[u0:u0 + 12] = w[12:24]; dx[u0 + 12:u0 + 24] = w[24:36]
+        dx[12 * N:12 * N + 12] = sigN[:12]
+        # slack / multiplier steps
+        Jdx = np.zeros(O.ng)
+        XN0 = 12 * N
+        Jdx[:12] = dx[:12]
+        Jdx[12:18] = dx[XN0:XN0 + 6]; Jdx[18:24] = dx[XN0:XN0 + 6]; Jdx[24:30] = dx[XN0 + 6:XN0 + 12]; Jdx[30:36] = dx[XN0 + 6:XN0 + 12]
+        for k in range(N):
+            nr = prob.nr[k]; u0 = 12 * (N + 1) + 24 * k
+            loc = np.zeros(60); loc[0:12] = dx[12 * k:12 * k + 12]; loc[12:36] = dx[u0:u0 + 24]; loc[36:48] = dx[12 * (k + 1):12 * (k + 1) + 12]
+            if k < N - 1: loc[48:60] = dx[u0 + 24:u0 + 36]
+            Jdx[36 + 104 * k:36 + 104 * k + nr] = J[k][:nr] @ loc
+        ds = np.where(ineq, Jdx + (g - s), 0.0)
+        ynew_d = Sig * ds + np.where(hasU, mu / dU, 0.0) - np.where(hasL, mu / dL, 0.0)
+        dzL = np.where(hasL, mu / dL - zL - zL / dL * ds, 0.0)
+        dzU = np.where(hasU, mu / dU - zU + zU / dU * ds, 0.0)
+        # equality multipliers: recover from stationarity of the QP (costates) -- compute by backward sweep
+        ynew = np.where(ineq, ynew_d, 0.0)
+        # costate recursion: y_dyn,k = -(grad wrt X_{k+1} of everything after) ; do it by stationarity at X_{k+1}:
+        # grad_{X_{k+1}} [ stage k+1 quadratic model ] + y_k(perm) = 0
+        Hdx_cache = None
+        # stationarity residual of QP wrt X_{k+1}: (M_{k+1} w_{k+1} + m_{k+1} + Jc_{k+1}' ydyn_{k+1})[X] + ydyn_k(state order) = 0
+        ydyn_next = None
+        for k in range(N - 1, -1, -1):
+            if k == N - 1:
+                grad = MN @ sigN[:12] + mN
+            else:
+                w = np.zeros(60); wk = dw[k + 1]
+                nctl = 12 if k + 1 == N - 1 else 24
+                w[SIG] = wk[:24]
+                w[(IF if k + 1 == N - 1 else CTL)] = wk[24:]
+                grad = (M[k + 1] @ w + m[k + 1])[IX] + delta * w[IX] + Arows[k + 1][:, IX].T @ ydyn_next
+            ydyn = -grad                      # state order
+            ydyn_next = ydyn
+            r0 = 36 + 104 * k
+            ynew[r0:r0 + 12] = ydyn[ROW2STATE]
+        dy = ynew - y
+        # ---- fraction to boundary
+        def max_step(v, dv, mask, tau):
+            neg = mask & (dv < 0)
+            if not np.any(neg): return 1.0
+            return min(1.0, np.min(-tau * v[neg] / dv[neg]))
+        a_pr = min(max_step(s - lb, ds, hasL, tau), max_step(ub - s, -ds, hasU, tau))
+        a_du = min(max_step(zL, dzL, hasL, tau), max_step(zU, dzU, hasU, tau))
+        # ---- filter line search on (theta, phi)
+        th0 = theta_of(g, s); ph0 = barrier(f, s, mu)
+        dphi = gf @ dx - mu * np.sum(ds[hasL] / dL[hasL]) + mu * np.sum(ds[hasU] / dU[hasU])
+        th_min = 1e-4 * max(1, hist[0][1] if False else 1.0)
+        th_max = 1e4 * max(1, th0) if it == 0 else th_max_keep
+        th_max_keep = th_max
+        alpha = a_pr; accepted = False; ls = 0
+        while alpha > 1e-10:
+            xt = x + alpha * dx; st = s + alpha * ds
+            ft, _, gt, _, _ = prob.eval(xt, None, want_J=False)
+            tht = theta_of(gt, st); pht = barrier(ft, st, mu)
+            ok_filter = tht <= th_max and all(not (tht >= ft_[0] and pht >= ft_[1]) for ft_ in filt)
+            switching = (dphi < 0) and (alpha * (-dphi) ** o["s_phi"] > o["delta_sw"] * th0 ** o["s_theta"]) and th0 <= th_min
+            if ok_filter and np.isfinite(pht):
+                if switching:
+                    if pht <= ph0 + o["eta_phi"] * alpha * dphi:
+                        accepted = True; ftype = "f"; break
+                else:
+                    if tht <= (1 - o["gamma_theta"]) * th0 or pht <= ph0 - o["gamma_phi"] * th0:
+                        accepted = True; ftype = "h"; break
+            alpha *= 0.5; ls += 1
+        if not accepted:
+            # fallback: tiny step, reset filter (no restoration phase in the prototype)
+            if verbose: print(f"   line search failed at it {it}: th0 {th0:.2e} dphi {dphi:.2e}; resetting filter")
+            filt = []
+            alpha = min(a_pr, 1e-2)
+            xt = x + alpha * dx; st = s + alpha * ds
+            ftype = "r"
+        else:
+            if ftype == "h" or not (switching and pht <= ph0 + o["eta_phi"] * alpha * dphi):
+                filt.append(((1 - o["gamma_theta"]) * th0, ph0 - o["gamma_phi"] * th0))
+        x = xt; s = st
+        y = y + alpha * dy if False else np.where(ineq, y, y + alpha * dy)   # eq multipliers: primal step size
+        zL = zL + a_du * dzL; zU = zU + a_du * dzU
+        # z safeguard (IPOPT kappa_sigma)
+        ks = 1e10
+        dLn = np.where(hasL, s - lb, 1.0); dUn = np.where(hasU, ub - s, 1.0)
+        zL = np.where(hasL, np.clip(zL, mu / (ks * dLn), ks * mu / dLn), 0.0)
+        zU = np.where(hasU, np.clip(zU, mu / (ks * dUn), ks * mu / dUn), 0.0)
+        y = np.where(ineq, zU - zL, y)
+        it += 1
+    return dict(x=x, y=y, s=s, zL=zL, zU=zU, iters=it, status=status, hist=hist, time=time.time() - t0)
+
+
+if __name__ == "__main__":
+    N = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    nprob = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+    O = Oracle(N)
+    Pb, X0, q, qd = P.make_batch(nprob, N, 0.6, seed=seed)
+    for b in range(nprob):
+        prob = Problem(O, Pb[b], X0[b])
+        r = solve(prob, verbose=(nprob == 1))
+        # reference-consistent KKT with lam_g = y (initial rows' multipliers recovered from stationarity)
+        lam = r["y"].copy()
+        _, _, gx, _ = O.grad(r["x"], Pb[b], 1.0, lam)
+        lam[:12] -= gx[:12]
+        k = O.kkt(r["x"], Pb[b], lam)
+        print(f"member {b}: {r['status']} iters {r['iters']} time {r['time']:.1f}s f {O.f(r['x'], Pb[b]):.3e} KKT pr {k[0]:.2e} du {k[1]:.2e} co {k[2]:.2e}  q0 pitch {q[b,4]:.2f} vz {qd[b,5]:.2f}")

@@ -1,0 +1,61 @@
+// hip_emu.h -- TEST INFRASTRUCTURE: a minimal host emulation of the HIP constructs the kernels in
+// landing-controller_amd/csrc use, so that their indexing / control logic can be exercised by the
+// CPU test-suite (-m "not gpu") in a container without a GPU.  The product library is always
+// built by hipcc for gfx950 from the very same sources; this header is never part of it.
+//
+// Model: one block at a time; the threads of a block are ucontext fibers scheduled round-robin,
+// __syncthreads() yields to the next fiber (valid because the kernels only communicate through
+// __shared__/global memory separated by __syncthreads()).  __shared__ maps to `static`.
+#pragma once
+#include <ucontext.h>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <vector>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __shared__ static
+#define __launch_bounds__(...)
+#define __restrict__
+
+struct dim3 { unsigned x, y, z; dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {} };
+struct emu_idx { unsigned x, y, z; };
+extern emu_idx threadIdx, blockIdx;
+extern dim3 blockDim, gridDim;
+
+typedef int hipError_t;
+typedef void* hipStream_t;
+typedef void* hipEvent_t;
+#define hipSuccess 0
+#define hipMemcpyHostToDevice 1
+#define hipMemcpyDeviceToHost 2
+#define hipMemcpyDeviceToDevice 3
+inline hipError_t hipMalloc(void** p, size_t n) { *p = std::malloc(n ? n : 1); return *p ? 0 : 2; }
+template <typename T> inline hipError_t hipMalloc(T** p, size_t n) { return hipMalloc((void**)p, n); }
+inline hipError_t hipFree(void* p) { std::free(p); return 0; }
+inline hipError_t hipMemcpy(void* d, const void* s, size_t n, int) { std::memcpy(d, s, n); return 0; }
+inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int, hipStream_t) { std::memcpy(d, s, n); return 0; }
+inline hipError_t hipMemset(void* d, int v, size_t n) { std::memset(d, v, n); return 0; }
+inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { std::memset(d, v, n); return 0; }
+inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
+inline hipError_t hipDeviceSynchronize() { return 0; }
+inline hipError_t hipGetLastError() { return 0; }
+inline hipError_t hipSetDevice(int) { return 0; }
+inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return 0; }
+inline const char* hipGetErrorString(hipError_t) { return "emulated"; }
+inline void sincos(double a, double* s, double* c) { *s = std::sin(a); *c = std::cos(a); }
+
+namespace hip_emu {
+void yield_barrier();
+void run_grid(dim3 grid, dim3 block, const std::function<void()>& body);
+}
+inline void __syncthreads() { hip_emu::yield_barrier(); }
+
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
+  hip_emu::run_grid(dim3(grid), dim3(block), [&]() { kernel(__VA_ARGS__); })

@@ -1,0 +1,122 @@
+"""CPU tests of the product's C ABI and host logic (no GPU needed):
+  * the hipcc-built library loads and exports every symbol include/*.h declares;
+  * the CCS patterns it reports equal the reference's casadi_s4/casadi_s5 (golden fixture);
+  * the kernels' indexing/emission logic, compiled for the host through tests/emu (the same
+    sources, fibers instead of lanes), reproduces the oracle -- no compute call touches a GPU here.
+"""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT, lc
+
+PKG = os.path.join(ROOT, "landing-controller_amd")
+
+
+@pytest.fixture(scope="session")
+def built():
+    subprocess.run(["make", "-C", os.path.join(PKG, "csrc"), "all", "emu"], check=True, capture_output=True)
+    return True
+
+
+def _declared(header, pat):
+    txt = open(os.path.join(ROOT, "include", header)).read()
+    return sorted(set(re.findall(pat, txt)))
+
+
+def test_library_exports_every_declared_symbol(built):
+    lib = C.CDLL(os.path.join(PKG, "liblanding_mi355x.so"))
+    names = _declared("landing_nlp.h", r"\b(landing_[a-z0-9_]+)\s*\(")
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), n
+
+
+@pytest.mark.parametrize("so", ["landingCtrller_IPOPT_mi355x.so", "landingCtrller_IPOPT_N40_mi355x.so"])
+def test_casadi_dropin_exports_reference_symbol_set(built, so):
+    lib = C.CDLL(os.path.join(PKG, so))
+    suffixes = ["", "_alloc_mem", "_init_mem", "_free_mem", "_checkout", "_release", "_incref", "_decref", "_n_in",
+                "_n_out", "_default_in", "_name_in", "_name_out", "_sparsity_in", "_sparsity_out", "_work"]
+    for f in ["nlp", "nlp_f", "nlp_g", "nlp_grad", "nlp_grad_f", "nlp_hess_l", "nlp_jac_g"]:  # landingCtrller_IPOPT.c:10916-10993
+        for s in suffixes:
+            assert hasattr(lib, f + s), f + s
+    # metadata CasADi asserts on (external.cpp:325-363)
+    lib.nlp_jac_g_name_out.restype = C.c_char_p; lib.nlp_jac_g_name_out.argtypes = [C.c_longlong]
+    assert lib.nlp_jac_g_name_out(1) == b"jac_g_x" and lib.nlp_jac_g_name_out(2) is None
+    lib.nlp_hess_l_name_out.restype = C.c_char_p; lib.nlp_hess_l_name_out.argtypes = [C.c_longlong]
+    assert lib.nlp_hess_l_name_out(0) == b"hess_gamma_x_x"
+    lib.nlp_grad_n_in.restype = C.c_longlong
+    assert lib.nlp_grad_n_in() == 4
+    sz = (C.c_longlong * 4)()
+    assert lib.nlp_work(C.byref(sz, 0), C.byref(sz, 8), C.byref(sz, 16), C.byref(sz, 24)) == 0 and list(sz) == [2, 2, 0, 0]
+
+
+def test_dropin_sparsity_equals_reference_pattern(built):
+    lib = C.CDLL(os.path.join(PKG, "landingCtrller_IPOPT_mi355x.so"))
+    d = np.load(os.path.join(GOLDEN, "n20_patterns.npz"))
+    for fn, idx, ci_k, r_k, nr, nc in (("nlp_jac_g_sparsity_out", 1, "jac_colind", "jac_row", 2092, 732),
+                                       ("nlp_hess_l_sparsity_out", 0, "hess_colind", "hess_row", 732, 732)):
+        f = getattr(lib, fn); f.restype = C.POINTER(C.c_longlong); f.argtypes = [C.c_longlong]
+        ptr = f(idx)
+        assert (ptr[0], ptr[1]) == (nr, nc)
+        ci = np.array([ptr[2 + i] for i in range(nc + 1)])
+        r = np.array([ptr[3 + nc + i] for i in range(int(ci[-1]))])
+        assert np.array_equal(ci, d[ci_k]) and np.array_equal(r, d[r_k])
+    f = lib.nlp_f_sparsity_in; f.restype = C.POINTER(C.c_longlong); f.argtypes = [C.c_longlong]
+    ptr = f(1)
+    assert [ptr[i] for i in range(4)] == [354, 1, 0, 354]   # casadi_s1, landingCtrller_IPOPT.c:60
+
+
+def test_no_device_means_loud_failure(built):
+    """The product has no CPU path: without a GPU landing_create must fail with a message."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    capi = lc("capi")
+    with pytest.raises(RuntimeError, match="no HIP device|landing_create failed"):
+        capi.LandingLib(20)
+
+
+@pytest.fixture(scope="module")
+def emu(built):
+    return os.path.join(ROOT, "tests", "emu", "liblanding_emu.so")
+
+
+@pytest.mark.parametrize("N", [20, 40])
+def test_emulated_kernels_match_oracle(emu, oracle_mod, N):
+    capi = lc("capi")
+    O = oracle_mod.Oracle(N)
+    lib = capi.LandingLib(N, lib_path=emu)
+    assert all(np.array_equal(a, b) for a, b in zip(lib.pattern_jac(), O.pattern_jac()))
+    assert all(np.array_equal(a, b) for a, b in zip(lib.pattern_hess(), O.pattern_hess()))
+    rng = np.random.default_rng(N)
+    B = 2
+    x = rng.normal(size=(B, O.nx)) * 0.5; p = rng.uniform(0.5, 1.5, size=(B, O.np_))
+    lam = rng.normal(size=(B, O.ng)); lf = rng.uniform(0.5, 2, size=B)
+    out = lib.eval_host(x, p, lf, lam)
+    for b in range(B):
+        f, gf = O.grad_f(x[b], p[b]); g, jac = O.jac_g(x[b], p[b])
+        h = O.hess_l(x[b], p[b], lf[b], lam[b]); _, _, gx, gp = O.grad(x[b], p[b], lf[b], lam[b])
+        assert abs(out["f"][b] - f) < 1e-12 and np.max(np.abs(out["grad_f"][b] - gf)) < 1e-12
+        assert np.max(np.abs(out["g"][b] - g)) < 1e-12 and np.max(np.abs(out["jac"][b] - jac)) < 1e-12
+        assert np.max(np.abs(out["hess"][b] - h)) < 1e-11
+        assert np.max(np.abs(out["grad_gamma_x"][b] - gx)) < 1e-11 and np.max(np.abs(out["grad_gamma_p"][b] - gp)) < 1e-10
+
+
+def test_emulated_kernels_match_reference_fixture(emu):
+    """the reference's own outputs (tests/golden/n20_eval.npz) through the emulated kernels"""
+    capi = lc("capi")
+    lib = capi.LandingLib(20, lib_path=emu)
+    d = np.load(os.path.join(GOLDEN, "n20_eval.npz"))
+    for c in range(3):
+        g = lambda k: d[f"c{c}_{k}"]
+        out = lib.eval_host(g("x"), g("p"), np.array([float(g("lam_f"))]), g("lam_g"))
+        assert np.max(np.abs(out["g"][0] - g("g"))) < 1e-12
+        assert np.max(np.abs(out["jac"][0] - g("jac"))) < 1e-12
+        assert np.max(np.abs(out["hess"][0] - g("hess"))) < 1e-11
+        assert np.max(np.abs(out["grad_gamma_x"][0] - g("grad_gamma_x"))) < 1e-11
+        assert np.max(np.abs(out["grad_gamma_p"][0] - g("grad_gamma_p"))) < 1e-10
