@@ -36,6 +36,10 @@ EXPORTS = ["landing_last_error", "landing_form_default", "landing_solver_opts_de
 
 def load(path=None):
     path = path or os.path.join(HERE, LIB_NAME)
+    try:  # torch ships its own libamdhip64: it must be the first HIP runtime loaded in the process,
+        import torch  # noqa: F401  (otherwise torch.cuda later reports "No HIP GPUs are available")
+    except ImportError:
+        pass
     if not os.path.exists(path):
         raise ImportError(f"{path} not found: build it with __graft_entry__.build() (hipcc, gfx950). No CPU fallback exists.")
     lib = C.CDLL(path)

@@ -7,6 +7,8 @@
 #include <string.h>
 
 #include <algorithm>
+#include <array>
+#include <map>
 #include <string>
 #include <vector>
 

@@ -178,14 +178,73 @@ __global__ void __launch_bounds__(64) landing_sweep_kernel(Layout L, int B, Eval
   }
 }
 
-// lbg/ubg from p (Opti canonical forms; SURVEY App. A).  One thread per (member,row).
-__global__ void landing_bounds_kernel(Layout L, int B, const double* p_all, double* lbg, double* ubg) {
-  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (size_t)B * L.ng) return;
-  const int m = (int)(idx / L.ng), r = (int)(idx % L.ng);
-  const double* p = p_all + (size_t)m * L.np;
+// ---- member-level device functions shared with the solver kernel (lane = stage) -------------------
+// residual g(x) of one member (boundary rows + all stages); the caller synchronises afterwards.
+__device__ __noinline__ void member_eval_g(const Layout& L, const double* x, const double* p, double* g) {
+  const int N = L.N;
+  for (int r = threadIdx.x; r < 36; r += blockDim.x) {
+    double v;
+    if (r < 12) v = x[r];
+    else if (r < 24) v = x[12 * N + (r - 12) % 6];
+    else v = x[12 * N + 6 + (r - 24) % 6];
+    g[r] = v;
+  }
+  for (int k = threadIdx.x; k < N; k += blockDim.x) {
+    srbm::StageVars z; srbm::StageParams P;
+    load_stage(L, x, p, k, z, P);
+    RowStore out{g + L.g_stage(k)};
+    srbm::stage_g(z, P, k == N - 1, out);
+  }
+}
+// Jacobian / Hessian nonzeros (CCS order) and gx = grad f + J^T y of one member.
+__device__ __noinline__ void member_eval_jh(const Layout& L, const double* x, const double* p, const double* y,
+                                            double* J, double* H, double* gx) {
+  const int N = L.N;
+  for (int i = threadIdx.x; i < 36; i += blockDim.x) J[L.jx(N) + i] = 1.0;
+  for (int i = threadIdx.x; i < 12; i += blockDim.x) {
+    H[L.hx(N) + i] = 2.0 * p[L.o_QN + i];
+    const double* lp = y + L.g_stage(N - 1);
+    double v = 2.0 * p[L.o_QN + i] * (x[12 * N + i] - p[12 * N + i]) + lp[dyn_row_of_state(i)];
+    v += (i < 6) ? y[12 + i] + y[18 + i] : y[24 + i - 6] + y[30 + i - 6];
+    gx[12 * N + i] = v;
+  }
+  for (int k = threadIdx.x; k < N; k += blockDim.x) {
+    const bool first = (k == 0), last = (k == N - 1);
+    srbm::StageVars z; srbm::StageParams P;
+    load_stage(L, x, p, k, z, P);
+    double fz_prev[4] = {0, 0, 0, 0};
+    double lps[12];
+    for (int i = 0; i < 12; ++i) lps[i] = 0.0;
+    if (!first) {
+      const double* Up = x + L.x_U(k - 1);
+      const double* lp = y + L.g_stage(k - 1);
+      for (int l = 0; l < 4; ++l) {
+        fz_prev[l] = Up[12 + 3 * l + 2];
+        for (int i = 0; i < 3; ++i) lps[3 * l + i] = lp[16 + 12 * l + 2 + i] + lp[16 + 12 * l + 5 + i];
+      }
+    }
+    {
+      SeqStoreJ ex{J + L.jx(k)}, eu{J + L.ju(k)};
+      srbm::stage_jac(z, P, first, last, fz_prev, ex, eu);
+    }
+    {
+      LamStage lam{y + L.g_stage(k)};
+      SeqStoreH hx{H + L.hx(k)}, hu{H + L.hu(k)};
+      srbm::stage_hess(z, P, first, last, lam, lps, hx, hu);
+    }
+    {
+      const double* lprev = first ? y : y + L.g_stage(k - 1);
+      DotLam ex{y + L.g_stage(k), lprev, first, gx + L.x_X(k), 0.0, false};
+      DotLam eu{y + L.g_stage(k), lprev, first, gx + L.x_U(k), 0.0, false};
+      srbm::stage_jac(z, P, first, last, fz_prev, ex, eu);
+      ex.finish(); eu.finish();
+    }
+  }
+}
+
+// lbg/ubg of one row from p (Opti canonical forms)
+__device__ __forceinline__ void bound_of(const Layout& L, const double* p, int r, double& lb, double& ub) {
   const double inf = INFINITY;
-  double lb, ub;
   if (r < 36) {
     const int i = r % 6;
     if (r < 6) lb = ub = p[L.o_q_init + i];
@@ -218,6 +277,15 @@ __global__ void landing_bounds_kernel(Layout L, int B, const double* p_all, doub
       else { lb = p[L.o_qd_min + i]; ub = inf; }
     }
   }
+}
+
+// lbg/ubg from p (Opti canonical forms; SURVEY App. A).  One thread per (member,row).
+__global__ void landing_bounds_kernel(Layout L, int B, const double* p_all, double* lbg, double* ubg) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)B * L.ng) return;
+  const int m = (int)(idx / L.ng), r = (int)(idx % L.ng);
+  double lb, ub;
+  bound_of(L, p_all + (size_t)m * L.np, r, lb, ub);
   lbg[idx] = lb; ubg[idx] = ub;
 }
 
