@@ -122,6 +122,11 @@ int landing_solve_batch_host(landing_ctx* ctx, int B, const double* p, const dou
                              const landing_solver_opts* opts,
                              double* x, double* f, double* lam_g, int* status, int* iters, double* kkt);
 
+/* development aid: d_prof [B][16] doubles receives per-member phase timers of the next solves (100 MHz
+ * wall-clock ticks: eval, error, sigma/rho, backward, forward, dual, line search, accept; then counts of
+ * factorisations, trial points, iterations); NULL disables. */
+int landing_set_profile_buffer(landing_ctx* ctx, double* d_prof);
+
 /* name of the dominant kernels (for profilers) and per-launch algorithmic bytes of the sweep */
 const char* landing_kernel_name_sweep(void);
 long long landing_sweep_bytes_per_member(int N);

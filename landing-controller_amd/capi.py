@@ -31,7 +31,7 @@ EXPORTS = ["landing_last_error", "landing_form_default", "landing_solver_opts_de
            "landing_np", "landing_nnz_jac", "landing_nnz_hess", "landing_pattern_jac", "landing_pattern_hess",
            "landing_create", "landing_destroy", "landing_device_count", "landing_eval_batch", "landing_eval_batch_host",
            "landing_bounds_batch", "landing_solve_batch", "landing_solve_batch_host", "landing_kernel_name_sweep",
-           "landing_sweep_bytes_per_member"]
+           "landing_sweep_bytes_per_member", "landing_set_profile_buffer"]
 
 
 def load(path=None):
@@ -58,6 +58,7 @@ def load(path=None):
     lib.landing_eval_batch_host.argtypes = [vp, C.c_int] + [_dp] * 11
     lib.landing_bounds_batch.argtypes = [vp, C.c_int, vp, vp, vp, vp]
     lib.landing_solve_batch.argtypes = [vp, C.c_int, vp, vp, C.POINTER(SolverOpts), vp, vp, vp, vp, vp, vp, vp]
+    lib.landing_set_profile_buffer.argtypes = [vp, vp]
     lib.landing_solve_batch_host.argtypes = [vp, C.c_int, _dp, _dp, C.POINTER(SolverOpts), _dp, _dp, _dp, _ip, _ip, _dp]
     return lib
 

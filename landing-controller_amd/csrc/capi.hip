@@ -32,6 +32,7 @@ struct landing_ctx {
   Layout L;
   int device;
   landing::SolverWorkspace ws;
+  double* d_prof = nullptr;
 };
 
 extern "C" {

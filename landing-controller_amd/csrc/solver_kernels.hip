@@ -27,43 +27,69 @@ constexpr int YS = 37;    // LDS row stride of 24x36 / 12x36 matrices
 // per-stage Riccati record (doubles): K 24x24 | kappa 24 | A^ 12x36 | b 12 | P_k rows of X (12x24) | p_k X part 12
 constexpr int RIC_K = 0, RIC_KAP = 576, RIC_AH = 600, RIC_B = 1032, RIC_PX = 1044, RIC_PV = 1332, RIC_STRIDE = 1344;
 constexpr int FILT_CAP = 64;
+constexpr int ES = 26;    // LDS row stride of the elimination side block [gamma_u | I] (24 x 25)
+constexpr int SOLVER_THREADS = 256;
+// condensed stage data (once per iteration): [G targets (table order) | gamma 48 | A^ values] per stage
+constexpr int COND_GAM = 480, COND_AH = 528, COND_STRIDE = 704;
 
 struct SolverWorkspace {
   double* buf = nullptr; size_t cap = 0;
   int* d_tab = nullptr; int* d_stage_tab = nullptr; int n_tab = 0;
+  int *d_cterm = nullptr, *d_cstart = nullptr, *d_rterm = nullptr, *d_rstart = nullptr;
   static size_t member_stride(const Layout& L) {
-    return (size_t)4 * L.nx + (size_t)14 * L.ng + L.nnz_jac + L.nnz_hess + (size_t)(L.N + 1) * RIC_STRIDE;
+    return (size_t)4 * L.nx + (size_t)14 * L.ng + L.nnz_jac + L.nnz_hess + (size_t)(L.N + 1) * RIC_STRIDE + (size_t)L.N * COND_STRIDE;
   }
   int ensure(const Layout& L, int B);
   void release();
 };
 
+// optional per-member phase timers (wall_clock64 ticks, 100 MHz) -- enabled when SolveArgs.prof != nullptr
+enum { PH_EVAL = 0, PH_ERR, PH_SIGRHO, PH_BACK, PH_FWD, PH_DUAL, PH_LS, PH_ACCEPT, PH_NFACT, PH_NTRIAL, PH_NITER, PH_B_LOAD, PH_B_ASM, PH_B_TPT, PH_B_ELIM, PH_B_POST, PH_COUNT = 16 };
+#define PROF_ADD(slot, tstart) do { if (SH.prof_on) { const long long n_ = (long long)wall_clock64(); if (threadIdx.x == 0) SH.prof[slot] += (double)(n_ - (tstart)); (tstart) = n_; } } while (0)
+
 struct SolveArgs {
-  Layout L; int B; landing_solver_opts o;
+  Layout L; int B; landing_solver_opts o; double* prof;
   const double* p; const double* x0;
   double* x_out; double* f_out; double* lam_out; int* status; int* iters; double* kkt;
   double* ws; size_t ws_stride;
   const int* tab; const int* stage_tab;
+  const int4* cterm; const int* cstart; const int4* rterm; const int* rstart;
 };
 
-// ---- block-wide reductions through LDS (deterministic order) -----------------------------------------
+// ---- block-wide reductions through LDS (deterministic order), K values at once ----------------------
 enum { RSUM = 0, RMAX = 1, RMIN = 2 };
-__device__ __forceinline__ double block_reduce(double v, int op, double* red) {
-  red[threadIdx.x] = v;
+__device__ __forceinline__ double red_op(double a, double b, int op) { return op == RSUM ? a + b : (op == RMAX ? fmax(a, b) : fmin(a, b)); }
+template <int K>
+__device__ __forceinline__ void block_reduce(double (&v)[K], const int (&op)[K], double* red) {
+  const int tid = threadIdx.x, NT = blockDim.x;
+  for (int i = 0; i < K; ++i) red[i * NT + tid] = v[i];
   __syncthreads();
-  double r = red[0];
-  for (unsigned t = 1; t < blockDim.x; ++t) {
-    const double u = red[t];
-    r = (op == RSUM) ? r + u : (op == RMAX ? fmax(r, u) : fmin(r, u));
+  if (tid < 64) {
+    for (int i = 0; i < K; ++i) {
+      double r = red[i * NT + tid];
+      for (int t = tid + 64; t < NT; t += 64) r = red_op(r, red[i * NT + t], op[i]);
+      red[i * NT + tid] = r;
+    }
   }
   __syncthreads();
-  return r;
+  const int n = NT < 64 ? NT : 64;
+  for (int i = 0; i < K; ++i) {
+    double r = red[i * NT];
+    for (int t = 1; t < n; ++t) r = red_op(r, red[i * NT + t], op[i]);
+    v[i] = r;
+  }
+  __syncthreads();
+}
+__device__ __forceinline__ double block_reduce1(double v, int op, double* red) {
+  double a[1] = {v}; const int o[1] = {op};
+  block_reduce<1>(a, o, red);
+  return a[0];
 }
 
 struct MemberMem {
   double *x, *xt, *dx, *gx;
   double *g, *gt, *s, *ds, *zL, *zU, *dzL, *dzU, *y, *yn, *lb, *ub, *sig, *rho;
-  double *J, *H, *ric;
+  double *J, *H, *ric, *cond;
 };
 
 __device__ __forceinline__ MemberMem carve(const Layout& L, double* w) {
@@ -73,7 +99,7 @@ __device__ __forceinline__ MemberMem carve(const Layout& L, double* w) {
   M.zL = w; w += L.ng; M.zU = w; w += L.ng; M.dzL = w; w += L.ng; M.dzU = w; w += L.ng;
   M.y = w; w += L.ng; M.yn = w; w += L.ng; M.lb = w; w += L.ng; M.ub = w; w += L.ng;
   M.sig = w; w += L.ng; M.rho = w; w += L.ng;
-  M.J = w; w += L.nnz_jac; M.H = w; w += L.nnz_hess; M.ric = w;
+  M.J = w; w += L.nnz_jac; M.H = w; w += L.nnz_hess; M.ric = w; w += (size_t)(L.N + 1) * RIC_STRIDE; M.cond = w;
   return M;
 }
 
@@ -82,14 +108,20 @@ struct Lds {
   double G[48 * GS];
   double P[24 * PS];
   double A1[NZ_TOT];          // stage nonzeros during assembly, then Y = P(:,0:12)*A^  (24 x YS = 888)
-  double Li[24 * PS];         // inverse Cholesky factor
-  double V[24 * PS];          // Li * G_us
+  double Ex[24 * ES];         // elimination side block: col 0 = gamma_u -> z, cols 1.. = I -> unit-lower inverse
   double Ah[12 * YS];
   double Sg[104], rh[104];
-  double gam[48], pv[24], q[24], bv[12], vv[24], sig[24], w[48], sgn[24];
-  double red[64];
+  double gam[48], pv[24], q[24], bv[12], sig[24], w[48], dinv[24];
+  double red[SOLVER_THREADS * 6];
   double filt_th[FILT_CAP], filt_ph[FILT_CAP];
+  double prof[16];
+  // member context, written once by every thread with identical values (read back as LDS broadcasts by the
+  // __noinline__ phases so that they carry no register state across calls)
+  MemberMem M; Layout L; const double* p; const int* tab; const int* stage_tab; int prof_on;
 };
+// One instance per workgroup (= per NLP).  Namespace scope keeps the LDS address space visible to every
+// phase function (ds_* instructions instead of flat_*).
+__shared__ Lds SH;
 
 // copy the CCS segments of stage k into the staging buffer
 __device__ __forceinline__ void load_stage_nz(const Layout& L, const MemberMem& M, int k, double* nz, bool with_h) {
@@ -105,47 +137,337 @@ __device__ __forceinline__ void load_stage_nz(const Layout& L, const MemberMem& 
   }
 }
 
-// In-place Cholesky of the n x n block at A (row stride ld), lower triangle; on success the strict lower
-// part holds L(i,j)*sqrt(d_j) un-normalised columns and rj[j] = 1/sqrt(d_j).  Returns false on a
-// non-positive / non-finite pivot (wave-uniform).
-__device__ __forceinline__ bool chol_lower(double* A, int ld, int n, double* rj) {
-  const int lane = threadIdx.x, NT = blockDim.x;
-  for (int j = 0; j < n; ++j) {
-    const double d = A[j * ld + j];
+// Fused LDL^T elimination of G_uu (rows/cols 24..24+NU of G) applied to [G_us | G_uu | gamma_u | I]:
+// afterwards rows 24.. of G hold Z = L~^{-1} G_us in columns 0..23, Ex(:,0) = z = L~^{-1} gamma_u, Ex(:,1+t) =
+// L~^{-1}(:,t) (unit lower triangular) and dinv[j] = 1/d_j.  One block barrier per pivot.  Returns false
+// (uniformly) on a non-positive / non-finite pivot: the caller raises delta_w (inertia correction).
+template <int NU>
+__device__ __forceinline__ bool ldl_eliminate(double* G, double* Ex, double* dinv) {
+  constexpr int NC = NU + 25;                          // 24 (G_us) + (NU-1-j) trailing + (j+2) side columns
+  constexpr int MAXQ = ((NU - 1) * NC + SOLVER_THREADS - 1) / SOLVER_THREADS;
+  const int tid = threadIdx.x, NT = blockDim.x;
+  const int EXOFF = (int)(Ex - G);                     // both live in the same LDS struct
+  for (int j = 0; j < NU; ++j) {
+    const double d = G[(24 + j) * GS + 24 + j];
     if (!(d > 0.0) || !(d < 1e300)) return false;
     const double inv = 1.0 / d;
-    const int m = n - 1 - j;                   // trailing size
-    for (int e = lane; e < m * m; e += NT) {   // (i,c) over the trailing square, lower part only
-      const int i = j + 1 + e / m, c = j + 1 + e % m;
-      if (c <= i) A[i * ld + c] -= A[i * ld + j] * A[c * ld + j] * inv;
+    const int nrow = NU - 1 - j, n = nrow * NC;
+    // branch-free addressing, all LDS loads of a pivot step issued before the stores (the elements of
+    // one step are independent: row j and column j are only read)
+    int ot[MAXQ]; double vt[MAXQ], vp[MAXQ], vl[MAXQ];
+#pragma unroll
+    for (int q = 0; q < MAXQ; ++q) {
+      const int e = tid + q * NT;
+      const bool act = e < n;
+      const int ee = act ? e : 0;
+      const int i = j + 1 + ee / NC, cc = ee % NC;
+      const bool inG = cc < 24 + nrow;
+      const int col = cc < 24 ? cc : cc + 1 + j;          // G_us column, or trailing G_uu column 24+j+1+(cc-24)
+      const int c = cc - 24 - nrow;                       // side-block column 0..j+1
+      ot[q] = act ? (inG ? (24 + i) * GS + col : EXOFF + i * ES + c) : -1;
+      const int op = inG ? (24 + j) * GS + col : EXOFF + j * ES + c;
+      vt[q] = G[act ? ot[q] : 0]; vp[q] = G[op]; vl[q] = G[(24 + i) * GS + 24 + j];
     }
-    if (lane == 0) rj[j] = 1.0 / sqrt(d);
+#pragma unroll
+    for (int q = 0; q < MAXQ; ++q) if (ot[q] >= 0) G[ot[q]] = vt[q] - vl[q] * inv * vp[q];
+    if (tid == 0) dinv[j] = inv;
     __syncthreads();
   }
-  // normalise: L(i,j) = A(i,j) * rj[j], L(j,j) = sqrt(d_j) = 1/rj[j]
-  for (int e = lane; e < n * n; e += NT) {
-    const int i = e / n, j = e % n;
-    if (j < i) A[i * ld + j] *= rj[j];
-    else if (j == i) A[i * ld + j] = 1.0 / rj[j];
+  return true;
+}
+
+// Everything of one backward Riccati step that follows the assembly of G, gamma (templated on the control
+// dimension: 24 = (f_k, c_{k+1}), 12 = last stage).  Writes P_k, p_k into S and the stage record.
+template <int NU>
+__device__ __forceinline__ bool riccati_step(double* rec) {
+  Lds& S = SH;
+  const int tid = threadIdx.x, NT = blockDim.x;
+  for (int e = tid; e < NU * 25; e += NT) {
+    const int i = e / 25, c = e % 25;
+    S.Ex[i * ES + c] = (c == 0) ? S.gam[24 + i] : (c - 1 == i ? 1.0 : 0.0);
   }
+  __syncthreads();
+  if (!ldl_eliminate<NU>(S.G, S.Ex, S.dinv)) return false;
+  // P_k = G_ss - Z^T D^-1 Z ; p_k = gamma_s - Z^T D^-1 z
+  for (int e = tid; e < 24 * 24; e += NT) {
+    const int i = e / 24, j = e % 24;
+    double acc = S.G[i * GS + j];
+#pragma unroll
+    for (int t = 0; t < NU; ++t) acc -= S.G[(24 + t) * GS + i] * S.G[(24 + t) * GS + j] * S.dinv[t];
+    S.P[i * PS + j] = acc;
+    if (i < 12) rec[RIC_PX + i * 24 + j] = acc;
+  }
+  for (int i = tid; i < 24; i += NT) {
+    double acc = S.gam[i];
+#pragma unroll
+    for (int t = 0; t < NU; ++t) acc -= S.G[(24 + t) * GS + i] * S.Ex[t * ES] * S.dinv[t];
+    S.pv[i] = acc;
+    if (i < 12) rec[RIC_PV + i] = acc;
+  }
+  // gains K = L~^-T D^-1 Z, kappa = L~^-T D^-1 z
+  for (int e = tid; e < NU * 24; e += NT) {
+    const int i = e / 24, j = e % 24;
+    double acc = 0.0;
+#pragma unroll
+    for (int t = 0; t < NU; ++t) acc += S.Ex[t * ES + 1 + i] * S.dinv[t] * S.G[(24 + t) * GS + j];
+    rec[RIC_K + i * 24 + j] = acc;
+  }
+  for (int i = tid; i < NU; i += NT) {
+    double acc = 0.0;
+#pragma unroll
+    for (int t = 0; t < NU; ++t) acc += S.Ex[t * ES + 1 + i] * S.dinv[t] * S.Ex[t * ES];
+    rec[RIC_KAP + i] = acc;
+  }
+  for (int e = tid; e < 12 * 36; e += NT) rec[RIC_AH + e] = S.Ah[(e / 36) * YS + e % 36];
+  if (tid < 12) rec[RIC_B + tid] = S.bv[tid];
   __syncthreads();
   return true;
 }
 
-// Li = L^{-1} (lower triangular), column j by lane j (uniform control flow, broadcast reads of L)
-__device__ __forceinline__ void tri_inverse(const double* Lm, int ld, int n, double* Li) {
-  const int j = threadIdx.x;
-  for (int i = 0; i < n; ++i) {
-    if (j < n) {
-      double acc = (i == j) ? 1.0 : 0.0;
-      for (int t = 0; t < i; ++t) acc -= Lm[i * ld + t] * Li[t * PS + j];
-      Li[i * PS + j] = (j <= i) ? acc / Lm[i * ld + i] : 0.0;
+__device__ __noinline__ void condense(const int4* __restrict__ cterm, const int* __restrict__ cstart) {
+  Lds& S = SH;
+  const Layout& L = S.L;
+  const MemberMem& M = S.M;
+  const double* p = S.p;
+  const int N = L.N, lane = threadIdx.x, NT = blockDim.x;
+  (void)p; (void)N; (void)lane; (void)NT;
+  const int ng = L.ng;
+  // ---------------------------------------------------------------- condensation (once per iteration):
+  // G targets = H + J_d^T Sigma J_d, gamma = J_d^T rho, A^ = -dg_dyn/d(X,c,f) for every stage, from the CCS
+  // nonzeros; flat per-thread term lists, deterministic summation order, independent loads batched
+  {
+    const double* __restrict__ JH = M.J;       // [J | H] are contiguous
+    const double* __restrict__ SR = M.sig;     // [sigma | rho] are contiguous
+    double* __restrict__ cond = M.cond;
+    double acc = 0.0;
+    const int e1 = cstart[lane + 1];
+#pragma unroll 4
+    for (int e = cstart[lane]; e < e1; ++e) {
+      const int4 t = cterm[e];
+      const double a = JH[t.y];
+      const double b = JH[t.z >= 0 ? t.z : 0];
+      const double c = SR[t.x >= 0 ? t.x + (t.z < 0 ? ng : 0) : 0];
+      const double cc = t.x >= 0 ? c : (t.x == -1 ? 1.0 : (t.x == -2 ? -1.0 : 0.0));
+      acc += a * (t.z >= 0 ? b : 1.0) * cc;
+      if (t.w >= 0) { cond[t.w] = acc; acc = 0.0; }
     }
   }
   __syncthreads();
 }
 
-__global__ void __launch_bounds__(64) landing_ipm_kernel(SolveArgs A) {
+// One backward Riccati sweep with regularisation delta (terminal cost-to-go, stages N-1..0, free feet of
+// stage 0).  false = a pivot was not positive (wrong inertia): the caller raises delta and retries.
+__device__ __noinline__ bool riccati_backward(double delta) {
+  Lds& S = SH;
+  const Layout& L = S.L;
+  const MemberMem& M = S.M;
+  const double* p = S.p;
+  const int N = L.N, lane = threadIdx.x, NT = blockDim.x;
+  (void)p; (void)N; (void)lane; (void)NT;
+  bool ok = true;
+  // terminal cost-to-go on sigma_N = X_N: diagonal (terminal rows are copies of X_N, gen:94-97)
+  for (int e = lane; e < 24 * PS; e += NT) S.P[e] = 0.0;
+  __syncthreads();
+  if (lane < 12) {
+    const int i = lane;
+    const int ra = i < 6 ? 12 + i : 24 + (i - 6), rb = i < 6 ? 18 + i : 30 + (i - 6);
+    const double qn2 = 2.0 * p[L.o_QN + i];
+    S.P[i * PS + i] = qn2 + M.sig[ra] + M.sig[rb] + delta;
+    S.pv[i] = qn2 * (M.x[12 * N + i] - p[12 * N + i]) + M.rho[ra] + M.rho[rb];
+    double* rec = M.ric + (size_t)N * RIC_STRIDE;      // record N: P_N (diag), p_N
+    for (int j = 0; j < 24; ++j) rec[RIC_PX + i * 24 + j] = (j == i) ? S.P[i * PS + i] : 0.0;
+    rec[RIC_PV + i] = S.pv[i];
+  }
+  __syncthreads();
+  for (int k = N - 1; k >= 0 && ok; --k) {
+    const bool last = (k == N - 1);
+    const int nu = last ? 12 : 24, nsn = last ? 12 : 24, nw = 24 + nu;
+    const int* tb = S.tab + S.stage_tab[k];
+    const int g0 = L.g_stage(k), nr = L.rows(k);
+    // ---- condensed stage data -> LDS (all loads independent)
+    long long tb_ = S.prof_on ? (long long)wall_clock64() : 0;
+    const double* cd = M.cond + (size_t)k * COND_STRIDE;
+    (void)nr;
+    for (int e = lane; e < 48 * GS; e += NT) S.G[e] = 0.0;
+    for (int e = lane; e < 12 * YS; e += NT) S.Ah[e] = 0.0;
+    __syncthreads();
+    PROF_ADD(PH_B_LOAD, tb_);
+    {
+      const int nT = tb[0];
+      const int* ab = S.tab + tb[1];
+      for (int t = lane; t < nT; t += NT) {
+        const double v = cd[t];
+        const int a = ab[t] & 255, b = ab[t] >> 8;
+        S.G[a * GS + b] = v; S.G[b * GS + a] = v;
+      }
+      for (int a = lane; a < 48; a += NT) S.gam[a] = cd[COND_GAM + a];
+      const int nA = tb[6]; const int* at = S.tab + tb[7];
+      for (int t = lane; t < nA; t += NT) S.Ah[at[3 * t + 1] * YS + at[3 * t + 2]] = cd[COND_AH + t];
+      if (lane < 12) S.bv[lane < 6 ? lane : (lane < 9 ? lane + 3 : lane - 3)] = -M.g[g0 + lane];
+    }
+    __syncthreads();
+    for (int a = lane; a < nw; a += NT) S.G[a * GS + a] += delta;
+    // ---- Y = P(:,0:12) A^  (nsn x 36), q = P(:,0:12) b + p   (A1 is free again: Y lives there)
+    double* Y = S.A1;
+    __syncthreads();
+    PROF_ADD(PH_B_ASM, tb_);
+    for (int e = lane; e < nsn * 36; e += NT) {
+      const int i = e / 36, j = e % 36;
+      double acc = 0.0;
+#pragma unroll
+      for (int t = 0; t < 12; ++t) acc += S.P[i * PS + t] * S.Ah[t * YS + j];
+      Y[i * YS + j] = acc;
+    }
+    for (int i = lane; i < nsn; i += NT) {
+      double acc = S.pv[i];
+#pragma unroll
+      for (int t = 0; t < 12; ++t) acc += S.P[i * PS + t] * S.bv[t];
+      S.q[i] = acc;
+    }
+    __syncthreads();
+    // ---- G += T^T P T, gamma += T^T q
+    for (int e = lane; e < 36 * 36; e += NT) {
+      const int i = e / 36, j = e % 36;
+      double acc = 0.0;
+#pragma unroll
+      for (int t = 0; t < 12; ++t) acc += S.Ah[t * YS + i] * Y[t * YS + j];
+      S.G[i * GS + j] += acc;
+    }
+    if (!last) {
+      for (int e = lane; e < 12 * 36; e += NT) {
+        const int i = e / 36, j = e % 36;
+        const double v = Y[(12 + i) * YS + j];
+        S.G[(36 + i) * GS + j] += v; S.G[j * GS + 36 + i] += v;
+      }
+      for (int e = lane; e < 144; e += NT) { const int i = e / 12, j = e % 12; S.G[(36 + i) * GS + 36 + j] += S.P[(12 + i) * PS + 12 + j]; }
+    }
+    for (int j = lane; j < 36; j += NT) {
+      double acc = 0.0;
+#pragma unroll
+      for (int t = 0; t < 12; ++t) acc += S.Ah[t * YS + j] * S.q[t];
+      S.gam[j] += acc;
+    }
+    if (!last && lane < 12) S.gam[36 + lane] += S.q[12 + lane];
+    __syncthreads();
+    PROF_ADD(PH_B_TPT, tb_);
+    // ---- eliminate the controls: P_k, p_k, gains -> record k
+    double* rec = M.ric + (size_t)k * RIC_STRIDE;
+    ok = last ? riccati_step<12>(rec) : riccati_step<24>(rec);
+    PROF_ADD(PH_B_ELIM, tb_);
+    if (!ok) break;
+  }
+  if (ok) {
+    // ---- stage 0: X_0 fixed, feet c_0 free: P_cc dc0 = -(p_c + P_cx dX0), same elimination on a 12x12 block
+    if (lane < 12) {
+      const int i = lane;
+      const double x0i = (i < 6) ? p[L.o_q_init + i] : p[L.o_qd_init + i - 6];
+      S.sig[i] = x0i - M.x[i];
+    }
+    for (int e = lane; e < 144; e += NT) { const int i = e / 12, j = e % 12; S.G[(24 + i) * GS + 24 + j] = S.P[(12 + i) * PS + 12 + j]; }
+    __syncthreads();
+    for (int e = lane; e < 12 * 25; e += NT) {
+      const int i = e / 25, c = e % 25;
+      double v = (c - 1 == i) ? 1.0 : 0.0;
+      if (c == 0) { v = S.pv[12 + i]; for (int t = 0; t < 12; ++t) v += S.P[(12 + i) * PS + t] * S.sig[t]; }
+      S.Ex[i * ES + c] = v;
+    }
+    __syncthreads();
+    ok = ldl_eliminate<12>(S.G, S.Ex, S.dinv);
+    if (ok) {
+      if (lane < 12) {
+        double acc = 0.0;
+        for (int t = 0; t < 12; ++t) acc += S.Ex[t * ES + 1 + lane] * S.dinv[t] * S.Ex[t * ES];
+        S.sig[12 + lane] = -acc;
+      }
+      __syncthreads();
+    }
+  }
+  return ok;
+}
+
+// Forward sweep: dx of every stage, next states, multipliers of the dynamics rows.
+__device__ __noinline__ void forward_pass() {
+  Lds& S = SH;
+  const Layout& L = S.L;
+  const MemberMem& M = S.M;
+  const double* p = S.p;
+  const int N = L.N, lane = threadIdx.x, NT = blockDim.x;
+  (void)p; (void)N; (void)lane; (void)NT;
+  // ================================================================ forward pass: dx, ds (stage rows), y_dyn
+  // the stage record (K, kappa, A^, b) and P_{k+1}(X rows) are staged through LDS with coalesced loads
+  for (int k = 0; k < N; ++k) {
+    const bool last = (k == N - 1);
+    const int nu = last ? 12 : 24;
+    const double* rec = M.ric + (size_t)k * RIC_STRIDE;
+    const double* recn = M.ric + (size_t)(k + 1) * RIC_STRIDE;
+    const int g0 = L.g_stage(k);
+    double* Kl = S.G;                 // nu x 24 (stride 24) | kappa at 576 | A^ 12x36 at 600 | b at 1032 | Px 12x24 at 1044 | pv at 1332
+    for (int e = lane; e < RIC_PX; e += NT) Kl[e] = rec[e];
+    for (int e = lane; e < RIC_STRIDE - RIC_PX; e += NT) Kl[RIC_PX + e] = recn[RIC_PX + e];
+    __syncthreads();
+    if (lane < nu) {
+      double acc = Kl[RIC_KAP + lane];
+#pragma unroll
+      for (int t = 0; t < 24; ++t) acc += Kl[RIC_K + lane * 24 + t] * S.sig[t];
+      S.w[24 + lane] = -acc;
+    } else if (lane >= 32 && lane < 56) S.w[lane - 32] = S.sig[lane - 32];
+    __syncthreads();
+    if (lane < 12) { M.dx[L.x_X(k) + lane] = S.w[lane]; M.dx[L.x_U(k) + lane] = S.w[12 + lane]; M.dx[L.x_U(k) + 12 + lane] = S.w[24 + lane]; }
+    // next state: X+ = A^ [sigma; f] + b ; c+ = u_c   (threads 128.. so that they do not queue behind the row loop)
+    if (lane >= 128 && lane < 140) {
+      const int i = lane - 128;
+      double acc = Kl[RIC_B + i];
+#pragma unroll
+      for (int t = 0; t < 36; ++t) acc += Kl[RIC_AH + i * 36 + t] * S.w[t];
+      S.q[i] = acc;
+    } else if (lane >= 140 && lane < 152) {
+      S.q[lane - 128] = last ? 0.0 : S.w[36 + (lane - 140)];
+    }
+    __syncthreads();
+    if (lane < 24) S.sig[lane] = S.q[lane];
+    // multipliers of the dynamics rows: y = -(P_{k+1} sigma_{k+1} + p_{k+1})_X   (state order -> row order)
+    if (lane >= 64 && lane < 76) {
+      const int i = lane - 64;
+      double acc = Kl[RIC_PV + i];
+      const int nn = last ? 12 : 24;
+      for (int t = 0; t < nn; ++t) acc += Kl[RIC_PX + i * 24 + t] * S.q[t];
+      const int q = i < 6 ? i : (i < 9 ? i + 3 : i - 3);   // state index -> dyn row
+      M.yn[g0 + q] = -acc;
+    }
+    __syncthreads();
+  }
+  if (lane < 12) {
+    const int i = lane;
+    M.dx[12 * N + i] = S.sig[i];
+    const int ra = i < 6 ? 12 + i : 24 + (i - 6), rb = i < 6 ? 18 + i : 30 + (i - 6);
+    M.ds[ra] = S.sig[i] + (M.g[ra] - M.s[ra]);
+    M.ds[rb] = S.sig[i] + (M.g[rb] - M.s[rb]);
+  }
+  __syncthreads();
+}
+
+__device__ __noinline__ void row_products(const int4* __restrict__ rterm, const int* __restrict__ rstart) {
+  Lds& S = SH;
+  const Layout& L = S.L;
+  const MemberMem& M = S.M;
+  const double* p = S.p;
+  const int N = L.N, lane = threadIdx.x, NT = blockDim.x;
+  (void)p; (void)N; (void)lane; (void)NT;
+  {   // ds = J_d dx + (g - s) for every stage inequality row (flat per-thread term lists, parallel over rows)
+    const double* __restrict__ Jn = M.J; const double* __restrict__ dxv = M.dx;
+    double acc = 0.0;
+    const int e1 = rstart[lane + 1];
+#pragma unroll 4
+    for (int e = rstart[lane]; e < e1; ++e) {
+      const int4 t = rterm[e];
+      acc += Jn[t.x] * dxv[t.y];
+      if (t.z >= 0) { M.ds[t.z] = acc + (M.g[t.z] - M.s[t.z]); acc = 0.0; }
+    }
+  }
+  __syncthreads();
+}
+
+__global__ void __launch_bounds__(SOLVER_THREADS) landing_ipm_kernel(SolveArgs A) {
   const int m = blockIdx.x;
   if (m >= A.B) return;
   const Layout& L = A.L;
@@ -154,8 +476,11 @@ __global__ void __launch_bounds__(64) landing_ipm_kernel(SolveArgs A) {
   const double* p = A.p + (size_t)m * L.np;
   const landing_solver_opts& o = A.o;
   const MemberMem M = carve(L, A.ws + (size_t)m * A.ws_stride);
-  __shared__ Lds S;
+  Lds& S = SH;
   const double INF = INFINITY;
+  S.M = M; S.L = L; S.p = p; S.tab = A.tab; S.stage_tab = A.stage_tab; S.prof_on = A.prof != nullptr;
+  if (lane < 16) S.prof[lane] = 0.0;
+  __syncthreads();
 
   // ------------------------------------------------------------------ initial point
   for (int i = lane; i < nx; i += NT) {
@@ -184,14 +509,17 @@ __global__ void __launch_bounds__(64) landing_ipm_kernel(SolveArgs A) {
   }
   __syncthreads();
 
+  long long tp = A.prof ? (long long)wall_clock64() : 0;
   double mu = o.mu_init, delta_last = 0.0, th_max = 0.0;
-  int nfilt = 0, it = 0, status = LANDING_MAX_ITER;
+  int nfilt = 0, it = 0, status = LANDING_MAX_ITER, need_reg_streak = 0;
   double e_pr = 0, e_du = 0, e_co = 0;
 
   for (it = 0; it <= o.max_iter; ++it) {
     // ---------------------------------------------------------------- derivatives at (x, y)
+    if (A.prof) tp = (long long)wall_clock64();
     member_eval_jh(L, M.x, p, M.y, M.J, M.H, M.gx);
     __syncthreads();
+    PROF_ADD(PH_EVAL, tp);
     // ---------------------------------------------------------------- optimality error (unscaled)
     double du = 0.0, pr = 0.0, co = 0.0;
     for (int i = lane + 12; i < nx; i += NT) du = fmax(du, fabs(M.gx[i]));
@@ -203,7 +531,7 @@ __global__ void __launch_bounds__(64) landing_ipm_kernel(SolveArgs A) {
       if (lb > -INF) co = fmax(co, (s - lb) * M.zL[r]);
       if (ub < INF) co = fmax(co, (ub - s) * M.zU[r]);
     }
-    du = block_reduce(du, RMAX, S.red); pr = block_reduce(pr, RMAX, S.red); co = block_reduce(co, RMAX, S.red);
+    { double v[3] = {du, pr, co}; const int op[3] = {RMAX, RMAX, RMAX}; block_reduce<3>(v, op, S.red); du = v[0]; pr = v[1]; co = v[2]; }
     e_pr = pr; e_du = du; e_co = co;
     if (!(du < 1e300) || !(pr < 1e300) || !(co < 1e300)) { status = LANDING_NUMERICAL; break; }
     if (fmax(du, fmax(pr, co)) <= o.tol) { status = LANDING_CONVERGED; break; }
@@ -218,13 +546,14 @@ __global__ void __launch_bounds__(64) landing_ipm_kernel(SolveArgs A) {
         if (lb > -INF) cm = fmax(cm, fabs((s - lb) * M.zL[r] - mu));
         if (ub < INF) cm = fmax(cm, fabs((ub - s) * M.zU[r] - mu));
       }
-      cm = block_reduce(cm, RMAX, S.red);
+      cm = block_reduce1(cm, RMAX, S.red);
       if (fmax(du, fmax(pr, cm)) <= o.kappa_eps * mu && mu > o.tol / 10.0) {
         mu = fmax(o.tol / 10.0, fmin(o.kappa_mu * mu, pow(mu, o.theta_mu)));
         nfilt = 0;
       } else break;
     }
     const double tau = fmax(0.99, 1.0 - mu);
+    PROF_ADD(PH_ERR, tp);
     // ---------------------------------------------------------------- Sigma, rho per inequality row
     for (int r = lane; r < ng; r += NT) {
       const double lb = M.lb[r], ub = M.ub[r];
@@ -239,8 +568,13 @@ __global__ void __launch_bounds__(64) landing_ipm_kernel(SolveArgs A) {
     }
     __syncthreads();
 
+    condense(A.cterm, A.cstart);
+    PROF_ADD(PH_SIGRHO, tp);
     // ================================================================ Riccati factorisation with inertia correction
-    double delta = 0.0;
+    // IPOPT's inertia-correction schedule (delta_w = 0 first, then max(1e-20, delta_last/3), then x8 / x100),
+    // except that an iteration following a regularised one starts from delta_last/3 directly when the
+    // unregularised attempt failed twice in a row (saves one full factorisation in nonconvex phases)
+    double delta = (need_reg_streak >= 2 && delta_last > 0.0) ? fmax(1e-20, delta_last / 3.0) : 0.0;
     bool fact_ok = false;
     for (int attempt = 0; attempt < 60 && !fact_ok; ++attempt) {
       if (attempt > 0) {
@@ -248,225 +582,19 @@ __global__ void __launch_bounds__(64) landing_ipm_kernel(SolveArgs A) {
         else delta *= (delta_last == 0.0 ? 100.0 : 8.0);
         if (delta > 1e40) break;
       }
-      bool ok = true;
-      // terminal cost-to-go on sigma_N = X_N: diagonal (terminal rows are copies of X_N, gen:94-97)
-      for (int e = lane; e < 24 * PS; e += NT) S.P[e] = 0.0;
-      __syncthreads();
-      if (lane < 12) {
-        const int i = lane;
-        const int ra = i < 6 ? 12 + i : 24 + (i - 6), rb = i < 6 ? 18 + i : 30 + (i - 6);
-        const double qn2 = 2.0 * p[L.o_QN + i];
-        S.P[i * PS + i] = qn2 + M.sig[ra] + M.sig[rb] + delta;
-        S.pv[i] = qn2 * (M.x[12 * N + i] - p[12 * N + i]) + M.rho[ra] + M.rho[rb];
-        double* rec = M.ric + (size_t)N * RIC_STRIDE;      // record N: P_N (diag), p_N
-        for (int j = 0; j < 24; ++j) rec[RIC_PX + i * 24 + j] = (j == i) ? S.P[i * PS + i] : 0.0;
-        rec[RIC_PV + i] = S.pv[i];
-      }
-      __syncthreads();
-      for (int k = N - 1; k >= 0 && ok; --k) {
-        const bool last = (k == N - 1);
-        const int nu = last ? 12 : 24, nsn = last ? 12 : 24, nw = 24 + nu;
-        const int* tb = A.tab + A.stage_tab[k];
-        const int g0 = L.g_stage(k), nr = L.rows(k);
-        // ---- stage data into LDS
-        load_stage_nz(L, M, k, S.A1, true);
-        for (int r = lane; r < nr; r += NT) { S.Sg[r] = M.sig[g0 + r]; S.rh[r] = M.rho[g0 + r]; }
-        for (int e = lane; e < 48 * GS; e += NT) S.G[e] = 0.0;
-        for (int e = lane; e < 12 * YS; e += NT) S.Ah[e] = 0.0;
-        __syncthreads();
-        // ---- G = H + J^T Sigma J (sparse targets), gamma = J^T rho, A^, b
-        {
-          const int nT = tb[0];
-          const int* ab = A.tab + tb[1]; const int* st = A.tab + tb[2]; const int* tm = A.tab + tb[3];
-          for (int t = lane; t < nT; t += NT) {
-            double acc = 0.0;
-            for (int e = st[t]; e < st[t + 1]; ++e) {
-              const int r = tm[3 * e], i1 = tm[3 * e + 1], i2 = tm[3 * e + 2];
-              acc += (r < 0) ? S.A1[i1] : S.Sg[r] * S.A1[i1] * S.A1[i2];
-            }
-            const int a = ab[t] & 255, b = ab[t] >> 8;
-            S.G[a * GS + b] = acc; S.G[b * GS + a] = acc;
-          }
-          const int* gs = A.tab + tb[4]; const int* gt = A.tab + tb[5];
-          for (int a = lane; a < 48; a += NT) {
-            double acc = 0.0;
-            for (int e = gs[a]; e < gs[a + 1]; ++e) acc += S.rh[gt[2 * e]] * S.A1[gt[2 * e + 1]];
-            S.gam[a] = acc;
-          }
-          const int nA = tb[6]; const int* at = A.tab + tb[7];
-          for (int t = lane; t < nA; t += NT) S.Ah[at[3 * t + 1] * YS + at[3 * t + 2]] = -S.A1[at[3 * t]];
-          if (lane < 12) S.bv[lane < 6 ? lane : (lane < 9 ? lane + 3 : lane - 3)] = -M.g[g0 + lane];
-        }
-        __syncthreads();
-        for (int a = lane; a < nw; a += NT) S.G[a * GS + a] += delta;
-        // ---- Y = P(:,0:12) A^  (nsn x 36), q = P(:,0:12) b + p   (A1 is free again: Y lives there)
-        double* Y = S.A1;
-        __syncthreads();
-        for (int e = lane; e < nsn * 36; e += NT) {
-          const int i = e / 36, j = e % 36;
-          double acc = 0.0;
-          for (int t = 0; t < 12; ++t) acc += S.P[i * PS + t] * S.Ah[t * YS + j];
-          Y[i * YS + j] = acc;
-        }
-        for (int i = lane; i < nsn; i += NT) {
-          double acc = S.pv[i];
-          for (int t = 0; t < 12; ++t) acc += S.P[i * PS + t] * S.bv[t];
-          S.q[i] = acc;
-        }
-        __syncthreads();
-        // ---- G += T^T P T, gamma += T^T q
-        for (int e = lane; e < 36 * 36; e += NT) {
-          const int i = e / 36, j = e % 36;
-          double acc = 0.0;
-          for (int t = 0; t < 12; ++t) acc += S.Ah[t * YS + i] * Y[t * YS + j];
-          S.G[i * GS + j] += acc;
-        }
-        if (!last) {
-          for (int e = lane; e < 12 * 36; e += NT) {
-            const int i = e / 36, j = e % 36;
-            const double v = Y[(12 + i) * YS + j];
-            S.G[(36 + i) * GS + j] += v; S.G[j * GS + 36 + i] += v;
-          }
-          for (int e = lane; e < 144; e += NT) { const int i = e / 12, j = e % 12; S.G[(36 + i) * GS + 36 + j] += S.P[(12 + i) * PS + 12 + j]; }
-        }
-        for (int j = lane; j < 36; j += NT) {
-          double acc = 0.0;
-          for (int t = 0; t < 12; ++t) acc += S.Ah[t * YS + j] * S.q[t];
-          S.gam[j] += acc;
-        }
-        if (!last && lane < 12) S.gam[36 + lane] += S.q[12 + lane];
-        __syncthreads();
-        // ---- Cholesky of G_uu, inverse factor
-        ok = chol_lower(S.G + 24 * GS + 24, GS, nu, S.sgn);
-        if (!ok) break;
-        tri_inverse(S.G + 24 * GS + 24, GS, nu, S.Li);
-        // ---- V = Li G_us (nu x 24), vv = Li gamma_u
-        for (int e = lane; e < nu * 24; e += NT) {
-          const int i = e / 24, j = e % 24;
-          double acc = 0.0;
-          for (int t = 0; t <= i; ++t) acc += S.Li[i * PS + t] * S.G[(24 + t) * GS + j];
-          S.V[i * PS + j] = acc;
-        }
-        for (int i = lane; i < nu; i += NT) {
-          double acc = 0.0;
-          for (int t = 0; t <= i; ++t) acc += S.Li[i * PS + t] * S.gam[24 + t];
-          S.vv[i] = acc;
-        }
-        __syncthreads();
-        // ---- P_k = G_ss - V^T V, p_k = gamma_s - V^T vv ; gains K = Li^T V, kappa = Li^T vv -> record k
-        double* rec = M.ric + (size_t)k * RIC_STRIDE;
-        for (int e = lane; e < 24 * 24; e += NT) {
-          const int i = e / 24, j = e % 24;
-          double acc = S.G[i * GS + j];
-          for (int t = 0; t < nu; ++t) acc -= S.V[t * PS + i] * S.V[t * PS + j];
-          S.P[i * PS + j] = acc;
-          if (i < 12) rec[RIC_PX + i * 24 + j] = acc;
-        }
-        for (int i = lane; i < 24; i += NT) {
-          double acc = S.gam[i];
-          for (int t = 0; t < nu; ++t) acc -= S.V[t * PS + i] * S.vv[t];
-          S.pv[i] = acc;
-          if (i < 12) rec[RIC_PV + i] = acc;
-        }
-        for (int e = lane; e < nu * 24; e += NT) {
-          const int i = e / 24, j = e % 24;
-          double acc = 0.0;
-          for (int t = i; t < nu; ++t) acc += S.Li[t * PS + i] * S.V[t * PS + j];
-          rec[RIC_K + i * 24 + j] = acc;
-        }
-        for (int i = lane; i < nu; i += NT) {
-          double acc = 0.0;
-          for (int t = i; t < nu; ++t) acc += S.Li[t * PS + i] * S.vv[t];
-          rec[RIC_KAP + i] = acc;
-        }
-        for (int e = lane; e < 12 * 36; e += NT) rec[RIC_AH + e] = S.Ah[(e / 36) * YS + e % 36];
-        if (lane < 12) rec[RIC_B + lane] = S.bv[lane];
-        __syncthreads();
-      }
-      if (ok) {
-        // ---- stage 0: X_0 fixed, feet c_0 free: P_cc dc0 = -(p_c + P_cx dX0)
-        for (int e = lane; e < 144; e += NT) { const int i = e / 12, j = e % 12; S.V[i * PS + j] = S.P[(12 + i) * PS + 12 + j]; }
-        if (lane < 12) {
-          const int i = lane;
-          const double x0i = (i < 6) ? p[L.o_q_init + i] : p[L.o_qd_init + i - 6];
-          S.sig[i] = x0i - M.x[i];
-        }
-        __syncthreads();
-        ok = chol_lower(S.V, PS, 12, S.sgn);
-        if (ok) {
-          tri_inverse(S.V, PS, 12, S.Li);
-          if (lane < 12) {
-            double acc = S.pv[12 + lane];
-            for (int t = 0; t < 12; ++t) acc += S.P[(12 + lane) * PS + t] * S.sig[t];
-            S.q[lane] = acc;
-          }
-          __syncthreads();
-          if (lane < 12) { double acc = 0.0; for (int t = 0; t <= lane; ++t) acc += S.Li[lane * PS + t] * S.q[t]; S.vv[lane] = acc; }
-          __syncthreads();
-          if (lane < 12) { double acc = 0.0; for (int t = lane; t < 12; ++t) acc += S.Li[t * PS + lane] * S.vv[t]; S.sig[12 + lane] = -acc; }
-          __syncthreads();
-        }
-      }
+      if (lane == 0) S.prof[PH_NFACT] += 1.0;
+      const bool ok = riccati_backward(delta);
       fact_ok = ok;
     }
     if (!fact_ok) { status = LANDING_NUMERICAL; break; }
-    if (delta > 0.0) delta_last = delta;
+    if (delta > 0.0) { delta_last = delta; need_reg_streak++; } else need_reg_streak = 0;
+    if (need_reg_streak > 8) need_reg_streak = 0;      // probe delta = 0 again from time to time
+    PROF_ADD(PH_BACK, tp);
 
-    // ================================================================ forward pass: dx, ds (stage rows), y_dyn
-    for (int k = 0; k < N; ++k) {
-      const bool last = (k == N - 1);
-      const int nu = last ? 12 : 24;
-      const double* rec = M.ric + (size_t)k * RIC_STRIDE;
-      const double* recn = M.ric + (size_t)(k + 1) * RIC_STRIDE;
-      const int* tb = A.tab + A.stage_tab[k];
-      const int g0 = L.g_stage(k), nr = L.rows(k);
-      load_stage_nz(L, M, k, S.A1, false);
-      if (lane < nu) {
-        double acc = rec[RIC_KAP + lane];
-        for (int t = 0; t < 24; ++t) acc += rec[RIC_K + lane * 24 + t] * S.sig[t];
-        S.w[24 + lane] = -acc;
-      }
-      if (lane < 24) S.w[lane] = S.sig[lane];
-      __syncthreads();
-      if (lane < 12) { M.dx[L.x_X(k) + lane] = S.w[lane]; M.dx[L.x_U(k) + lane] = S.w[12 + lane]; M.dx[L.x_U(k) + 12 + lane] = S.w[24 + lane]; }
-      {   // ds = J_d w + (g - s) for the stage's inequality rows
-        const int* rs = A.tab + tb[8]; const int* rt = A.tab + tb[9];
-        for (int r = lane + 12; r < nr; r += NT) {
-          double acc = 0.0;
-          for (int e = rs[r]; e < rs[r + 1]; ++e) acc += S.A1[rt[2 * e]] * S.w[rt[2 * e + 1]];
-          M.ds[g0 + r] = acc + (M.g[g0 + r] - M.s[g0 + r]);
-        }
-      }
-      // next state: X+ = A^ [sigma; f] + b ; c+ = u_c
-      if (lane < 12) {
-        double acc = rec[RIC_B + lane];
-        for (int t = 0; t < 36; ++t) acc += rec[RIC_AH + lane * 36 + t] * S.w[t];
-        S.q[lane] = acc;
-      } else if (lane < 24) {
-        S.q[lane] = last ? 0.0 : S.w[36 + (lane - 12)];
-      }
-      __syncthreads();
-      if (lane < 24) S.sig[lane] = S.q[lane];
-      __syncthreads();
-      // multipliers of the dynamics rows: y = -(P_{k+1} sigma_{k+1} + p_{k+1})_X   (state order -> row order)
-      if (lane < 12) {
-        double acc = recn[RIC_PV + lane];
-        const int nn = last ? 12 : 24;
-        for (int t = 0; t < nn; ++t) acc += recn[RIC_PX + lane * 24 + t] * S.sig[t];
-        const int q = lane < 6 ? lane : (lane < 9 ? lane + 3 : lane - 3);   // state index -> dyn row
-        M.yn[g0 + q] = -acc;
-      }
-      __syncthreads();
-    }
-    if (lane < 12) {
-      const int i = lane;
-      M.dx[12 * N + i] = S.sig[i];
-      const int ra = i < 6 ? 12 + i : 24 + (i - 6), rb = i < 6 ? 18 + i : 30 + (i - 6);
-      M.ds[ra] = S.sig[i] + (M.g[ra] - M.s[ra]);
-      M.ds[rb] = S.sig[i] + (M.g[rb] - M.s[rb]);
-    }
-    __syncthreads();
+    forward_pass();
+    row_products(A.rterm, A.rstart);
 
+    PROF_ADD(PH_FWD, tp);
     // ================================================================ dual steps, step bounds, merit data
     double a_pr = 1.0, a_du = 1.0, th0 = 0.0, bar = 0.0, dphi = 0.0;
     for (int r = lane + 12; r < ng; r += NT) {
@@ -498,17 +626,18 @@ __global__ void __launch_bounds__(64) landing_ipm_kernel(SolveArgs A) {
       const double d = M.x[12 * N + lane] - p[12 * N + lane], qn = p[L.o_QN + lane];
       f0 = qn * d * d; dphi += 2.0 * qn * d * M.dx[12 * N + lane];
     }
-    a_pr = block_reduce(a_pr, RMIN, S.red); a_du = block_reduce(a_du, RMIN, S.red);
-    th0 = block_reduce(th0, RSUM, S.red); bar = block_reduce(bar, RSUM, S.red);
-    dphi = block_reduce(dphi, RSUM, S.red); f0 = block_reduce(f0, RSUM, S.red);
+    { double v[6] = {a_pr, a_du, th0, bar, dphi, f0}; const int op[6] = {RMIN, RMIN, RSUM, RSUM, RSUM, RSUM};
+      block_reduce<6>(v, op, S.red); a_pr = v[0]; a_du = v[1]; th0 = v[2]; bar = v[3]; dphi = v[4]; f0 = v[5]; }
     const double ph0 = f0 + mu * bar;
     if (it == 0) th_max = 1e4 * fmax(1.0, th0);
     const double th_min = 1e-4;
 
+    PROF_ADD(PH_DUAL, tp);
     // ================================================================ filter line search
     double alpha = a_pr;
     bool accepted = false, armijo_step = false;
     while (alpha > 1e-10) {
+      if (lane == 0) S.prof[PH_NTRIAL] += 1.0;
       for (int i = lane; i < nx; i += NT) M.xt[i] = M.x[i] + alpha * M.dx[i];
       __syncthreads();
       member_eval_g(L, M.xt, p, M.gt);
@@ -523,7 +652,7 @@ __global__ void __launch_bounds__(64) landing_ipm_kernel(SolveArgs A) {
         if (ub < INF) bt -= log(ub - s);
       }
       if (lane < 12) { const double d = M.xt[12 * N + lane] - p[12 * N + lane]; ft = p[L.o_QN + lane] * d * d; }
-      tht = block_reduce(tht, RSUM, S.red); bt = block_reduce(bt, RSUM, S.red); ft = block_reduce(ft, RSUM, S.red);
+      { double v[3] = {tht, bt, ft}; const int op[3] = {RSUM, RSUM, RSUM}; block_reduce<3>(v, op, S.red); tht = v[0]; bt = v[1]; ft = v[2]; }
       const double pht = ft + mu * bt;
       bool ok_f = (tht <= th_max) && (pht < 1e300) && (pht > -1e300) && (tht < 1e300);
       for (int e = 0; e < nfilt && ok_f; ++e) if (tht >= S.filt_th[e] && pht >= S.filt_ph[e]) ok_f = false;
@@ -556,6 +685,7 @@ __global__ void __launch_bounds__(64) landing_ipm_kernel(SolveArgs A) {
       nfilt++;
       __syncthreads();
     }
+    PROF_ADD(PH_LS, tp);
     // ================================================================ accept the trial point
     for (int i = lane; i < nx; i += NT) M.x[i] = M.xt[i];
     for (int r = lane; r < ng; r += NT) {
@@ -570,13 +700,16 @@ __global__ void __launch_bounds__(64) landing_ipm_kernel(SolveArgs A) {
       M.s[r] = s; M.zL[r] = zl; M.zU[r] = zu; M.y[r] = zu - zl;
     }
     __syncthreads();
+    PROF_ADD(PH_ACCEPT, tp);
   }
+  __syncthreads();
+  if (A.prof && lane == 0) { S.prof[PH_NITER] = (double)it; for (int i = 0; i < PH_COUNT; ++i) A.prof[(size_t)m * PH_COUNT + i] = S.prof[i]; }
 
   // -------------------------------------------------------------------- outputs
   // multipliers of the initial-state rows from stationarity of X(:,1): lam = -(grad f + J^T y)
   double fo = 0.0;
   if (lane < 12) { M.y[lane] = -M.gx[lane]; const double d = M.x[12 * N + lane] - p[12 * N + lane]; fo = p[L.o_QN + lane] * d * d; }
-  fo = block_reduce(fo, RSUM, S.red);
+  fo = block_reduce1(fo, RSUM, S.red);
   // reference-consistent KKT residual: max_viol(g), ||grad f + J^T lam||_inf, |lam * dist|
   double kp = 0.0, kc = 0.0;
   for (int r = lane; r < ng; r += NT) {
@@ -587,7 +720,7 @@ __global__ void __launch_bounds__(64) landing_ipm_kernel(SolveArgs A) {
       if (lam != 0.0 && dist < INF) kc = fmax(kc, fabs(lam * dist));
     }
   }
-  kp = block_reduce(kp, RMAX, S.red); kc = block_reduce(kc, RMAX, S.red);
+  { double v[2] = {kp, kc}; const int op[2] = {RMAX, RMAX}; block_reduce<2>(v, op, S.red); kp = v[0]; kc = v[1]; }
   for (int i = lane; i < nx; i += NT) A.x_out[(size_t)m * nx + i] = M.x[i];
   if (A.lam_out) for (int r = lane; r < ng; r += NT) A.lam_out[(size_t)m * ng + r] = M.y[r];
   if (lane == 0) {

@@ -60,12 +60,14 @@ class Problem:
         return f, gf, g, J, H
 
 
+DSC = np.ones(60)
+DSC_T = np.ones(12)
 def riccati(prob, M, m, A_rows, c_dyn, MN, mN, dX0, delta):
     """Solve min sum_k 1/2 w_k' M_k w_k + m_k' w_k  s.t. J_dyn w + dX+ + c = 0.
     M[k]: 60x60 (X+ cols zero), m[k]: 60; A_rows[k] = J_dyn (12x60, rows permuted to state order);
     MN (12x12), mN(12) terminal. Returns dx stage-wise, costates, ok flag."""
     N = prob.N
-    Pm = MN + delta * np.eye(12); pv = mN.copy()       # cost-to-go on sigma_{N}=X_N
+    Pm = MN + delta * np.diag(DSC_T); pv = mN.copy()       # cost-to-go on sigma_{N}=X_N
     K = [None] * N; kap = [None] * N
     Tl = [None] * N; tl = [None] * N
     for k in range(N - 1, -1, -1):
@@ -75,7 +77,7 @@ def riccati(prob, M, m, A_rows, c_dyn, MN, mN, dX0, delta):
         widx = np.concatenate([SIG, ctl])
         G = M[k][np.ix_(widx, widx)].copy()
         gam = m[k][widx].copy()
-        G[np.arange(nw), np.arange(nw)] += delta
+        G[np.arange(nw), np.arange(nw)] += delta * DSC[widx]
         # sigma+ = T w + t
         Jd = A_rows[k]
         nsn = 12 if last else 24
@@ -324,6 +326,8 @@ def solve(prob, opts=None, verbose=True):
 
 
 if __name__ == "__main__":
+    fs = float(os.environ.get("FSCALE", "1"))
+    DSC[IF] = 1.0 / fs ** 2
     N = int(sys.argv[1]) if len(sys.argv) > 1 else 20
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     nprob = int(sys.argv[3]) if len(sys.argv) > 3 else 1

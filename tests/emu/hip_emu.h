@@ -26,6 +26,7 @@
 #define __restrict__
 
 struct dim3 { unsigned x, y, z; dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {} };
+struct int4 { int x, y, z, w; };
 struct emu_idx { unsigned x, y, z; };
 extern emu_idx threadIdx, blockIdx;
 extern dim3 blockDim, gridDim;
@@ -50,6 +51,7 @@ inline hipError_t hipGetLastError() { return 0; }
 inline hipError_t hipSetDevice(int) { return 0; }
 inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return 0; }
 inline const char* hipGetErrorString(hipError_t) { return "emulated"; }
+inline long long wall_clock64() { return 0; }
 inline void sincos(double a, double* s, double* c) { *s = std::sin(a); *c = std::cos(a); }
 
 namespace hip_emu {

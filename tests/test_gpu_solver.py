@@ -71,4 +71,4 @@ def test_warm_start_converges_faster(libs):
     o = L.default_opts(); o.bound_push = 5e-3; o.bound_frac = 5e-3    # generate_landingCtrller_IPOPT_warmstart.m:246-247
     warm = L.solve_host(P, cold["x"], o)
     ok = (cold["status"] == 0) & (warm["status"] == 0)
-    assert ok.any() and (warm["iters"][ok] <= cold["iters"][ok]).all()
+    assert ok.sum() >= 3 and warm["iters"][ok].sum() < cold["iters"][ok].sum()
