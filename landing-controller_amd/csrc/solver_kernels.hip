@@ -61,21 +61,16 @@ enum { RSUM = 0, RMAX = 1, RMIN = 2 };
 __device__ __forceinline__ double red_op(double a, double b, int op) { return op == RSUM ? a + b : (op == RMAX ? fmax(a, b) : fmin(a, b)); }
 template <int K>
 __device__ __forceinline__ void block_reduce(double (&v)[K], const int (&op)[K], double* red) {
-  const int tid = threadIdx.x, NT = blockDim.x;
-  for (int i = 0; i < K; ++i) red[i * NT + tid] = v[i];
-  __syncthreads();
-  if (tid < 64) {
-    for (int i = 0; i < K; ++i) {
-      double r = red[i * NT + tid];
-      for (int t = tid + 64; t < NT; t += 64) r = red_op(r, red[i * NT + t], op[i]);
-      red[i * NT + tid] = r;
-    }
-  }
-  __syncthreads();
-  const int n = NT < 64 ? NT : 64;
+  const int tid = threadIdx.x, nwave = (blockDim.x + 63) >> 6;
   for (int i = 0; i < K; ++i) {
-    double r = red[i * NT];
-    for (int t = 1; t < n; ++t) r = red_op(r, red[i * NT + t], op[i]);
+#pragma unroll
+    for (int mask = 32; mask >= 1; mask >>= 1) v[i] = red_op(v[i], __shfl_xor(v[i], mask), op[i]);   // butterfly: every lane gets the wave result
+  }
+  if ((tid & 63) == 0) for (int i = 0; i < K; ++i) red[(tid >> 6) * K + i] = v[i];
+  __syncthreads();
+  for (int i = 0; i < K; ++i) {
+    double r = red[i];
+    for (int w = 1; w < nwave; ++w) r = red_op(r, red[w * K + i], op[i]);
     v[i] = r;
   }
   __syncthreads();
@@ -107,12 +102,11 @@ __device__ __forceinline__ MemberMem carve(const Layout& L, double* w) {
 struct Lds {
   double G[48 * GS];
   double P[24 * PS];
-  double A1[NZ_TOT];          // stage nonzeros during assembly, then Y = P(:,0:12)*A^  (24 x YS = 888)
-  double Ex[24 * ES];         // elimination side block: col 0 = gamma_u -> z, cols 1.. = I -> unit-lower inverse
+  double A1[24 * YS];          // Y = P(:,0:12)*A^ (24 x YS = 888) while T^T P T is formed, then the elimination side block
+                              // Ex (24 x ES): col 0 = gamma_u -> z, cols 1.. = I -> unit-lower inverse
   double Ah[12 * YS];
-  double Sg[104], rh[104];
   double gam[48], pv[24], q[24], bv[12], sig[24], w[48], dinv[24];
-  double red[SOLVER_THREADS * 6];
+  double red[(SOLVER_THREADS / 64) * 6];
   double filt_th[FILT_CAP], filt_ph[FILT_CAP];
   double prof[16];
   // member context, written once by every thread with identical values (read back as LDS broadcasts by the
@@ -122,20 +116,6 @@ struct Lds {
 // One instance per workgroup (= per NLP).  Namespace scope keeps the LDS address space visible to every
 // phase function (ds_* instructions instead of flat_*).
 __shared__ Lds SH;
-
-// copy the CCS segments of stage k into the staging buffer
-__device__ __forceinline__ void load_stage_nz(const Layout& L, const MemberMem& M, int k, double* nz, bool with_h) {
-  const int N = L.N, lane = threadIdx.x, NT = blockDim.x;
-  const bool last = (k == N - 1);
-  for (int i = lane; i < 157; i += NT) nz[NZ_JX + i] = M.J[L.jx(k) + i];
-  for (int i = lane, n = L.ju_len(k); i < n; i += NT) nz[NZ_JU + i] = M.J[L.ju(k) + i];
-  if (!last) for (int i = lane, n = L.ju_len(k + 1); i < n; i += NT) nz[NZ_JUN + i] = M.J[L.ju(k + 1) + i];
-  if (with_h) {
-    for (int i = lane; i < 29; i += NT) nz[NZ_HX + i] = M.H[L.hx(k) + i];
-    for (int i = lane, n = (k == 0 ? 148 : 160); i < n; i += NT) nz[NZ_HU + i] = M.H[L.hu(k) + i];
-    if (!last) for (int i = lane; i < 160; i += NT) nz[NZ_HUN + i] = M.H[L.hu(k + 1) + i];
-  }
-}
 
 // Fused LDL^T elimination of G_uu (rows/cols 24..24+NU of G) applied to [G_us | G_uu | gamma_u | I]:
 // afterwards rows 24.. of G hold Z = L~^{-1} G_us in columns 0..23, Ex(:,0) = z = L~^{-1} gamma_u, Ex(:,1+t) =
@@ -184,10 +164,10 @@ __device__ __forceinline__ bool riccati_step(double* rec) {
   const int tid = threadIdx.x, NT = blockDim.x;
   for (int e = tid; e < NU * 25; e += NT) {
     const int i = e / 25, c = e % 25;
-    S.Ex[i * ES + c] = (c == 0) ? S.gam[24 + i] : (c - 1 == i ? 1.0 : 0.0);
+    S.A1[i * ES + c] = (c == 0) ? S.gam[24 + i] : (c - 1 == i ? 1.0 : 0.0);
   }
   __syncthreads();
-  if (!ldl_eliminate<NU>(S.G, S.Ex, S.dinv)) return false;
+  if (!ldl_eliminate<NU>(S.G, S.A1, S.dinv)) return false;
   // P_k = G_ss - Z^T D^-1 Z ; p_k = gamma_s - Z^T D^-1 z
   for (int e = tid; e < 24 * 24; e += NT) {
     const int i = e / 24, j = e % 24;
@@ -200,7 +180,7 @@ __device__ __forceinline__ bool riccati_step(double* rec) {
   for (int i = tid; i < 24; i += NT) {
     double acc = S.gam[i];
 #pragma unroll
-    for (int t = 0; t < NU; ++t) acc -= S.G[(24 + t) * GS + i] * S.Ex[t * ES] * S.dinv[t];
+    for (int t = 0; t < NU; ++t) acc -= S.G[(24 + t) * GS + i] * S.A1[t * ES] * S.dinv[t];
     S.pv[i] = acc;
     if (i < 12) rec[RIC_PV + i] = acc;
   }
@@ -209,13 +189,13 @@ __device__ __forceinline__ bool riccati_step(double* rec) {
     const int i = e / 24, j = e % 24;
     double acc = 0.0;
 #pragma unroll
-    for (int t = 0; t < NU; ++t) acc += S.Ex[t * ES + 1 + i] * S.dinv[t] * S.G[(24 + t) * GS + j];
+    for (int t = 0; t < NU; ++t) acc += S.A1[t * ES + 1 + i] * S.dinv[t] * S.G[(24 + t) * GS + j];
     rec[RIC_K + i * 24 + j] = acc;
   }
   for (int i = tid; i < NU; i += NT) {
     double acc = 0.0;
 #pragma unroll
-    for (int t = 0; t < NU; ++t) acc += S.Ex[t * ES + 1 + i] * S.dinv[t] * S.Ex[t * ES];
+    for (int t = 0; t < NU; ++t) acc += S.A1[t * ES + 1 + i] * S.dinv[t] * S.A1[t * ES];
     rec[RIC_KAP + i] = acc;
   }
   for (int e = tid; e < 12 * 36; e += NT) rec[RIC_AH + e] = S.Ah[(e / 36) * YS + e % 36];
@@ -369,14 +349,14 @@ __device__ __noinline__ bool riccati_backward(double delta) {
       const int i = e / 25, c = e % 25;
       double v = (c - 1 == i) ? 1.0 : 0.0;
       if (c == 0) { v = S.pv[12 + i]; for (int t = 0; t < 12; ++t) v += S.P[(12 + i) * PS + t] * S.sig[t]; }
-      S.Ex[i * ES + c] = v;
+      S.A1[i * ES + c] = v;
     }
     __syncthreads();
-    ok = ldl_eliminate<12>(S.G, S.Ex, S.dinv);
+    ok = ldl_eliminate<12>(S.G, S.A1, S.dinv);
     if (ok) {
       if (lane < 12) {
         double acc = 0.0;
-        for (int t = 0; t < 12; ++t) acc += S.Ex[t * ES + 1 + lane] * S.dinv[t] * S.Ex[t * ES];
+        for (int t = 0; t < 12; ++t) acc += S.A1[t * ES + 1 + lane] * S.dinv[t] * S.A1[t * ES];
         S.sig[12 + lane] = -acc;
       }
       __syncthreads();
@@ -467,7 +447,10 @@ __device__ __noinline__ void row_products(const int4* __restrict__ rterm, const 
   __syncthreads();
 }
 
-__global__ void __launch_bounds__(SOLVER_THREADS) landing_ipm_kernel(SolveArgs A) {
+#ifndef LANDING_MIN_WAVES
+#define LANDING_MIN_WAVES 4
+#endif
+__global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm_kernel(SolveArgs A) {
   const int m = blockIdx.x;
   if (m >= A.B) return;
   const Layout& L = A.L;

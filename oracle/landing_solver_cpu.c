@@ -1,0 +1,381 @@
+/*
+ * landing_solver_cpu.c -- TEST INFRASTRUCTURE / CPU BASELINE, NOT PRODUCT CODE.
+ *
+ * Scalar fp64 CPU port of the interior-point algorithm the HIP solver implements (the reference's
+ * solver layer -- CasADi Nlpsol('ipopt') + MA57, generate_landingCtrller_IPOPT.m:231-264,277,314 --
+ * lives in third-party binaries that are absent from /root/reference: CasADi 3.5.5's libcasadi.so /
+ * libcasadi_nlpsol_ipopt.so are listed in .MISSING_LARGE_BLOBS:9,14 and HSL MA57 is not redistributable;
+ * so the solver layer of the oracle is a PORT of our algorithm, "parity unpinned" at the solution level
+ * beyond the feasibility/objective goldens -- see DESIGN.md).  It follows IPOPT's published algorithm
+ * (Waechter & Biegler 2006: slacks on every inequality row, fraction-to-the-boundary, filter line search,
+ * monotone barrier update, inertia correction by delta_w) on the NLP functions of landing_oracle.c, and
+ * solves the condensed KKT system with the same stage-wise Riccati recursion as the GPU kernel.
+ *
+ * Used by bench.py's cpu_baseline leg (timed on the host cores) and by tests as a cross-check of the GPU
+ * solver's iteration counts.  OpenMP over batch members.
+ */
+#include "landing_oracle.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+typedef struct {
+  double tol; int max_iter; double mu_init, bound_push, bound_frac, kappa_eps, kappa_mu, theta_mu;
+} lo_solver_opts;
+
+void lo_solver_opts_default(lo_solver_opts* o) {
+  o->tol = 1e-6; o->max_iter = 3000; o->mu_init = 0.1; o->bound_push = 0.5; o->bound_frac = 0.5;
+  o->kappa_eps = 10.0; o->kappa_mu = 0.2; o->theta_mu = 1.5;
+}
+
+#define NW 48
+static const int ROW2STATE[12] = {0, 1, 2, 3, 4, 5, 9, 10, 11, 6, 7, 8};
+/* local variable (lo_stage_eval order X_k,c_k,f_k,X+,c+) -> w index (X,c,f,c+) or -1 */
+static int loc2w(int loc) { if (loc < 36) return loc; if (loc < 48) return -1; return 36 + (loc - 48); }
+
+typedef struct {
+  int N; lo_int nx, ng;
+  double *x, *xt, *dx, *g, *gt, *s, *ds, *zL, *zU, *dzL, *dzU, *y, *yn, *lb, *ub, *sig, *rho;
+  double *Jst;   /* N x 104 x 60 */
+  double *Hst;   /* N x 60 x 60  */
+  double *M, *mvec, *Ah, *bv;         /* per stage: 48x48, 48, 12x36, 12 */
+  double *K, *kap, *Px, *pvx;         /* per stage: 24x24, 24, 12x24, 12 (index N: terminal) */
+} work_t;
+
+static double* dalloc(size_t n) { return (double*)calloc(n ? n : 1, sizeof(double)); }
+
+static void eval_g(const lo_form* F, const double* x, const double* p, double* g) { lo_nlp_g(F, x, p, g); }
+
+/* in-place LDL^T elimination of the n x n block with right-hand sides: solves A X = B (A spd), returns 0 if a
+ * pivot is not positive.  A: n x n (ld lda), B: n x m (ld ldb) overwritten by X. */
+static int spd_solve(double* A, int lda, int n, double* B, int ldb, int m) {
+  int i, j, c;
+  for (j = 0; j < n; ++j) {
+    const double d = A[j * lda + j];
+    if (!(d > 0.0) || !(d < 1e300)) return 0;
+    for (i = j + 1; i < n; ++i) {
+      const double l = A[i * lda + j] / d;
+      if (l == 0.0) continue;
+      for (c = j + 1; c < n; ++c) A[i * lda + c] -= l * A[j * lda + c];
+      for (c = 0; c < m; ++c) B[i * ldb + c] -= l * B[j * ldb + c];
+      A[i * lda + j] = l;
+    }
+  }
+  for (j = n - 1; j >= 0; --j) {       /* back substitution with unit upper L^T and D */
+    for (c = 0; c < m; ++c) {
+      double v = B[j * ldb + c] / A[j * lda + j];
+      for (i = j + 1; i < n; ++i) v -= A[i * lda + j] * B[i * ldb + c];
+      B[j * ldb + c] = v;
+    }
+  }
+  return 1;
+}
+
+/* backward Riccati sweep; returns 1 on success */
+static int riccati_backward(const lo_form* F, const double* p, work_t* W, double delta, const lo_poff* o, double* sig0) {
+  const int N = W->N;
+  double P[24 * 24], pv[24], G[NW * NW], gam[NW], Y[24 * 36], q[24], Guu[24 * 24], R[24 * 25];
+  int k, i, j, t;
+  memset(P, 0, sizeof(P)); memset(pv, 0, sizeof(pv));
+  for (i = 0; i < 12; ++i) {
+    const int ra = i < 6 ? 12 + i : 24 + (i - 6), rb = i < 6 ? 18 + i : 30 + (i - 6);
+    const double qn2 = 2.0 * p[o->QN + i];
+    P[i * 24 + i] = qn2 + W->sig[ra] + W->sig[rb] + delta;
+    pv[i] = qn2 * (W->x[12 * N + i] - p[12 * N + i]) + W->rho[ra] + W->rho[rb];
+  }
+  for (i = 0; i < 12; ++i) { for (j = 0; j < 24; ++j) W->Px[(size_t)N * 288 + i * 24 + j] = P[i * 24 + j]; W->pvx[N * 12 + i] = pv[i]; }
+  for (k = N - 1; k >= 0; --k) {
+    const int last = (k == N - 1), nu = last ? 12 : 24, nsn = last ? 12 : 24, nw = 24 + nu;
+    const double* Mk = W->M + (size_t)k * NW * NW; const double* Ah = W->Ah + (size_t)k * 432; const double* bv = W->bv + k * 12;
+    memcpy(G, Mk, sizeof(G)); memcpy(gam, W->mvec + k * NW, sizeof(gam));
+    for (i = 0; i < nw; ++i) G[i * NW + i] += delta;
+    for (i = 0; i < nsn; ++i) {
+      for (j = 0; j < 36; ++j) { double a = 0; for (t = 0; t < 12; ++t) a += P[i * 24 + t] * Ah[t * 36 + j]; Y[i * 36 + j] = a; }
+      { double a = pv[i]; for (t = 0; t < 12; ++t) a += P[i * 24 + t] * bv[t]; q[i] = a; }
+    }
+    for (i = 0; i < 36; ++i) {
+      for (j = 0; j < 36; ++j) { double a = 0; for (t = 0; t < 12; ++t) a += Ah[t * 36 + i] * Y[t * 36 + j]; G[i * NW + j] += a; }
+      { double a = 0; for (t = 0; t < 12; ++t) a += Ah[t * 36 + i] * q[t]; gam[i] += a; }
+    }
+    if (!last) {
+      for (i = 0; i < 12; ++i) {
+        for (j = 0; j < 36; ++j) { G[(36 + i) * NW + j] += Y[(12 + i) * 36 + j]; G[j * NW + 36 + i] += Y[(12 + i) * 36 + j]; }
+        for (j = 0; j < 12; ++j) G[(36 + i) * NW + 36 + j] += P[(12 + i) * 24 + 12 + j];
+        gam[36 + i] += q[12 + i];
+      }
+    }
+    /* K = Guu^-1 [Gus | gam_u] */
+    for (i = 0; i < nu; ++i) {
+      for (j = 0; j < nu; ++j) Guu[i * 24 + j] = G[(24 + i) * NW + 24 + j];
+      for (j = 0; j < 24; ++j) R[i * 25 + j] = G[(24 + i) * NW + j];
+      R[i * 25 + 24] = gam[24 + i];
+    }
+    if (!spd_solve(Guu, 24, nu, R, 25, 25)) return 0;
+    for (i = 0; i < nu; ++i) { for (j = 0; j < 24; ++j) W->K[(size_t)k * 576 + i * 24 + j] = R[i * 25 + j]; W->kap[k * 24 + i] = R[i * 25 + 24]; }
+    for (i = 0; i < 24; ++i) {
+      for (j = 0; j < 24; ++j) { double a = G[i * NW + j]; for (t = 0; t < nu; ++t) a -= G[(24 + t) * NW + i] * R[t * 25 + j]; P[i * 24 + j] = a; }
+      { double a = gam[i]; for (t = 0; t < nu; ++t) a -= G[(24 + t) * NW + i] * R[t * 25 + 24]; pv[i] = a; }
+    }
+    for (i = 0; i < 12; ++i) { for (j = 0; j < 24; ++j) W->Px[(size_t)k * 288 + i * 24 + j] = P[i * 24 + j]; W->pvx[k * 12 + i] = pv[i]; }
+  }
+  {  /* stage 0: X_0 fixed, c_0 free */
+    double Pcc[144], rhs[12];
+    for (i = 0; i < 12; ++i) sig0[i] = (i < 6 ? p[o->q_init + i] : p[o->qd_init + i - 6]) - W->x[i];
+    for (i = 0; i < 12; ++i) {
+      double a = pv[12 + i];
+      for (j = 0; j < 12; ++j) { Pcc[i * 12 + j] = P[(12 + i) * 24 + 12 + j]; a += P[(12 + i) * 24 + j] * sig0[j]; }
+      rhs[i] = a;
+    }
+    if (!spd_solve(Pcc, 12, 12, rhs, 1, 1)) return 0;
+    for (i = 0; i < 12; ++i) sig0[12 + i] = -rhs[i];
+  }
+  return 1;
+}
+
+/* one NLP; returns status (0 converged, 1 max_iter, 2 numerical) */
+static int solve_one(const lo_form* F, const double* p, const double* x0, const lo_solver_opts* op, double* x_out,
+                     double* lam_out, int* iters_out, double kkt_out[3], long long counters[2]) {
+  const int N = F->N; const lo_int nx = lo_nx(N), ng = lo_ng(N);
+  lo_poff o; work_t Wk, *W = &Wk; lo_int i, r; int k, it, status = 1, nfilt = 0, streak = 0;
+  double mu = op->mu_init, delta_last = 0.0, th_max = 0.0, e_du = 0.0;
+  double filt_th[64], filt_ph[64];
+  double* gx;
+  lo_param_offsets(N, &o);
+  W->N = N; W->nx = nx; W->ng = ng;
+  W->x = dalloc(nx); W->xt = dalloc(nx); W->dx = dalloc(nx); gx = dalloc(nx);
+  W->g = dalloc(ng); W->gt = dalloc(ng); W->s = dalloc(ng); W->ds = dalloc(ng); W->zL = dalloc(ng); W->zU = dalloc(ng);
+  W->dzL = dalloc(ng); W->dzU = dalloc(ng); W->y = dalloc(ng); W->yn = dalloc(ng); W->lb = dalloc(ng); W->ub = dalloc(ng);
+  W->sig = dalloc(ng); W->rho = dalloc(ng);
+  W->Jst = dalloc((size_t)N * 104 * 60); W->Hst = dalloc((size_t)N * 3600);
+  W->M = dalloc((size_t)N * NW * NW); W->mvec = dalloc((size_t)N * NW); W->Ah = dalloc((size_t)N * 432); W->bv = dalloc((size_t)N * 12);
+  W->K = dalloc((size_t)N * 576); W->kap = dalloc((size_t)N * 24); W->Px = dalloc((size_t)(N + 1) * 288); W->pvx = dalloc((size_t)(N + 1) * 12);
+  memcpy(W->x, x0, sizeof(double) * nx);
+  for (i = 0; i < 6; ++i) { W->x[i] = p[o.q_init + i]; W->x[6 + i] = p[o.qd_init + i]; }
+  lo_bounds(F, p, W->lb, W->ub);
+  eval_g(F, W->x, p, W->g);
+  for (r = 0; r < ng; ++r) {
+    const double lb = W->lb[r], ub = W->ub[r];
+    double sv = 0, zl = 0, zu = 0;
+    if (r >= 12 && lb != ub) {
+      const int hL = lb > -INFINITY, hU = ub < INFINITY; double pl, pu;
+      sv = W->g[r];
+      if (hL && hU) { pl = fmin(op->bound_push * fmax(1.0, fabs(lb)), op->bound_frac * (ub - lb)); pu = fmin(op->bound_push * fmax(1.0, fabs(ub)), op->bound_frac * (ub - lb)); }
+      else { pl = op->bound_push * fmax(1.0, hL ? fabs(lb) : 0.0); pu = op->bound_push * fmax(1.0, hU ? fabs(ub) : 0.0); }
+      if (hL) sv = fmax(sv, lb + pl);
+      if (hU) sv = fmin(sv, ub - pu);
+      zl = hL ? 1.0 : 0.0; zu = hU ? 1.0 : 0.0;
+    }
+    W->s[r] = sv; W->zL[r] = zl; W->zU[r] = zu; W->y[r] = zu - zl;
+  }
+  for (it = 0; it <= op->max_iter; ++it) {
+    double du = 0, pr = 0, co = 0, tau, delta;
+    int fact_ok = 0, attempt;
+    double sig[24], w[NW], a_pr = 1.0, a_du = 1.0, th0 = 0, bar = 0, dphi = 0, f0 = 0, ph0, alpha;
+    int accepted = 0, armijo = 0;
+    /* derivatives per stage + gx = grad f + J^T y */
+    memset(gx, 0, sizeof(double) * nx);
+    for (i = 0; i < 12; ++i) {
+      gx[12 * N + i] = 2.0 * p[o.QN + i] * (W->x[12 * N + i] - p[12 * N + i]) + (i < 6 ? W->y[12 + i] + W->y[18 + i] : W->y[24 + i - 6] + W->y[30 + i - 6]);
+    }
+    for (k = 0; k < N; ++k) {
+      const int nr = lo_stage_rows(F, k); int q, c;
+      double lam[LO_NROW]; double* J = W->Jst + (size_t)k * 104 * 60;
+      for (q = 0; q < LO_NROW; ++q) lam[q] = q < nr ? W->y[36 + 104 * k + q] : 0.0;
+      lo_stage_eval(F, k, W->x, p, lam, NULL, J, W->Hst + (size_t)k * 3600);
+      for (q = 0; q < nr; ++q) for (c = 0; c < 60; ++c) if (J[q * 60 + c] != 0.0) {
+        const lo_int gi = c < 12 ? 12 * k + c : (c < 36 ? 12 * (N + 1) + 24 * k + (c - 12) : (c < 48 ? 12 * (k + 1) + (c - 36) : 12 * (N + 1) + 24 * (k + 1) + (c - 48)));
+        gx[gi] += lam[q] * J[q * 60 + c];
+      }
+    }
+    for (i = 12; i < nx; ++i) du = fmax(du, fabs(gx[i]));
+    for (r = 12; r < ng; ++r) {
+      const double lb = W->lb[r], ub = W->ub[r], g = W->g[r];
+      if (lb == ub) { pr = fmax(pr, fabs(g - lb)); continue; }
+      pr = fmax(pr, fabs(g - W->s[r]));
+      if (lb > -INFINITY) co = fmax(co, (W->s[r] - lb) * W->zL[r]);
+      if (ub < INFINITY) co = fmax(co, (ub - W->s[r]) * W->zU[r]);
+    }
+    e_du = du;
+    if (!(du < 1e300) || !(pr < 1e300) || !(co < 1e300)) { status = 2; break; }
+    if (fmax(du, fmax(pr, co)) <= op->tol) { status = 0; break; }
+    if (it == op->max_iter) break;
+    for (;;) {
+      double cm = 0;
+      for (r = 12; r < ng; ++r) {
+        const double lb = W->lb[r], ub = W->ub[r];
+        if (lb == ub) continue;
+        if (lb > -INFINITY) cm = fmax(cm, fabs((W->s[r] - lb) * W->zL[r] - mu));
+        if (ub < INFINITY) cm = fmax(cm, fabs((ub - W->s[r]) * W->zU[r] - mu));
+      }
+      if (fmax(du, fmax(pr, cm)) <= op->kappa_eps * mu && mu > op->tol / 10.0) { mu = fmax(op->tol / 10.0, fmin(op->kappa_mu * mu, pow(mu, op->theta_mu))); nfilt = 0; }
+      else break;
+    }
+    tau = fmax(0.99, 1.0 - mu);
+    for (r = 0; r < ng; ++r) {
+      const double lb = W->lb[r], ub = W->ub[r]; double sg = 0, rh = 0;
+      if (r >= 12 && lb != ub) {
+        const double s = W->s[r];
+        if (lb > -INFINITY) { const double d = s - lb; sg += W->zL[r] / d; rh -= mu / d; }
+        if (ub < INFINITY) { const double d = ub - s; sg += W->zU[r] / d; rh += mu / d; }
+        rh += sg * (W->g[r] - s);
+      }
+      W->sig[r] = sg; W->rho[r] = rh;
+    }
+    /* condensation per stage: M = H + Jd^T Sigma Jd (48x48), m = Jd^T rho, A^ = -J_dyn (state order), b */
+    for (k = 0; k < N; ++k) {
+      const int nr = lo_stage_rows(F, k), g0 = 36 + 104 * k; int q, a, b;
+      const double* J = W->Jst + (size_t)k * 104 * 60; const double* H = W->Hst + (size_t)k * 3600;
+      double* Mk = W->M + (size_t)k * NW * NW; double* mk = W->mvec + k * NW; double* Ah = W->Ah + (size_t)k * 432;
+      memset(mk, 0, sizeof(double) * NW); memset(Ah, 0, sizeof(double) * 432);
+      for (a = 0; a < 60; ++a) { const int wa = loc2w(a); if (wa < 0) continue; for (b = 0; b < 60; ++b) { const int wb = loc2w(b); if (wb >= 0) Mk[wa * NW + wb] = H[a * 60 + b]; } }
+      for (q = 12; q < nr; ++q) {
+        int idx[16], n = 0; double val[16]; const double sg = W->sig[g0 + q], rh = W->rho[g0 + q];
+        for (a = 0; a < 60; ++a) if (J[q * 60 + a] != 0.0 && loc2w(a) >= 0) { idx[n] = loc2w(a); val[n] = J[q * 60 + a]; ++n; }
+        for (a = 0; a < n; ++a) { mk[idx[a]] += rh * val[a]; for (b = 0; b < n; ++b) Mk[idx[a] * NW + idx[b]] += sg * val[a] * val[b]; }
+      }
+      for (q = 0; q < 12; ++q) { for (a = 0; a < 36; ++a) Ah[ROW2STATE[q] * 36 + a] = -J[q * 60 + a]; W->bv[k * 12 + ROW2STATE[q]] = -W->g[g0 + q]; }
+    }
+    /* factorisation with inertia correction (same schedule as the HIP kernel) */
+    delta = (streak >= 2 && delta_last > 0.0) ? fmax(1e-20, delta_last / 3.0) : 0.0;
+    for (attempt = 0; attempt < 60 && !fact_ok; ++attempt) {
+      if (attempt > 0) {
+        if (delta == 0.0) delta = (delta_last == 0.0) ? 1e-4 : fmax(1e-20, delta_last / 3.0);
+        else delta *= (delta_last == 0.0 ? 100.0 : 8.0);
+        if (delta > 1e40) break;
+      }
+      counters[0]++;
+      fact_ok = riccati_backward(F, p, W, delta, &o, sig);
+    }
+    if (!fact_ok) { status = 2; break; }
+    if (delta > 0.0) { delta_last = delta; streak++; } else streak = 0;
+    if (streak > 8) streak = 0;
+    /* forward sweep */
+    for (k = 0; k < N; ++k) {
+      const int last = (k == N - 1), nu = last ? 12 : 24, nr = lo_stage_rows(F, k), g0 = 36 + 104 * k; int q, a, t;
+      const double* J = W->Jst + (size_t)k * 104 * 60; double signext[24];
+      for (a = 0; a < 24; ++a) w[a] = sig[a];
+      for (a = 0; a < nu; ++a) { double v = W->kap[k * 24 + a]; for (t = 0; t < 24; ++t) v += W->K[(size_t)k * 576 + a * 24 + t] * sig[t]; w[24 + a] = -v; }
+      for (a = nu; a < 24; ++a) w[24 + a] = 0.0;
+      for (a = 0; a < 12; ++a) { W->dx[12 * k + a] = w[a]; W->dx[12 * (N + 1) + 24 * k + a] = w[12 + a]; W->dx[12 * (N + 1) + 24 * k + 12 + a] = w[24 + a]; }
+      for (q = 12; q < nr; ++q) {
+        double v = 0; for (a = 0; a < 60; ++a) { const int wa = loc2w(a); if (wa >= 0 && J[q * 60 + a] != 0.0) v += J[q * 60 + a] * w[wa]; }
+        W->ds[g0 + q] = v + (W->g[g0 + q] - W->s[g0 + q]);
+      }
+      for (a = 0; a < 12; ++a) { double v = W->bv[k * 12 + a]; for (t = 0; t < 36; ++t) v += W->Ah[(size_t)k * 432 + a * 36 + t] * w[t]; signext[a] = v; }
+      for (a = 0; a < 12; ++a) signext[12 + a] = last ? 0.0 : w[36 + a];
+      for (a = 0; a < 12; ++a) {
+        double v = W->pvx[(k + 1) * 12 + a]; const int nn = last ? 12 : 24;
+        for (t = 0; t < nn; ++t) v += W->Px[(size_t)(k + 1) * 288 + a * 24 + t] * signext[t];
+        W->yn[g0 + (a < 6 ? a : (a < 9 ? a + 3 : a - 3))] = -v;
+      }
+      memcpy(sig, signext, sizeof(sig));
+    }
+    for (i = 0; i < 12; ++i) {
+      const int ra = i < 6 ? 12 + i : 24 + (i - 6), rb = i < 6 ? 18 + i : 30 + (i - 6);
+      W->dx[12 * N + i] = sig[i];
+      W->ds[ra] = sig[i] + (W->g[ra] - W->s[ra]); W->ds[rb] = sig[i] + (W->g[rb] - W->s[rb]);
+    }
+    /* dual steps, step bounds, merit data */
+    for (r = 12; r < ng; ++r) {
+      const double lb = W->lb[r], ub = W->ub[r], g = W->g[r]; double s, ds, yn;
+      if (lb == ub) { th0 += fabs(g - lb); continue; }
+      s = W->s[r]; ds = W->ds[r]; th0 += fabs(g - s); yn = W->sig[r] * ds;
+      if (lb > -INFINITY) {
+        const double d = s - lb, zl = W->zL[r], dz = mu / d - zl - zl / d * ds;
+        W->dzL[r] = dz; yn -= mu / d;
+        if (ds < 0.0) a_pr = fmin(a_pr, -tau * d / ds);
+        if (dz < 0.0) a_du = fmin(a_du, -tau * zl / dz);
+        bar -= log(d); dphi -= mu * ds / d;
+      } else W->dzL[r] = 0.0;
+      if (ub < INFINITY) {
+        const double d = ub - s, zu = W->zU[r], dz = mu / d - zu + zu / d * ds;
+        W->dzU[r] = dz; yn += mu / d;
+        if (ds > 0.0) a_pr = fmin(a_pr, tau * d / ds);
+        if (dz < 0.0) a_du = fmin(a_du, -tau * zu / dz);
+        bar -= log(d); dphi += mu * ds / d;
+      } else W->dzU[r] = 0.0;
+      W->yn[r] = yn;
+    }
+    for (i = 0; i < 12; ++i) { const double d = W->x[12 * N + i] - p[12 * N + i], qn = p[o.QN + i]; f0 += qn * d * d; dphi += 2.0 * qn * d * W->dx[12 * N + i]; }
+    ph0 = f0 + mu * bar;
+    if (it == 0) th_max = 1e4 * fmax(1.0, th0);
+    alpha = a_pr;
+    while (alpha > 1e-10) {
+      double tht = 0, bt = 0, ft = 0, pht; int ok_f, e, switching;
+      counters[1]++;
+      for (i = 0; i < nx; ++i) W->xt[i] = W->x[i] + alpha * W->dx[i];
+      eval_g(F, W->xt, p, W->gt);
+      for (r = 12; r < ng; ++r) {
+        const double lb = W->lb[r], ub = W->ub[r], g = W->gt[r]; double s;
+        if (lb == ub) { tht += fabs(g - lb); continue; }
+        s = W->s[r] + alpha * W->ds[r]; tht += fabs(g - s);
+        if (lb > -INFINITY) bt -= log(s - lb);
+        if (ub < INFINITY) bt -= log(ub - s);
+      }
+      for (i = 0; i < 12; ++i) { const double d = W->xt[12 * N + i] - p[12 * N + i]; ft += p[o.QN + i] * d * d; }
+      pht = ft + mu * bt;
+      ok_f = (tht <= th_max) && (pht < 1e300) && (pht > -1e300) && (tht < 1e300);
+      for (e = 0; e < nfilt && ok_f; ++e) if (tht >= filt_th[e] && pht >= filt_ph[e]) ok_f = 0;
+      switching = (dphi < 0.0) && (th0 <= 1e-4) && (alpha * pow(-dphi, 2.3) > pow(th0, 1.1));
+      if (ok_f) {
+        if (switching) { if (pht <= ph0 + 1e-8 * alpha * dphi) { accepted = 1; armijo = 1; } }
+        else if (tht <= (1.0 - 1e-5) * th0 || pht <= ph0 - 1e-8 * th0) accepted = 1;
+      }
+      if (accepted) break;
+      alpha *= 0.5;
+    }
+    if (!accepted) {
+      nfilt = 0; alpha = fmin(a_pr, 1e-2);
+      for (i = 0; i < nx; ++i) W->xt[i] = W->x[i] + alpha * W->dx[i];
+      eval_g(F, W->xt, p, W->gt);
+    } else if (!armijo) {
+      if (nfilt == 64) { memmove(filt_th, filt_th + 1, 63 * sizeof(double)); memmove(filt_ph, filt_ph + 1, 63 * sizeof(double)); nfilt = 63; }
+      filt_th[nfilt] = (1.0 - 1e-5) * th0; filt_ph[nfilt] = ph0 - 1e-8 * th0; nfilt++;
+    }
+    memcpy(W->x, W->xt, sizeof(double) * nx);
+    for (r = 0; r < ng; ++r) {
+      const double lb = W->lb[r], ub = W->ub[r]; double s, zl = 0, zu = 0;
+      W->g[r] = W->gt[r];
+      if (r < 12) continue;
+      if (lb == ub) { W->y[r] += alpha * (W->yn[r] - W->y[r]); continue; }
+      s = W->s[r] + alpha * W->ds[r];
+      if (lb > -INFINITY) { const double d = s - lb; zl = W->zL[r] + a_du * W->dzL[r]; zl = fmin(fmax(zl, mu / (1e10 * d)), 1e10 * mu / d); }
+      if (ub < INFINITY) { const double d = ub - s; zu = W->zU[r] + a_du * W->dzU[r]; zu = fmin(fmax(zu, mu / (1e10 * d)), 1e10 * mu / d); }
+      W->s[r] = s; W->zL[r] = zl; W->zU[r] = zu; W->y[r] = zu - zl;
+    }
+  }
+  for (i = 0; i < 12; ++i) W->y[i] = -gx[i];
+  memcpy(x_out, W->x, sizeof(double) * nx);
+  if (lam_out) memcpy(lam_out, W->y, sizeof(double) * ng);
+  if (iters_out) *iters_out = it;
+  if (kkt_out) { lo_kkt(F, W->x, p, W->y, kkt_out); (void)e_du; }
+  free(W->x); free(W->xt); free(W->dx); free(gx); free(W->g); free(W->gt); free(W->s); free(W->ds); free(W->zL); free(W->zU);
+  free(W->dzL); free(W->dzU); free(W->y); free(W->yn); free(W->lb); free(W->ub); free(W->sig); free(W->rho); free(W->Jst); free(W->Hst);
+  free(W->M); free(W->mvec); free(W->Ah); free(W->bv); free(W->K); free(W->kap); free(W->Px); free(W->pvx);
+  return status;
+}
+
+/* batch driver: B members, `threads` OpenMP threads (<=0: all).  counters[0..1] = total factorisations, trial points. */
+int lo_solve_batch(const lo_form* F, int B, const double* p, const double* x0, const lo_solver_opts* opts, int threads,
+                   double* x, double* lam_g, int* status, int* iters, double* kkt, long long* counters) {
+  const lo_int nx = lo_nx(F->N), ng = lo_ng(F->N), np = lo_np(F->N);
+  lo_solver_opts o; long long c0 = 0, c1 = 0; int b;
+  if (opts) o = *opts; else lo_solver_opts_default(&o);
+#ifdef _OPENMP
+  if (threads > 0) omp_set_num_threads(threads);
+#else
+  (void)threads;
+#endif
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : c0, c1)
+  for (b = 0; b < B; ++b) {
+    long long cc[2] = {0, 0};
+    status[b] = solve_one(F, p + (size_t)b * np, x0 + (size_t)b * nx, &o, x + (size_t)b * nx, lam_g ? lam_g + (size_t)b * ng : NULL,
+                          iters ? iters + b : NULL, kkt ? kkt + 3 * (size_t)b : NULL, cc);
+    c0 += cc[0]; c1 += cc[1];
+  }
+  if (counters) { counters[0] = c0; counters[1] = c1; }
+  return 0;
+}

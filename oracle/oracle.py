@@ -123,6 +123,29 @@ class Oracle:
         return out
 
 
+class _SolverOpts(C.Structure):
+    _fields_ = [("tol", C.c_double), ("max_iter", C.c_int), ("mu_init", C.c_double), ("bound_push", C.c_double),
+                ("bound_frac", C.c_double), ("kappa_eps", C.c_double), ("kappa_mu", C.c_double), ("theta_mu", C.c_double)]
+
+
+def cpu_solve_batch(O, P, X0, threads=0, max_iter=None, tol=None):
+    """oracle/landing_solver_cpu.c: scalar CPU port of the interior-point algorithm (cpu_baseline / cross-check)."""
+    P = np.ascontiguousarray(np.atleast_2d(P), float); X0 = np.ascontiguousarray(np.atleast_2d(X0), float)
+    B = P.shape[0]
+    o = _SolverOpts()
+    O.lib.lo_solver_opts_default(C.byref(o))
+    if max_iter is not None:
+        o.max_iter = max_iter
+    if tol is not None:
+        o.tol = tol
+    x = np.zeros((B, O.nx)); lam = np.zeros((B, O.ng)); st = np.zeros(B, np.int32); it = np.zeros(B, np.int32)
+    kkt = np.zeros((B, 3)); cnt = np.zeros(2, np.int64)
+    ip = C.POINTER(C.c_int)
+    O.lib.lo_solve_batch(O._F, C.c_int(B), _p(P), _p(X0), C.byref(o), C.c_int(threads), _p(x), _p(lam),
+                         st.ctypes.data_as(ip), it.ctypes.data_as(ip), _p(kkt), cnt.ctypes.data_as(C.POINTER(_ll)))
+    return dict(x=x, lam_g=lam, status=st, iters=it, kkt=kkt, factorizations=int(cnt[0]), trials=int(cnt[1]))
+
+
 class RefOracle:
     """The reference's generated C through its CasADi external ABI (N=20: x[732], p[354])."""
     N, nx, np_, ng, nnz_jac, nnz_hess = 20, 732, 354, 2092, 7664, 3780

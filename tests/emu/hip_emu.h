@@ -59,6 +59,15 @@ void yield_barrier();
 void run_grid(dim3 grid, dim3 block, const std::function<void()>& body);
 }
 inline void __syncthreads() { hip_emu::yield_barrier(); }
+// wave shuffle (all threads of the block must call it convergently, as on the device within a wave)
+inline double __shfl_xor(double v, int mask) {
+  static double buf[1024];
+  buf[threadIdx.x] = v;
+  hip_emu::yield_barrier();
+  const double r = buf[threadIdx.x ^ (unsigned)mask];
+  hip_emu::yield_barrier();
+  return r;
+}
 
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
   hip_emu::run_grid(dim3(grid), dim3(block), [&]() { kernel(__VA_ARGS__); })

@@ -5,10 +5,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 ap = argparse.ArgumentParser(); ap.add_argument("--B", type=int, default=1024); ap.add_argument("--N", type=int, default=40)
-ap.add_argument("--steps", type=int, default=2); ap.add_argument("--seed", type=int, default=20211); ap.add_argument("--max_iter", type=int, default=3000); ap.add_argument("--prof", action="store_true")
+ap.add_argument("--steps", type=int, default=2); ap.add_argument("--seed", type=int, default=20211); ap.add_argument("--max_iter", type=int, default=3000); ap.add_argument("--prof", action="store_true"); ap.add_argument("--lib", default=None)
 a = ap.parse_args()
 capi = importlib.import_module("landing-controller_amd.capi"); problem = importlib.import_module("landing-controller_amd.problem")
-L = capi.LandingLib(a.N, 0)
+L = capi.LandingLib(a.N, 0, lib_path=a.lib)
 P, X0, _, _ = problem.make_batch(a.B, a.N, 0.6, seed=a.seed)
 dev = "cuda"
 dP, dX0 = torch.tensor(P, device=dev), torch.tensor(X0, device=dev)
