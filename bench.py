@@ -53,7 +53,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="NLPs per GPU (weak scaling)")
-    ap.add_argument("--max-iter", type=int, default=400)
+    ap.add_argument("--max-iter", type=int, default=300)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 
@@ -173,7 +173,7 @@ def main():
             orc.build()
             O = orc.Oracle(N)
             cores = os.cpu_count() or 1
-            ns = int(min(B, max(8, min(64, 2 * cores))))
+            ns = int(min(B, max(16, 4 * cores)))
             tc = time.perf_counter()
             r = orc.cpu_solve_batch(O, P[:ns], X0[:ns], threads=cores, max_iter=a.max_iter)
             tcpu = time.perf_counter() - tc

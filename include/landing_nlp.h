@@ -69,7 +69,10 @@ typedef struct {
   double kappa_mu;       /* 0.2                                                    */
   double theta_mu;       /* 1.5                                                    */
   int max_soc;           /* reserved                                               */
-  int reserved[7];
+  int max_resets;        /* multiplier resets allowed per NLP (default 8), see reset_du          */
+  double reset_du;       /* dual infeasibility above which slacks/multipliers/mu are re-initialised
+                            at the current x (jammed iterate; IPOPT would enter restoration), 1e9  */
+  int reserved[4];
 } landing_solver_opts;
 
 /* status codes written per batch member by landing_solve_batch */

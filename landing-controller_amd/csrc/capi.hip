@@ -47,7 +47,7 @@ void landing_form_default(landing_form* f) {
 void landing_solver_opts_default(landing_solver_opts* o) {
   memset(o, 0, sizeof(*o));
   o->tol = 1e-6; o->max_iter = 3000; o->mu_init = 0.1; o->bound_push = 0.5; o->bound_frac = 0.5;
-  o->kappa_eps = 10.0; o->kappa_mu = 0.2; o->theta_mu = 1.5; o->max_soc = 0;
+  o->kappa_eps = 10.0; o->kappa_mu = 0.2; o->theta_mu = 1.5; o->max_soc = 0; o->max_resets = 8; o->reset_du = 1e9;
 }
 
 long long landing_nx(int N) { return 36LL * N + 12; }

@@ -109,6 +109,7 @@ struct Lds {
   double red[(SOLVER_THREADS / 64) * 6];
   double filt_th[FILT_CAP], filt_ph[FILT_CAP];
   double prof[16];
+  int flag;
   // member context, written once by every thread with identical values (read back as LDS broadcasts by the
   // __noinline__ phases so that they carry no register state across calls)
   MemberMem M; Layout L; const double* p; const int* tab; const int* stage_tab; int prof_on;
@@ -117,43 +118,52 @@ struct Lds {
 // phase function (ds_* instructions instead of flat_*).
 __shared__ Lds SH;
 
-// Fused LDL^T elimination of G_uu (rows/cols 24..24+NU of G) applied to [G_us | G_uu | gamma_u | I]:
-// afterwards rows 24.. of G hold Z = L~^{-1} G_us in columns 0..23, Ex(:,0) = z = L~^{-1} gamma_u, Ex(:,1+t) =
-// L~^{-1}(:,t) (unit lower triangular) and dinv[j] = 1/d_j.  One block barrier per pivot.  Returns false
-// (uniformly) on a non-positive / non-finite pivot: the caller raises delta_w (inertia correction).
+// Broadcast of one lane's fp64 value to the whole wave through the scalar unit (v_readlane_b32 x2; `src` must be
+// wave-uniform -- it is a compile-time constant in the unrolled elimination below).
+__device__ __forceinline__ double lane_bcast(double v, int src) {
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+  return __hiloint2double(hi, lo);
+}
+
+// Elimination of the controls of one stage by ONE wavefront, entirely in registers: Gauss-Jordan on
+// [G_uu | G_us | gamma_u], lane c owning column c (NU + 24 + 1 <= 49 lanes, NU values each).  The pivot of step j is
+// broadcast from lane j, the multipliers from lane j's column; no LDS traffic and no barrier inside the 24 steps
+// (the serial pivot chain is what bounds a Riccati stage).  On success Kl (LDS, NU x 24, row stride 24) holds
+// K = G_uu^-1 G_us and kl the vector kappa = G_uu^-1 gamma_u.  A non-positive / non-finite pivot (wrong inertia)
+// is reported through *flag = 0; the caller raises delta_w.
 template <int NU>
-__device__ __forceinline__ bool ldl_eliminate(double* G, double* Ex, double* dinv) {
-  constexpr int NC = NU + 25;                          // 24 (G_us) + (NU-1-j) trailing + (j+2) side columns
-  constexpr int MAXQ = ((NU - 1) * NC + SOLVER_THREADS - 1) / SOLVER_THREADS;
-  const int tid = threadIdx.x, NT = blockDim.x;
-  const int EXOFF = (int)(Ex - G);                     // both live in the same LDS struct
+__device__ __forceinline__ void gauss_jordan_wave(const double* G, const double* gam, double* Kl, double* kl, int* flag) {
+  const int lane = threadIdx.x;        // called by the first wave only (threadIdx.x < 64)
+  double col[NU];
+  const bool isUU = lane < NU, isUS = lane >= NU && lane < NU + 24, isG = lane == NU + 24;
+#pragma unroll
+  for (int i = 0; i < NU; ++i)
+    col[i] = isUU ? G[(24 + i) * GS + 24 + lane] : (isUS ? G[(24 + i) * GS + (lane - NU)] : (isG ? gam[24 + i] : 0.0));
+  bool ok = true;
+#pragma unroll
   for (int j = 0; j < NU; ++j) {
-    const double d = G[(24 + j) * GS + 24 + j];
-    if (!(d > 0.0) || !(d < 1e300)) return false;
+    const double d = lane_bcast(col[j], j);
+    if (!(d > 0.0) || !(d < 1e300)) ok = false;        // wave-uniform; keep going (values are discarded)
     const double inv = 1.0 / d;
-    const int nrow = NU - 1 - j, n = nrow * NC;
-    // branch-free addressing, all LDS loads of a pivot step issued before the stores (the elements of
-    // one step are independent: row j and column j are only read)
-    int ot[MAXQ]; double vt[MAXQ], vp[MAXQ], vl[MAXQ];
+    const double pj = col[j] * inv;
 #pragma unroll
-    for (int q = 0; q < MAXQ; ++q) {
-      const int e = tid + q * NT;
-      const bool act = e < n;
-      const int ee = act ? e : 0;
-      const int i = j + 1 + ee / NC, cc = ee % NC;
-      const bool inG = cc < 24 + nrow;
-      const int col = cc < 24 ? cc : cc + 1 + j;          // G_us column, or trailing G_uu column 24+j+1+(cc-24)
-      const int c = cc - 24 - nrow;                       // side-block column 0..j+1
-      ot[q] = act ? (inG ? (24 + i) * GS + col : EXOFF + i * ES + c) : -1;
-      const int op = inG ? (24 + j) * GS + col : EXOFF + j * ES + c;
-      vt[q] = G[act ? ot[q] : 0]; vp[q] = G[op]; vl[q] = G[(24 + i) * GS + 24 + j];
+    for (int i = 0; i < NU; ++i) {
+      if (i == j) continue;
+      const double m = lane_bcast(col[i], j);
+      col[i] -= m * pj;
     }
-#pragma unroll
-    for (int q = 0; q < MAXQ; ++q) if (ot[q] >= 0) G[ot[q]] = vt[q] - vl[q] * inv * vp[q];
-    if (tid == 0) dinv[j] = inv;
-    __syncthreads();
+    col[j] = pj;
   }
-  return true;
+  if (isUS) {
+#pragma unroll
+    for (int i = 0; i < NU; ++i) Kl[i * 24 + (lane - NU)] = col[i];
+  }
+  if (isG) {
+#pragma unroll
+    for (int i = 0; i < NU; ++i) kl[i] = col[i];
+  }
+  if (lane == 0) *flag = ok ? 1 : 0;
 }
 
 // Everything of one backward Riccati step that follows the assembly of G, gamma (templated on the control
@@ -162,42 +172,29 @@ template <int NU>
 __device__ __forceinline__ bool riccati_step(double* rec) {
   Lds& S = SH;
   const int tid = threadIdx.x, NT = blockDim.x;
-  for (int e = tid; e < NU * 25; e += NT) {
-    const int i = e / 25, c = e % 25;
-    S.A1[i * ES + c] = (c == 0) ? S.gam[24 + i] : (c - 1 == i ? 1.0 : 0.0);
-  }
+  double* Kl = S.A1;            // NU x 24 gains (Y is dead by now)
+  double* kl = S.A1 + 24 * 24;  // kappa
+  if (tid < 64) gauss_jordan_wave<NU>(S.G, S.gam, Kl, kl, &S.flag);
   __syncthreads();
-  if (!ldl_eliminate<NU>(S.G, S.A1, S.dinv)) return false;
-  // P_k = G_ss - Z^T D^-1 Z ; p_k = gamma_s - Z^T D^-1 z
+  if (!S.flag) return false;
+  // P_k = G_ss - G_su K ; p_k = gamma_s - G_su kappa   (G_su(i,t) = G(24+t, i) by symmetry)
   for (int e = tid; e < 24 * 24; e += NT) {
     const int i = e / 24, j = e % 24;
     double acc = S.G[i * GS + j];
 #pragma unroll
-    for (int t = 0; t < NU; ++t) acc -= S.G[(24 + t) * GS + i] * S.G[(24 + t) * GS + j] * S.dinv[t];
+    for (int t = 0; t < NU; ++t) acc -= S.G[(24 + t) * GS + i] * Kl[t * 24 + j];
     S.P[i * PS + j] = acc;
     if (i < 12) rec[RIC_PX + i * 24 + j] = acc;
   }
   for (int i = tid; i < 24; i += NT) {
     double acc = S.gam[i];
 #pragma unroll
-    for (int t = 0; t < NU; ++t) acc -= S.G[(24 + t) * GS + i] * S.A1[t * ES] * S.dinv[t];
+    for (int t = 0; t < NU; ++t) acc -= S.G[(24 + t) * GS + i] * kl[t];
     S.pv[i] = acc;
     if (i < 12) rec[RIC_PV + i] = acc;
   }
-  // gains K = L~^-T D^-1 Z, kappa = L~^-T D^-1 z
-  for (int e = tid; e < NU * 24; e += NT) {
-    const int i = e / 24, j = e % 24;
-    double acc = 0.0;
-#pragma unroll
-    for (int t = 0; t < NU; ++t) acc += S.A1[t * ES + 1 + i] * S.dinv[t] * S.G[(24 + t) * GS + j];
-    rec[RIC_K + i * 24 + j] = acc;
-  }
-  for (int i = tid; i < NU; i += NT) {
-    double acc = 0.0;
-#pragma unroll
-    for (int t = 0; t < NU; ++t) acc += S.A1[t * ES + 1 + i] * S.dinv[t] * S.A1[t * ES];
-    rec[RIC_KAP + i] = acc;
-  }
+  for (int e = tid; e < NU * 24; e += NT) rec[RIC_K + e] = Kl[e];
+  for (int i = tid; i < NU; i += NT) rec[RIC_KAP + i] = kl[i];
   for (int e = tid; e < 12 * 36; e += NT) rec[RIC_AH + e] = S.Ah[(e / 36) * YS + e % 36];
   if (tid < 12) rec[RIC_B + tid] = S.bv[tid];
   __syncthreads();
@@ -345,20 +342,17 @@ __device__ __noinline__ bool riccati_backward(double delta) {
     }
     for (int e = lane; e < 144; e += NT) { const int i = e / 12, j = e % 12; S.G[(24 + i) * GS + 24 + j] = S.P[(12 + i) * PS + 12 + j]; }
     __syncthreads();
-    for (int e = lane; e < 12 * 25; e += NT) {
-      const int i = e / 25, c = e % 25;
-      double v = (c - 1 == i) ? 1.0 : 0.0;
-      if (c == 0) { v = S.pv[12 + i]; for (int t = 0; t < 12; ++t) v += S.P[(12 + i) * PS + t] * S.sig[t]; }
-      S.A1[i * ES + c] = v;
+    if (lane < 12) {
+      double v = S.pv[12 + lane];
+      for (int t = 0; t < 12; ++t) v += S.P[(12 + lane) * PS + t] * S.sig[t];
+      S.gam[24 + lane] = v;
     }
     __syncthreads();
-    ok = ldl_eliminate<12>(S.G, S.A1, S.dinv);
+    if (lane < 64) gauss_jordan_wave<12>(S.G, S.gam, S.A1, S.A1 + 24 * 24, &S.flag);
+    __syncthreads();
+    ok = S.flag != 0;
     if (ok) {
-      if (lane < 12) {
-        double acc = 0.0;
-        for (int t = 0; t < 12; ++t) acc += S.A1[t * ES + 1 + lane] * S.dinv[t] * S.A1[t * ES];
-        S.sig[12 + lane] = -acc;
-      }
+      if (lane < 12) S.sig[12 + lane] = -S.A1[24 * 24 + lane];
       __syncthreads();
     }
   }
@@ -475,26 +469,29 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
   __syncthreads();
   member_eval_g(L, M.x, p, M.g);
   __syncthreads();
-  for (int r = lane; r < ng; r += NT) {
-    const double lb = M.lb[r], ub = M.ub[r];
-    double sv = 0.0, zl = 0.0, zu = 0.0;
-    if (r >= 12 && lb != ub) {               // inequality row: slack pushed into the interior (IPOPT bound_push/frac)
-      const bool hL = lb > -INF, hU = ub < INF;
-      sv = M.g[r];
-      double pl, pu;
-      if (hL && hU) { pl = fmin(o.bound_push * fmax(1.0, fabs(lb)), o.bound_frac * (ub - lb)); pu = fmin(o.bound_push * fmax(1.0, fabs(ub)), o.bound_frac * (ub - lb)); }
-      else { pl = o.bound_push * fmax(1.0, hL ? fabs(lb) : 0.0); pu = o.bound_push * fmax(1.0, hU ? fabs(ub) : 0.0); }
-      if (hL) sv = fmax(sv, lb + pl);
-      if (hU) sv = fmin(sv, ub - pu);
-      zl = hL ? 1.0 : 0.0; zu = hU ? 1.0 : 0.0;
+  auto init_slacks = [&]() {     // slack pushed into the interior (IPOPT bound_push/frac), z = 1, y = z_U - z_L, y_dyn = 0
+    for (int r = lane; r < ng; r += NT) {
+      const double lb = M.lb[r], ub = M.ub[r];
+      double sv = 0.0, zl = 0.0, zu = 0.0;
+      if (r >= 12 && lb != ub) {
+        const bool hL = lb > -INF, hU = ub < INF;
+        sv = M.g[r];
+        double pl, pu;
+        if (hL && hU) { pl = fmin(o.bound_push * fmax(1.0, fabs(lb)), o.bound_frac * (ub - lb)); pu = fmin(o.bound_push * fmax(1.0, fabs(ub)), o.bound_frac * (ub - lb)); }
+        else { pl = o.bound_push * fmax(1.0, hL ? fabs(lb) : 0.0); pu = o.bound_push * fmax(1.0, hU ? fabs(ub) : 0.0); }
+        if (hL) sv = fmax(sv, lb + pl);
+        if (hU) sv = fmin(sv, ub - pu);
+        zl = hL ? 1.0 : 0.0; zu = hU ? 1.0 : 0.0;
+      }
+      M.s[r] = sv; M.zL[r] = zl; M.zU[r] = zu; M.y[r] = zu - zl;
     }
-    M.s[r] = sv; M.zL[r] = zl; M.zU[r] = zu; M.y[r] = zu - zl;
-  }
-  __syncthreads();
+    __syncthreads();
+  };
+  init_slacks();
 
   long long tp = A.prof ? (long long)wall_clock64() : 0;
   double mu = o.mu_init, delta_last = 0.0, th_max = 0.0;
-  int nfilt = 0, it = 0, status = LANDING_MAX_ITER, need_reg_streak = 0;
+  int nfilt = 0, it = 0, status = LANDING_MAX_ITER, need_reg_streak = 0, nreset = 0;
   double e_pr = 0, e_du = 0, e_co = 0;
 
   for (it = 0; it <= o.max_iter; ++it) {
@@ -519,6 +516,15 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
     if (!(du < 1e300) || !(pr < 1e300) || !(co < 1e300)) { status = LANDING_NUMERICAL; break; }
     if (fmax(du, fmax(pr, co)) <= o.tol) { status = LANDING_CONVERGED; break; }
     if (it == o.max_iter) break;
+    if (du > o.reset_du && nreset >= o.max_resets && o.max_resets > 0) { status = LANDING_NUMERICAL; break; }   // jammed again: give up
+    if (du > o.reset_du && nreset < o.max_resets) {
+      // jammed iterate (multipliers blown up): keep x, re-initialise slacks, multipliers, barrier parameter and
+      // filter -- the role IPOPT's restoration phase plays on this problem class
+      nreset++;
+      init_slacks();
+      mu = o.mu_init; nfilt = 0; delta_last = 0.0; need_reg_streak = 0;
+      continue;
+    }
     // ---------------------------------------------------------------- barrier parameter (monotone)
     for (;;) {
       double cm = 0.0;

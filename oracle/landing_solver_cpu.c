@@ -24,11 +24,12 @@
 
 typedef struct {
   double tol; int max_iter; double mu_init, bound_push, bound_frac, kappa_eps, kappa_mu, theta_mu;
+  int max_resets; double reset_du;
 } lo_solver_opts;
 
 void lo_solver_opts_default(lo_solver_opts* o) {
   o->tol = 1e-6; o->max_iter = 3000; o->mu_init = 0.1; o->bound_push = 0.5; o->bound_frac = 0.5;
-  o->kappa_eps = 10.0; o->kappa_mu = 0.2; o->theta_mu = 1.5;
+  o->kappa_eps = 10.0; o->kappa_mu = 0.2; o->theta_mu = 1.5; o->max_resets = 8; o->reset_du = 1e9;
 }
 
 #define NW 48
@@ -135,11 +136,29 @@ static int riccati_backward(const lo_form* F, const double* p, work_t* W, double
   return 1;
 }
 
+static void init_slacks(work_t* W, const lo_solver_opts* op) {
+  lo_int r;
+  for (r = 0; r < W->ng; ++r) {
+    const double lb = W->lb[r], ub = W->ub[r];
+    double sv = 0, zl = 0, zu = 0;
+    if (r >= 12 && lb != ub) {
+      const int hL = lb > -INFINITY, hU = ub < INFINITY; double pl, pu;
+      sv = W->g[r];
+      if (hL && hU) { pl = fmin(op->bound_push * fmax(1.0, fabs(lb)), op->bound_frac * (ub - lb)); pu = fmin(op->bound_push * fmax(1.0, fabs(ub)), op->bound_frac * (ub - lb)); }
+      else { pl = op->bound_push * fmax(1.0, hL ? fabs(lb) : 0.0); pu = op->bound_push * fmax(1.0, hU ? fabs(ub) : 0.0); }
+      if (hL) sv = fmax(sv, lb + pl);
+      if (hU) sv = fmin(sv, ub - pu);
+      zl = hL ? 1.0 : 0.0; zu = hU ? 1.0 : 0.0;
+    }
+    W->s[r] = sv; W->zL[r] = zl; W->zU[r] = zu; W->y[r] = zu - zl;
+  }
+}
+
 /* one NLP; returns status (0 converged, 1 max_iter, 2 numerical) */
 static int solve_one(const lo_form* F, const double* p, const double* x0, const lo_solver_opts* op, double* x_out,
                      double* lam_out, int* iters_out, double kkt_out[3], long long counters[2]) {
   const int N = F->N; const lo_int nx = lo_nx(N), ng = lo_ng(N);
-  lo_poff o; work_t Wk, *W = &Wk; lo_int i, r; int k, it, status = 1, nfilt = 0, streak = 0;
+  lo_poff o; work_t Wk, *W = &Wk; lo_int i, r; int k, it, status = 1, nfilt = 0, streak = 0, nreset = 0;
   double mu = op->mu_init, delta_last = 0.0, th_max = 0.0, e_du = 0.0;
   double filt_th[64], filt_ph[64];
   double* gx;
@@ -156,20 +175,7 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
   for (i = 0; i < 6; ++i) { W->x[i] = p[o.q_init + i]; W->x[6 + i] = p[o.qd_init + i]; }
   lo_bounds(F, p, W->lb, W->ub);
   eval_g(F, W->x, p, W->g);
-  for (r = 0; r < ng; ++r) {
-    const double lb = W->lb[r], ub = W->ub[r];
-    double sv = 0, zl = 0, zu = 0;
-    if (r >= 12 && lb != ub) {
-      const int hL = lb > -INFINITY, hU = ub < INFINITY; double pl, pu;
-      sv = W->g[r];
-      if (hL && hU) { pl = fmin(op->bound_push * fmax(1.0, fabs(lb)), op->bound_frac * (ub - lb)); pu = fmin(op->bound_push * fmax(1.0, fabs(ub)), op->bound_frac * (ub - lb)); }
-      else { pl = op->bound_push * fmax(1.0, hL ? fabs(lb) : 0.0); pu = op->bound_push * fmax(1.0, hU ? fabs(ub) : 0.0); }
-      if (hL) sv = fmax(sv, lb + pl);
-      if (hU) sv = fmin(sv, ub - pu);
-      zl = hL ? 1.0 : 0.0; zu = hU ? 1.0 : 0.0;
-    }
-    W->s[r] = sv; W->zL[r] = zl; W->zU[r] = zu; W->y[r] = zu - zl;
-  }
+  init_slacks(W, op);
   for (it = 0; it <= op->max_iter; ++it) {
     double du = 0, pr = 0, co = 0, tau, delta;
     int fact_ok = 0, attempt;
@@ -202,6 +208,11 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
     if (!(du < 1e300) || !(pr < 1e300) || !(co < 1e300)) { status = 2; break; }
     if (fmax(du, fmax(pr, co)) <= op->tol) { status = 0; break; }
     if (it == op->max_iter) break;
+    if (du > op->reset_du && nreset >= op->max_resets && op->max_resets > 0) { status = 2; break; }
+    if (du > op->reset_du && nreset < op->max_resets) {
+      nreset++; init_slacks(W, op); mu = op->mu_init; nfilt = 0; delta_last = 0.0; streak = 0;
+      continue;
+    }
     for (;;) {
       double cm = 0;
       for (r = 12; r < ng; ++r) {

@@ -6,7 +6,7 @@ dim3 blockDim, gridDim;
 
 namespace hip_emu {
 namespace {
-struct Fiber { ucontext_t ctx; std::vector<char> stack; bool done = false; };
+struct Fiber { ucontext_t ctx; std::vector<char> stack; bool done = false; const unsigned* wait_ptr = nullptr; unsigned wait_val = 0; };
 std::vector<Fiber>* g_fibers = nullptr;
 ucontext_t g_sched;
 int g_cur = -1;
@@ -18,7 +18,29 @@ void trampoline() {
 }
 }  // namespace
 
-void yield_barrier() { swapcontext(&(*g_fibers)[g_cur].ctx, &g_sched); }
+static void yield_once() { const int me = g_cur; swapcontext(&(*g_fibers)[me].ctx, &g_sched); }
+
+// generation-counted barriers: a fiber that arrives re-yields until everybody of its group has arrived, so groups
+// (block / wave) may synchronise independently of each other
+static unsigned g_block_arrived = 0, g_block_gen = 0, g_block_size = 0;
+static unsigned g_wave_arrived[64], g_wave_gen[64], g_wave_size[64];
+
+static void wait_for_change(const unsigned* gen_ptr, unsigned gen) {
+  Fiber& f = (*g_fibers)[g_cur];
+  f.wait_ptr = gen_ptr; f.wait_val = gen;      // the scheduler skips this fiber until *gen_ptr changes
+  yield_once();
+}
+void yield_barrier() {
+  const unsigned gen = g_block_gen;
+  if (++g_block_arrived == g_block_size) { g_block_arrived = 0; ++g_block_gen; return; }
+  wait_for_change(&g_block_gen, gen);
+}
+void wave_barrier() {
+  const unsigned w = (unsigned)g_cur >> 6;
+  const unsigned gen = g_wave_gen[w];
+  if (++g_wave_arrived[w] == g_wave_size[w]) { g_wave_arrived[w] = 0; ++g_wave_gen[w]; return; }
+  wait_for_change(&g_wave_gen[w], gen);
+}
 
 void run_grid(dim3 grid, dim3 block, const std::function<void()>& body) {
   const size_t STACK = 1u << 20;
@@ -30,19 +52,22 @@ void run_grid(dim3 grid, dim3 block, const std::function<void()>& body) {
   for (unsigned bz = 0; bz < grid.z; ++bz) for (unsigned by = 0; by < grid.y; ++by) for (unsigned bx = 0; bx < grid.x; ++bx) {
     for (unsigned t = 0; t < nthreads; ++t) {
       Fiber& f = fibers[t];
-      f.done = false;
+      f.done = false; f.wait_ptr = nullptr;
       getcontext(&f.ctx);
       f.ctx.uc_stack.ss_sp = f.stack.data();
       f.ctx.uc_stack.ss_size = STACK;
       f.ctx.uc_link = &g_sched;
       makecontext(&f.ctx, (void (*)())trampoline, 0);
     }
+    g_block_arrived = 0; g_block_gen = 0; g_block_size = nthreads;
+    for (unsigned w = 0; w < 64; ++w) { g_wave_arrived[w] = 0; g_wave_gen[w] = 0; const unsigned lo = w * 64; g_wave_size[w] = nthreads > lo ? (nthreads - lo < 64 ? nthreads - lo : 64) : 0; }
     bool any = true;
     while (any) {
       any = false;
       for (unsigned t = 0; t < nthreads; ++t) {
         if (fibers[t].done) continue;
         any = true;
+        if (fibers[t].wait_ptr) { if (*fibers[t].wait_ptr == fibers[t].wait_val) continue; fibers[t].wait_ptr = nullptr; }
         g_cur = (int)t;
         blockIdx = {bx, by, bz};
         threadIdx = {t % block.x, (t / block.x) % block.y, t / (block.x * block.y)};

@@ -55,19 +55,32 @@ inline long long wall_clock64() { return 0; }
 inline void sincos(double a, double* s, double* c) { *s = std::sin(a); *c = std::cos(a); }
 
 namespace hip_emu {
-void yield_barrier();
+void yield_barrier();        // block-wide barrier (generation counted)
+void wave_barrier();         // barrier among the 64 fibers of the caller's wave
 void run_grid(dim3 grid, dim3 block, const std::function<void()>& body);
 }
 inline void __syncthreads() { hip_emu::yield_barrier(); }
-// wave shuffle (all threads of the block must call it convergently, as on the device within a wave)
+// wave-level data exchange: only the 64 fibers of one wave have to call these convergently (as on the device)
 inline double __shfl_xor(double v, int mask) {
   static double buf[1024];
   buf[threadIdx.x] = v;
-  hip_emu::yield_barrier();
+  hip_emu::wave_barrier();
   const double r = buf[threadIdx.x ^ (unsigned)mask];
-  hip_emu::yield_barrier();
+  hip_emu::wave_barrier();
   return r;
 }
+inline int __builtin_amdgcn_readlane(int v, int lane) {
+  // double-buffered per wave: one barrier per call is enough (a slot is rewritten two calls later)
+  static int buf[2][1024];
+  static unsigned cnt[1024];                      // per-fiber call counter: all lanes of a wave make the same calls
+  const unsigned p = cnt[threadIdx.x]++ & 1u;
+  buf[p][threadIdx.x] = v;
+  hip_emu::wave_barrier();
+  return buf[p][(threadIdx.x & ~63u) + (unsigned)lane];
+}
+inline int __double2hiint(double d) { long long b; std::memcpy(&b, &d, 8); return (int)(b >> 32); }
+inline int __double2loint(double d) { long long b; std::memcpy(&b, &d, 8); return (int)(b & 0xffffffffLL); }
+inline double __hiloint2double(int hi, int lo) { long long b = ((long long)hi << 32) | (unsigned int)lo; double d; std::memcpy(&d, &b, 8); return d; }
 
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
   hip_emu::run_grid(dim3(grid), dim3(block), [&]() { kernel(__VA_ARGS__); })
