@@ -196,6 +196,34 @@ __device__ __noinline__ void member_eval_g(const Layout& L, const double* x, con
     srbm::stage_g(z, P, k == N - 1, out);
   }
 }
+__device__ __noinline__ void eval_task_jac(const Layout& L, const srbm::StageVars& z, const srbm::StageParams& P, int k,
+                                           const double* fz_prev, double* J) {
+  SeqStoreJ ex{J + L.jx(k)}, eu{J + L.ju(k)};
+  srbm::stage_jac(z, P, k == 0, k == L.N - 1, fz_prev, ex, eu);
+}
+__device__ __noinline__ void eval_task_jty(const Layout& L, const srbm::StageVars& z, const srbm::StageParams& P, int k,
+                                           const double* fz_prev, const double* y, double* gx) {
+  const bool first = (k == 0);
+  const double* lprev = first ? y : y + L.g_stage(k - 1);
+  DotLam ex{y + L.g_stage(k), lprev, first, gx + L.x_X(k), 0.0, false};
+  DotLam eu{y + L.g_stage(k), lprev, first, gx + L.x_U(k), 0.0, false};
+  srbm::stage_jac(z, P, first, k == L.N - 1, fz_prev, ex, eu);
+  ex.finish(); eu.finish();
+}
+__device__ __noinline__ void eval_task_hess(const Layout& L, const srbm::StageVars& z, const srbm::StageParams& P, int k,
+                                            const double* y, double* H) {
+  const bool first = (k == 0);
+  double lps[12];
+  for (int i = 0; i < 12; ++i) lps[i] = 0.0;
+  if (!first) {
+    const double* lp = y + L.g_stage(k - 1);
+    for (int l = 0; l < 4; ++l) for (int i = 0; i < 3; ++i) lps[3 * l + i] = lp[16 + 12 * l + 2 + i] + lp[16 + 12 * l + 5 + i];
+  }
+  LamStage lam{y + L.g_stage(k)};
+  SeqStoreH hx{H + L.hx(k)}, hu{H + L.hu(k)};
+  srbm::stage_hess(z, P, first, k == L.N - 1, lam, lps, hx, hu);
+}
+
 // Jacobian / Hessian nonzeros (CCS order) and gx = grad f + J^T y of one member.
 __device__ __noinline__ void member_eval_jh(const Layout& L, const double* x, const double* p, const double* y,
                                             double* J, double* H, double* gx) {
@@ -208,37 +236,20 @@ __device__ __noinline__ void member_eval_jh(const Layout& L, const double* x, co
     v += (i < 6) ? y[12 + i] + y[18 + i] : y[24 + i - 6] + y[30 + i - 6];
     gx[12 * N + i] = v;
   }
-  for (int k = threadIdx.x; k < N; k += blockDim.x) {
-    const bool first = (k == 0), last = (k == N - 1);
+  // (stage, task) pairs over the threads: task 0 = Jacobian values, 1 = J^T y (column dot products), 2 = Hessian
+  // one wavefront per task (no divergent calls): wave 0 -> Jacobian, wave 1 -> J^T y, wave 2 -> Hessian; with fewer
+  // than 3 waves the tasks are looped
+  const int nwave = (blockDim.x + 63) >> 6, wave = threadIdx.x >> 6;
+  for (int task = wave; task < 3; task += nwave)
+  for (int k = threadIdx.x & 63; k < N; k += 64) {
+    const bool first = (k == 0);
     srbm::StageVars z; srbm::StageParams P;
     load_stage(L, x, p, k, z, P);
     double fz_prev[4] = {0, 0, 0, 0};
-    double lps[12];
-    for (int i = 0; i < 12; ++i) lps[i] = 0.0;
-    if (!first) {
-      const double* Up = x + L.x_U(k - 1);
-      const double* lp = y + L.g_stage(k - 1);
-      for (int l = 0; l < 4; ++l) {
-        fz_prev[l] = Up[12 + 3 * l + 2];
-        for (int i = 0; i < 3; ++i) lps[3 * l + i] = lp[16 + 12 * l + 2 + i] + lp[16 + 12 * l + 5 + i];
-      }
-    }
-    {
-      SeqStoreJ ex{J + L.jx(k)}, eu{J + L.ju(k)};
-      srbm::stage_jac(z, P, first, last, fz_prev, ex, eu);
-    }
-    {
-      LamStage lam{y + L.g_stage(k)};
-      SeqStoreH hx{H + L.hx(k)}, hu{H + L.hu(k)};
-      srbm::stage_hess(z, P, first, last, lam, lps, hx, hu);
-    }
-    {
-      const double* lprev = first ? y : y + L.g_stage(k - 1);
-      DotLam ex{y + L.g_stage(k), lprev, first, gx + L.x_X(k), 0.0, false};
-      DotLam eu{y + L.g_stage(k), lprev, first, gx + L.x_U(k), 0.0, false};
-      srbm::stage_jac(z, P, first, last, fz_prev, ex, eu);
-      ex.finish(); eu.finish();
-    }
+    if (!first) { const double* Up = x + L.x_U(k - 1); for (int l = 0; l < 4; ++l) fz_prev[l] = Up[12 + 3 * l + 2]; }
+    if (task == 0) eval_task_jac(L, z, P, k, fz_prev, J);
+    else if (task == 1) eval_task_jty(L, z, P, k, fz_prev, y, gx);
+    else eval_task_hess(L, z, P, k, y, H);
   }
 }
 

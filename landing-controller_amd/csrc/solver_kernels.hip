@@ -35,7 +35,7 @@ constexpr int COND_GAM = 480, COND_AH = 528, COND_STRIDE = 704;
 struct SolverWorkspace {
   double* buf = nullptr; size_t cap = 0;
   int* d_tab = nullptr; int* d_stage_tab = nullptr; int n_tab = 0;
-  int *d_cterm = nullptr, *d_cstart = nullptr, *d_rterm = nullptr, *d_rstart = nullptr;
+  int *d_cterm = nullptr, *d_cstart = nullptr, *d_rterm = nullptr, *d_rstart = nullptr; int clen = 0, rlen = 0;
   static size_t member_stride(const Layout& L) {
     return (size_t)4 * L.nx + (size_t)14 * L.ng + L.nnz_jac + L.nnz_hess + (size_t)(L.N + 1) * RIC_STRIDE + (size_t)L.N * COND_STRIDE;
   }
@@ -53,7 +53,7 @@ struct SolveArgs {
   double* x_out; double* f_out; double* lam_out; int* status; int* iters; double* kkt;
   double* ws; size_t ws_stride;
   const int* tab; const int* stage_tab;
-  const int4* cterm; const int* cstart; const int4* rterm; const int* rstart;
+  const int4* cterm; int clen; const int4* rterm; int rlen;
 };
 
 // ---- block-wide reductions through LDS (deterministic order), K values at once ----------------------
@@ -201,33 +201,26 @@ __device__ __forceinline__ bool riccati_step(double* rec) {
   return true;
 }
 
-__device__ __noinline__ void condense(const int4* __restrict__ cterm, const int* __restrict__ cstart) {
+// Condensation (once per iteration): G targets = H + J_d^T Sigma J_d, gamma = J_d^T rho, A^ = -dg_dyn/d(X,c,f) of
+// every stage, straight from the CCS nonzeros.  Each thread owns a fixed list of terms (host-built, interleaved so
+// that the 16-byte records load coalesced; deterministic summation order); loads are batched 4 deep.
+__device__ __noinline__ void condense(const int4* __restrict__ cterm, int clen) {
   Lds& S = SH;
-  const Layout& L = S.L;
   const MemberMem& M = S.M;
-  const double* p = S.p;
-  const int N = L.N, lane = threadIdx.x, NT = blockDim.x;
-  (void)p; (void)N; (void)lane; (void)NT;
-  const int ng = L.ng;
-  // ---------------------------------------------------------------- condensation (once per iteration):
-  // G targets = H + J_d^T Sigma J_d, gamma = J_d^T rho, A^ = -dg_dyn/d(X,c,f) for every stage, from the CCS
-  // nonzeros; flat per-thread term lists, deterministic summation order, independent loads batched
-  {
-    const double* __restrict__ JH = M.J;       // [J | H] are contiguous
-    const double* __restrict__ SR = M.sig;     // [sigma | rho] are contiguous
-    double* __restrict__ cond = M.cond;
-    double acc = 0.0;
-    const int e1 = cstart[lane + 1];
+  const int ng = S.L.ng, tid = threadIdx.x, NT = blockDim.x;
+  const double* __restrict__ JH = M.J;       // [J | H] are contiguous
+  const double* __restrict__ SR = M.sig;     // [sigma | rho] are contiguous
+  double* __restrict__ cond = M.cond;
+  double acc = 0.0;
 #pragma unroll 4
-    for (int e = cstart[lane]; e < e1; ++e) {
-      const int4 t = cterm[e];
-      const double a = JH[t.y];
-      const double b = JH[t.z >= 0 ? t.z : 0];
-      const double c = SR[t.x >= 0 ? t.x + (t.z < 0 ? ng : 0) : 0];
-      const double cc = t.x >= 0 ? c : (t.x == -1 ? 1.0 : (t.x == -2 ? -1.0 : 0.0));
-      acc += a * (t.z >= 0 ? b : 1.0) * cc;
-      if (t.w >= 0) { cond[t.w] = acc; acc = 0.0; }
-    }
+  for (int j = 0; j < clen; ++j) {
+    const int4 t = cterm[(size_t)j * NT + tid];
+    const double a = JH[t.y];
+    const double b = JH[t.z >= 0 ? t.z : 0];
+    const double c = SR[t.x >= 0 ? t.x + (t.z < 0 ? ng : 0) : 0];
+    const double cc = t.x >= 0 ? c : (t.x == -1 ? 1.0 : (t.x == -2 ? -1.0 : 0.0));
+    acc += a * (t.z >= 0 ? b : 1.0) * cc;
+    if (t.w >= 0) { cond[t.w] = acc; acc = 0.0; }
   }
   __syncthreads();
 }
@@ -420,23 +413,20 @@ __device__ __noinline__ void forward_pass() {
   __syncthreads();
 }
 
-__device__ __noinline__ void row_products(const int4* __restrict__ rterm, const int* __restrict__ rstart) {
+// ds = J_d dx + (g - s) for every stage inequality row (fixed per-thread term lists, parallel over rows)
+__device__ __noinline__ void row_products(const int4* __restrict__ rterm, int rlen) {
   Lds& S = SH;
-  const Layout& L = S.L;
   const MemberMem& M = S.M;
-  const double* p = S.p;
-  const int N = L.N, lane = threadIdx.x, NT = blockDim.x;
-  (void)p; (void)N; (void)lane; (void)NT;
-  {   // ds = J_d dx + (g - s) for every stage inequality row (flat per-thread term lists, parallel over rows)
-    const double* __restrict__ Jn = M.J; const double* __restrict__ dxv = M.dx;
-    double acc = 0.0;
-    const int e1 = rstart[lane + 1];
+  const int tid = threadIdx.x, NT = blockDim.x;
+  const double* __restrict__ Jn = M.J; const double* __restrict__ dxv = M.dx;
+  const double* __restrict__ gv = M.g; const double* __restrict__ sv = M.s; double* __restrict__ dsv = M.ds;
+  double acc = 0.0;
 #pragma unroll 4
-    for (int e = rstart[lane]; e < e1; ++e) {
-      const int4 t = rterm[e];
-      acc += Jn[t.x] * dxv[t.y];
-      if (t.z >= 0) { M.ds[t.z] = acc + (M.g[t.z] - M.s[t.z]); acc = 0.0; }
-    }
+  for (int j = 0; j < rlen; ++j) {
+    const int4 t = rterm[(size_t)j * NT + tid];
+    const double v = Jn[t.x] * dxv[t.y];
+    acc += t.w ? v : 0.0;
+    if (t.z >= 0) { dsv[t.z] = acc + (gv[t.z] - sv[t.z]); acc = 0.0; }
   }
   __syncthreads();
 }
@@ -455,6 +445,11 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
   const MemberMem M = carve(L, A.ws + (size_t)m * A.ws_stride);
   Lds& S = SH;
   const double INF = INFINITY;
+  // the workspace arrays never overlap: tell the compiler so that the row passes can batch their loads
+  const double* __restrict__ r_lb = M.lb; const double* __restrict__ r_ub = M.ub;
+  double* __restrict__ r_g = M.g; double* __restrict__ r_gt = M.gt; double* __restrict__ r_s = M.s; double* __restrict__ r_ds = M.ds;
+  double* __restrict__ r_zL = M.zL; double* __restrict__ r_zU = M.zU; double* __restrict__ r_dzL = M.dzL; double* __restrict__ r_dzU = M.dzU;
+  double* __restrict__ r_y = M.y; double* __restrict__ r_yn = M.yn; double* __restrict__ r_sig = M.sig; double* __restrict__ r_rho = M.rho;
   S.M = M; S.L = L; S.p = p; S.tab = A.tab; S.stage_tab = A.stage_tab; S.prof_on = A.prof != nullptr;
   if (lane < 16) S.prof[lane] = 0.0;
   __syncthreads();
@@ -503,13 +498,14 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
     // ---------------------------------------------------------------- optimality error (unscaled)
     double du = 0.0, pr = 0.0, co = 0.0;
     for (int i = lane + 12; i < nx; i += NT) du = fmax(du, fabs(M.gx[i]));
+#pragma unroll 2
     for (int r = lane + 12; r < ng; r += NT) {
-      const double lb = M.lb[r], ub = M.ub[r], g = M.g[r];
+      const double lb = r_lb[r], ub = r_ub[r], g = r_g[r];
       if (lb == ub) { pr = fmax(pr, fabs(g - lb)); continue; }
-      const double s = M.s[r];
+      const double s = r_s[r];
       pr = fmax(pr, fabs(g - s));
-      if (lb > -INF) co = fmax(co, (s - lb) * M.zL[r]);
-      if (ub < INF) co = fmax(co, (ub - s) * M.zU[r]);
+      if (lb > -INF) co = fmax(co, (s - lb) * r_zL[r]);
+      if (ub < INF) co = fmax(co, (ub - s) * r_zU[r]);
     }
     { double v[3] = {du, pr, co}; const int op[3] = {RMAX, RMAX, RMAX}; block_reduce<3>(v, op, S.red); du = v[0]; pr = v[1]; co = v[2]; }
     e_pr = pr; e_du = du; e_co = co;
@@ -528,12 +524,13 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
     // ---------------------------------------------------------------- barrier parameter (monotone)
     for (;;) {
       double cm = 0.0;
-      for (int r = lane + 12; r < ng; r += NT) {
-        const double lb = M.lb[r], ub = M.ub[r];
+  #pragma unroll 2
+    for (int r = lane + 12; r < ng; r += NT) {
+        const double lb = r_lb[r], ub = r_ub[r];
         if (lb == ub) continue;
-        const double s = M.s[r];
-        if (lb > -INF) cm = fmax(cm, fabs((s - lb) * M.zL[r] - mu));
-        if (ub < INF) cm = fmax(cm, fabs((ub - s) * M.zU[r] - mu));
+        const double s = r_s[r];
+        if (lb > -INF) cm = fmax(cm, fabs((s - lb) * r_zL[r] - mu));
+        if (ub < INF) cm = fmax(cm, fabs((ub - s) * r_zU[r] - mu));
       }
       cm = block_reduce1(cm, RMAX, S.red);
       if (fmax(du, fmax(pr, cm)) <= o.kappa_eps * mu && mu > o.tol / 10.0) {
@@ -544,20 +541,21 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
     const double tau = fmax(0.99, 1.0 - mu);
     PROF_ADD(PH_ERR, tp);
     // ---------------------------------------------------------------- Sigma, rho per inequality row
+#pragma unroll 2
     for (int r = lane; r < ng; r += NT) {
-      const double lb = M.lb[r], ub = M.ub[r];
+      const double lb = r_lb[r], ub = r_ub[r];
       double sg = 0.0, rh = 0.0;
       if (r >= 12 && lb != ub) {
-        const double s = M.s[r];
-        if (lb > -INF) { const double d = s - lb; sg += M.zL[r] / d; rh -= mu / d; }
-        if (ub < INF) { const double d = ub - s; sg += M.zU[r] / d; rh += mu / d; }
-        rh += sg * (M.g[r] - s);
+        const double s = r_s[r];
+        if (lb > -INF) { const double d = s - lb; sg += r_zL[r] / d; rh -= mu / d; }
+        if (ub < INF) { const double d = ub - s; sg += r_zU[r] / d; rh += mu / d; }
+        rh += sg * (r_g[r] - s);
       }
-      M.sig[r] = sg; M.rho[r] = rh;
+      r_sig[r] = sg; r_rho[r] = rh;
     }
     __syncthreads();
 
-    condense(A.cterm, A.cstart);
+    condense(A.cterm, A.clen);
     PROF_ADD(PH_SIGRHO, tp);
     // ================================================================ Riccati factorisation with inertia correction
     // IPOPT's inertia-correction schedule (delta_w = 0 first, then max(1e-20, delta_last/3), then x8 / x100),
@@ -581,34 +579,35 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
     PROF_ADD(PH_BACK, tp);
 
     forward_pass();
-    row_products(A.rterm, A.rstart);
+    row_products(A.rterm, A.rlen);
 
     PROF_ADD(PH_FWD, tp);
     // ================================================================ dual steps, step bounds, merit data
     double a_pr = 1.0, a_du = 1.0, th0 = 0.0, bar = 0.0, dphi = 0.0;
+#pragma unroll 2
     for (int r = lane + 12; r < ng; r += NT) {
-      const double lb = M.lb[r], ub = M.ub[r], g = M.g[r];
+      const double lb = r_lb[r], ub = r_ub[r], g = r_g[r];
       if (lb == ub) { th0 += fabs(g - lb); continue; }
-      const double s = M.s[r], ds = M.ds[r];
+      const double s = r_s[r], ds = r_ds[r];
       th0 += fabs(g - s);
-      double yn = M.sig[r] * ds;
+      double yn = r_sig[r] * ds;
       if (lb > -INF) {
-        const double d = s - lb, zl = M.zL[r];
+        const double d = s - lb, zl = r_zL[r];
         const double dz = mu / d - zl - zl / d * ds;
-        M.dzL[r] = dz; yn -= mu / d;
+        r_dzL[r] = dz; yn -= mu / d;
         if (ds < 0.0) a_pr = fmin(a_pr, -tau * d / ds);
         if (dz < 0.0) a_du = fmin(a_du, -tau * zl / dz);
         bar -= log(d); dphi -= mu * ds / d;
-      } else M.dzL[r] = 0.0;
+      } else r_dzL[r] = 0.0;
       if (ub < INF) {
-        const double d = ub - s, zu = M.zU[r];
+        const double d = ub - s, zu = r_zU[r];
         const double dz = mu / d - zu + zu / d * ds;
-        M.dzU[r] = dz; yn += mu / d;
+        r_dzU[r] = dz; yn += mu / d;
         if (ds > 0.0) a_pr = fmin(a_pr, tau * d / ds);
         if (dz < 0.0) a_du = fmin(a_du, -tau * zu / dz);
         bar -= log(d); dphi += mu * ds / d;
-      } else M.dzU[r] = 0.0;
-      M.yn[r] = yn;
+      } else r_dzU[r] = 0.0;
+      r_yn[r] = yn;
     }
     double f0 = 0.0;
     if (lane < 12) {
@@ -632,10 +631,11 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
       member_eval_g(L, M.xt, p, M.gt);
       __syncthreads();
       double tht = 0.0, bt = 0.0, ft = 0.0;
-      for (int r = lane + 12; r < ng; r += NT) {
-        const double lb = M.lb[r], ub = M.ub[r], g = M.gt[r];
+  #pragma unroll 2
+    for (int r = lane + 12; r < ng; r += NT) {
+        const double lb = r_lb[r], ub = r_ub[r], g = r_gt[r];
         if (lb == ub) { tht += fabs(g - lb); continue; }
-        const double s = M.s[r] + alpha * M.ds[r];
+        const double s = r_s[r] + alpha * r_ds[r];
         tht += fabs(g - s);
         if (lb > -INF) bt -= log(s - lb);
         if (ub < INF) bt -= log(ub - s);
@@ -677,16 +677,17 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
     PROF_ADD(PH_LS, tp);
     // ================================================================ accept the trial point
     for (int i = lane; i < nx; i += NT) M.x[i] = M.xt[i];
+#pragma unroll 2
     for (int r = lane; r < ng; r += NT) {
-      const double lb = M.lb[r], ub = M.ub[r];
-      M.g[r] = M.gt[r];
+      const double lb = r_lb[r], ub = r_ub[r];
+      r_g[r] = r_gt[r];
       if (r < 12) continue;
-      if (lb == ub) { M.y[r] += alpha * (M.yn[r] - M.y[r]); continue; }
-      const double s = M.s[r] + alpha * M.ds[r];
+      if (lb == ub) { r_y[r] += alpha * (r_yn[r] - r_y[r]); continue; }
+      const double s = r_s[r] + alpha * r_ds[r];
       double zl = 0.0, zu = 0.0;
-      if (lb > -INF) { const double d = s - lb; zl = M.zL[r] + a_du * M.dzL[r]; zl = fmin(fmax(zl, mu / (1e10 * d)), 1e10 * mu / d); }
-      if (ub < INF) { const double d = ub - s; zu = M.zU[r] + a_du * M.dzU[r]; zu = fmin(fmax(zu, mu / (1e10 * d)), 1e10 * mu / d); }
-      M.s[r] = s; M.zL[r] = zl; M.zU[r] = zu; M.y[r] = zu - zl;
+      if (lb > -INF) { const double d = s - lb; zl = r_zL[r] + a_du * r_dzL[r]; zl = fmin(fmax(zl, mu / (1e10 * d)), 1e10 * mu / d); }
+      if (ub < INF) { const double d = ub - s; zu = r_zU[r] + a_du * r_dzU[r]; zu = fmin(fmax(zu, mu / (1e10 * d)), 1e10 * mu / d); }
+      r_s[r] = s; r_zL[r] = zl; r_zU[r] = zu; r_y[r] = zu - zl;
     }
     __syncthreads();
     PROF_ADD(PH_ACCEPT, tp);
