@@ -31,6 +31,7 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
 struct landing_ctx {
   Layout L;
   int device;
+  int* d_edge_map = nullptr;
   landing::SolverWorkspace ws;
   double* d_prof = nullptr;
 };
@@ -156,6 +157,28 @@ landing_ctx* landing_create(int N, int device, const landing_form* form) {
   landing_ctx* c = new landing_ctx();
   c->L = landing::make_layout(N);
   c->device = device;
+  {  // positions of the U_k Jacobian entries of stages 0 / N-1 inside the uniform (middle-stage) emission sequence
+    struct RecCodes { std::vector<int>* v; void col() {} void put(int r, double) { v->push_back(r); } };
+    std::vector<int> cx, cu;
+    srbm::StageVars z; srbm::StageParams P;
+    memset(&z, 0, sizeof(z)); memset(&P, 0, sizeof(P)); P.mass = 1.0;
+    const double fzp[4] = {0, 0, 0, 0};
+    RecCodes ex{&cx}, eu{&cu};
+    srbm::stage_jac(z, P, false, false, fzp, ex, eu);
+    std::vector<int> map(456, -1);
+    int nf = 0, nl = 0;
+    for (size_t i = 0; i < cu.size() && i < 228; ++i) {
+      const int r = cu[i];
+      const bool prev_entry = r <= -100;                                   // no-slip rows of stage k-1: absent for stage 0
+      const bool slip_entry = r >= 16 && r < 64 && ((r - 16) % 12) >= 2 && ((r - 16) % 12) < 8;   // own no-slip rows: absent for stage N-1
+      if (!prev_entry) map[i] = nf++;
+      if (!slip_entry) map[228 + i] = nl++;
+    }
+    if (cu.size() != 228 || nf != 204 || nl != 180 || hipMalloc((void**)&c->d_edge_map, 456 * sizeof(int)) != hipSuccess ||
+        hipMemcpy(c->d_edge_map, map.data(), 456 * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) {
+      fail(LANDING_E_HIP, "landing_create: edge map setup failed"); delete c; return nullptr;
+    }
+  }
   if (form) {
     for (int i = 0; i < 3; ++i) c->L.kin_box[i] = form->kin_box[i];
     c->L.kin_z_off = form->kin_z_off; c->L.comp_eps = form->comp_eps; c->L.slip_eps = form->slip_eps;
@@ -167,6 +190,7 @@ void landing_destroy(landing_ctx* ctx) {
   if (!ctx) return;
   hipSetDevice(ctx->device);
   ctx->ws.release();
+  if (ctx->d_edge_map) (void)hipFree(ctx->d_edge_map);
   delete ctx;
 }
 
@@ -178,8 +202,11 @@ int landing_eval_batch(landing_ctx* ctx, int B, const double* d_x, const double*
   if ((d_hess || d_ggx || d_ggp) && !d_lam_g) return fail(LANDING_E_ARG, "landing_eval_batch: lam_g required for hess/grad_gamma");
   if (B == 0) return 0;
   HIP_TRY(hipSetDevice(ctx->device));
-  landing::EvalArgs A{d_x, d_p, d_lam_f, d_lam_g, d_f, d_g, d_grad_f, d_jac, d_hess, d_ggx, d_ggp};
-  hipLaunchKernelGGL(landing::landing_sweep_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, ctx->L, B, A);
+  landing::EvalArgs A{d_x, d_p, d_lam_f, d_lam_g, d_f, d_g, d_grad_f, d_jac, d_hess, d_ggx, d_ggp, ctx->d_edge_map};
+  if (ctx->L.N < 3) return fail(LANDING_E_ARG, "landing_eval_batch: N >= 3 required");
+  if (d_jac) hipLaunchKernelGGL(landing::landing_sweep_kernel<0>, dim3(B), dim3(64), 0, (hipStream_t)stream, ctx->L, B, A);
+  if (d_hess) hipLaunchKernelGGL(landing::landing_sweep_kernel<1>, dim3(B), dim3(64), 0, (hipStream_t)stream, ctx->L, B, A);
+  hipLaunchKernelGGL(landing::landing_sweep_misc_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, ctx->L, B, A);
   HIP_TRY(hipGetLastError());
   return 0;
 }

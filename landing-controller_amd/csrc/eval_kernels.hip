@@ -16,6 +16,7 @@ namespace landing {
 struct EvalArgs {
   const double* x; const double* p; const double* lam_f; const double* lam_g;
   double* f; double* g; double* grad_f; double* jac; double* hess; double* ggx; double* ggp;
+  const int* edge_map;   // [0..227] U-part Jacobian positions of stage 0, [228..455] of stage N-1 (-1 = entry absent)
 };
 
 __host__ __device__ __forceinline__ int dyn_row_of_state(int i) {  // state index -> dynamics row (pos,rpy,v,omega)
@@ -57,8 +58,98 @@ struct DotLam {
   __device__ __forceinline__ void finish() { if (open) *out++ = acc; open = false; }
 };
 
-// name is reported by landing_kernel_name_sweep() for profilers
+// Sequential store of one CCS segment per lane, coalesced through a 64x16 LDS tile: every lane of the wavefront
+// appends its value to its own tile row; every 16 values the wave writes the tile out row by row, so that one store
+// instruction covers four 128-byte runs instead of 64 scattered 8-byte words (the direct per-lane stores are bound
+// by the L2 request rate, not by bytes: profiles/README.md).  All lanes emit the SAME sequence -- stages 0 and N-1,
+// whose segments lack the entries of the neighbouring stage's no-slip rows, emit placeholders there and the
+// write-out compacts them through `map` (position in the uniform sequence -> position in the segment, -1 = absent).
+constexpr int TILE_LD = 17;
+// write-out of one tile (kept out of line: inlined 25 times per stage it pushes the emission code into scratch spills)
+template <int KIND>
+__device__ __noinline__ void tile_flush(const double* tile, double* gbase, const Layout* L, const int* map, int k0, int nrow, int cnt, int n) {
+  __builtin_amdgcn_wave_barrier();
+  const int lane = threadIdx.x & 63, c = lane & 15, N = L->N;
+  if (c < n) {
+    for (int row = lane >> 4; row < nrow; row += 4) {
+      const int k = k0 + row;
+      int pos = cnt - n + c;
+      int seg;
+      if (KIND == 0) seg = L->jx(k);
+      else if (KIND == 1) { seg = L->ju(k); if (k == 0) pos = map[pos]; else if (k == N - 1) pos = map[228 + pos]; }
+      else if (KIND == 2) seg = L->hx(k);
+      else { seg = L->hu(k); if (k == 0) pos = (pos < 72) ? ((pos % 6 == 4) ? -1 : pos - (pos / 6) - (pos % 6 > 4 ? 1 : 0)) : pos - 12; }
+      if (pos >= 0) gbase[seg + pos] = tile[row * TILE_LD + c];
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+template <int KIND>   // 0: Jacobian X_k columns, 1: Jacobian U_k columns, 2: Hessian X_k columns, 3: Hessian U_k columns
+struct TileStore {
+  double* tile;          // LDS, 64 x TILE_LD
+  double* gbase;         // member's J or H array
+  const Layout* L;
+  const int* map;        // edge_map (KIND 1) or nullptr
+  int k0, nrow, cnt;     // stage of tile row 0, rows really written
+  __device__ __forceinline__ void col() {}
+  __device__ __forceinline__ void put(int, double v) { put(v); }
+  __device__ __forceinline__ void put(double v) {
+    tile[(threadIdx.x & 63) * TILE_LD + (cnt & 15)] = v;
+    ++cnt;
+    if ((cnt & 15) == 0) tile_flush<KIND>(tile, gbase, L, map, k0, nrow, cnt, 16);
+  }
+  __device__ __forceinline__ void finish() { if (cnt & 15) tile_flush<KIND>(tile, gbase, L, map, k0, nrow, cnt, cnt & 15); }
+};
+
+// Jacobian (FAM 0) or Hessian (FAM 1) nonzeros of every stage of one member: one wavefront per member, lane = stage,
+// every lane runs the middle-stage instruction stream (first = last = false) and the tile write-out drops the
+// placeholders of the two edge stages.  Reported by landing_kernel_name_sweep() for profilers.
+template <int FAM>
 __global__ void __launch_bounds__(64) landing_sweep_kernel(Layout L, int B, EvalArgs A) {
+  const int m = blockIdx.x;
+  if (m >= B) return;
+  const int N = L.N, ln = threadIdx.x;
+  const double* x = A.x + (size_t)m * L.nx;
+  const double* p = A.p + (size_t)m * L.np;
+  const double* lam_g = A.lam_g ? A.lam_g + (size_t)m * L.ng : nullptr;
+  __shared__ double tileX[64 * TILE_LD], tileU[64 * TILE_LD];
+  for (int k0 = 0; k0 < N; k0 += 64) {
+    const int rows_here = N - k0 < 64 ? N - k0 : 64;
+    int k = k0 + ln;
+    if (k > N - 1) k = N - 1;                       // idle lanes replay the last stage (never written out)
+    srbm::StageVars z; srbm::StageParams P;
+    load_stage(L, x, p, k, z, P);
+    if (FAM == 0) {
+      double fz_prev[4] = {0, 0, 0, 0};
+      if (k > 0) { const double* Up = x + L.x_U(k - 1); for (int l = 0; l < 4; ++l) fz_prev[l] = Up[12 + 3 * l + 2]; }
+      double* J = A.jac + (size_t)m * L.nnz_jac;
+      TileStore<0> ex{tileX, J, &L, nullptr, k0, rows_here, 0};
+      TileStore<1> eu{tileU, J, &L, A.edge_map, k0, rows_here, 0};
+      srbm::stage_jac(z, P, false, false, fz_prev, ex, eu);
+      ex.finish(); eu.finish();
+    } else {
+      double* H = A.hess + (size_t)m * L.nnz_hess;
+      double lps[12];
+      for (int i = 0; i < 12; ++i) lps[i] = 0.0;
+      if (k > 0) {
+        const double* lp = lam_g + L.g_stage(k - 1);
+        for (int l = 0; l < 4; ++l) for (int i = 0; i < 3; ++i) lps[3 * l + i] = lp[16 + 12 * l + 2 + i] + lp[16 + 12 * l + 5 + i];
+      }
+      LamStage lam{lam_g + L.g_stage(k)};
+      TileStore<2> hx{tileX, H, &L, nullptr, k0, rows_here, 0};
+      TileStore<3> hu{tileU, H, &L, nullptr, k0, rows_here, 0};
+      // the last stage reads its multipliers through its own row numbering (80 rows); the emitted sequence is the same
+      // for every lane (runtime `last` only selects row offsets), so the tile write-outs stay convergent
+      srbm::stage_hess(z, P, false, k == N - 1, lam, lps, hx, hu);
+      hx.finish(); hu.finish();
+    }
+  }
+}
+
+// name is reported by landing_kernel_name_sweep() for profilers
+// Everything else of the function layer (direct stores): f, grad_f, boundary rows, g of every stage, the X_N blocks
+// of J and H, grad_gamma_x / grad_gamma_p.  `A.jac` / `A.hess` stage segments are written by the kernels above.
+__global__ void __launch_bounds__(64) landing_sweep_misc_kernel(Layout L, int B, EvalArgs A) {
   const int m = blockIdx.x;
   if (m >= B) return;
   const int N = L.N;
@@ -126,23 +217,6 @@ __global__ void __launch_bounds__(64) landing_sweep_kernel(Layout L, int B, Eval
     }
     double fz_prev[4] = {0, 0, 0, 0};
     if (!first) { const double* Up = x + L.x_U(k - 1); for (int l = 0; l < 4; ++l) fz_prev[l] = Up[12 + 3 * l + 2]; }
-    if (A.jac) {
-      double* J = A.jac + (size_t)m * L.nnz_jac;
-      SeqStoreJ ex{J + L.jx(k)}, eu{J + L.ju(k)};
-      srbm::stage_jac(z, P, first, last, fz_prev, ex, eu);
-    }
-    if (A.hess && lam_g) {
-      double* H = A.hess + (size_t)m * L.nnz_hess;
-      double lps[12];
-      for (int i = 0; i < 12; ++i) lps[i] = 0.0;
-      if (!first) {
-        const double* lp = lam_g + L.g_stage(k - 1);
-        for (int l = 0; l < 4; ++l) for (int i = 0; i < 3; ++i) lps[3 * l + i] = lp[16 + 12 * l + 2 + i] + lp[16 + 12 * l + 5 + i];
-      }
-      LamStage lam{lam_g + L.g_stage(k)};
-      SeqStoreH hx{H + L.hx(k)}, hu{H + L.hu(k)};
-      srbm::stage_hess(z, P, first, last, lam, lps, hx, hu);
-    }
     if (A.ggx && lam_g) {
       double* gx = A.ggx + (size_t)m * L.nx;
       const double* lprev = first ? lam_g : lam_g + L.g_stage(k - 1);

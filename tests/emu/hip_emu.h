@@ -78,6 +78,7 @@ inline int __builtin_amdgcn_readlane(int v, int lane) {
   hip_emu::wave_barrier();
   return buf[p][(threadIdx.x & ~63u) + (unsigned)lane];
 }
+inline void __builtin_amdgcn_wave_barrier() { hip_emu::wave_barrier(); }
 inline int __double2hiint(double d) { long long b; std::memcpy(&b, &d, 8); return (int)(b >> 32); }
 inline int __double2loint(double d) { long long b; std::memcpy(&b, &d, 8); return (int)(b & 0xffffffffLL); }
 inline double __hiloint2double(int hi, int lo) { long long b = ((long long)hi << 32) | (unsigned int)lo; double d; std::memcpy(&d, &b, 8); return d; }

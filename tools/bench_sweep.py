@@ -6,10 +6,10 @@ sys.path.insert(0, ROOT)
 import numpy as np, torch
 
 ap = argparse.ArgumentParser(); ap.add_argument("--B", type=int, default=1024); ap.add_argument("--N", type=int, default=40)
-ap.add_argument("--steps", type=int, default=50); ap.add_argument("--warmup", type=int, default=5)
+ap.add_argument("--steps", type=int, default=50); ap.add_argument("--lib", default=None); ap.add_argument("--warmup", type=int, default=5)
 a = ap.parse_args()
 capi = importlib.import_module("landing-controller_amd.capi"); problem = importlib.import_module("landing-controller_amd.problem")
-L = capi.LandingLib(a.N, 0)
+L = capi.LandingLib(a.N, 0, lib_path=a.lib)
 nb = min(a.B, 256)
 P, X0, _, _ = problem.make_batch(nb, a.N, 0.6, seed=1)
 reps = (a.B + nb - 1) // nb
