@@ -73,6 +73,12 @@ typedef struct {
   double reset_du;       /* dual infeasibility above which slacks/multipliers/mu are re-initialised
                             at the current x (jammed iterate; IPOPT would enter restoration), 1e9  */
   int reserved[4];
+  double delta_init;     /* first trial regularisation when none was needed before (IPOPT first_hessian_perturbation, 1e-4) */
+  double delta_inc_first;/* growth factor while no regularised iteration happened yet (IPOPT 100; default 10)            */
+  double delta_inc;      /* growth factor afterwards (IPOPT 8; default 4: finer steps over-regularise less, tools/strag.py) */
+  double delta_dec;      /* first trial = delta_last * delta_dec (IPOPT 1/3)                                             */
+  double tau_min;        /* fraction-to-the-boundary floor (IPOPT 0.99; default 0.9)                                     */
+  double alpha_fallback; /* step taken (and filter restarted) when the line search finds no acceptable point (1e-2)      */
 } landing_solver_opts;
 
 /* status codes written per batch member by landing_solve_batch */

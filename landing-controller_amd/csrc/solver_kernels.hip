@@ -538,7 +538,7 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
         nfilt = 0;
       } else break;
     }
-    const double tau = fmax(0.99, 1.0 - mu);
+    const double tau = fmax(o.tau_min, 1.0 - mu);
     PROF_ADD(PH_ERR, tp);
     // ---------------------------------------------------------------- Sigma, rho per inequality row
 #pragma unroll 2
@@ -561,12 +561,12 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
     // IPOPT's inertia-correction schedule (delta_w = 0 first, then max(1e-20, delta_last/3), then x8 / x100),
     // except that an iteration following a regularised one starts from delta_last/3 directly when the
     // unregularised attempt failed twice in a row (saves one full factorisation in nonconvex phases)
-    double delta = (need_reg_streak >= 2 && delta_last > 0.0) ? fmax(1e-20, delta_last / 3.0) : 0.0;
+    double delta = (need_reg_streak >= 2 && delta_last > 0.0) ? fmax(1e-20, delta_last * o.delta_dec) : 0.0;
     bool fact_ok = false;
     for (int attempt = 0; attempt < 60 && !fact_ok; ++attempt) {
       if (attempt > 0) {
-        if (delta == 0.0) delta = (delta_last == 0.0) ? 1e-4 : fmax(1e-20, delta_last / 3.0);
-        else delta *= (delta_last == 0.0 ? 100.0 : 8.0);
+        if (delta == 0.0) delta = (delta_last == 0.0) ? o.delta_init : fmax(1e-20, delta_last * o.delta_dec);
+        else delta *= (delta_last == 0.0 ? o.delta_inc_first : o.delta_inc);
         if (delta > 1e40) break;
       }
       if (lane == 0) S.prof[PH_NFACT] += 1.0;
@@ -659,7 +659,7 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
     if (!accepted) {
       // no acceptable step: take a short step along the Newton direction and restart the filter
       nfilt = 0;
-      alpha = fmin(a_pr, 1e-2);
+      alpha = fmin(a_pr, o.alpha_fallback);
       for (int i = lane; i < nx; i += NT) M.xt[i] = M.x[i] + alpha * M.dx[i];
       __syncthreads();
       member_eval_g(L, M.xt, p, M.gt);

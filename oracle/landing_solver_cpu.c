@@ -25,11 +25,13 @@
 typedef struct {
   double tol; int max_iter; double mu_init, bound_push, bound_frac, kappa_eps, kappa_mu, theta_mu;
   int max_resets; double reset_du;
+  double delta_init, delta_inc_first, delta_inc, delta_dec, tau_min, alpha_fallback;
 } lo_solver_opts;
 
 void lo_solver_opts_default(lo_solver_opts* o) {
   o->tol = 1e-6; o->max_iter = 3000; o->mu_init = 0.1; o->bound_push = 0.5; o->bound_frac = 0.5;
   o->kappa_eps = 10.0; o->kappa_mu = 0.2; o->theta_mu = 1.5; o->max_resets = 8; o->reset_du = 1e9;
+  o->delta_init = 1e-4; o->delta_inc_first = 10.0; o->delta_inc = 4.0; o->delta_dec = 1.0 / 3.0; o->tau_min = 0.9; o->alpha_fallback = 1e-2;
 }
 
 #define NW 48
@@ -224,7 +226,7 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
       if (fmax(du, fmax(pr, cm)) <= op->kappa_eps * mu && mu > op->tol / 10.0) { mu = fmax(op->tol / 10.0, fmin(op->kappa_mu * mu, pow(mu, op->theta_mu))); nfilt = 0; }
       else break;
     }
-    tau = fmax(0.99, 1.0 - mu);
+    tau = fmax(op->tau_min, 1.0 - mu);
     for (r = 0; r < ng; ++r) {
       const double lb = W->lb[r], ub = W->ub[r]; double sg = 0, rh = 0;
       if (r >= 12 && lb != ub) {
@@ -250,11 +252,11 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
       for (q = 0; q < 12; ++q) { for (a = 0; a < 36; ++a) Ah[ROW2STATE[q] * 36 + a] = -J[q * 60 + a]; W->bv[k * 12 + ROW2STATE[q]] = -W->g[g0 + q]; }
     }
     /* factorisation with inertia correction (same schedule as the HIP kernel) */
-    delta = (streak >= 2 && delta_last > 0.0) ? fmax(1e-20, delta_last / 3.0) : 0.0;
+    delta = (streak >= 2 && delta_last > 0.0) ? fmax(1e-20, delta_last * op->delta_dec) : 0.0;
     for (attempt = 0; attempt < 60 && !fact_ok; ++attempt) {
       if (attempt > 0) {
-        if (delta == 0.0) delta = (delta_last == 0.0) ? 1e-4 : fmax(1e-20, delta_last / 3.0);
-        else delta *= (delta_last == 0.0 ? 100.0 : 8.0);
+        if (delta == 0.0) delta = (delta_last == 0.0) ? op->delta_init : fmax(1e-20, delta_last * op->delta_dec);
+        else delta *= (delta_last == 0.0 ? op->delta_inc_first : op->delta_inc);
         if (delta > 1e40) break;
       }
       counters[0]++;
@@ -339,7 +341,7 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
       alpha *= 0.5;
     }
     if (!accepted) {
-      nfilt = 0; alpha = fmin(a_pr, 1e-2);
+      nfilt = 0; alpha = fmin(a_pr, op->alpha_fallback);
       for (i = 0; i < nx; ++i) W->xt[i] = W->x[i] + alpha * W->dx[i];
       eval_g(F, W->xt, p, W->gt);
     } else if (!armijo) {
