@@ -199,9 +199,9 @@ void landing_destroy(landing_ctx* ctx) {
 int landing_eval_batch(landing_ctx* ctx, int B, const double* d_x, const double* d_p, const double* d_lam_f,
                        const double* d_lam_g, double* d_f, double* d_g, double* d_grad_f, double* d_jac,
                        double* d_hess, double* d_ggx, double* d_ggp, void* stream) {
+  if (ctx && B == 0) return 0;          // empty batch: nothing to do
   if (!ctx || B < 0 || !d_x || !d_p) return fail(LANDING_E_ARG, "landing_eval_batch: bad argument");
   if ((d_hess || d_ggx || d_ggp) && !d_lam_g) return fail(LANDING_E_ARG, "landing_eval_batch: lam_g required for hess/grad_gamma");
-  if (B == 0) return 0;
   HIP_TRY(hipSetDevice(ctx->device));
   landing::EvalArgs A{d_x, d_p, d_lam_f, d_lam_g, d_f, d_g, d_grad_f, d_jac, d_hess, d_ggx, d_ggp, ctx->d_edge_map};
   if (ctx->L.N < 3) return fail(LANDING_E_ARG, "landing_eval_batch: N >= 3 required");
@@ -254,8 +254,8 @@ int landing_eval_batch_host(landing_ctx* ctx, int B, const double* x, const doub
 }
 
 int landing_bounds_batch(landing_ctx* ctx, int B, const double* d_p, double* d_lbg, double* d_ubg, void* stream) {
+  if (ctx && B == 0) return 0;
   if (!ctx || B < 0 || !d_p || !d_lbg || !d_ubg) return fail(LANDING_E_ARG, "landing_bounds_batch: bad argument");
-  if (B == 0) return 0;
   HIP_TRY(hipSetDevice(ctx->device));
   const size_t n = (size_t)B * ctx->L.ng;
   hipLaunchKernelGGL(landing::landing_bounds_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ctx->L, B, d_p, d_lbg, d_ubg);

@@ -72,3 +72,62 @@ def test_warm_start_converges_faster(libs):
     warm = L.solve_host(P, cold["x"], o)
     ok = (cold["status"] == 0) & (warm["status"] == 0)
     assert ok.sum() >= 3 and warm["iters"][ok].sum() < cold["iters"][ok].sum()
+
+
+def test_solver_other_horizons_and_limits(oracle_mod):
+    """N is a runtime parameter of the solver too (N <= 64: one lane per stage in the derivative phases)."""
+    capi = lc("capi")
+    for N in (16, 30):
+        O = oracle_mod.Oracle(N)
+        L = capi.LandingLib(N, device=0)
+        P, X0, _, _ = lc("problem").make_batch(6, N, 0.6, seed=4)
+        r = L.solve_host(P, X0)
+        ok = r["status"] == 0
+        assert ok.sum() >= 4
+        for b in np.nonzero(ok)[0]:
+            assert O.kkt(r["x"][b], P[b], r["lam_g"][b]).max() <= KKT_TOL * 1.0001
+        L.close()
+    L = capi.LandingLib(80, device=0)
+    P, X0, _, _ = lc("problem").make_batch(1, 80, 0.6, seed=4)
+    with pytest.raises(RuntimeError, match="N <= 64"):
+        L.solve_host(P, X0)
+    L.close()
+
+
+def test_solver_is_deterministic_and_batch_independent(libs):
+    """same member alone or inside a batch, run twice: identical bits (no atomics, fixed summation order)"""
+    N = 20
+    P, X0, _, _ = lc("problem").make_batch(5, N, 0.6, seed=8)
+    a = libs[N].solve_host(P, X0)
+    b = libs[N].solve_host(P, X0)
+    c = libs[N].solve_host(P[2:3], X0[2:3])
+    assert np.array_equal(a["x"], b["x"]) and np.array_equal(a["iters"], b["iters"])
+    assert np.array_equal(a["x"][2], c["x"][0]) and a["iters"][2] == c["iters"][0]
+
+
+def test_solver_full_size_batch_properties(libs, oracle_mod):
+    """BASELINE configs[1] size (N=40, B=1024), device-pointer entry point: >= 93 % converge within 300 iterations,
+    every converged member satisfies the reported KKT bound, initial state rows are met exactly, a sample is
+    re-certified with the oracle's functions."""
+    import torch
+    N, B = 40, 1024
+    L = libs[N]
+    O = oracle_mod.Oracle(N)
+    P, X0, _, _ = lc("problem").make_batch(B, N, 0.6, seed=20211)
+    dev = "cuda"
+    dP, dX0 = torch.tensor(P, device=dev), torch.tensor(X0, device=dev)
+    mk = lambda *s, dt=torch.float64: torch.empty(*s, device=dev, dtype=dt)
+    x, f, lam, kkt = mk(B, L.nx), mk(B), mk(B, L.ng), mk(B, 3)
+    st, it = mk(B, dt=torch.int32), mk(B, dt=torch.int32)
+    o = L.default_opts(); o.max_iter = 300
+    L.solve_device(B, dP.data_ptr(), dX0.data_ptr(), o, x.data_ptr(), f.data_ptr(), lam.data_ptr(), st.data_ptr(), it.data_ptr(), kkt.data_ptr(),
+                   torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    sth, kh, xh, lh = st.cpu().numpy(), kkt.cpu().numpy(), x.cpu().numpy(), lam.cpu().numpy()
+    ok = sth == 0
+    assert ok.mean() >= 0.93
+    assert kh[ok].max() <= KKT_TOL * 1.0001
+    po = O.param_offsets()
+    assert np.array_equal(xh[:, :6], P[:, po["q_init"]:po["q_init"] + 6]) and np.array_equal(xh[:, 6:12], P[:, po["qd_init"]:po["qd_init"] + 6])
+    for b in np.nonzero(ok)[0][::97]:
+        assert O.kkt(xh[b], P[b], lh[b]).max() <= KKT_TOL * 1.0001

@@ -149,3 +149,40 @@ def test_full_size_batch_properties(libs):
         assert np.max(np.abs(J @ dxn[b] - fd_g[b])) < 1e-5 * max(1, np.max(np.abs(fd_g[b])))
         assert np.max(np.abs(gx_h[b] - (gf_h[b] + J.T @ lam[b]))) < 1e-9
         assert np.max(np.abs(H @ dxn[b] - fd_gx[b])) < 1e-4 * max(1, np.max(np.abs(fd_gx[b])))
+
+
+@pytest.mark.parametrize("N", [3, 7, 33, 64, 100])
+def test_sweep_other_horizon_lengths(oracle_mod, N):
+    """N is a runtime parameter here (the reference regenerates code per N: N=16/18/21/41/61 variants exist as
+    separate scripts): odd N, the smallest N, N=64 (one full wavefront of stages) and N>64 (stage chunks)."""
+    capi = lc("capi")
+    O = oracle_mod.Oracle(N)
+    L = capi.LandingLib(N, device=0)
+    assert all(np.array_equal(a, b) for a, b in zip(L.pattern_jac(), O.pattern_jac()))
+    assert all(np.array_equal(a, b) for a, b in zip(L.pattern_hess(), O.pattern_hess()))
+    rng = np.random.default_rng(N)
+    B = 3
+    x = rng.normal(size=(B, O.nx)) * 0.5; p = rng.uniform(0.5, 1.5, size=(B, O.np_))
+    lam = rng.normal(size=(B, O.ng)); lf = rng.uniform(0.5, 2, size=B)
+    _cmp(L.eval_host(x, p, lf, lam), O, x, p, lf, lam)
+    L.close()
+
+
+def test_empty_and_single_member_batches(libs):
+    """ragged / degenerate batch sizes: B=0 is a no-op, B=1 works, output subsets may be skipped (res[i]==NULL)"""
+    import torch
+    L = libs[20]
+    L.eval_device(0, 0, 0)                                   # empty batch: returns without touching memory
+    P, X0, _, _ = lc("problem").make_batch(1, 20, 0.6, seed=2)
+    out = L.eval_host(X0, P, want=("g",))
+    assert set(out) == {"g"} and np.all(np.isfinite(out["g"]))
+    with pytest.raises(RuntimeError):                        # hess without lam_g is an argument error, not a crash
+        L.eval_host(X0, P, want=("hess",))
+
+
+def test_bad_arguments_are_reported():
+    capi = lc("capi")
+    with pytest.raises(RuntimeError, match="N must be"):
+        capi.LandingLib(1, device=0)
+    with pytest.raises(RuntimeError, match="bad device"):
+        capi.LandingLib(20, device=99)
