@@ -118,6 +118,18 @@ struct Lds {
 // phase function (ds_* instructions instead of flat_*).
 __shared__ Lds SH;
 
+// fp64 matrix-core tile: D(16x16) = C + A(16 x 4KT) B(4KT x 16) with v_mfma_f64_16x16x4_f64.  Operand layout
+// (cdna_hip_programming.md section 3): lane l supplies A[i = l&15][k = l>>4] and B[k = l>>4][j = l&15]; the accumulator holds
+// D[row = (l>>4) + 4r][col = l&15], r = 0..3.  fa(i,k) / fb(k,j) fetch operands (LDS, zero outside the matrix).
+typedef double f64x4 __attribute__((vector_size(32)));
+template <int KT, class FA, class FB>
+__device__ __forceinline__ f64x4 mfma_tile(f64x4 c, FA fa, FB fb) {
+  const int l = threadIdx.x & 63, ij = l & 15, kq = l >> 4;
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt) c = __builtin_amdgcn_mfma_f64_16x16x4f64(fa(ij, kt * 4 + kq), fb(kt * 4 + kq, ij), c, 0, 0, 0);
+  return c;
+}
+
 // Broadcast of one lane's fp64 value to the whole wave through the scalar unit (v_readlane_b32 x2; `src` must be
 // wave-uniform -- it is a compile-time constant in the unrolled elimination below).
 __device__ __forceinline__ double lane_bcast(double v, int src) {
@@ -145,7 +157,9 @@ __device__ __forceinline__ void gauss_jordan_wave(const double* G, const double*
   for (int j = 0; j < NU; ++j) {
     const double d = lane_bcast(col[j], j);
     if (!(d > 0.0) || !(d < 1e300)) ok = false;        // wave-uniform; keep going (values are discarded)
-    const double inv = 1.0 / d;
+    double inv = __builtin_amdgcn_rcp(d);               // v_rcp_f64 + two Newton steps instead of the IEEE division
+    inv = fma(inv, fma(-d, inv, 1.0), inv);             // sequence: the reciprocal sits on the serial pivot chain
+    inv = fma(inv, fma(-d, inv, 1.0), inv);
     const double pj = col[j] * inv;
 #pragma unroll
     for (int i = 0; i < NU; ++i) {
@@ -178,13 +192,23 @@ __device__ __forceinline__ bool riccati_step(double* rec) {
   __syncthreads();
   if (!S.flag) return false;
   // P_k = G_ss - G_su K ; p_k = gamma_s - G_su kappa   (G_su(i,t) = G(24+t, i) by symmetry)
-  for (int e = tid; e < 24 * 24; e += NT) {
-    const int i = e / 24, j = e % 24;
-    double acc = S.G[i * GS + j];
+  {   // matrix cores: 2 x 2 tiles of 16 x 16 over the 24 x 24 block, K = NU
+    const int wave = tid >> 6, nwave = NT >> 6, l = tid & 63;
+    for (int t = wave; t < 4; t += nwave) {
+      const int mt = t >> 1, nt = t & 1;
+      const int c = nt * 16 + (l & 15);
+      f64x4 acc;
 #pragma unroll
-    for (int t = 0; t < NU; ++t) acc -= S.G[(24 + t) * GS + i] * Kl[t * 24 + j];
-    S.P[i * PS + j] = acc;
-    if (i < 12) rec[RIC_PX + i * 24 + j] = acc;
+      for (int r = 0; r < 4; ++r) { const int row = mt * 16 + (l >> 4) + 4 * r; acc[r] = (row < 24 && c < 24) ? S.G[row * GS + c] : 0.0; }
+      acc = mfma_tile<NU / 4>(acc,
+                              [&](int i, int k) { const int row = mt * 16 + i; return row < 24 ? -S.G[(24 + k) * GS + row] : 0.0; },
+                              [&](int k, int j) { const int cj = nt * 16 + j; return cj < 24 ? Kl[k * 24 + cj] : 0.0; });
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = mt * 16 + (l >> 4) + 4 * r;
+        if (row < 24 && c < 24) { S.P[row * PS + c] = acc[r]; if (row < 12) rec[RIC_PX + row * 24 + c] = acc[r]; }
+      }
+    }
   }
   for (int i = tid; i < 24; i += NT) {
     double acc = S.gam[i];
@@ -281,12 +305,19 @@ __device__ __noinline__ bool riccati_backward(double delta) {
     double* Y = S.A1;
     __syncthreads();
     PROF_ADD(PH_B_ASM, tb_);
-    for (int e = lane; e < nsn * 36; e += NT) {
-      const int i = e / 36, j = e % 36;
-      double acc = 0.0;
+    {   // Y = P(:,0:12) A^ on the matrix cores: (nsn/16 rounded up) x 3 tiles, K = 12, tiles dealt to the waves
+      const int wave = lane >> 6, nwave = NT >> 6, l = lane & 63;
+      const int MT = (nsn + 15) >> 4;
+      for (int t = wave; t < MT * 3; t += nwave) {
+        const int mt = t / 3, nt = t % 3;
+        f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+        acc = mfma_tile<3>(acc,
+                           [&](int i, int k) { const int r = mt * 16 + i; return r < nsn ? S.P[r * PS + k] : 0.0; },
+                           [&](int k, int j) { const int c = nt * 16 + j; return c < 36 ? S.Ah[k * YS + c] : 0.0; });
+        const int c = nt * 16 + (l & 15);
 #pragma unroll
-      for (int t = 0; t < 12; ++t) acc += S.P[i * PS + t] * S.Ah[t * YS + j];
-      Y[i * YS + j] = acc;
+        for (int r = 0; r < 4; ++r) { const int row = mt * 16 + (l >> 4) + 4 * r; if (row < nsn && c < 36) Y[row * YS + c] = acc[r]; }
+      }
     }
     for (int i = lane; i < nsn; i += NT) {
       double acc = S.pv[i];
@@ -296,12 +327,20 @@ __device__ __noinline__ bool riccati_backward(double delta) {
     }
     __syncthreads();
     // ---- G += T^T P T, gamma += T^T q
-    for (int e = lane; e < 36 * 36; e += NT) {
-      const int i = e / 36, j = e % 36;
-      double acc = 0.0;
+    {   // G(0:36,0:36) += A^T Y(0:12,:) on the matrix cores: 3 x 3 tiles, K = 12
+      const int wave = lane >> 6, nwave = NT >> 6, l = lane & 63;
+      for (int t = wave; t < 9; t += nwave) {
+        const int mt = t / 3, nt = t % 3;
+        const int c = nt * 16 + (l & 15);
+        f64x4 acc;
 #pragma unroll
-      for (int t = 0; t < 12; ++t) acc += S.Ah[t * YS + i] * Y[t * YS + j];
-      S.G[i * GS + j] += acc;
+        for (int r = 0; r < 4; ++r) { const int row = mt * 16 + (l >> 4) + 4 * r; acc[r] = (row < 36 && c < 36) ? S.G[row * GS + c] : 0.0; }
+        acc = mfma_tile<3>(acc,
+                           [&](int i, int k) { const int ci = mt * 16 + i; return ci < 36 ? S.Ah[k * YS + ci] : 0.0; },
+                           [&](int k, int j) { const int cj = nt * 16 + j; return cj < 36 ? Y[k * YS + cj] : 0.0; });
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const int row = mt * 16 + (l >> 4) + 4 * r; if (row < 36 && c < 36) S.G[row * GS + c] = acc[r]; }
+      }
     }
     if (!last) {
       for (int e = lane; e < 12 * 36; e += NT) {
@@ -483,6 +522,33 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
     __syncthreads();
   };
   init_slacks();
+  // primal / complementarity errors, Sigma and rho of the CURRENT point for barrier parameter mu_ (one pass over the
+  // rows; the accept pass below produces the same quantities for the next iterate, so this runs only at the start,
+  // after a multiplier reset and when mu changes)
+  double c_pr = 0.0, c_co = 0.0, c_cm = 0.0;
+  auto point_pass = [&](double mu_) {
+    double pr = 0.0, co = 0.0, cm = 0.0;
+#pragma unroll 2
+    for (int r = lane; r < ng; r += NT) {
+      const double lb = r_lb[r], ub = r_ub[r];
+      double sg = 0.0, rh = 0.0;
+      if (r >= 12) {
+        const double g = r_g[r];
+        if (lb == ub) pr = fmax(pr, fabs(g - lb));
+        else {
+          const double s = r_s[r];
+          pr = fmax(pr, fabs(g - s));
+          if (lb > -INF) { const double d = s - lb, zl = r_zL[r]; co = fmax(co, d * zl); cm = fmax(cm, fabs(d * zl - mu_)); sg += zl / d; rh -= mu_ / d; }
+          if (ub < INF) { const double d = ub - s, zu = r_zU[r]; co = fmax(co, d * zu); cm = fmax(cm, fabs(d * zu - mu_)); sg += zu / d; rh += mu_ / d; }
+          rh += sg * (g - s);
+        }
+      }
+      r_sig[r] = sg; r_rho[r] = rh;
+    }
+    double v[3] = {pr, co, cm}; const int op[3] = {RMAX, RMAX, RMAX};
+    block_reduce<3>(v, op, S.red);
+    c_pr = v[0]; c_co = v[1]; c_cm = v[2];
+  };
 
   long long tp = A.prof ? (long long)wall_clock64() : 0;
   double mu = o.mu_init, delta_last = 0.0, th_max = 0.0;
@@ -496,18 +562,11 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
     __syncthreads();
     PROF_ADD(PH_EVAL, tp);
     // ---------------------------------------------------------------- optimality error (unscaled)
-    double du = 0.0, pr = 0.0, co = 0.0;
+    if (it == 0) point_pass(mu);
+    double du = 0.0;
     for (int i = lane + 12; i < nx; i += NT) du = fmax(du, fabs(M.gx[i]));
-#pragma unroll 2
-    for (int r = lane + 12; r < ng; r += NT) {
-      const double lb = r_lb[r], ub = r_ub[r], g = r_g[r];
-      if (lb == ub) { pr = fmax(pr, fabs(g - lb)); continue; }
-      const double s = r_s[r];
-      pr = fmax(pr, fabs(g - s));
-      if (lb > -INF) co = fmax(co, (s - lb) * r_zL[r]);
-      if (ub < INF) co = fmax(co, (ub - s) * r_zU[r]);
-    }
-    { double v[3] = {du, pr, co}; const int op[3] = {RMAX, RMAX, RMAX}; block_reduce<3>(v, op, S.red); du = v[0]; pr = v[1]; co = v[2]; }
+    du = block_reduce1(du, RMAX, S.red);
+    const double pr = c_pr, co = c_co;
     e_pr = pr; e_du = du; e_co = co;
     if (!(du < 1e300) || !(pr < 1e300) || !(co < 1e300)) { status = LANDING_NUMERICAL; break; }
     if (fmax(du, fmax(pr, co)) <= o.tol) { status = LANDING_CONVERGED; break; }
@@ -519,41 +578,17 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
       nreset++;
       init_slacks();
       mu = o.mu_init; nfilt = 0; delta_last = 0.0; need_reg_streak = 0;
+      point_pass(mu);
       continue;
     }
     // ---------------------------------------------------------------- barrier parameter (monotone)
-    for (;;) {
-      double cm = 0.0;
-  #pragma unroll 2
-    for (int r = lane + 12; r < ng; r += NT) {
-        const double lb = r_lb[r], ub = r_ub[r];
-        if (lb == ub) continue;
-        const double s = r_s[r];
-        if (lb > -INF) cm = fmax(cm, fabs((s - lb) * r_zL[r] - mu));
-        if (ub < INF) cm = fmax(cm, fabs((ub - s) * r_zU[r] - mu));
-      }
-      cm = block_reduce1(cm, RMAX, S.red);
-      if (fmax(du, fmax(pr, cm)) <= o.kappa_eps * mu && mu > o.tol / 10.0) {
-        mu = fmax(o.tol / 10.0, fmin(o.kappa_mu * mu, pow(mu, o.theta_mu)));
-        nfilt = 0;
-      } else break;
+    while (fmax(du, fmax(pr, c_cm)) <= o.kappa_eps * mu && mu > o.tol / 10.0) {
+      mu = fmax(o.tol / 10.0, fmin(o.kappa_mu * mu, pow(mu, o.theta_mu)));
+      nfilt = 0;
+      point_pass(mu);                     // complementarity error, Sigma, rho for the new mu
     }
     const double tau = fmax(o.tau_min, 1.0 - mu);
     PROF_ADD(PH_ERR, tp);
-    // ---------------------------------------------------------------- Sigma, rho per inequality row
-#pragma unroll 2
-    for (int r = lane; r < ng; r += NT) {
-      const double lb = r_lb[r], ub = r_ub[r];
-      double sg = 0.0, rh = 0.0;
-      if (r >= 12 && lb != ub) {
-        const double s = r_s[r];
-        if (lb > -INF) { const double d = s - lb; sg += r_zL[r] / d; rh -= mu / d; }
-        if (ub < INF) { const double d = ub - s; sg += r_zU[r] / d; rh += mu / d; }
-        rh += sg * (r_g[r] - s);
-      }
-      r_sig[r] = sg; r_rho[r] = rh;
-    }
-    __syncthreads();
 
     condense(A.cterm, A.clen);
     PROF_ADD(PH_SIGRHO, tp);
@@ -590,24 +625,20 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
       if (lb == ub) { th0 += fabs(g - lb); continue; }
       const double s = r_s[r], ds = r_ds[r];
       th0 += fabs(g - s);
-      double yn = r_sig[r] * ds;
       if (lb > -INF) {
         const double d = s - lb, zl = r_zL[r];
         const double dz = mu / d - zl - zl / d * ds;
-        r_dzL[r] = dz; yn -= mu / d;
         if (ds < 0.0) a_pr = fmin(a_pr, -tau * d / ds);
         if (dz < 0.0) a_du = fmin(a_du, -tau * zl / dz);
         bar -= log(d); dphi -= mu * ds / d;
-      } else r_dzL[r] = 0.0;
+      }
       if (ub < INF) {
         const double d = ub - s, zu = r_zU[r];
         const double dz = mu / d - zu + zu / d * ds;
-        r_dzU[r] = dz; yn += mu / d;
         if (ds > 0.0) a_pr = fmin(a_pr, tau * d / ds);
         if (dz < 0.0) a_du = fmin(a_du, -tau * zu / dz);
         bar -= log(d); dphi += mu * ds / d;
-      } else r_dzU[r] = 0.0;
-      r_yn[r] = yn;
+      }
     }
     double f0 = 0.0;
     if (lane < 12) {
@@ -675,21 +706,42 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
       __syncthreads();
     }
     PROF_ADD(PH_LS, tp);
-    // ================================================================ accept the trial point
+    // ================================================================ accept the trial point; the same pass produces the
+    // primal / complementarity errors, Sigma and rho of the new iterate (what point_pass computes)
     for (int i = lane; i < nx; i += NT) M.x[i] = M.xt[i];
+    {
+      double npr = 0.0, nco = 0.0, ncm = 0.0;
 #pragma unroll 2
-    for (int r = lane; r < ng; r += NT) {
-      const double lb = r_lb[r], ub = r_ub[r];
-      r_g[r] = r_gt[r];
-      if (r < 12) continue;
-      if (lb == ub) { r_y[r] += alpha * (r_yn[r] - r_y[r]); continue; }
-      const double s = r_s[r] + alpha * r_ds[r];
-      double zl = 0.0, zu = 0.0;
-      if (lb > -INF) { const double d = s - lb; zl = r_zL[r] + a_du * r_dzL[r]; zl = fmin(fmax(zl, mu / (1e10 * d)), 1e10 * mu / d); }
-      if (ub < INF) { const double d = ub - s; zu = r_zU[r] + a_du * r_dzU[r]; zu = fmin(fmax(zu, mu / (1e10 * d)), 1e10 * mu / d); }
-      r_s[r] = s; r_zL[r] = zl; r_zU[r] = zu; r_y[r] = zu - zl;
+      for (int r = lane; r < ng; r += NT) {
+        const double lb = r_lb[r], ub = r_ub[r], g = r_gt[r];
+        r_g[r] = g;
+        double sg = 0.0, rh = 0.0;
+        if (r >= 12) {
+          if (lb == ub) { r_y[r] += alpha * (r_yn[r] - r_y[r]); npr = fmax(npr, fabs(g - lb)); }
+          else {
+            const double so = r_s[r], ds = r_ds[r], s = so + alpha * ds;
+            double zl = 0.0, zu = 0.0;
+            if (lb > -INF) {
+              const double dold = so - lb, zo = r_zL[r], dz = mu / dold - zo - zo / dold * ds, d = s - lb;
+              zl = fmin(fmax(zo + a_du * dz, mu / (1e10 * d)), 1e10 * mu / d);
+              nco = fmax(nco, d * zl); ncm = fmax(ncm, fabs(d * zl - mu)); sg += zl / d; rh -= mu / d;
+            }
+            if (ub < INF) {
+              const double dold = ub - so, zo = r_zU[r], dz = mu / dold - zo + zo / dold * ds, d = ub - s;
+              zu = fmin(fmax(zo + a_du * dz, mu / (1e10 * d)), 1e10 * mu / d);
+              nco = fmax(nco, d * zu); ncm = fmax(ncm, fabs(d * zu - mu)); sg += zu / d; rh += mu / d;
+            }
+            npr = fmax(npr, fabs(g - s));
+            rh += sg * (g - s);
+            r_s[r] = s; r_zL[r] = zl; r_zU[r] = zu; r_y[r] = zu - zl;
+          }
+        }
+        r_sig[r] = sg; r_rho[r] = rh;
+      }
+      double v[3] = {npr, nco, ncm}; const int op[3] = {RMAX, RMAX, RMAX};
+      block_reduce<3>(v, op, S.red);
+      c_pr = v[0]; c_co = v[1]; c_cm = v[2];
     }
-    __syncthreads();
     PROF_ADD(PH_ACCEPT, tp);
   }
   __syncthreads();
