@@ -113,6 +113,7 @@ struct Lds {
   // member context, written once by every thread with identical values (read back as LDS broadcasts by the
   // __noinline__ phases so that they carry no register state across calls)
   MemberMem M; Layout L; const double* p; const int* tab; const int* stage_tab; int prof_on;
+  double d_init, d_incf, d_inc, d_dec, d_last, d_used; int d_local, n_stage_retry;
 };
 // One instance per workgroup (= per NLP).  Namespace scope keeps the LDS address space visible to every
 // phase function (ds_* instructions instead of flat_*).
@@ -361,7 +362,20 @@ __device__ __noinline__ bool riccati_backward(double delta) {
     PROF_ADD(PH_B_TPT, tb_);
     // ---- eliminate the controls: P_k, p_k, gains -> record k
     double* rec = M.ric + (size_t)k * RIC_STRIDE;
-    ok = last ? riccati_step<12>(rec) : riccati_step<24>(rec);
+    for (;;) {
+      ok = last ? riccati_step<12>(rec) : riccati_step<24>(rec);
+      if (ok || !S.d_local) break;
+      // stage-local inertia correction: the elimination works in registers and leaves G untouched, so a wrong
+      // inertia in THIS stage only costs a larger diagonal shift and one more elimination (not a new sweep);
+      // the larger delta is carried on to the remaining stages
+      const double dnew = (delta == 0.0) ? (S.d_last == 0.0 ? S.d_init : fmax(1e-20, S.d_last * S.d_dec))
+                                         : delta * (S.d_last == 0.0 ? S.d_incf : S.d_inc);
+      if (!(dnew < 1e40)) break;
+      for (int a = lane; a < nw; a += NT) S.G[a * GS + a] += dnew - delta;
+      delta = dnew;
+      if (lane == 0) S.n_stage_retry++;
+      __syncthreads();
+    }
     PROF_ADD(PH_B_ELIM, tb_);
     if (!ok) break;
   }
@@ -380,14 +394,26 @@ __device__ __noinline__ bool riccati_backward(double delta) {
       S.gam[24 + lane] = v;
     }
     __syncthreads();
-    if (lane < 64) gauss_jordan_wave<12>(S.G, S.gam, S.A1, S.A1 + 24 * 24, &S.flag);
-    __syncthreads();
-    ok = S.flag != 0;
+    for (;;) {
+      if (lane < 64) gauss_jordan_wave<12>(S.G, S.gam, S.A1, S.A1 + 24 * 24, &S.flag);
+      __syncthreads();
+      ok = S.flag != 0;
+      if (ok || !S.d_local) break;
+      const double dnew = (delta == 0.0) ? (S.d_last == 0.0 ? S.d_init : fmax(1e-20, S.d_last * S.d_dec))
+                                         : delta * (S.d_last == 0.0 ? S.d_incf : S.d_inc);
+      if (!(dnew < 1e40)) break;
+      if (lane < 12) S.G[(24 + lane) * GS + 24 + lane] += dnew - delta;
+      delta = dnew;
+      if (lane == 0) S.n_stage_retry++;
+      __syncthreads();
+    }
     if (ok) {
       if (lane < 12) S.sig[12 + lane] = -S.A1[24 * 24 + lane];
       __syncthreads();
     }
   }
+  if (lane == 0) S.d_used = delta;
+  __syncthreads();
   return ok;
 }
 
@@ -490,6 +516,8 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
   double* __restrict__ r_zL = M.zL; double* __restrict__ r_zU = M.zU; double* __restrict__ r_dzL = M.dzL; double* __restrict__ r_dzU = M.dzU;
   double* __restrict__ r_y = M.y; double* __restrict__ r_yn = M.yn; double* __restrict__ r_sig = M.sig; double* __restrict__ r_rho = M.rho;
   S.M = M; S.L = L; S.p = p; S.tab = A.tab; S.stage_tab = A.stage_tab; S.prof_on = A.prof != nullptr;
+  S.d_init = o.delta_init; S.d_incf = o.delta_inc_first; S.d_inc = o.delta_inc; S.d_dec = o.delta_dec; S.d_last = 0.0; S.d_used = 0.0;
+  S.d_local = o.reserved[0]; S.n_stage_retry = 0;
   if (lane < 16) S.prof[lane] = 0.0;
   __syncthreads();
 
@@ -604,9 +632,11 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
         else delta *= (delta_last == 0.0 ? o.delta_inc_first : o.delta_inc);
         if (delta > 1e40) break;
       }
-      if (lane == 0) S.prof[PH_NFACT] += 1.0;
+      if (lane == 0) { S.prof[PH_NFACT] += 1.0; S.d_last = delta_last; }
+      __syncthreads();
       const bool ok = riccati_backward(delta);
       fact_ok = ok;
+      if (S.d_local) { delta = S.d_used; break; }          // stage-local mode: one sweep, delta = largest shift used
     }
     if (!fact_ok) { status = LANDING_NUMERICAL; break; }
     if (delta > 0.0) { delta_last = delta; need_reg_streak++; } else need_reg_streak = 0;
