@@ -250,6 +250,42 @@ __device__ __noinline__ void condense(const int4* __restrict__ cterm, int clen) 
   __syncthreads();
 }
 
+// Condensed data of one stage, fetched into registers by the three waves that idle while the first wave runs the
+// pivot chain of the previous stage (global-memory latency leaves the serial chain).  192 threads x 4 items cover
+// the <= 480 G targets, 48 gamma entries, <= 160 A^ values and the 12 dynamics residuals of a stage.
+struct StagePre { double v[4]; int code[4]; };
+__device__ __forceinline__ void stage_prefetch(int k, StagePre& R) {
+  Lds& S = SH;
+  const MemberMem& M = S.M;
+  const int t = (int)threadIdx.x - 64;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) R.code[j] = 0;
+  if (t < 0 || k < 0) return;
+  const int* tb = S.tab + S.stage_tab[k];
+  const double* cd = M.cond + (size_t)k * COND_STRIDE;
+  const int nT = tb[0], nA = tb[6], g0 = S.L.g_stage(k);
+  const int* ab = S.tab + tb[1]; const int* at = S.tab + tb[7];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int e = t + j * 192;
+    if (e < nT) { R.v[j] = cd[e]; R.code[j] = (1 << 28) | ab[e]; }
+    else if (e < nT + 48) { const int a = e - nT; R.v[j] = cd[COND_GAM + a]; R.code[j] = (2 << 28) | a; }
+    else if (e < nT + 48 + nA) { const int q = e - nT - 48; R.v[j] = cd[COND_AH + q]; R.code[j] = (3 << 28) | (at[3 * q + 1] * YS + at[3 * q + 2]); }
+    else if (e < nT + 60 + nA) { const int i = e - nT - 48 - nA; R.v[j] = -M.g[g0 + i]; R.code[j] = (4 << 28) | (i < 6 ? i : (i < 9 ? i + 3 : i - 3)); }
+  }
+}
+__device__ __forceinline__ void stage_scatter(const StagePre& R) {
+  Lds& S = SH;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int c = R.code[j], kind = c >> 28, idx = c & 0xfffffff;
+    if (kind == 1) { const int a = idx & 255, b = idx >> 8; S.G[a * GS + b] = R.v[j]; S.G[b * GS + a] = R.v[j]; }
+    else if (kind == 2) S.gam[idx] = R.v[j];
+    else if (kind == 3) S.Ah[idx] = R.v[j];
+    else if (kind == 4) S.bv[idx] = R.v[j];
+  }
+}
+
 // One backward Riccati sweep with regularisation delta (terminal cost-to-go, stages N-1..0, free feet of
 // stage 0).  false = a pivot was not positive (wrong inertia): the caller raises delta and retries.
 __device__ __noinline__ bool riccati_backward(double delta) {
@@ -273,33 +309,22 @@ __device__ __noinline__ bool riccati_backward(double delta) {
     for (int j = 0; j < 24; ++j) rec[RIC_PX + i * 24 + j] = (j == i) ? S.P[i * PS + i] : 0.0;
     rec[RIC_PV + i] = S.pv[i];
   }
+  StagePre pre;
+  stage_prefetch(N - 1, pre);
   __syncthreads();
   for (int k = N - 1; k >= 0 && ok; --k) {
     const bool last = (k == N - 1);
     const int nu = last ? 12 : 24, nsn = last ? 12 : 24, nw = 24 + nu;
     const int* tb = S.tab + S.stage_tab[k];
     const int g0 = L.g_stage(k), nr = L.rows(k);
-    // ---- condensed stage data -> LDS (all loads independent)
+    // ---- condensed stage data (prefetched into registers during the previous stage) -> LDS
     long long tb_ = S.prof_on ? (long long)wall_clock64() : 0;
-    const double* cd = M.cond + (size_t)k * COND_STRIDE;
-    (void)nr;
+    (void)nr; (void)tb; (void)g0;
     for (int e = lane; e < 48 * GS; e += NT) S.G[e] = 0.0;
     for (int e = lane; e < 12 * YS; e += NT) S.Ah[e] = 0.0;
     __syncthreads();
     PROF_ADD(PH_B_LOAD, tb_);
-    {
-      const int nT = tb[0];
-      const int* ab = S.tab + tb[1];
-      for (int t = lane; t < nT; t += NT) {
-        const double v = cd[t];
-        const int a = ab[t] & 255, b = ab[t] >> 8;
-        S.G[a * GS + b] = v; S.G[b * GS + a] = v;
-      }
-      for (int a = lane; a < 48; a += NT) S.gam[a] = cd[COND_GAM + a];
-      const int nA = tb[6]; const int* at = S.tab + tb[7];
-      for (int t = lane; t < nA; t += NT) S.Ah[at[3 * t + 1] * YS + at[3 * t + 2]] = cd[COND_AH + t];
-      if (lane < 12) S.bv[lane < 6 ? lane : (lane < 9 ? lane + 3 : lane - 3)] = -M.g[g0 + lane];
-    }
+    stage_scatter(pre);
     __syncthreads();
     for (int a = lane; a < nw; a += NT) S.G[a * GS + a] += delta;
     // ---- Y = P(:,0:12) A^  (nsn x 36), q = P(:,0:12) b + p   (A1 is free again: Y lives there)
@@ -362,6 +387,7 @@ __device__ __noinline__ bool riccati_backward(double delta) {
     PROF_ADD(PH_B_TPT, tb_);
     // ---- eliminate the controls: P_k, p_k, gains -> record k
     double* rec = M.ric + (size_t)k * RIC_STRIDE;
+    stage_prefetch(k - 1, pre);          // waves 1..3: loads in flight while wave 0 eliminates this stage's controls
     for (;;) {
       ok = last ? riccati_step<12>(rec) : riccati_step<24>(rec);
       if (ok || !S.d_local) break;
