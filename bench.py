@@ -146,7 +146,7 @@ def main():
         achieved = flops / (k_ms * 1e-3) / 1e12
         roofline = {"kernel": "landing_ipm_kernel", "bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": achieved / FP64_PEAK_TFLOPS, "traffic": None, "launch_ms": k_ms, "flops_per_launch": flops,
-                    "note": "fp64; latency-bound persistent kernel (one workgroup per NLP), VALU fp64 only (no MFMA yet)"}
+                    "note": "fp64; latency-bound persistent kernel (one workgroup per NLP): serial stage x pivot chain, v_mfma_f64_16x16x4 for the dense stage products only"}
         # ---- function-layer sweep kernel (HBM bound)
         Bs = 4096
         reps = (Bs + B - 1) // B

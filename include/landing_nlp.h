@@ -72,7 +72,12 @@ typedef struct {
   int max_resets;        /* multiplier resets allowed per NLP (default 8), see reset_du          */
   double reset_du;       /* dual infeasibility above which slacks/multipliers/mu are re-initialised
                             at the current x (jammed iterate; IPOPT would enter restoration), 1e9  */
-  int reserved[4];
+  int stage_local_reg;   /* experimental: per-stage delta_w (one sweep, hurts convergence); default 0                       */
+  int sticky_delta;      /* experimental: restart from delta_last when the previous first trial failed; default 0          */
+  int restart_period;    /* re-initialise slacks/multipliers/filter at the current x when the first barrier problem (mu = mu_init)
+                            is still not solved this many iterations after the last (re)start (crawling iterate; counts
+                            against max_resets); 0 = never; default 80                                                      */
+  int reserved;
   double delta_init;     /* first trial regularisation when none was needed before (IPOPT first_hessian_perturbation, 1e-4) */
   double delta_inc_first;/* growth factor while no regularised iteration happened yet (IPOPT 100; default 10)            */
   double delta_inc;      /* growth factor afterwards (IPOPT 8; default 4: finer steps over-regularise less, tools/strag.py) */

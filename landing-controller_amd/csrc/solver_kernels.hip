@@ -543,7 +543,7 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
   double* __restrict__ r_y = M.y; double* __restrict__ r_yn = M.yn; double* __restrict__ r_sig = M.sig; double* __restrict__ r_rho = M.rho;
   S.M = M; S.L = L; S.p = p; S.tab = A.tab; S.stage_tab = A.stage_tab; S.prof_on = A.prof != nullptr;
   S.d_init = o.delta_init; S.d_incf = o.delta_inc_first; S.d_inc = o.delta_inc; S.d_dec = o.delta_dec; S.d_last = 0.0; S.d_used = 0.0;
-  S.d_local = o.reserved[0]; S.n_stage_retry = 0;
+  S.d_local = o.stage_local_reg; S.n_stage_retry = 0;
   if (lane < 16) S.prof[lane] = 0.0;
   __syncthreads();
 
@@ -607,6 +607,8 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
   long long tp = A.prof ? (long long)wall_clock64() : 0;
   double mu = o.mu_init, delta_last = 0.0, th_max = 0.0;
   int nfilt = 0, it = 0, status = LANDING_MAX_ITER, need_reg_streak = 0, nreset = 0;
+  bool first_failed = false;
+  int last_reset_it = 0, ncrawl = 0;
   double e_pr = 0, e_du = 0, e_co = 0;
 
   for (it = 0; it <= o.max_iter; ++it) {
@@ -626,7 +628,11 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
     if (fmax(du, fmax(pr, co)) <= o.tol) { status = LANDING_CONVERGED; break; }
     if (it == o.max_iter) break;
     if (du > o.reset_du && nreset >= o.max_resets && o.max_resets > 0) { status = LANDING_NUMERICAL; break; }   // jammed again: give up
-    if (du > o.reset_du && nreset < o.max_resets) {
+    // crawling: still in the first barrier problem (mu never decreased) restart_period iterations after the last (re)start
+    const bool stalled = o.restart_period > 0 && it - last_reset_it >= o.restart_period && mu >= o.mu_init && nreset < o.max_resets && ncrawl < 1;
+    if ((du > o.reset_du && nreset < o.max_resets) || stalled) {
+      last_reset_it = it;
+      if (stalled) ncrawl++;
       // jammed iterate (multipliers blown up): keep x, re-initialise slacks, multipliers, barrier parameter and
       // filter -- the role IPOPT's restoration phase plays on this problem class
       nreset++;
@@ -650,7 +656,9 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
     // IPOPT's inertia-correction schedule (delta_w = 0 first, then max(1e-20, delta_last/3), then x8 / x100),
     // except that an iteration following a regularised one starts from delta_last/3 directly when the
     // unregularised attempt failed twice in a row (saves one full factorisation in nonconvex phases)
-    double delta = (need_reg_streak >= 2 && delta_last > 0.0) ? fmax(1e-20, delta_last * o.delta_dec) : 0.0;
+    // (o.sticky_delta = 1: when the first trial of the previous iteration failed, start from delta_last itself)
+    double delta = (need_reg_streak >= 2 && delta_last > 0.0) ? fmax(1e-20, delta_last * ((o.sticky_delta && first_failed) ? 1.0 : o.delta_dec)) : 0.0;
+    const bool skipped_zero = delta > 0.0;
     bool fact_ok = false;
     for (int attempt = 0; attempt < 60 && !fact_ok; ++attempt) {
       if (attempt > 0) {
@@ -663,6 +671,7 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
       const bool ok = riccati_backward(delta);
       fact_ok = ok;
       if (S.d_local) { delta = S.d_used; break; }          // stage-local mode: one sweep, delta = largest shift used
+      if (attempt == 0) first_failed = skipped_zero && !ok;
     }
     if (!fact_ok) { status = LANDING_NUMERICAL; break; }
     if (delta > 0.0) { delta_last = delta; need_reg_streak++; } else need_reg_streak = 0;

@@ -26,12 +26,13 @@ typedef struct {
   double tol; int max_iter; double mu_init, bound_push, bound_frac, kappa_eps, kappa_mu, theta_mu;
   int max_resets; double reset_du;
   double delta_init, delta_inc_first, delta_inc, delta_dec, tau_min, alpha_fallback;
+  int restart_period;
 } lo_solver_opts;
 
 void lo_solver_opts_default(lo_solver_opts* o) {
   o->tol = 1e-6; o->max_iter = 3000; o->mu_init = 0.1; o->bound_push = 0.5; o->bound_frac = 0.5;
   o->kappa_eps = 10.0; o->kappa_mu = 0.2; o->theta_mu = 1.5; o->max_resets = 8; o->reset_du = 1e9;
-  o->delta_init = 1e-4; o->delta_inc_first = 10.0; o->delta_inc = 4.0; o->delta_dec = 1.0 / 3.0; o->tau_min = 0.9; o->alpha_fallback = 1e-2;
+  o->delta_init = 1e-4; o->delta_inc_first = 10.0; o->delta_inc = 4.0; o->delta_dec = 1.0 / 3.0; o->tau_min = 0.9; o->alpha_fallback = 1e-2; o->restart_period = 80;
 }
 
 #define NW 48
@@ -160,7 +161,7 @@ static void init_slacks(work_t* W, const lo_solver_opts* op) {
 static int solve_one(const lo_form* F, const double* p, const double* x0, const lo_solver_opts* op, double* x_out,
                      double* lam_out, int* iters_out, double kkt_out[3], long long counters[2]) {
   const int N = F->N; const lo_int nx = lo_nx(N), ng = lo_ng(N);
-  lo_poff o; work_t Wk, *W = &Wk; lo_int i, r; int k, it, status = 1, nfilt = 0, streak = 0, nreset = 0;
+  lo_poff o; work_t Wk, *W = &Wk; lo_int i, r; int k, it, status = 1, nfilt = 0, streak = 0, nreset = 0, last_reset_it = 0, ncrawl = 0;
   double mu = op->mu_init, delta_last = 0.0, th_max = 0.0, e_du = 0.0;
   double filt_th[64], filt_ph[64];
   double* gx;
@@ -211,10 +212,15 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
     if (fmax(du, fmax(pr, co)) <= op->tol) { status = 0; break; }
     if (it == op->max_iter) break;
     if (du > op->reset_du && nreset >= op->max_resets && op->max_resets > 0) { status = 2; break; }
-    if (du > op->reset_du && nreset < op->max_resets) {
+    {
+      const int stalled = op->restart_period > 0 && it - last_reset_it >= op->restart_period && mu >= op->mu_init && nreset < op->max_resets && ncrawl < 1;
+      if (stalled) ncrawl++;
+      if (!((du > op->reset_du && nreset < op->max_resets) || stalled)) goto no_reset;
+      last_reset_it = it;
       nreset++; init_slacks(W, op); mu = op->mu_init; nfilt = 0; delta_last = 0.0; streak = 0;
       continue;
     }
+    no_reset:;
     for (;;) {
       double cm = 0;
       for (r = 12; r < ng; ++r) {

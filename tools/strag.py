@@ -4,29 +4,18 @@ capi=importlib.import_module("landing-controller_amd.capi"); problem=importlib.i
 N,B=40,1024
 P,X0,q,qd=problem.make_batch(B,N,0.6,seed=20211)
 L=capi.LandingLib(N,0)
-def run(label, X, **kw):
-    o=L.default_opts(); o.max_iter=300
-    for k,v in kw.items(): setattr(o,k,v)
-    r=L.solve_host(P,X,o)
+prof=torch.zeros(B,16,device='cuda',dtype=torch.float64)
+def run(label, r1=0, **kw):
+    o=L.default_opts(); o.max_iter=300; o.sticky_delta=r1
+    for k,v in kw.items():
+        if k=='reserved2': o.restart_period=v
+        else: setattr(o,k,v)
+    L.lib.landing_set_profile_buffer(L.ctx, prof.data_ptr()); prof.zero_()
+    r=L.solve_host(P,X0,o)
+    ph=prof.cpu().numpy(); L.lib.landing_set_profile_buffer(L.ctx, None)
+    t=time.time(); r=L.solve_host(P,X0,o); dt=time.time()-t
     c=r['status']==0
-    print('%-44s conv %4d  iters mean %.1f med %.0f p90 %.0f p99conv %.0f'%(label,c.sum(),r['iters'].mean(),np.median(r['iters']),np.percentile(r['iters'],90),np.percentile(r['iters'][c],99)))
-    return r
-rng=np.random.default_rng(0)
-nX=12*(N+1)
-r0=run('baseline x0', X0)
-for sig in (1e-4,1e-3,1e-2):
-    Xp=X0.copy(); Xp[:,nX:]+=sig*rng.normal(size=Xp[:,nX:].shape)
-    run('U jitter sigma %g'%sig, Xp)
-# forces initial guess: static weight support instead of zero
-Xp=X0.copy()
-U=Xp[:,nX:].reshape(B,N,24)
-U[:,:,12+2::3]+=8.252*9.81/4
-run('fz guess = mg/4', Xp)
-Xp=X0.copy(); U=Xp[:,nX:].reshape(B,N,24); U[:,N//2:,12+2::3]+=8.252*9.81/4*2
-run('fz guess = mg/2 second half', Xp)
-# feet guess on the ground (c_z = 0) for the second half of the horizon
-Xp=X0.copy(); U=Xp[:,nX:].reshape(B,N,24); U[:,:,2:12:3]=np.maximum(U[:,:,2:12:3],0.0)
-run('feet clipped to c_z>=0', Xp)
-# X guess: keep initial state constant (no interpolation)
-Xp=X0.copy(); X=Xp[:,:nX].reshape(B,N+1,12); X[:,1:,:]=X[:,:1,:]
-run('X guess = X0 constant', Xp)
+    print('%-40s conv %4d  iters mean %.1f med %.0f p90 %.0f  fact/iter %.2f  sec %.3f  nlp/s %.0f'%(label,c.sum(),r['iters'].mean(),np.median(r['iters']),np.percentile(r['iters'],90),ph[:,8].sum()/ph[:,10].sum(),dt,c.sum()/dt))
+run('default')
+for per in (0,60,80,100,150):
+    run('periodic reset %d'%per, 0, reserved2=per)
