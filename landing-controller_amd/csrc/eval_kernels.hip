@@ -65,12 +65,23 @@ struct DotLam {
 // whose segments lack the entries of the neighbouring stage's no-slip rows, emit placeholders there and the
 // write-out compacts them through `map` (position in the uniform sequence -> position in the segment, -1 = absent).
 constexpr int TILE_LD = 17;
-// write-out of one tile (kept out of line: inlined 25 times per stage it pushes the emission code into scratch spills)
+// hides a wave-uniform value from the optimiser (empty asm on an SGPR); a no-op for the g++ host emulation of tests/emu
+#if defined(__HIP__)
+#define LANDING_OPAQUE_UNIFORM(x) asm volatile("" : "+s"(x))
+#else
+#define LANDING_OPAQUE_UNIFORM(x) ((void)0)
+#endif
+// write-out of one tile.  Inlined (an out-of-line call makes every write-out wait for its stores at the return), but
+// the position counter is laundered through an empty asm so that the 25 call sites of a stage are not specialised
+// and hoisted into one giant live range (that version spilled 1.9 KB per lane).
 template <int KIND>
-__device__ __noinline__ void tile_flush(const double* tile, double* gbase, const Layout* L, const int* map, int k0, int nrow, int cnt, int n) {
+__device__ __forceinline__ void tile_flush(const double* tile, double* gbase, const Layout* L, const int* map, int k0, int nrow, int cnt_, int n_) {
+  int cnt = cnt_, n = n_;
+  LANDING_OPAQUE_UNIFORM(cnt); LANDING_OPAQUE_UNIFORM(n);
   __builtin_amdgcn_wave_barrier();
   const int lane = threadIdx.x & 63, c = lane & 15, N = L->N;
   if (c < n) {
+#pragma unroll 1
     for (int row = lane >> 4; row < nrow; row += 4) {
       const int k = k0 + row;
       int pos = cnt - n + c;

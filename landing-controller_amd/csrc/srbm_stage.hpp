@@ -49,6 +49,7 @@ __host__ __device__ __forceinline__ double hip_y(int l) { return (l & 1) ? 0.1 :
 // Rz(psi) * Q  and  Rz'(psi) * Q, Rz''(psi)*Q  (rz.m:8-13 transposed: [c -s 0; s c 0; 0 0 1])
 __host__ __device__ __forceinline__ M3 rz_mul(double c, double s, const M3& q) {
   M3 r;
+#pragma unroll
   for (int j = 0; j < 3; ++j) {
     r.a[0][j] = c * q.a[0][j] - s * q.a[1][j];
     r.a[1][j] = s * q.a[0][j] + c * q.a[1][j];
@@ -58,6 +59,7 @@ __host__ __device__ __forceinline__ M3 rz_mul(double c, double s, const M3& q) {
 }
 __host__ __device__ __forceinline__ M3 rz1_mul(double c, double s, const M3& q) {  // d/dpsi
   M3 r;
+#pragma unroll
   for (int j = 0; j < 3; ++j) {
     r.a[0][j] = -s * q.a[0][j] - c * q.a[1][j];
     r.a[1][j] = c * q.a[0][j] - s * q.a[1][j];
@@ -94,6 +96,7 @@ struct RotSet {
       d2[3] = rz_mul(cs, ss, Qtt);
       d2[4] = rz1_mul(cs, ss, Qt);
       // Rz'' Q = -(rows 0,1 of R), row 2 = 0
+#pragma unroll
       for (int j = 0; j < 3; ++j) { d2[5].a[0][j] = -R.a[0][j]; d2[5].a[1][j] = -R.a[1][j]; d2[5].a[2][j] = 0.0; }
     }
   }
@@ -125,6 +128,7 @@ __host__ __device__ __forceinline__ void stage_g(const StageVars& z, const Stage
   const double aa = RS.sp * w.y + RS.cp * w.z, bb = RS.cp * w.y - RS.sp * w.z;
   const V3 edot = v3(w.x + tt * aa, bb, aa * sec);            // Binv(rpy)*(R*omega), gen:128
   V3 fs = v3(0, 0, 0), tau = v3(0, 0, 0);
+#pragma unroll
   for (int l = 0; l < 4; ++l) {
     const V3 r = v3(z.c[3 * l] - pos.x, z.c[3 * l + 1] - pos.y, z.c[3 * l + 2] - pos.z);
     const V3 f = v3(z.f[3 * l], z.f[3 * l + 1], z.f[3 * l + 2]);
@@ -148,6 +152,7 @@ __host__ __device__ __forceinline__ void stage_g(const StageVars& z, const Stage
   out.put(10, z.Xn[7] - w.y - omd.y * P.dt);
   out.put(11, z.Xn[8] - w.z - omd.z * P.dt);
   const int stride = last ? 6 : 12, kin = last ? 2 : 8, fric = last ? 40 : 64, box = last ? 56 : 80;
+#pragma unroll
   for (int l = 0; l < 4; ++l) {
     const int rb = 16 + stride * l;
     const double fz = z.f[3 * l + 2], cz = z.c[3 * l + 2];
@@ -155,6 +160,7 @@ __host__ __device__ __forceinline__ void stage_g(const StageVars& z, const Stage
     out.put(rb, cz);                                           // gen:139
     out.put(rb + 1, fz * cz);                                  // gen:140
     if (!last) {
+#pragma unroll
       for (int i = 0; i < 3; ++i) {
         const double d = fz * (z.cn[3 * l + i] - z.c[3 * l + i]);   // gen:143-144
         out.put(rb + 2 + i, d);
@@ -173,6 +179,7 @@ __host__ __device__ __forceinline__ void stage_g(const StageVars& z, const Stage
     out.put(fric + 8 + l, fy - P.km * fz);
     out.put(fric + 12 + l, -P.km * fz - fy);
   }
+#pragma unroll
   for (int i = 0; i < 6; ++i) {                                // gen:166-169
     out.put(box + i, z.X[i]);
     out.put(box + 6 + i, z.X[i]);
@@ -205,6 +212,7 @@ __host__ __device__ __forceinline__ void stage_jac(const StageVars& z, const Sta
   const int stride = last ? 6 : 12, kin = last ? 2 : 8, fric = last ? 40 : 64, box = last ? 56 : 80;
   V3 F = v3(0, 0, 0), tau = v3(0, 0, 0);
   V3 r[4], f[4], prel[4], Rah[3][4];
+#pragma unroll
   for (int l = 0; l < 4; ++l) {
     r[l] = v3(z.c[3 * l] - pos.x, z.c[3 * l + 1] - pos.y, z.c[3 * l + 2] - pos.z);
     f[l] = v3(z.f[3 * l], z.f[3 * l + 1], z.f[3 * l + 2]);
@@ -212,15 +220,18 @@ __host__ __device__ __forceinline__ void stage_jac(const StageVars& z, const Sta
     tau = tau + cross(r[l], f[l]);
     const V3 Rh = mul_hip(RS.R, hip_x(l), hip_y(l));
     prel[l] = r[l] - Rh;
+#pragma unroll
     for (int a = 0; a < 3; ++a) Rah[a][l] = mul_hip(RS.d1[a], hip_x(l), hip_y(l));
   }
   // ---- X_k columns ----
+#pragma unroll
   for (int j = 0; j < 3; ++j) {                  // pos_j
     ex.col();
     ex.put(PREV_ID(j), 1.0);
     ex.put(j, -1.0);                             // g_pos_j
     const V3 t = mulT(RS.R, cross(unit(j), F));  // + dt*Ibi*R^T(e_j x F)
     ex.put(9, dt * P.Ibi[0] * t.x); ex.put(10, dt * P.Ibi[1] * t.y); ex.put(11, dt * P.Ibi[2] * t.z);
+#pragma unroll
     for (int l = 0; l < 4; ++l) {
       const int rk = 16 + stride * l + kin;
       ex.put(rk + j, -1.0); ex.put(rk + 3, -2.0 * comp(prel[l], j));
@@ -230,6 +241,7 @@ __host__ __device__ __forceinline__ void stage_jac(const StageVars& z, const Sta
   {
     // d edot / d e : phi, theta (psi: 0)
     const V3 de[3] = {v3(tt * bb, -aa, bb * sec), v3(aa * sec2, 0.0, aa * sec * tt), v3(0, 0, 0)};
+#pragma unroll
     for (int a = 0; a < 3; ++a) {                // rpy_a
       ex.col();
       ex.put(PREV_ID(3 + a), 1.0);
@@ -239,6 +251,7 @@ __host__ __device__ __forceinline__ void stage_jac(const StageVars& z, const Sta
       const V3 t = mulT(RS.d1[a], tau);
       if (a != 0) ex.put(9, -dt * P.Ibi[0] * t.x);  // R(:,1) has no roll dependence: not in the pattern
       ex.put(10, -dt * P.Ibi[1] * t.y); ex.put(11, -dt * P.Ibi[2] * t.z);
+#pragma unroll
       for (int l = 0; l < 4; ++l) {
         const int rk = 16 + stride * l + kin;
         ex.put(rk, -Rah[a][l].x); ex.put(rk + 1, -Rah[a][l].y);
@@ -254,22 +267,28 @@ __host__ __device__ __forceinline__ void stage_jac(const StageVars& z, const Sta
     const double dn[3][3] = {{0.0, (P.Ib[2] - P.Ib[1]) * w.z, (P.Ib[2] - P.Ib[1]) * w.y},
                              {(P.Ib[0] - P.Ib[2]) * w.z, 0.0, (P.Ib[0] - P.Ib[2]) * w.x},
                              {(P.Ib[1] - P.Ib[0]) * w.y, (P.Ib[1] - P.Ib[0]) * w.x, 0.0}};
+#pragma unroll
     for (int j = 0; j < 3; ++j) {                // omega_j
       ex.col();
       ex.put(PREV_ID(6 + j), 1.0);
+#pragma unroll
       for (int i = 0; i < 3; ++i) ex.put(3 + i, -dt * T[i][j]);
+#pragma unroll
       for (int i = 0; i < 3; ++i) ex.put(9 + i, (i == j ? -1.0 : 0.0) + dt * P.Ibi[i] * dn[i][j]);
       ex.put(box + 12 + j, 1.0); ex.put(box + 18 + j, 1.0);
     }
   }
+#pragma unroll
   for (int j = 0; j < 3; ++j) {                  // v_j
     ex.col();
     ex.put(PREV_ID(9 + j), 1.0); ex.put(j, -dt); ex.put(6 + j, -1.0); ex.put(box + 15 + j, 1.0); ex.put(box + 21 + j, 1.0);
   }
   // ---- U_k columns: feet ----
+#pragma unroll
   for (int l = 0; l < 4; ++l) {
     const double fz = f[l].z;
     const int rb = 16 + stride * l, rk = rb + kin;
+#pragma unroll
     for (int j = 0; j < 3; ++j) {
       eu.col();
       if (!first) { eu.put(PREV_SLIP(l, j, 0), fz_prev[l]); eu.put(PREV_SLIP(l, j, 1), fz_prev[l]); }
@@ -282,8 +301,10 @@ __host__ __device__ __forceinline__ void stage_jac(const StageVars& z, const Sta
     }
   }
   // ---- U_k columns: forces ----
+#pragma unroll
   for (int l = 0; l < 4; ++l) {
     const int rb = 16 + stride * l;
+#pragma unroll
     for (int j = 0; j < 3; ++j) {
       eu.col();
       eu.put(6 + j, -P.dt_over_m);                              // g_v_j
@@ -323,19 +344,23 @@ __host__ __device__ __forceinline__ void stage_hess(const StageVars& z, const St
   const V3 mub = v3(lam(9) * P.Ibi[0], lam(10) * P.Ibi[1], lam(11) * P.Ibi[2]);
   const V3 m = mul(RS.R, mub);
   V3 Ram[3];
+#pragma unroll
   for (int a = 0; a < 3; ++a) Ram[a] = mul(RS.d1[a], mub);
   V3 tau = v3(0, 0, 0);
   V3 r[4], f[4], prel[4], Rah[3][4];
   double lL[4], lslip[4][3], lcomp[4];
   V3 lbox[4];
+#pragma unroll
   for (int l = 0; l < 4; ++l) {
     const int rb = 16 + stride * l;
     r[l] = v3(z.c[3 * l] - pos.x, z.c[3 * l + 1] - pos.y, z.c[3 * l + 2] - pos.z);
     f[l] = v3(z.f[3 * l], z.f[3 * l + 1], z.f[3 * l + 2]);
     tau = tau + cross(r[l], f[l]);
     prel[l] = r[l] - mul_hip(RS.R, hip_x(l), hip_y(l));
+#pragma unroll
     for (int a = 0; a < 3; ++a) Rah[a][l] = mul_hip(RS.d1[a], hip_x(l), hip_y(l));
     lcomp[l] = lam(rb + 1);
+#pragma unroll
     for (int i = 0; i < 3; ++i) lslip[l][i] = last ? 0.0 : (lam(rb + 2 + i) + lam(rb + 5 + i));
     lbox[l] = v3(lam(rb + kin), lam(rb + kin + 1), lam(rb + kin + 2));
     lL[l] = lam(rb + kin + 3);
@@ -347,16 +372,20 @@ __host__ __device__ __forceinline__ void stage_hess(const StageVars& z, const St
   // second derivatives of edot (closed form of Binv*R): pp, pt, tt ; anything with psi = 0
   const V3 dde_pp = v3(-tt * aa, -bb, -aa * sec), dde_pt = v3(bb * sec2, 0.0, bb * sec * tt),
            dde_tt = v3(2.0 * aa * sec2 * tt, 0.0, aa * sec * (tt * tt + sec2));
+#pragma unroll
   for (int a = 0; a < 3; ++a) {
     V3 hp = v3(0, 0, 0);
+#pragma unroll
     for (int l = 0; l < 4; ++l) hp = hp + dt * cross(f[l], Ram[a]) + (2.0 * lL[l]) * Rah[a][l];
     hx.put(hp.x); hx.put(hp.y); hx.put(hp.z);
+#pragma unroll
     for (int b = 0; b <= a; ++b) {
       const M3& Rab = RS.D2(a, b);
       double s = -dt * dot(mul(Rab, mub), tau);
       if (a == 0 && b == 0) s += -dt * dot(le, dde_pp);
       if (a == 1 && b == 0) s += -dt * dot(le, dde_pt);
       if (a == 1 && b == 1) s += -dt * dot(le, dde_tt);
+#pragma unroll
       for (int l = 0; l < 4; ++l) {
         const V3 t = mul_hip(Rab, hip_x(l), hip_y(l));
         s += -dot(lbox[l], t) + 2.0 * lL[l] * (dot(Rah[a][l], Rah[b][l]) - dot(prel[l], t));
@@ -370,6 +399,7 @@ __host__ __device__ __forceinline__ void stage_hess(const StageVars& z, const St
     const double Tt[3][3] = {{0.0, RS.sp * sec2, RS.cp * sec2}, {0.0, 0.0, 0.0}, {0.0, RS.sp * sec * tt, RS.cp * sec * tt}};
     const double lev[3] = {le.x, le.y, le.z};
     double hew[3][3];  // [a][j]
+#pragma unroll
     for (int j = 0; j < 3; ++j) {
       hew[0][j] = -dt * (lev[0] * Tp[0][j] + lev[1] * Tp[1][j] + lev[2] * Tp[2][j]);
       hew[1][j] = -dt * (lev[0] * Tt[0][j] + lev[1] * Tt[1][j] + lev[2] * Tt[2][j]);
@@ -382,9 +412,12 @@ __host__ __device__ __forceinline__ void stage_hess(const StageVars& z, const St
     hx.put(hew[0][2]); hx.put(hew[1][2]); hx.put(hew[2][2]); hx.put(hw02); hx.put(hw12);
   }
   // ---- U_k columns: feet ----
+#pragma unroll
   for (int l = 0; l < 4; ++l) {
+#pragma unroll
     for (int j = 0; j < 3; ++j) {
       hu.put(-2.0 * lL[l]);                                             // (pos_j, c_lj)
+#pragma unroll
       for (int a = 0; a < 3; ++a)
         hu.put(-dt * comp(cross(f[l], Ram[a]), j) - 2.0 * lL[l] * comp(Rah[a][l], j));
       if (!first) hu.put(lam_prev_slip[3 * l + j]);                     // (f_z of stage k-1, c_lj)
@@ -393,16 +426,21 @@ __host__ __device__ __forceinline__ void stage_hess(const StageVars& z, const St
   }
   // ---- U_k columns: forces ----
   const double mm[3] = {m.x, m.y, m.z};
+#pragma unroll
   for (int l = 0; l < 4; ++l) {
+#pragma unroll
     for (int j = 0; j < 3; ++j) {
       // eps_{ijq} m_q for i != j
+#pragma unroll
       for (int i = 0; i < 3; ++i) {
         if (i == j) continue;
         const int q = 3 - i - j;
         const double e = ((j - i + 3) % 3 == 1) ? 1.0 : -1.0;
         hu.put(dt * e * mm[q]);                                         // (pos_i, f_lj)
       }
+#pragma unroll
       for (int a = 0; a < 3; ++a) hu.put(-dt * comp(cross(Ram[a], r[l]), j));   // (e_a, f_lj)
+#pragma unroll
       for (int i = 0; i < 3; ++i) {
         if (i == j && j != 2) continue;
         double val = 0.0;
@@ -433,6 +471,7 @@ __host__ __device__ __forceinline__ void stage_gradp(const StageVars& z, const S
   V3 fs = v3(0, 0, 0), tau = v3(0, 0, 0);
   double smu = 0.0;
   const int fric = last ? 40 : 64;
+#pragma unroll
   for (int l = 0; l < 4; ++l) {
     const V3 r = v3(z.c[3 * l] - pos.x, z.c[3 * l + 1] - pos.y, z.c[3 * l + 2] - pos.z);
     const V3 f = v3(z.f[3 * l], z.f[3 * l + 1], z.f[3 * l + 2]);
