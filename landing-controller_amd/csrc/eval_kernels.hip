@@ -115,8 +115,10 @@ struct TileStore {
 // Jacobian (FAM 0) or Hessian (FAM 1) nonzeros of every stage of one member: one wavefront per member, lane = stage,
 // every lane runs the middle-stage instruction stream (first = last = false) and the tile write-out drops the
 // placeholders of the two edge stages.  Reported by landing_kernel_name_sweep() for profilers.
+// (register budget: the Jacobian stream fits 256 VGPRs -> 2 waves/SIMD; the Hessian stream needs the AGPR overflow
+// of the default bound, capping it costs 750 B of scratch per lane and doubles its time)
 template <int FAM>
-__global__ void __launch_bounds__(64) landing_sweep_kernel(Layout L, int B, EvalArgs A) {
+__global__ void __launch_bounds__(64, FAM == 0 ? 2 : 1) landing_sweep_kernel(Layout L, int B, EvalArgs A) {
   const int m = blockIdx.x;
   if (m >= B) return;
   const int N = L.N, ln = threadIdx.x;
