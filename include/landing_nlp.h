@@ -84,6 +84,8 @@ typedef struct {
   double delta_dec;      /* first trial = delta_last * delta_dec (IPOPT 1/3)                                             */
   double tau_min;        /* fraction-to-the-boundary floor (IPOPT 0.99; default 0.9)                                     */
   double alpha_fallback; /* step taken (and filter restarted) when the line search finds no acceptable point (1e-2)      */
+  double reset_delta;    /* regularisation above which the iterate counts as jammed too (steps degenerate to damped
+                            gradient steps); <= 0 disables; default 1e5                                                   */
 } landing_solver_opts;
 
 /* status codes written per batch member by landing_solve_batch */

@@ -630,7 +630,8 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
     if (du > o.reset_du && nreset >= o.max_resets && o.max_resets > 0) { status = LANDING_NUMERICAL; break; }   // jammed again: give up
     // crawling: still in the first barrier problem (mu never decreased) restart_period iterations after the last (re)start
     const bool stalled = o.restart_period > 0 && it - last_reset_it >= o.restart_period && mu >= o.mu_init && nreset < o.max_resets && ncrawl < 1;
-    if ((du > o.reset_du && nreset < o.max_resets) || stalled) {
+    const bool overreg = o.reset_delta > 0.0 && delta_last > o.reset_delta && nreset < o.max_resets;
+    if ((du > o.reset_du && nreset < o.max_resets) || stalled || overreg) {
       last_reset_it = it;
       if (stalled) ncrawl++;
       // jammed iterate (multipliers blown up): keep x, re-initialise slacks, multipliers, barrier parameter and

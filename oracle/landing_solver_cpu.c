@@ -18,6 +18,7 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#include <stdio.h>
 #ifdef _OPENMP
 #include <omp.h>
 #endif
@@ -27,12 +28,13 @@ typedef struct {
   int max_resets; double reset_du;
   double delta_init, delta_inc_first, delta_inc, delta_dec, tau_min, alpha_fallback;
   int restart_period;
+  double reset_delta;
 } lo_solver_opts;
 
 void lo_solver_opts_default(lo_solver_opts* o) {
   o->tol = 1e-6; o->max_iter = 3000; o->mu_init = 0.1; o->bound_push = 0.5; o->bound_frac = 0.5;
   o->kappa_eps = 10.0; o->kappa_mu = 0.2; o->theta_mu = 1.5; o->max_resets = 8; o->reset_du = 1e9;
-  o->delta_init = 1e-4; o->delta_inc_first = 10.0; o->delta_inc = 4.0; o->delta_dec = 1.0 / 3.0; o->tau_min = 0.9; o->alpha_fallback = 1e-2; o->restart_period = 80;
+  o->delta_init = 1e-4; o->delta_inc_first = 10.0; o->delta_inc = 4.0; o->delta_dec = 1.0 / 3.0; o->tau_min = 0.9; o->alpha_fallback = 1e-2; o->restart_period = 80; o->reset_delta = 1e5;
 }
 
 #define NW 48
@@ -208,6 +210,7 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
       if (ub < INFINITY) co = fmax(co, (ub - W->s[r]) * W->zU[r]);
     }
     e_du = du;
+    if (getenv("LO_TRACE")) fprintf(stderr, "it %4d pr %9.2e du %9.2e co %9.2e mu %8.1e dlast %8.1e nreset %d nfilt %d\n", it, pr, du, co, mu, delta_last, nreset, nfilt);
     if (!(du < 1e300) || !(pr < 1e300) || !(co < 1e300)) { status = 2; break; }
     if (fmax(du, fmax(pr, co)) <= op->tol) { status = 0; break; }
     if (it == op->max_iter) break;
@@ -215,7 +218,7 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
     {
       const int stalled = op->restart_period > 0 && it - last_reset_it >= op->restart_period && mu >= op->mu_init && nreset < op->max_resets && ncrawl < 1;
       if (stalled) ncrawl++;
-      if (!((du > op->reset_du && nreset < op->max_resets) || stalled)) goto no_reset;
+      if (!((du > op->reset_du && nreset < op->max_resets) || stalled || (op->reset_delta > 0.0 && delta_last > op->reset_delta && nreset < op->max_resets))) goto no_reset;
       last_reset_it = it;
       nreset++; init_slacks(W, op); mu = op->mu_init; nfilt = 0; delta_last = 0.0; streak = 0;
       continue;

@@ -17,5 +17,8 @@ def run(label, r1=0, **kw):
     c=r['status']==0
     print('%-40s conv %4d  iters mean %.1f med %.0f p90 %.0f  fact/iter %.2f  sec %.3f  nlp/s %.0f'%(label,c.sum(),r['iters'].mean(),np.median(r['iters']),np.percentile(r['iters'],90),ph[:,8].sum()/ph[:,10].sum(),dt,c.sum()/dt))
 run('default')
-for per in (0,60,80,100,150):
-    run('periodic reset %d'%per, 0, reserved2=per)
+for rd in (1e2,1e3,1e4,1e5):
+    run('reset_delta %g'%rd, 0, reset_delta=rd)
+run('reset_du 1e8', 0, reset_du=1e8)
+run('reset_du 1e8 reset_delta 1e4', 0, reset_du=1e8, reset_delta=1e4)
+run('reset_delta 1e3 max_resets 16', 0, reset_delta=1e3, max_resets=16)
