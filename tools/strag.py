@@ -16,9 +16,9 @@ def run(label, r1=0, **kw):
     t=time.time(); r=L.solve_host(P,X0,o); dt=time.time()-t
     c=r['status']==0
     print('%-40s conv %4d  iters mean %.1f med %.0f p90 %.0f  fact/iter %.2f  sec %.3f  nlp/s %.0f'%(label,c.sum(),r['iters'].mean(),np.median(r['iters']),np.percentile(r['iters'],90),ph[:,8].sum()/ph[:,10].sum(),dt,c.sum()/dt))
-run('default')
-for rd in (1e2,1e3,1e4,1e5):
-    run('reset_delta %g'%rd, 0, reset_delta=rd)
-run('reset_du 1e8', 0, reset_du=1e8)
-run('reset_du 1e8 reset_delta 1e4', 0, reset_du=1e8, reset_delta=1e4)
-run('reset_delta 1e3 max_resets 16', 0, reset_delta=1e3, max_resets=16)
+run('default', 0, max_iter=300)
+run('sticky', 1, max_iter=300)
+run('sticky inc 3', 1, max_iter=300, delta_inc=3.0)
+run('sticky inc 2', 1, max_iter=300, delta_inc=2.0)
+run('sticky dec .5', 1, max_iter=300, delta_dec=0.5)
+run('sticky inc 3 max_iter 250', 1, max_iter=250, delta_inc=3.0)
