@@ -37,7 +37,7 @@ struct SolverWorkspace {
   int* d_tab = nullptr; int* d_stage_tab = nullptr; int n_tab = 0;
   int *d_cterm = nullptr, *d_cstart = nullptr, *d_rterm = nullptr, *d_rstart = nullptr; int clen = 0, rlen = 0;
   static size_t member_stride(const Layout& L) {
-    return (size_t)4 * L.nx + (size_t)14 * L.ng + L.nnz_jac + L.nnz_hess + (size_t)(L.N + 1) * RIC_STRIDE + (size_t)L.N * COND_STRIDE;
+    return (size_t)4 * L.nx + (size_t)12 * L.ng + L.nnz_jac + L.nnz_hess + (size_t)(L.N + 1) * RIC_STRIDE + (size_t)L.N * COND_STRIDE;
   }
   int ensure(const Layout& L, int B);
   void release();
@@ -83,7 +83,7 @@ __device__ __forceinline__ double block_reduce1(double v, int op, double* red) {
 
 struct MemberMem {
   double *x, *xt, *dx, *gx;
-  double *g, *gt, *s, *ds, *zL, *zU, *dzL, *dzU, *y, *yn, *lb, *ub, *sig, *rho;
+  double *g, *gt, *s, *ds, *zL, *zU, *y, *yn, *lb, *ub, *sig, *rho;
   double *J, *H, *ric, *cond;
 };
 
@@ -91,7 +91,7 @@ __device__ __forceinline__ MemberMem carve(const Layout& L, double* w) {
   MemberMem M;
   M.x = w; w += L.nx; M.xt = w; w += L.nx; M.dx = w; w += L.nx; M.gx = w; w += L.nx;
   M.g = w; w += L.ng; M.gt = w; w += L.ng; M.s = w; w += L.ng; M.ds = w; w += L.ng;
-  M.zL = w; w += L.ng; M.zU = w; w += L.ng; M.dzL = w; w += L.ng; M.dzU = w; w += L.ng;
+  M.zL = w; w += L.ng; M.zU = w; w += L.ng;
   M.y = w; w += L.ng; M.yn = w; w += L.ng; M.lb = w; w += L.ng; M.ub = w; w += L.ng;
   M.sig = w; w += L.ng; M.rho = w; w += L.ng;
   M.J = w; w += L.nnz_jac; M.H = w; w += L.nnz_hess; M.ric = w; w += (size_t)(L.N + 1) * RIC_STRIDE; M.cond = w;
@@ -539,7 +539,7 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
   // the workspace arrays never overlap: tell the compiler so that the row passes can batch their loads
   const double* __restrict__ r_lb = M.lb; const double* __restrict__ r_ub = M.ub;
   double* __restrict__ r_g = M.g; double* __restrict__ r_gt = M.gt; double* __restrict__ r_s = M.s; double* __restrict__ r_ds = M.ds;
-  double* __restrict__ r_zL = M.zL; double* __restrict__ r_zU = M.zU; double* __restrict__ r_dzL = M.dzL; double* __restrict__ r_dzU = M.dzU;
+  double* __restrict__ r_zL = M.zL; double* __restrict__ r_zU = M.zU;
   double* __restrict__ r_y = M.y; double* __restrict__ r_yn = M.yn; double* __restrict__ r_sig = M.sig; double* __restrict__ r_rho = M.rho;
   S.M = M; S.L = L; S.p = p; S.tab = A.tab; S.stage_tab = A.stage_tab; S.prof_on = A.prof != nullptr;
   S.d_init = o.delta_init; S.d_incf = o.delta_inc_first; S.d_inc = o.delta_inc; S.d_dec = o.delta_dec; S.d_last = 0.0; S.d_used = 0.0;
