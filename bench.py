@@ -164,7 +164,7 @@ def main():
         torch.cuda.synchronize()
         s_ms = ev0.elapsed_time(ev1) / 20
         by = lib.lib.landing_sweep_bytes_per_member(N) * Bs
-        sweep = {"kernel": "landing_sweep_kernel<0>+<1>+landing_sweep_misc_kernel (one landing_eval_batch call)", "bound": "hbm", "achieved": by / s_ms / 1e6, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+        sweep = {"kernel": "landing_sweep_kernel<0>+<1>+<2>+landing_sweep_misc_kernel (one landing_eval_batch call)", "bound": "hbm", "achieved": by / s_ms / 1e6, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                  "frac": by / s_ms / 1e6 / HBM_PEAK_GBPS, "traffic": None, "launch_ms": s_ms, "members": Bs}
         # ---- CPU baseline (oracle port) on a bounded sample of the same workload
         cpu = None

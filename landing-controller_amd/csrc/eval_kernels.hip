@@ -16,7 +16,8 @@ namespace landing {
 struct EvalArgs {
   const double* x; const double* p; const double* lam_f; const double* lam_g;
   double* f; double* g; double* grad_f; double* jac; double* hess; double* ggx; double* ggp;
-  const int* edge_map;   // [0..227] U-part Jacobian positions of stage 0, [228..455] of stage N-1 (-1 = entry absent)
+  const int* edge_map;
+  int g_staged;          // 1: the stage rows of g are written by landing_sweep_kernel<2> (misc kernel writes the 36 boundary rows only)   // [0..227] U-part Jacobian positions of stage 0, [228..455] of stage N-1 (-1 = entry absent)
 };
 
 __host__ __device__ __forceinline__ int dyn_row_of_state(int i) {  // state index -> dynamics row (pos,rpy,v,omega)
@@ -89,13 +90,20 @@ __device__ __forceinline__ void tile_flush(const double* tile, double* gbase, co
       if (KIND == 0) seg = L->jx(k);
       else if (KIND == 1) { seg = L->ju(k); if (k == 0) pos = map[pos]; else if (k == N - 1) pos = map[228 + pos]; }
       else if (KIND == 2) seg = L->hx(k);
-      else { seg = L->hu(k); if (k == 0) pos = (pos < 72) ? ((pos % 6 == 4) ? -1 : pos - (pos / 6) - (pos % 6 > 4 ? 1 : 0)) : pos - 12; }
+      else if (KIND == 3) { seg = L->hu(k); if (k == 0) pos = (pos < 72) ? ((pos % 6 == 4) ? -1 : pos - (pos / 6) - (pos % 6 > 4 ? 1 : 0)) : pos - 12; }
+      else {   // KIND 4: residual rows; the last stage has no no-slip rows (80 instead of 104 rows)
+        seg = L->g_stage(k);
+        if (k == N - 1) {
+          if (pos >= 64) pos -= 24;
+          else if (pos >= 16) { const int l = (pos - 16) / 12, t = (pos - 16) % 12; pos = t < 2 ? 16 + 6 * l + t : (t < 8 ? -1 : 16 + 6 * l + t - 6); }
+        }
+      }
       if (pos >= 0) gbase[seg + pos] = tile[row * TILE_LD + c];
     }
   }
   __builtin_amdgcn_wave_barrier();
 }
-template <int KIND>   // 0: Jacobian X_k columns, 1: Jacobian U_k columns, 2: Hessian X_k columns, 3: Hessian U_k columns
+template <int KIND>   // 0: Jacobian X_k columns, 1: Jacobian U_k columns, 2: Hessian X_k columns, 3: Hessian U_k columns, 4: g rows
 struct TileStore {
   double* tile;          // LDS, 64 x TILE_LD
   double* gbase;         // member's J or H array
@@ -112,13 +120,13 @@ struct TileStore {
   __device__ __forceinline__ void finish() { if (cnt & 15) tile_flush<KIND>(tile, gbase, L, map, k0, nrow, cnt, cnt & 15); }
 };
 
-// Jacobian (FAM 0) or Hessian (FAM 1) nonzeros of every stage of one member: one wavefront per member, lane = stage,
+// Jacobian (FAM 0), Hessian (FAM 1) nonzeros or residual rows (FAM 2) of every stage of one member: one wavefront per member, lane = stage,
 // every lane runs the middle-stage instruction stream (first = last = false) and the tile write-out drops the
 // placeholders of the two edge stages.  Reported by landing_kernel_name_sweep() for profilers.
 // (register budget: the Jacobian stream fits 256 VGPRs -> 2 waves/SIMD; the Hessian stream needs the AGPR overflow
 // of the default bound, capping it costs 750 B of scratch per lane and doubles its time)
 template <int FAM>
-__global__ void __launch_bounds__(64, FAM == 0 ? 2 : 1) landing_sweep_kernel(Layout L, int B, EvalArgs A) {
+__global__ void __launch_bounds__(64, FAM == 1 ? 1 : 2) landing_sweep_kernel(Layout L, int B, EvalArgs A) {
   const int m = blockIdx.x;
   if (m >= B) return;
   const int N = L.N, ln = threadIdx.x;
@@ -140,6 +148,10 @@ __global__ void __launch_bounds__(64, FAM == 0 ? 2 : 1) landing_sweep_kernel(Lay
       TileStore<1> eu{tileU, J, &L, A.edge_map, k0, rows_here, 0};
       srbm::stage_jac(z, P, false, false, fz_prev, ex, eu);
       ex.finish(); eu.finish();
+    } else if (FAM == 2) {
+      TileStore<4> og{tileX, A.g + (size_t)m * L.ng, &L, nullptr, k0, rows_here, 0};
+      srbm::stage_g(z, P, false, og);
+      og.finish();
     } else {
       double* H = A.hess + (size_t)m * L.nnz_hess;
       double lps[12];
@@ -219,12 +231,13 @@ __global__ void __launch_bounds__(64) landing_sweep_misc_kernel(Layout L, int B,
   double gp_acc[9];
   for (int i = 0; i < 9; ++i) gp_acc[i] = 0.0;
 
-  // ---- stages ----
-  for (int k = threadIdx.x; k < N; k += blockDim.x) {
+  // ---- stages (only when a per-stage output is left for this kernel) ----
+  const bool stage_work = (A.g && !A.g_staged) || (A.ggx && lam_g) || (A.ggp && lam_g);
+  for (int k = threadIdx.x; stage_work && k < N; k += blockDim.x) {
     const bool first = (k == 0), last = (k == N - 1);
     srbm::StageVars z; srbm::StageParams P;
     load_stage(L, x, p, k, z, P);
-    if (A.g) {
+    if (A.g && !A.g_staged) {
       RowStore out{A.g + (size_t)m * L.ng + L.g_stage(k)};
       srbm::stage_g(z, P, last, out);
     }

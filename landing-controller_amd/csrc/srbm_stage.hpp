@@ -151,21 +151,20 @@ __host__ __device__ __forceinline__ void stage_g(const StageVars& z, const Stage
   out.put(9, z.Xn[6] - w.x - omd.x * P.dt);                    // gen:130
   out.put(10, z.Xn[7] - w.y - omd.y * P.dt);
   out.put(11, z.Xn[8] - w.z - omd.z * P.dt);
+  // rows are emitted in increasing order (sequential emitters rely on it)
   const int stride = last ? 6 : 12, kin = last ? 2 : 8, fric = last ? 40 : 64, box = last ? 56 : 80;
+#pragma unroll
+  for (int l = 0; l < 4; ++l) out.put(12 + l, z.f[3 * l + 2]);                        // gen:133
 #pragma unroll
   for (int l = 0; l < 4; ++l) {
     const int rb = 16 + stride * l;
     const double fz = z.f[3 * l + 2], cz = z.c[3 * l + 2];
-    out.put(12 + l, fz);                                       // gen:133
     out.put(rb, cz);                                           // gen:139
     out.put(rb + 1, fz * cz);                                  // gen:140
     if (!last) {
-#pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        const double d = fz * (z.cn[3 * l + i] - z.c[3 * l + i]);   // gen:143-144
-        out.put(rb + 2 + i, d);
-        out.put(rb + 5 + i, d);
-      }
+      const double d0 = fz * (z.cn[3 * l] - z.c[3 * l]), d1 = fz * (z.cn[3 * l + 1] - z.c[3 * l + 1]), d2 = fz * (z.cn[3 * l + 2] - z.c[3 * l + 2]);
+      out.put(rb + 2, d0); out.put(rb + 3, d1); out.put(rb + 4, d2);   // gen:143
+      out.put(rb + 5, d0); out.put(rb + 6, d1); out.put(rb + 7, d2);   // gen:144
     }
     const V3 Rh = mul_hip(RS.R, hip_x(l), hip_y(l));
     const V3 pr = v3(z.c[3 * l] - (pos.x + Rh.x), z.c[3 * l + 1] - (pos.y + Rh.y), z.c[3 * l + 2] - (pos.z + Rh.z));
@@ -173,19 +172,23 @@ __host__ __device__ __forceinline__ void stage_g(const StageVars& z, const Stage
     out.put(rb + kin + 1, pr.y);
     out.put(rb + kin + 2, pr.z + P.kin_z_off);
     out.put(rb + kin + 3, dot(pr, pr));
-    const double fx = z.f[3 * l], fy = z.f[3 * l + 1];
-    out.put(fric + l, fx - P.km * fz);                         // gen:160-163
-    out.put(fric + 4 + l, -P.km * fz - fx);
-    out.put(fric + 8 + l, fy - P.km * fz);
-    out.put(fric + 12 + l, -P.km * fz - fy);
   }
 #pragma unroll
-  for (int i = 0; i < 6; ++i) {                                // gen:166-169
-    out.put(box + i, z.X[i]);
-    out.put(box + 6 + i, z.X[i]);
-    out.put(box + 12 + i, z.X[6 + i]);
-    out.put(box + 18 + i, z.X[6 + i]);
-  }
+  for (int l = 0; l < 4; ++l) out.put(fric + l, z.f[3 * l] - P.km * z.f[3 * l + 2]);            // gen:160-163
+#pragma unroll
+  for (int l = 0; l < 4; ++l) out.put(fric + 4 + l, -P.km * z.f[3 * l + 2] - z.f[3 * l]);
+#pragma unroll
+  for (int l = 0; l < 4; ++l) out.put(fric + 8 + l, z.f[3 * l + 1] - P.km * z.f[3 * l + 2]);
+#pragma unroll
+  for (int l = 0; l < 4; ++l) out.put(fric + 12 + l, -P.km * z.f[3 * l + 2] - z.f[3 * l + 1]);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) out.put(box + i, z.X[i]);                               // gen:166-169
+#pragma unroll
+  for (int i = 0; i < 6; ++i) out.put(box + 6 + i, z.X[i]);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) out.put(box + 12 + i, z.X[6 + i]);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) out.put(box + 18 + i, z.X[6 + i]);
 }
 
 // ------------------------------------------------------------------------------------------------
