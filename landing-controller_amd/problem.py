@@ -174,3 +174,26 @@ def split_solution(N, x):
     """X*[12,N+1], U*[24,N] (generate_training_data_automated.m:139-141)."""
     x = np.asarray(x)
     return x[:12 * (N + 1)].reshape(12, N + 1, order="F"), x[12 * (N + 1):].reshape(24, N, order="F")
+
+
+def reference_default_problem(N=20, T=0.6):
+    """The fixed drop the generator script itself solves for verification, BASELINE configs[0]
+    (generate_landingCtrller_IPOPT.m:173-224,332-338): returns (p, x0) with x0 = [Xref(:); Uref(:)]."""
+    mass, Ib, Ib_inv = robot_constants()
+    q_init = np.array([0, 0, 0.6, 0, np.pi / 4, -np.pi / 6]); qd_init = np.array([0, 4, 5, 1.3, -2, -2.0])
+    q_term_ref = np.array([0, 0, 0.275, 0, 0, 0]); qd_term_ref = np.zeros(6)
+    Xref = np.zeros((12, N + 1))
+    for i in range(6):
+        Xref[i] = np.linspace(q_init[i], q_term_ref[i], N + 1)
+        Xref[6 + i] = np.linspace(qd_init[i], qd_term_ref[i], N + 1)
+    c_ref = SIDE_SIGN * np.tile([0.2, 0.1, -0.2], 4)                       # :189
+    Uref = np.zeros((24, N))
+    for leg in range(4):
+        for xyz in range(3):
+            Uref[3 * leg + xyz] = Xref[xyz, :-1] + c_ref[3 * leg + xyz]     # :205 (no rotation in this script)
+    p = pack_params(N, Xref, np.full(N, T / N), [-10, -10, 0.1, -10, -10, -10], [10, 10, 1.0, 10, 10, 10],
+                    [-10, -10, -10, -40, -40, -40], [10, 10, 10, 40, 40, 40], q_init, qd_init,
+                    [-10, -10, 0.2, -0.1, -0.1, -10], [10, 10, 5, 0.1, 0.1, 10], [-10, -10, -10, -40, -40, -40],
+                    [10, 10, 10, 40, 40, 40], [0, 0, 100, 100, 100, 0, 10, 10, 10, 10, 10, 10], 1.0, 0.35, 200.0, mass, Ib, Ib_inv)
+    x0 = np.concatenate([Xref.flatten(order="F"), Uref.flatten(order="F")])
+    return p, x0

@@ -52,6 +52,15 @@ def test_solver_golden_known_answer(libs, oracle_mod):
     assert O.kkt(r["x"][0], p, r["lam_g"][0]).max() <= KKT_TOL * 1.0001
 
 
+def test_solver_reference_default_problem(libs, oracle_mod):
+    """BASELINE configs[0]: the generator script's own verification drop (generate_landingCtrller_IPOPT.m:173-224), f* = 0"""
+    O = oracle_mod.Oracle(20)
+    p, x0 = lc("problem").reference_default_problem()
+    r = libs[20].solve_host(p[None], x0[None])
+    assert r["status"][0] == 0 and r["f"][0] <= 1e-8
+    assert O.kkt(r["x"][0], p, r["lam_g"][0]).max() <= KKT_TOL * 1.0001
+
+
 def test_failed_member_does_not_poison_batch(libs, oracle_mod):
     """a member with NaN parameters is flagged and the others still converge (failure isolation)"""
     N = 20

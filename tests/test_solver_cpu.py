@@ -42,6 +42,16 @@ def test_cpu_port_golden_known_answer(oracle_mod):
     assert r["status"][0] == 0 and O.f(r["x"][0], p) <= 2e-5     # reference optimum f* in [0, 1.64e-5]
 
 
+def test_cpu_port_reference_default_problem(oracle_mod):
+    """BASELINE configs[0]: the drop the generator script solves itself (generate_landingCtrller_IPOPT.m:173-224);
+    its terminal reference is reachable, so the optimum is f* = 0."""
+    O = oracle_mod.Oracle(20)
+    p, x0 = lc("problem").reference_default_problem()
+    r = oracle_mod.cpu_solve_batch(O, p[None], x0[None], threads=1, max_iter=600)
+    assert r["status"][0] == 0 and O.f(r["x"][0], p) <= 1e-8
+    assert O.kkt(r["x"][0], p, r["lam_g"][0]).max() <= 1e-6 * 1.0001
+
+
 def test_emulated_kernel_follows_cpu_port(emu_lib, oracle_mod):
     N, K = 20, 6
     O = oracle_mod.Oracle(N)
