@@ -99,10 +99,12 @@ __device__ __forceinline__ MemberMem carve(const Layout& L, double* w) {
 }
 
 // LDS of one member
+constexpr int XCH = 448;   // one exchange buffer of the blocked elimination: pivot rows [64][4] + pivot columns [48][4]
+static_assert(2 * XCH >= 24 * YS, "A1 also holds Y (24 x YS)");
 struct Lds {
   double G[48 * GS];
   double P[24 * PS];
-  double A1[24 * YS];          // Y = P(:,0:12)*A^ (24 x YS = 888) while T^T P T is formed, then the elimination side block
+  double A1[2 * XCH];          // Y = P(:,0:12)*A^ (24 x YS = 888) while T^T P T is formed, then the elimination side block
                               // Ex (24 x ES): col 0 = gamma_u -> z, cols 1.. = I -> unit-lower inverse
   double Ah[12 * YS];
   double gam[48], pv[24], q[24], bv[12], sig[24], w[48], dinv[24];
@@ -139,36 +141,56 @@ __device__ __forceinline__ double lane_bcast(double v, int src) {
   return __hiloint2double(hi, lo);
 }
 
+// The same broadcast through the LDS crossbar (ds_bpermute_b32 x2): result in vector registers, issued on the LDS
+// pipe, so it runs beside the VALU stream instead of inside it.
+__device__ __forceinline__ double lane_bcast_xbar(double v, int src) {
+  const int hi = __builtin_amdgcn_ds_bpermute(src << 2, __double2hiint(v));
+  const int lo = __builtin_amdgcn_ds_bpermute(src << 2, __double2loint(v));
+  return __hiloint2double(hi, lo);
+}
+
 // Elimination of the controls of one stage by ONE wavefront, entirely in registers: Gauss-Jordan on
 // [G_uu | G_us | gamma_u], lane c owning column c (NU + 24 + 1 <= 49 lanes, NU values each).  The pivot of step j is
 // broadcast from lane j, the multipliers from lane j's column; no LDS traffic and no barrier inside the 24 steps
 // (the serial pivot chain is what bounds a Riccati stage).  On success Kl (LDS, NU x 24, row stride 24) holds
 // K = G_uu^-1 G_us and kl the vector kappa = G_uu^-1 gamma_u.  A non-positive / non-finite pivot (wrong inertia)
 // is reported through *flag = 0; the caller raises delta_w.
+#ifndef GJ_XBAR_ROWS
+#define GJ_XBAR_ROWS 0
+#endif
 template <int NU>
-__device__ __forceinline__ void gauss_jordan_wave(const double* G, const double* gam, double* Kl, double* kl, int* flag) {
+__device__ __noinline__ void gauss_jordan_wave(const double* G, const double* gam, double* Kl, double* kl, int* flag) {
   const int lane = threadIdx.x;        // called by the first wave only (threadIdx.x < 64)
   double col[NU];
   const bool isUU = lane < NU, isUS = lane >= NU && lane < NU + 24, isG = lane == NU + 24;
+  {   // branch-free column fetch: every lane walks its own (base, stride); idle lanes re-read column 0
+    const double* src = isG ? gam + 24 : G + 24 * GS + (isUU ? 24 + lane : (isUS ? lane - NU : 0));
+    const int stride = isG ? 1 : GS;
 #pragma unroll
-  for (int i = 0; i < NU; ++i)
-    col[i] = isUU ? G[(24 + i) * GS + 24 + lane] : (isUS ? G[(24 + i) * GS + (lane - NU)] : (isG ? gam[24 + i] : 0.0));
+    for (int i = 0; i < NU; ++i) col[i] = src[i * stride];
+  }
   bool ok = true;
-#pragma unroll
+  // Rolled pivot loop with a rotating row file: step j finds its pivot row in col[0]; every update writes row i
+  // into slot i-1 (the FMA destination differs from its accumulator source, so the rotation costs nothing) and the
+  // normalised pivot row goes to the last slot.  After NU steps the rows are back in place.  One small loop body
+  // (instruction-cache resident) instead of NU unrolled copies; the lane select of the broadcasts is the loop
+  // counter (scalar).
+#pragma unroll 1
   for (int j = 0; j < NU; ++j) {
-    const double d = lane_bcast(col[j], j);
+    const double d = lane_bcast(col[0], j);
     if (!(d > 0.0) || !(d < 1e300)) ok = false;        // wave-uniform; keep going (values are discarded)
     double inv = __builtin_amdgcn_rcp(d);               // v_rcp_f64 + two Newton steps instead of the IEEE division
     inv = fma(inv, fma(-d, inv, 1.0), inv);             // sequence: the reciprocal sits on the serial pivot chain
     inv = fma(inv, fma(-d, inv, 1.0), inv);
-    const double pj = col[j] * inv;
+    const double pj = col[0] * inv;
+    // multipliers first (independent scalar broadcasts, back to back), then the row updates
+    double m[NU];
 #pragma unroll
-    for (int i = 0; i < NU; ++i) {
-      if (i == j) continue;
-      const double m = lane_bcast(col[i], j);
-      col[i] -= m * pj;
-    }
-    col[j] = pj;
+    for (int i = 1; i < NU; ++i) m[i] = (i >= NU - GJ_XBAR_ROWS) ? lane_bcast_xbar(col[i], j) : lane_bcast(col[i], j);
+    __builtin_amdgcn_sched_barrier(0);      // all broadcasts in flight before the first update consumes one
+#pragma unroll
+    for (int i = 1; i < NU; ++i) col[i - 1] = fma(-m[i], pj, col[i]);
+    col[NU - 1] = pj;
   }
   if (isUS) {
 #pragma unroll
@@ -181,45 +203,116 @@ __device__ __forceinline__ void gauss_jordan_wave(const double* G, const double*
   if (lane == 0) *flag = ok ? 1 : 0;
 }
 
+// Elimination of the controls of one stage by the whole workgroup on the matrix cores: blocked Gauss-Jordan with
+// 4 x 4 pivot blocks on the (NU + 24) x (NU + 25) array  [G_uu G_us gamma_u ; G_su G_ss gamma_s]  (rows/columns: controls
+// first).  After NU/4 block steps the control rows hold [I | K | kappa] and the state rows hold the Schur complement
+// [0 | P_k | p_k] -- gains and cost-to-go in one pass.  The array lives in v_mfma_f64_16x16x4 accumulator tiles: wave w
+// owns column tile w (16 columns x 48 rows = 3 tiles).  One block step = one LDS exchange (the owner of the pivot
+// columns publishes them, every wave publishes its slice of the 4 pivot rows), one barrier, the 4 x 4 LDL^T
+// (recomputed by every lane from the broadcast block: no further communication), the normalised pivot rows of the
+// own columns, and ONE rank-4 MFMA per tile:  T -= C R  (C = pivot columns with the pivot rows blanked; the pivot
+// rows are then overwritten by R itself -- forming them as W - (D - I) R would cancel at the scale of W).  The pivots of the 4 x 4 LDL^T are the scalar pivots of the unblocked
+// elimination, so the inertia test (all pivots positive) is unchanged.  Returns false on a non-positive pivot.
+template <int NU>
+__device__ __noinline__ bool block_eliminate(double* __restrict__ rec) {
+  Lds& S = SH;
+  constexpr int NR = NU + 24;                         // rows; column NR is gamma
+  const int tid = threadIdx.x, ct = tid >> 6, l = tid & 63, lj = l & 15, lk = l >> 4;
+  const int c = 16 * ct + lj;
+  f64x4 T[3];
+  {   // tile fetch: every lane walks its own column (base, stride) of the symmetric G / of gamma
+    const bool isg = (c == NR), live = (c <= NR);
+    const double* src = isg ? S.gam : S.G + (c < NU ? 24 + c : (live ? c - NU : 0));
+    const int stride = isg ? 1 : GS;
+#pragma unroll
+    for (int rt = 0; rt < 3; ++rt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int rho = 16 * rt + lk + 4 * r;
+        const int a = rho < NU ? 24 + rho : (rho < NR ? rho - NU : 0);
+        const double v = src[a * stride];
+        T[rt][r] = (live && rho < NR) ? v : 0.0;
+      }
+  }
+#pragma unroll
+  for (int b = 0; b < NU / 4; ++b) {
+    const int rtb = (4 * b) >> 4, rb = b & 3;
+    double* W = S.A1 + (b & 1) * XCH;
+    double* C = W + 256;
+    W[c * 4 + lk] = T[rtb][rb];
+    if (ct == rtb && (lj >> 2) == rb) {
+#pragma unroll
+      for (int rt = 0; rt < 3; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) C[(16 * rt + lk + 4 * r) * 4 + (lj & 3)] = T[rt][r];
+    }
+    __syncthreads();
+    // 4 x 4 pivot block (uniform reads), LDL^T, inverse
+    const double* Dp = C + 16 * b;
+    const double a00 = Dp[0], a10 = Dp[4], a11 = Dp[5], a20 = Dp[8], a21 = Dp[9], a22 = Dp[10], a30 = Dp[12], a31 = Dp[13], a32 = Dp[14], a33 = Dp[15];
+    const double w0 = W[c * 4 + 0], w1 = W[c * 4 + 1], w2 = W[c * 4 + 2], w3 = W[c * 4 + 3];
+    double am[3];
+#pragma unroll
+    for (int rt = 0; rt < 3; ++rt) { const double cv = C[(16 * rt + lj) * 4 + lk]; am[rt] = ((16 * rt + lj) >> 2 == b) ? 0.0 : cv; }   // pivot rows: no update
+    auto recip = [](double d) { double i = __builtin_amdgcn_rcp(d); i = fma(i, fma(-d, i, 1.0), i); return fma(i, fma(-d, i, 1.0), i); };
+    const double d0 = a00, i0 = recip(d0);
+    const double l10 = a10 * i0, l20 = a20 * i0, l30 = a30 * i0;
+    const double d1 = fma(-l10, a10, a11), i1 = recip(d1);
+    const double t21 = fma(-l20, a10, a21), t31 = fma(-l30, a10, a31);
+    const double l21 = t21 * i1, l31 = t31 * i1;
+    const double d2 = fma(-l21, t21, fma(-l20, a20, a22)), i2 = recip(d2);
+    const double t32 = fma(-l31, t21, fma(-l30, a20, a32));
+    const double l32 = t32 * i2;
+    const double d3 = fma(-l32, t32, fma(-l31, t31, fma(-l30, a30, a33))), i3 = recip(d3);
+    const bool ok = (d0 > 0.0) && (d0 < 1e300) && (d1 > 0.0) && (d1 < 1e300) && (d2 > 0.0) && (d2 < 1e300) && (d3 > 0.0) && (d3 < 1e300);
+    if (!ok) return false;                               // identical in every lane of the workgroup
+    // normalised pivot rows of the own column: D r = w by the two triangular solves (no explicit inverse: a badly
+    // conditioned pivot block costs no more accuracy than the scalar elimination would); lane group lk keeps r[lk]
+    const double y1 = fma(-l10, w0, w1);
+    const double y2 = fma(-l21, y1, fma(-l20, w0, w2));
+    const double y3 = fma(-l32, y2, fma(-l31, y1, fma(-l30, w0, w3)));
+    const double r3 = y3 * i3;
+    const double r2 = fma(-l32, r3, y2 * i2);
+    const double r1 = fma(-l31, r3, fma(-l21, r2, y1 * i1));
+    const double r0 = fma(-l30, r3, fma(-l20, r2, fma(-l10, r1, w0 * i0)));
+    const double R = lk == 0 ? r0 : (lk == 1 ? r1 : (lk == 2 ? r2 : r3));
+    if (16 * ct + 16 > 4 * b) {                          // tiles whose columns are all eliminated already stay as they are
+#pragma unroll
+      for (int rt = 0; rt < 3; ++rt) T[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(-am[rt], R, T[rt], 0, 0, 0);
+      T[rtb][rb] = R;                                    // the pivot rows become the normalised rows, exactly
+    }
+  }
+  // gains to the stage record, cost-to-go to LDS (+ its state rows to the record)
+  if (c >= NU && c <= NR) {
+    const int sj = c - NU;
+#pragma unroll
+    for (int rt = 0; rt < 3; ++rt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int rho = 16 * rt + lk + 4 * r;
+        const double v = T[rt][r];
+        if (rho < NU) {
+          if (c < NR) rec[RIC_K + rho * 24 + sj] = v; else rec[RIC_KAP + rho] = v;
+        } else if (rho < NR) {
+          const int i = rho - NU;
+          if (c < NR) { S.P[i * PS + sj] = v; if (i < 12) rec[RIC_PX + i * 24 + sj] = v; }
+          else { S.pv[i] = v; if (i < 12) rec[RIC_PV + i] = v; }
+        }
+      }
+  }
+  return true;
+}
+
 // Everything of one backward Riccati step that follows the assembly of G, gamma (templated on the control
 // dimension: 24 = (f_k, c_{k+1}), 12 = last stage).  Writes P_k, p_k into S and the stage record.
 template <int NU>
 __device__ __forceinline__ bool riccati_step(double* rec) {
   Lds& S = SH;
   const int tid = threadIdx.x, NT = blockDim.x;
-  double* Kl = S.A1;            // NU x 24 gains (Y is dead by now)
-  double* kl = S.A1 + 24 * 24;  // kappa
-  if (tid < 64) gauss_jordan_wave<NU>(S.G, S.gam, Kl, kl, &S.flag);
-  __syncthreads();
-  if (!S.flag) return false;
-  // P_k = G_ss - G_su K ; p_k = gamma_s - G_su kappa   (G_su(i,t) = G(24+t, i) by symmetry)
-  {   // matrix cores: 2 x 2 tiles of 16 x 16 over the 24 x 24 block, K = NU
-    const int wave = tid >> 6, nwave = NT >> 6, l = tid & 63;
-    for (int t = wave; t < 4; t += nwave) {
-      const int mt = t >> 1, nt = t & 1;
-      const int c = nt * 16 + (l & 15);
-      f64x4 acc;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) { const int row = mt * 16 + (l >> 4) + 4 * r; acc[r] = (row < 24 && c < 24) ? S.G[row * GS + c] : 0.0; }
-      acc = mfma_tile<NU / 4>(acc,
-                              [&](int i, int k) { const int row = mt * 16 + i; return row < 24 ? -S.G[(24 + k) * GS + row] : 0.0; },
-                              [&](int k, int j) { const int cj = nt * 16 + j; return cj < 24 ? Kl[k * 24 + cj] : 0.0; });
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = mt * 16 + (l >> 4) + 4 * r;
-        if (row < 24 && c < 24) { S.P[row * PS + c] = acc[r]; if (row < 12) rec[RIC_PX + row * 24 + c] = acc[r]; }
-      }
-    }
-  }
-  for (int i = tid; i < 24; i += NT) {
-    double acc = S.gam[i];
-#pragma unroll
-    for (int t = 0; t < NU; ++t) acc -= S.G[(24 + t) * GS + i] * kl[t];
-    S.pv[i] = acc;
-    if (i < 12) rec[RIC_PV + i] = acc;
-  }
-  for (int e = tid; e < NU * 24; e += NT) rec[RIC_K + e] = Kl[e];
-  for (int i = tid; i < NU; i += NT) rec[RIC_KAP + i] = kl[i];
+  long long tg_ = S.prof_on ? (long long)wall_clock64() : 0;
+  const bool ok = block_eliminate<NU>(rec);
+  PROF_ADD(PH_B_POST, tg_);          // slot 15 = the blocked elimination alone (slot 14 = elimination + record stores)
+  if (!ok) { __syncthreads(); return false; }
   for (int e = tid; e < 12 * 36; e += NT) rec[RIC_AH + e] = S.Ah[(e / 36) * YS + e % 36];
   if (tid < 12) rec[RIC_B + tid] = S.bv[tid];
   __syncthreads();

@@ -78,6 +78,14 @@ inline int __builtin_amdgcn_readlane(int v, int lane) {
   hip_emu::wave_barrier();
   return buf[p][(threadIdx.x & ~63u) + (unsigned)lane];
 }
+inline int __builtin_amdgcn_ds_bpermute(int byte_addr, int v) {     // every lane reads lane (byte_addr / 4) & 63
+  static int buf[2][1024];
+  static unsigned cnt[1024];
+  const unsigned p = cnt[threadIdx.x]++ & 1u;
+  buf[p][threadIdx.x] = v;
+  hip_emu::wave_barrier();
+  return buf[p][(threadIdx.x & ~63u) + (((unsigned)byte_addr >> 2) & 63u)];
+}
 typedef double hip_emu_f64x4 __attribute__((vector_size(32)));
 // v_mfma_f64_16x16x4_f64: lane l supplies A[l&15][l>>4], B[l>>4][l&15]; D[(l>>4)+4r][l&15] (all 64 lanes of the wave call it)
 inline hip_emu_f64x4 __builtin_amdgcn_mfma_f64_16x16x4f64(double a, double b, hip_emu_f64x4 c, int, int, int) {
@@ -96,6 +104,7 @@ inline hip_emu_f64x4 __builtin_amdgcn_mfma_f64_16x16x4f64(double a, double b, hi
   return c;
 }
 inline double __builtin_amdgcn_rcp(double x) { return 1.0 / x; }
+inline void __builtin_amdgcn_sched_barrier(int) {}
 inline void __builtin_amdgcn_wave_barrier() { hip_emu::wave_barrier(); }
 inline int __double2hiint(double d) { long long b; std::memcpy(&b, &d, 8); return (int)(b >> 32); }
 inline int __double2loint(double d) { long long b; std::memcpy(&b, &d, 8); return (int)(b & 0xffffffffLL); }

@@ -37,4 +37,4 @@ for step in range(a.steps):
         nit, nfact, ntrial = ph[:, 10].sum(), ph[:, 8].sum(), ph[:, 9].sum()
         print(json.dumps({"phase_ms_per_iter": {n: 1e3 * t / nit for n, t in zip(names, tot)}, "ms_per_iter_total": 1e3 * tot.sum() / nit,
                           "fact_per_iter": nfact / nit, "trials_per_iter": ntrial / nit, "ms_per_fact": 1e3 * tot[3] / nfact, "ms_per_trial": 1e3 * tot[6] / ntrial,
-                          "back_us_per_stage_fact": {n: 1e6 * ph[:, 11 + i].sum() / 100e6 / nfact / a.N for i, n in enumerate(["load", "asm", "tpt", "elim+post"])}}))
+                          "back_us_per_stage_fact": {n: 1e6 * ph[:, 11 + i].sum() / 100e6 / nfact / a.N for i, n in enumerate(["load", "asm", "tpt", "elim+post", "pivot_chain"])}}))
