@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <array>
 #include <map>
+#include <set>
 #include <string>
 #include <vector>
 

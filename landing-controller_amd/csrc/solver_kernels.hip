@@ -214,15 +214,16 @@ __device__ __noinline__ void gauss_jordan_wave(const double* G, const double* ga
 // rows are then overwritten by R itself -- forming them as W - (D - I) R would cancel at the scale of W).  The pivots of the 4 x 4 LDL^T are the scalar pivots of the unblocked
 // elimination, so the inertia test (all pivots positive) is unchanged.  Returns false on a non-positive pivot.
 template <int NU>
-__device__ __noinline__ bool block_eliminate(double* __restrict__ rec) {
+__device__ __noinline__ bool block_eliminate(double* __restrict__ rec, double delta) {
   Lds& S = SH;
   constexpr int NR = NU + 24;                         // rows; column NR is gamma
   const int tid = threadIdx.x, ct = tid >> 6, l = tid & 63, lj = l & 15, lk = l >> 4;
   const int c = 16 * ct + lj;
+  const bool isg = (c == NR), live = (c <= NR);
+  const int bcol = c < NU ? 24 + c : (c < NR ? c - NU : 0);        // position of the own column in the (sigma, f, c+) order of G
   f64x4 T[3];
-  {   // tile fetch: every lane walks its own column (base, stride) of the symmetric G / of gamma
-    const bool isg = (c == NR), live = (c <= NR);
-    const double* src = isg ? S.gam : S.G + (c < NU ? 24 + c : (live ? c - NU : 0));
+  {   // tile fetch: every lane walks its own column (base, stride) of the condensed G / of gamma; delta_w on the diagonal
+    const double* src = isg ? S.gam : S.G + bcol;
     const int stride = isg ? 1 : GS;
 #pragma unroll
     for (int rt = 0; rt < 3; ++rt)
@@ -230,9 +231,55 @@ __device__ __noinline__ bool block_eliminate(double* __restrict__ rec) {
       for (int r = 0; r < 4; ++r) {
         const int rho = 16 * rt + lk + 4 * r;
         const int a = rho < NU ? 24 + rho : (rho < NR ? rho - NU : 0);
-        const double v = src[a * stride];
+        const double v = src[a * stride] + (rho == c ? delta : 0.0);
         T[rt][r] = (live && rho < NR) ? v : 0.0;
       }
+  }
+  {   // + T^T P T and T^T (P b + p) of the next stage's cost-to-go, formed where it is consumed.  With
+      // A_ext = [A^ | b] (12 rows) the own column of Y = P(:,0:12) A_ext comes out of the matrix cores in accumulator
+      // layout, which IS the B-operand layout of the next product (row 4kt+k of k-step kt sits in lane group k):
+      // Y never touches LDS.  Columns of c+ and the p-part of gamma enter P T directly.
+    const bool cplus = live && !isg && bcol >= 36;
+    double be[3];
+#pragma unroll
+    for (int kt = 0; kt < 3; ++kt) {
+      const double va = S.Ah[(4 * kt + lk) * YS + (bcol < 36 ? bcol : 0)], vb = S.bv[4 * kt + lk];
+      be[kt] = isg ? vb : ((live && bcol < 36) ? va : 0.0);
+    }
+    f64x4 Y1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kt = 0; kt < 3; ++kt) Y1 = __builtin_amdgcn_mfma_f64_16x16x4f64(S.P[lj * PS + 4 * kt + lk], be[kt], Y1, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const int row = lk + 4 * r;
+      const double dp = S.P[row * PS + (cplus ? 12 + bcol - 36 : 0)], dv = S.pv[row];
+      Y1[r] += cplus ? dp : (isg ? dv : 0.0);
+    }
+#pragma unroll
+    for (int rt = 0; rt < 3; ++rt) {
+      const int rho = 16 * rt + lj;
+      const int a = rho < NU ? 24 + rho : (rho < NR ? rho - NU : 99);
+#pragma unroll
+      for (int kt = 0; kt < 3; ++kt) {
+        const double av = S.Ah[(4 * kt + lk) * YS + (a < 36 ? a : 0)];
+        T[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a < 36 ? av : 0.0, Y1[kt], T[rt], 0, 0, 0);
+      }
+    }
+    if (NU == 24) {   // rows of c+ (control rows 12..23): + rows 12..23 of P T
+      f64x4 Y2 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int kt = 0; kt < 3; ++kt) {
+        const double pa = S.P[(lj < 12 ? 12 + lj : 0) * PS + 4 * kt + lk];
+        Y2 = __builtin_amdgcn_mfma_f64_16x16x4f64(lj < 12 ? pa : 0.0, be[kt], Y2, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const int row = 12 + lk + 4 * r;
+        const double dp = S.P[row * PS + (cplus ? 12 + bcol - 36 : 0)], dv = S.pv[row];
+        Y2[r] += cplus ? dp : (isg ? dv : 0.0);
+      }
+      T[0][3] += Y2[0]; T[1][0] += Y2[1]; T[1][1] += Y2[2];
+    }
   }
 #pragma unroll
   for (int b = 0; b < NU / 4; ++b) {
@@ -306,12 +353,10 @@ __device__ __noinline__ bool block_eliminate(double* __restrict__ rec) {
 // Everything of one backward Riccati step that follows the assembly of G, gamma (templated on the control
 // dimension: 24 = (f_k, c_{k+1}), 12 = last stage).  Writes P_k, p_k into S and the stage record.
 template <int NU>
-__device__ __forceinline__ bool riccati_step(double* rec) {
+__device__ __forceinline__ bool riccati_step(double* rec, double delta) {
   Lds& S = SH;
   const int tid = threadIdx.x, NT = blockDim.x;
-  long long tg_ = S.prof_on ? (long long)wall_clock64() : 0;
-  const bool ok = block_eliminate<NU>(rec);
-  PROF_ADD(PH_B_POST, tg_);          // slot 15 = the blocked elimination alone (slot 14 = elimination + record stores)
+  const bool ok = block_eliminate<NU>(rec, delta);
   if (!ok) { __syncthreads(); return false; }
   for (int e = tid; e < 12 * 36; e += NT) rec[RIC_AH + e] = S.Ah[(e / 36) * YS + e % 36];
   if (tid < 12) rec[RIC_B + tid] = S.bv[tid];
@@ -402,101 +447,33 @@ __device__ __noinline__ bool riccati_backward(double delta) {
     for (int j = 0; j < 24; ++j) rec[RIC_PX + i * 24 + j] = (j == i) ? S.P[i * PS + i] : 0.0;
     rec[RIC_PV + i] = S.pv[i];
   }
+  // background of the condensed stage data: the scatter below writes the structural nonzeros only (the patterns
+  // of the stages nest along the sweep unless the tables say otherwise), nothing else writes G / A^ any more
+  for (int e = lane; e < 48 * GS; e += NT) S.G[e] = 0.0;
+  for (int e = lane; e < 12 * YS; e += NT) S.Ah[e] = 0.0;
+  if (lane < 24) S.pv[lane] = (lane < 12) ? S.pv[lane] : 0.0;
+  const bool zero_each = S.tab[S.stage_tab[0] + 11] != 0;
   StagePre pre;
   stage_prefetch(N - 1, pre);
   __syncthreads();
   for (int k = N - 1; k >= 0 && ok; --k) {
     const bool last = (k == N - 1);
-    const int nu = last ? 12 : 24, nsn = last ? 12 : 24, nw = 24 + nu;
-    const int* tb = S.tab + S.stage_tab[k];
-    const int g0 = L.g_stage(k), nr = L.rows(k);
-    // ---- condensed stage data (prefetched into registers during the previous stage) -> LDS
     long long tb_ = S.prof_on ? (long long)wall_clock64() : 0;
-    (void)nr; (void)tb; (void)g0;
-    for (int e = lane; e < 48 * GS; e += NT) S.G[e] = 0.0;
-    for (int e = lane; e < 12 * YS; e += NT) S.Ah[e] = 0.0;
-    __syncthreads();
-    PROF_ADD(PH_B_LOAD, tb_);
-    stage_scatter(pre);
-    __syncthreads();
-    for (int a = lane; a < nw; a += NT) S.G[a * GS + a] += delta;
-    // ---- Y = P(:,0:12) A^  (nsn x 36), q = P(:,0:12) b + p   (A1 is free again: Y lives there)
-    double* Y = S.A1;
-    __syncthreads();
-    PROF_ADD(PH_B_ASM, tb_);
-    {   // Y = P(:,0:12) A^ on the matrix cores: (nsn/16 rounded up) x 3 tiles, K = 12, tiles dealt to the waves
-      const int wave = lane >> 6, nwave = NT >> 6, l = lane & 63;
-      const int MT = (nsn + 15) >> 4;
-      for (int t = wave; t < MT * 3; t += nwave) {
-        const int mt = t / 3, nt = t % 3;
-        f64x4 acc = {0.0, 0.0, 0.0, 0.0};
-        acc = mfma_tile<3>(acc,
-                           [&](int i, int k) { const int r = mt * 16 + i; return r < nsn ? S.P[r * PS + k] : 0.0; },
-                           [&](int k, int j) { const int c = nt * 16 + j; return c < 36 ? S.Ah[k * YS + c] : 0.0; });
-        const int c = nt * 16 + (l & 15);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { const int row = mt * 16 + (l >> 4) + 4 * r; if (row < nsn && c < 36) Y[row * YS + c] = acc[r]; }
-      }
-    }
-    for (int i = lane; i < nsn; i += NT) {
-      double acc = S.pv[i];
-#pragma unroll
-      for (int t = 0; t < 12; ++t) acc += S.P[i * PS + t] * S.bv[t];
-      S.q[i] = acc;
-    }
-    __syncthreads();
-    // ---- G += T^T P T, gamma += T^T q
-    {   // G(0:36,0:36) += A^T Y(0:12,:) on the matrix cores: 3 x 3 tiles, K = 12
-      const int wave = lane >> 6, nwave = NT >> 6, l = lane & 63;
-      for (int t = wave; t < 9; t += nwave) {
-        const int mt = t / 3, nt = t % 3;
-        const int c = nt * 16 + (l & 15);
-        f64x4 acc;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { const int row = mt * 16 + (l >> 4) + 4 * r; acc[r] = (row < 36 && c < 36) ? S.G[row * GS + c] : 0.0; }
-        acc = mfma_tile<3>(acc,
-                           [&](int i, int k) { const int ci = mt * 16 + i; return ci < 36 ? S.Ah[k * YS + ci] : 0.0; },
-                           [&](int k, int j) { const int cj = nt * 16 + j; return cj < 36 ? Y[k * YS + cj] : 0.0; });
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { const int row = mt * 16 + (l >> 4) + 4 * r; if (row < 36 && c < 36) S.G[row * GS + c] = acc[r]; }
-      }
-    }
-    if (!last) {
-      for (int e = lane; e < 12 * 36; e += NT) {
-        const int i = e / 36, j = e % 36;
-        const double v = Y[(12 + i) * YS + j];
-        S.G[(36 + i) * GS + j] += v; S.G[j * GS + 36 + i] += v;
-      }
-      for (int e = lane; e < 144; e += NT) { const int i = e / 12, j = e % 12; S.G[(36 + i) * GS + 36 + j] += S.P[(12 + i) * PS + 12 + j]; }
-    }
-    for (int j = lane; j < 36; j += NT) {
-      double acc = 0.0;
-#pragma unroll
-      for (int t = 0; t < 12; ++t) acc += S.Ah[t * YS + j] * S.q[t];
-      S.gam[j] += acc;
-    }
-    if (!last && lane < 12) S.gam[36 + lane] += S.q[12 + lane];
-    __syncthreads();
-    PROF_ADD(PH_B_TPT, tb_);
-    // ---- eliminate the controls: P_k, p_k, gains -> record k
-    double* rec = M.ric + (size_t)k * RIC_STRIDE;
-    stage_prefetch(k - 1, pre);          // waves 1..3: loads in flight while wave 0 eliminates this stage's controls
-    for (;;) {
-      ok = last ? riccati_step<12>(rec) : riccati_step<24>(rec);
-      if (ok || !S.d_local) break;
-      // stage-local inertia correction: the elimination works in registers and leaves G untouched, so a wrong
-      // inertia in THIS stage only costs a larger diagonal shift and one more elimination (not a new sweep);
-      // the larger delta is carried on to the remaining stages
-      const double dnew = (delta == 0.0) ? (S.d_last == 0.0 ? S.d_init : fmax(1e-20, S.d_last * S.d_dec))
-                                         : delta * (S.d_last == 0.0 ? S.d_incf : S.d_inc);
-      if (!(dnew < 1e40)) break;
-      for (int a = lane; a < nw; a += NT) S.G[a * GS + a] += dnew - delta;
-      delta = dnew;
-      if (lane == 0) S.n_stage_retry++;
+    if (zero_each && !last) {
+      for (int e = lane; e < 48 * GS; e += NT) S.G[e] = 0.0;
+      for (int e = lane; e < 12 * YS; e += NT) S.Ah[e] = 0.0;
       __syncthreads();
     }
+    PROF_ADD(PH_B_LOAD, tb_);
+    // ---- condensed stage data (prefetched into registers during the previous stage) -> LDS
+    stage_scatter(pre);
+    __syncthreads();
+    PROF_ADD(PH_B_ASM, tb_);
+    // ---- G + T^T P T, elimination of the controls: P_k, p_k, gains -> record k
+    double* rec = M.ric + (size_t)k * RIC_STRIDE;
+    stage_prefetch(k - 1, pre);          // loads of the next stage's data in flight during the elimination
+    ok = last ? riccati_step<12>(rec, delta) : riccati_step<24>(rec, delta);
     PROF_ADD(PH_B_ELIM, tb_);
-    if (!ok) break;
   }
   if (ok) {
     // ---- stage 0: X_0 fixed, feet c_0 free: P_cc dc0 = -(p_c + P_cx dX0), same elimination on a 12x12 block
@@ -513,19 +490,9 @@ __device__ __noinline__ bool riccati_backward(double delta) {
       S.gam[24 + lane] = v;
     }
     __syncthreads();
-    for (;;) {
-      if (lane < 64) gauss_jordan_wave<12>(S.G, S.gam, S.A1, S.A1 + 24 * 24, &S.flag);
-      __syncthreads();
-      ok = S.flag != 0;
-      if (ok || !S.d_local) break;
-      const double dnew = (delta == 0.0) ? (S.d_last == 0.0 ? S.d_init : fmax(1e-20, S.d_last * S.d_dec))
-                                         : delta * (S.d_last == 0.0 ? S.d_incf : S.d_inc);
-      if (!(dnew < 1e40)) break;
-      if (lane < 12) S.G[(24 + lane) * GS + 24 + lane] += dnew - delta;
-      delta = dnew;
-      if (lane == 0) S.n_stage_retry++;
-      __syncthreads();
-    }
+    if (lane < 64) gauss_jordan_wave<12>(S.G, S.gam, S.A1, S.A1 + 24 * 24, &S.flag);
+    __syncthreads();
+    ok = S.flag != 0;
     if (ok) {
       if (lane < 12) S.sig[12 + lane] = -S.A1[24 * 24 + lane];
       __syncthreads();
@@ -764,7 +731,6 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
       __syncthreads();
       const bool ok = riccati_backward(delta);
       fact_ok = ok;
-      if (S.d_local) { delta = S.d_used; break; }          // stage-local mode: one sweep, delta = largest shift used
       if (attempt == 0) first_failed = skipped_zero && !ok;
     }
     if (!fact_ok) { status = LANDING_NUMERICAL; break; }
