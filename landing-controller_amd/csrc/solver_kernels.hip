@@ -582,8 +582,11 @@ __device__ __noinline__ void row_products(const int4* __restrict__ rterm, int rl
   __syncthreads();
 }
 
+// Workgroups per CU the register budget is sized for.  Measured on MI355X (N = 40): 3 per CU (168 VGPRs) beats 4 (128)
+// at every batch size tried -- 1024: 2050 vs 1890 NLPs/s, 2048: 2810 vs 2730, 4096: 3500 vs 3420 -- the phases are
+// latency-bound, so the fourth resident workgroup mostly adds contention; 2 per CU is level at 1024 and worse beyond.
 #ifndef LANDING_MIN_WAVES
-#define LANDING_MIN_WAVES 4
+#define LANDING_MIN_WAVES 3
 #endif
 __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm_kernel(SolveArgs A) {
   const int m = blockIdx.x;
