@@ -311,8 +311,12 @@ __device__ __noinline__ bool block_eliminate(double* __restrict__ rec, double de
     const double t32 = fma(-l31, t21, fma(-l30, a20, a32));
     const double l32 = t32 * i2;
     const double d3 = fma(-l32, t32, fma(-l31, t31, fma(-l30, a30, a33))), i3 = recip(d3);
-    const bool ok = (d0 > 0.0) && (d0 < 1e300) && (d1 > 0.0) && (d1 < 1e300) && (d2 > 0.0) && (d2 < 1e300) && (d3 > 0.0) && (d3 < 1e300);
-    if (!ok) return false;                               // identical in every lane of the workgroup
+    // all four pivots in (2^-1022, ~1e300): one unsigned range test on the high words (negative, zero, subnormal,
+    // huge, inf and NaN pivots all fall outside)
+    const unsigned h0 = (unsigned)__double2hiint(d0) - 0x00100000u, h1 = (unsigned)__double2hiint(d1) - 0x00100000u;
+    const unsigned h2 = (unsigned)__double2hiint(d2) - 0x00100000u, h3 = (unsigned)__double2hiint(d3) - 0x00100000u;
+    const unsigned h01 = h0 > h1 ? h0 : h1, h23 = h2 > h3 ? h2 : h3, hm = h01 > h23 ? h01 : h23;
+    const bool ok = hm < (0x7e37e43cu - 0x00100000u);
     // normalised pivot rows of the own column: D r = w by the two triangular solves (no explicit inverse: a badly
     // conditioned pivot block costs no more accuracy than the scalar elimination would); lane group lk keeps r[lk]
     const double y1 = fma(-l10, w0, w1);
@@ -325,9 +329,11 @@ __device__ __noinline__ bool block_eliminate(double* __restrict__ rec, double de
     const double R = lk == 0 ? r0 : (lk == 1 ? r1 : (lk == 2 ? r2 : r3));
     if (16 * ct + 16 > 4 * b) {                          // tiles whose columns are all eliminated already stay as they are
 #pragma unroll
-      for (int rt = 0; rt < 3; ++rt) T[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(-am[rt], R, T[rt], 0, 0, 0);
+      for (int rt = 0; rt < 3; ++rt) T[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(am[rt], -R, T[rt], 0, 0, 0);
       T[rtb][rb] = R;                                    // the pivot rows become the normalised rows, exactly
     }
+    if (!ok) return false;                               // identical in every lane of the workgroup (tested after the
+                                                         // update so that the operand fetches are not held behind it)
   }
   // gains to the stage record, cost-to-go to LDS (+ its state rows to the record)
   if (c >= NU && c <= NR) {
