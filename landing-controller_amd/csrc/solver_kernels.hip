@@ -25,7 +25,10 @@ constexpr int GS = 49;    // LDS row stride of G (48x48)
 constexpr int PS = 25;    // LDS row stride of 24x24 matrices
 constexpr int YS = 37;    // LDS row stride of 24x36 / 12x36 matrices
 // per-stage Riccati record (doubles): K 24x24 | kappa 24 | A^ 12x36 | b 12 | P_k rows of X (12x24) | p_k X part 12
-constexpr int RIC_K = 0, RIC_KAP = 576, RIC_AH = 600, RIC_B = 1032, RIC_PX = 1044, RIC_PV = 1332, RIC_STRIDE = 1344;
+// stage record: gains K (nu x 24) | kappa (24) | closed-loop state map of the forward sweep X+ = Mt sigma + mv (12 x 24 | 12) |
+// state rows of the cost-to-go P (12 x 24) | p (12)
+constexpr int RIC_K = 0, RIC_KAP = 576, RIC_MT = 600, RIC_MV = 888, RIC_PX = 900, RIC_PV = 1188, RIC_STRIDE = 1200;
+constexpr int RIC_FWD0 = 288, RIC_FWDN = 612;   // forward chain reads rec[288, 900): K rows of c+ | kappa | Mt | mv
 constexpr int FILT_CAP = 64;
 constexpr int ES = 26;    // LDS row stride of the elimination side block [gamma_u | I] (24 x 25)
 constexpr int SOLVER_THREADS = 256;
@@ -335,6 +338,24 @@ __device__ __noinline__ bool block_eliminate(double* __restrict__ rec, double de
     if (!ok) return false;                               // identical in every lane of the workgroup (tested after the
                                                          // update so that the operand fetches are not held behind it)
   }
+  {   // closed-loop state map for the forward sweep: X+ = A^_sigma sigma + A^_f f + b with f = -(K_f sigma + kappa_f), i.e.
+      // Mt = A^_sigma - A^_f K_f, mv = b - A^_f kappa_f.  K_f / kappa_f are rows 0..11 of the first row tile, already in
+      // B-operand layout (k-step kt = accumulator kt).
+    f64x4 Mq = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kt = 0; kt < 3; ++kt) {
+      const double af = S.Ah[(lj < 12 ? lj : 0) * YS + 24 + 4 * kt + lk];
+      Mq = __builtin_amdgcn_mfma_f64_16x16x4f64(lj < 12 ? af : 0.0, T[0][kt], Mq, 0, 0, 0);
+    }
+    if (c >= NU && c <= NR) {
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const int i = lk + 4 * r;
+        if (c < NR) rec[RIC_MT + i * 24 + (c - NU)] = S.Ah[i * YS + (c - NU)] - Mq[r];
+        else rec[RIC_MV + i] = S.bv[i] - Mq[r];
+      }
+    }
+  }
   // gains to the stage record, cost-to-go to LDS (+ its state rows to the record)
   if (c >= NU && c <= NR) {
     const int sj = c - NU;
@@ -361,11 +382,8 @@ __device__ __noinline__ bool block_eliminate(double* __restrict__ rec, double de
 template <int NU>
 __device__ __forceinline__ bool riccati_step(double* rec, double delta) {
   Lds& S = SH;
-  const int tid = threadIdx.x, NT = blockDim.x;
   const bool ok = block_eliminate<NU>(rec, delta);
   if (!ok) { __syncthreads(); return false; }
-  for (int e = tid; e < 12 * 36; e += NT) rec[RIC_AH + e] = S.Ah[(e / 36) * YS + e % 36];
-  if (tid < 12) rec[RIC_B + tid] = S.bv[tid];
   __syncthreads();
   return true;
 }
@@ -510,62 +528,87 @@ __device__ __noinline__ bool riccati_backward(double delta) {
 }
 
 // Forward sweep: dx of every stage, next states, multipliers of the dynamics rows.
+// The serial part is the state recursion alone: sigma_{k+1} = [Mt; -K_c] sigma_k + [mv; -kappa_c] (one 24 x 24
+// product and one barrier per stage; the 612 doubles of a stage are prefetched four stages ahead into registers
+// and passed on through a double-buffered LDS slot).  The forces f_k = -(K_f sigma_k + kappa_f) and the multipliers
+// of the dynamics rows y_k = -(P_{k+1} sigma_{k+1} + p_{k+1})_X do not feed the recursion: they are evaluated for
+// all stages at once afterwards.
 __device__ __noinline__ void forward_pass() {
   Lds& S = SH;
   const Layout& L = S.L;
   const MemberMem& M = S.M;
-  const double* p = S.p;
-  const int N = L.N, lane = threadIdx.x, NT = blockDim.x;
-  (void)p; (void)N; (void)lane; (void)NT;
-  // ================================================================ forward pass: dx, ds (stage rows), y_dyn
-  // the stage record (K, kappa, A^, b) and P_{k+1}(X rows) are staged through LDS with coalesced loads
-  for (int k = 0; k < N; ++k) {
-    const bool last = (k == N - 1);
-    const int nu = last ? 12 : 24;
-    const double* rec = M.ric + (size_t)k * RIC_STRIDE;
-    const double* recn = M.ric + (size_t)(k + 1) * RIC_STRIDE;
-    const int g0 = L.g_stage(k);
-    double* Kl = S.G;                 // nu x 24 (stride 24) | kappa at 576 | A^ 12x36 at 600 | b at 1032 | Px 12x24 at 1044 | pv at 1332
-    for (int e = lane; e < RIC_PX; e += NT) Kl[e] = rec[e];
-    for (int e = lane; e < RIC_STRIDE - RIC_PX; e += NT) Kl[RIC_PX + e] = recn[RIC_PX + e];
-    __syncthreads();
-    if (lane < nu) {
-      double acc = Kl[RIC_KAP + lane];
+  const int N = L.N, tid = threadIdx.x, NT = blockDim.x;
+  double* sg = S.G;                    // sigma_k, k = 0..N  at sg[24 k]           (N <= 64: 1560 doubles)
+  double* buf = S.G + 24 * 65;         // two stage slots of RIC_FWDN doubles       (up to 1560 + 1224 = 2784 > 48*GS: second slot in A1)
+  double* buf1 = S.A1;
+  static_assert(24 * 65 + RIC_FWDN <= 48 * GS && RIC_FWDN <= XCH * 2, "forward scratch fits");
+  auto slot = [&](int k) { return (k & 1) ? buf1 : buf; };
+  auto fetch = [&](int k, double (&r)[3]) {
+    const double* rec = M.ric + (size_t)k * RIC_STRIDE + RIC_FWD0;
 #pragma unroll
-      for (int t = 0; t < 24; ++t) acc += Kl[RIC_K + lane * 24 + t] * S.sig[t];
-      S.w[24 + lane] = -acc;
-    } else if (lane >= 32 && lane < 56) S.w[lane - 32] = S.sig[lane - 32];
-    __syncthreads();
-    if (lane < 12) { M.dx[L.x_X(k) + lane] = S.w[lane]; M.dx[L.x_U(k) + lane] = S.w[12 + lane]; M.dx[L.x_U(k) + 12 + lane] = S.w[24 + lane]; }
-    // next state: X+ = A^ [sigma; f] + b ; c+ = u_c   (threads 128.. so that they do not queue behind the row loop)
-    if (lane >= 128 && lane < 140) {
-      const int i = lane - 128;
-      double acc = Kl[RIC_B + i];
+    for (int j = 0; j < 3; ++j) { const int e = tid + j * 256; r[j] = (k < N && e < RIC_FWDN) ? rec[e] : 0.0; }
+  };
+  auto stash = [&](int k, const double (&r)[3]) {
+    double* b = slot(k);
 #pragma unroll
-      for (int t = 0; t < 36; ++t) acc += Kl[RIC_AH + i * 36 + t] * S.w[t];
-      S.q[i] = acc;
-    } else if (lane >= 140 && lane < 152) {
-      S.q[lane - 128] = last ? 0.0 : S.w[36 + (lane - 140)];
+    for (int j = 0; j < 3; ++j) { const int e = tid + j * 256; if (k < N && e < RIC_FWDN) b[e] = r[j]; }
+  };
+  if (tid < 24) sg[tid] = S.sig[tid];
+  double r0[3], r1[3], r2[3], r3[3];
+  fetch(0, r0); fetch(1, r1); fetch(2, r2); fetch(3, r3);
+  stash(0, r0); fetch(4, r0);
+  __syncthreads();
+  auto stage = [&](int k, double (&rn)[3]) {
+    // rn holds stage k+1 (loaded four stages ago): hand it to LDS, refill it with stage k+5
+    if (k < N) {
+      const double* b = slot(k);                 // [0,288) K rows of c+ | [288,312) kappa | [312,600) Mt | [600,612) mv
+      const bool lastk = (k == N - 1);
+      if (tid < 192) {
+        const int r = tid >> 3, j = tid & 7;
+        const double* row = (r < 12) ? b + 312 + r * 24 : b + (r - 12) * 24;
+        const double* sk = sg + 24 * k;
+        double acc = row[3 * j] * sk[3 * j] + row[3 * j + 1] * sk[3 * j + 1] + row[3 * j + 2] * sk[3 * j + 2];
+        acc += __shfl_xor(acc, 1); acc += __shfl_xor(acc, 2); acc += __shfl_xor(acc, 4);
+        if (j == 0) sg[24 * (k + 1) + r] = (r < 12) ? b[600 + r] + acc : (lastk ? 0.0 : -(b[300 + (r - 12)] + acc));
+      }
     }
+    stash(k + 1, rn);
+    fetch(k + 5, rn);
     __syncthreads();
-    if (lane < 24) S.sig[lane] = S.q[lane];
-    // multipliers of the dynamics rows: y = -(P_{k+1} sigma_{k+1} + p_{k+1})_X   (state order -> row order)
-    if (lane >= 64 && lane < 76) {
-      const int i = lane - 64;
-      double acc = Kl[RIC_PV + i];
-      const int nn = last ? 12 : 24;
-      for (int t = 0; t < nn; ++t) acc += Kl[RIC_PX + i * 24 + t] * S.q[t];
-      const int q = i < 6 ? i : (i < 9 ? i + 3 : i - 3);   // state index -> dyn row
-      M.yn[g0 + q] = -acc;
-    }
-    __syncthreads();
+  };
+  for (int k0 = 0; k0 < N; k0 += 4) {
+    stage(k0, r1); stage(k0 + 1, r2); stage(k0 + 2, r3); stage(k0 + 3, r0);
   }
-  if (lane < 12) {
-    const int i = lane;
-    M.dx[12 * N + i] = S.sig[i];
+  // ---- everything that hangs off the states, all stages at once
+  for (int e = tid; e < 24 * (N + 1); e += NT) {
+    const int k = e / 24, i = e % 24;
+    if (i < 12) M.dx[L.x_X(k) + i] = sg[e];
+    else if (k < N) M.dx[L.x_U(k) + (i - 12)] = sg[e];
+  }
+  for (int e = tid; e < 24 * N; e += NT) {
+    const int k = e / 24, h = e % 24, i = h % 12;
+    const double* sk = sg + 24 * (h < 12 ? k : k + 1);
+    if (h < 12) {            // forces of stage k
+      const double* rec = M.ric + (size_t)k * RIC_STRIDE;
+      double acc = rec[RIC_KAP + i];
+#pragma unroll
+      for (int t = 0; t < 24; ++t) acc += rec[RIC_K + i * 24 + t] * sk[t];
+      M.dx[L.x_U(k) + 12 + i] = -acc;
+    } else {                 // multipliers of the dynamics rows of stage k (state order -> row order)
+      const double* recn = M.ric + (size_t)(k + 1) * RIC_STRIDE;
+      double acc = recn[RIC_PV + i];
+#pragma unroll
+      for (int t = 0; t < 24; ++t) acc += recn[RIC_PX + i * 24 + t] * sk[t];
+      const int q = i < 6 ? i : (i < 9 ? i + 3 : i - 3);
+      M.yn[L.g_stage(k) + q] = -acc;
+    }
+  }
+  if (tid < 12) {
+    const int i = tid;
+    const double v = sg[24 * N + i];
     const int ra = i < 6 ? 12 + i : 24 + (i - 6), rb = i < 6 ? 18 + i : 30 + (i - 6);
-    M.ds[ra] = S.sig[i] + (M.g[ra] - M.s[ra]);
-    M.ds[rb] = S.sig[i] + (M.g[rb] - M.s[rb]);
+    M.ds[ra] = v + (M.g[ra] - M.s[ra]);
+    M.ds[rb] = v + (M.g[rb] - M.s[rb]);
   }
   __syncthreads();
 }
