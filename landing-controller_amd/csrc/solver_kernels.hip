@@ -390,7 +390,7 @@ __device__ __forceinline__ bool riccati_step(double* rec, double delta) {
 
 // Condensation (once per iteration): G targets = H + J_d^T Sigma J_d, gamma = J_d^T rho, A^ = -dg_dyn/d(X,c,f) of
 // every stage, straight from the CCS nonzeros.  Each thread owns a fixed list of terms (host-built, interleaved so
-// that the 16-byte records load coalesced; deterministic summation order); loads are batched 4 deep.
+// that the 16-byte records load coalesced; deterministic summation order).
 __device__ __noinline__ void condense(const int4* __restrict__ cterm, int clen) {
   Lds& S = SH;
   const MemberMem& M = S.M;
@@ -399,15 +399,32 @@ __device__ __noinline__ void condense(const int4* __restrict__ cterm, int clen) 
   const double* __restrict__ SR = M.sig;     // [sigma | rho] are contiguous
   double* __restrict__ cond = M.cond;
   double acc = 0.0;
-#pragma unroll 4
-  for (int j = 0; j < clen; ++j) {
-    const int4 t = cterm[(size_t)j * NT + tid];
-    const double a = JH[t.y];
-    const double b = JH[t.z >= 0 ? t.z : 0];
-    const double c = SR[t.x >= 0 ? t.x + (t.z < 0 ? ng : 0) : 0];
-    const double cc = t.x >= 0 ? c : (t.x == -1 ? 1.0 : (t.x == -2 ? -1.0 : 0.0));
-    acc += a * (t.z >= 0 ? b : 1.0) * cc;
-    if (t.w >= 0) { cond[t.w] = acc; acc = 0.0; }
+  // batches of 8 terms: the records of the next batch are fetched while the 24 gathers of this one are in flight
+  // (two dependent memory round trips per batch otherwise; the phase is pure latency)
+  constexpr int BW = 8;
+  const int4 padterm = {-3, 0, -1, -1};
+  int4 tn[BW];
+#pragma unroll
+  for (int u = 0; u < BW; ++u) tn[u] = (u < clen) ? cterm[(size_t)u * NT + tid] : padterm;
+  for (int j0 = 0; j0 < clen; j0 += BW) {
+    int4 t[BW];
+#pragma unroll
+    for (int u = 0; u < BW; ++u) t[u] = tn[u];
+#pragma unroll
+    for (int u = 0; u < BW; ++u) { const int j = j0 + BW + u; tn[u] = (j < clen) ? cterm[(size_t)j * NT + tid] : padterm; }
+    double a[BW], b[BW], c[BW];
+#pragma unroll
+    for (int u = 0; u < BW; ++u) {
+      a[u] = JH[t[u].y];
+      b[u] = JH[t[u].z >= 0 ? t[u].z : 0];
+      c[u] = SR[t[u].x >= 0 ? t[u].x + (t[u].z < 0 ? ng : 0) : 0];
+    }
+#pragma unroll
+    for (int u = 0; u < BW; ++u) {
+      const double cc = t[u].x >= 0 ? c[u] : (t[u].x == -1 ? 1.0 : (t[u].x == -2 ? -1.0 : 0.0));
+      acc += a[u] * (t[u].z >= 0 ? b[u] : 1.0) * cc;
+      if (t[u].w >= 0) { cond[t[u].w] = acc; acc = 0.0; }
+    }
   }
   __syncthreads();
 }
