@@ -136,6 +136,13 @@ __device__ __forceinline__ f64x4 mfma_tile(f64x4 c, FA fa, FB fb) {
   return c;
 }
 
+// 1/d by v_rcp_f64 + two Newton steps (<= 1 ulp measured, tools/dev/rcp_prec.hip; the IEEE division sequence is 4x longer).
+__device__ __forceinline__ double fast_rcp(double d) {
+  double i = __builtin_amdgcn_rcp(d);
+  i = fma(i, fma(-d, i, 1.0), i);
+  return fma(i, fma(-d, i, 1.0), i);
+}
+
 // Broadcast of one lane's fp64 value to the whole wave through the scalar unit (v_readlane_b32 x2; `src` must be
 // wave-uniform -- it is a compile-time constant in the unrolled elimination below).
 __device__ __forceinline__ double lane_bcast(double v, int src) {
@@ -721,8 +728,8 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
         else {
           const double s = r_s[r];
           pr = fmax(pr, fabs(g - s));
-          if (lb > -INF) { const double d = s - lb, zl = r_zL[r]; co = fmax(co, d * zl); cm = fmax(cm, fabs(d * zl - mu_)); sg += zl / d; rh -= mu_ / d; }
-          if (ub < INF) { const double d = ub - s, zu = r_zU[r]; co = fmax(co, d * zu); cm = fmax(cm, fabs(d * zu - mu_)); sg += zu / d; rh += mu_ / d; }
+          if (lb > -INF) { const double d = s - lb, rd = fast_rcp(d), zl = r_zL[r]; co = fmax(co, d * zl); cm = fmax(cm, fabs(d * zl - mu_)); sg += zl * rd; rh -= mu_ * rd; }
+          if (ub < INF) { const double d = ub - s, rd = fast_rcp(d), zu = r_zU[r]; co = fmax(co, d * zu); cm = fmax(cm, fabs(d * zu - mu_)); sg += zu * rd; rh += mu_ * rd; }
           rh += sg * (g - s);
         }
       }
@@ -812,35 +819,41 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
 
     PROF_ADD(PH_FWD, tp);
     // ================================================================ dual steps, step bounds, merit data
-    double a_pr = 1.0, a_du = 1.0, th0 = 0.0, bar = 0.0, dphi = 0.0;
-#pragma unroll 2
+    // fraction-to-the-boundary as tau / max(-ds/d), tau / max(-dz/z): reciprocals instead of divisions in the row
+    // loop, one logarithm per row (log of the product of the two distances)
+    double m_pr = 0.0, m_du = 0.0, th0 = 0.0, bar = 0.0, dphi = 0.0;
+#pragma unroll 2   // (unroll 4 of this loop hangs the kernel on gfx950 / ROCm 7.2 -- observed, not understood; keep 2)
     for (int r = lane + 12; r < ng; r += NT) {
       const double lb = r_lb[r], ub = r_ub[r], g = r_g[r];
       if (lb == ub) { th0 += fabs(g - lb); continue; }
       const double s = r_s[r], ds = r_ds[r];
       th0 += fabs(g - s);
+      double dprod = 1.0;
       if (lb > -INF) {
-        const double d = s - lb, zl = r_zL[r];
-        const double dz = mu / d - zl - zl / d * ds;
-        if (ds < 0.0) a_pr = fmin(a_pr, -tau * d / ds);
-        if (dz < 0.0) a_du = fmin(a_du, -tau * zl / dz);
-        bar -= log(d); dphi -= mu * ds / d;
+        const double d = s - lb, rd = fast_rcp(d), zl = r_zL[r];
+        const double dz = fma(-zl * rd, ds, mu * rd - zl);
+        m_pr = fmax(m_pr, -ds * rd);
+        m_du = fmax(m_du, -dz * fast_rcp(zl));
+        dprod = d; dphi -= mu * ds * rd;
       }
       if (ub < INF) {
-        const double d = ub - s, zu = r_zU[r];
-        const double dz = mu / d - zu + zu / d * ds;
-        if (ds > 0.0) a_pr = fmin(a_pr, tau * d / ds);
-        if (dz < 0.0) a_du = fmin(a_du, -tau * zu / dz);
-        bar -= log(d); dphi += mu * ds / d;
+        const double d = ub - s, rd = fast_rcp(d), zu = r_zU[r];
+        const double dz = fma(zu * rd, ds, mu * rd - zu);
+        m_pr = fmax(m_pr, ds * rd);
+        m_du = fmax(m_du, -dz * fast_rcp(zu));
+        dprod *= d; dphi += mu * ds * rd;
       }
+      bar -= log(dprod);
     }
     double f0 = 0.0;
     if (lane < 12) {
       const double d = M.x[12 * N + lane] - p[12 * N + lane], qn = p[L.o_QN + lane];
       f0 = qn * d * d; dphi += 2.0 * qn * d * M.dx[12 * N + lane];
     }
-    { double v[6] = {a_pr, a_du, th0, bar, dphi, f0}; const int op[6] = {RMIN, RMIN, RSUM, RSUM, RSUM, RSUM};
-      block_reduce<6>(v, op, S.red); a_pr = v[0]; a_du = v[1]; th0 = v[2]; bar = v[3]; dphi = v[4]; f0 = v[5]; }
+    double a_pr, a_du;
+    { double v[6] = {m_pr, m_du, th0, bar, dphi, f0}; const int op[6] = {RMAX, RMAX, RSUM, RSUM, RSUM, RSUM};
+      block_reduce<6>(v, op, S.red); th0 = v[2]; bar = v[3]; dphi = v[4]; f0 = v[5];
+      a_pr = (v[0] > tau) ? tau / v[0] : 1.0; a_du = (v[1] > tau) ? tau / v[1] : 1.0; }
     const double ph0 = f0 + mu * bar;
     if (it == 0) th_max = 1e4 * fmax(1.0, th0);
     const double th_min = 1e-4;
@@ -862,8 +875,7 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
         if (lb == ub) { tht += fabs(g - lb); continue; }
         const double s = r_s[r] + alpha * r_ds[r];
         tht += fabs(g - s);
-        if (lb > -INF) bt -= log(s - lb);
-        if (ub < INF) bt -= log(ub - s);
+        bt -= log((lb > -INF ? s - lb : 1.0) * (ub < INF ? ub - s : 1.0));
       }
       if (lane < 12) { const double d = M.xt[12 * N + lane] - p[12 * N + lane]; ft = p[L.o_QN + lane] * d * d; }
       { double v[3] = {tht, bt, ft}; const int op[3] = {RSUM, RSUM, RSUM}; block_reduce<3>(v, op, S.red); tht = v[0]; bt = v[1]; ft = v[2]; }
@@ -916,14 +928,14 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
             const double so = r_s[r], ds = r_ds[r], s = so + alpha * ds;
             double zl = 0.0, zu = 0.0;
             if (lb > -INF) {
-              const double dold = so - lb, zo = r_zL[r], dz = mu / dold - zo - zo / dold * ds, d = s - lb;
-              zl = fmin(fmax(zo + a_du * dz, mu / (1e10 * d)), 1e10 * mu / d);
-              nco = fmax(nco, d * zl); ncm = fmax(ncm, fabs(d * zl - mu)); sg += zl / d; rh -= mu / d;
+              const double dold = so - lb, ro = fast_rcp(dold), zo = r_zL[r], dz = fma(-zo * ro, ds, mu * ro - zo), d = s - lb, rd = fast_rcp(d);
+              zl = fmin(fmax(zo + a_du * dz, 1e-10 * mu * rd), 1e10 * mu * rd);
+              nco = fmax(nco, d * zl); ncm = fmax(ncm, fabs(d * zl - mu)); sg += zl * rd; rh -= mu * rd;
             }
             if (ub < INF) {
-              const double dold = ub - so, zo = r_zU[r], dz = mu / dold - zo + zo / dold * ds, d = ub - s;
-              zu = fmin(fmax(zo + a_du * dz, mu / (1e10 * d)), 1e10 * mu / d);
-              nco = fmax(nco, d * zu); ncm = fmax(ncm, fabs(d * zu - mu)); sg += zu / d; rh += mu / d;
+              const double dold = ub - so, ro = fast_rcp(dold), zo = r_zU[r], dz = fma(zo * ro, ds, mu * ro - zo), d = ub - s, rd = fast_rcp(d);
+              zu = fmin(fmax(zo + a_du * dz, 1e-10 * mu * rd), 1e10 * mu * rd);
+              nco = fmax(nco, d * zu); ncm = fmax(ncm, fabs(d * zu - mu)); sg += zu * rd; rh += mu * rd;
             }
             npr = fmax(npr, fabs(g - s));
             rh += sg * (g - s);
