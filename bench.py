@@ -33,16 +33,20 @@ HBM_PEAK_GBPS = 8000.0       # MI355X_MICROARCH.md
 
 
 def flop_model(N):
-    """fp64 flops of the implemented recursion (DESIGN.md 'flop model'), per factorisation / iteration / trial."""
-    mid = (24 * 36 * 12 * 2 + 24 * 12 * 2 + 36 * 36 * 12 * 2 + 12 * 36 * 2 + 144 + 36 * 12 * 2 + 276 * 49 * 2
-           + 24 * 24 * 24 * 3 + 24 * 24 * 3 + 24 * 24 * 24 * 3 + 24 * 24 * 3)
-    last = (12 * 36 * 12 * 2 + 12 * 12 * 2 + 36 * 36 * 12 * 2 + 36 * 12 * 2 + 66 * 37 * 2 + 24 * 24 * 12 * 3 + 24 * 12 * 3
-            + 12 * 24 * 12 * 3 + 12 * 12 * 3)
-    fact = (N - 1) * mid + last + 66 * 37 * 2 + 12 * 12 * 3
+    """fp64 flops of the implemented recursion (DESIGN.md 'flop model'), per factorisation / iteration / trial.
+    Algorithmic counts (no tile padding): multiply-add = 2."""
+    def stage(nu):
+        nr, nc = nu + 24, nu + 25                      # rows (u, sigma) and columns (u, sigma, gamma) of the stage array
+        y = 24 * 12 * 37 * 2                           # Y = P(:,0:12) [A^ | b]
+        tpt = 36 * nc * 12 * 2 + 24 * nc               # G += A^T Y  (+ the c+ rows / columns and p entering directly)
+        gj = (nu // 4) * (nr * nc * 4 * 2 + nc * 28 + 60)   # blocked Gauss-Jordan: rank-4 updates, 4x4 solves, 4x4 LDL^T
+        cl = 12 * 12 * 25 * 2 + 12 * 25                # closed-loop map Mt = A^_s - A^_f K_f, mv
+        return y + tpt + gj + cl
+    fact = (N - 1) * stage(24) + stage(12) + 12 * 12 * 13 * 2 + 12 * 24 * 2      # + stage-0 foot block
     nnz_j = 36 + 385 * (N - 1) + 313
     n_terms = 1125 * N                                  # condensation terms per stage (tables in solver_capi.inc)
     it = (2 * 3500 * N          # Jacobian (twice: store + J^T y) and Hessian values, ~3.5 kflop per stage sweep each
-          + 3 * n_terms + N * (24 * 24 * 2 + 12 * 36 * 2 + 12 * 24 * 2) + 2 * (nnz_j - 149 * N) + 40 * (104 * N + 12))
+          + 3 * n_terms + N * (24 * 24 * 2 * 2 + 12 * 24 * 2) + 2 * (nnz_j - 149 * N) + 40 * (104 * N + 12))
     trial = 360 * N + 12 * (104 * N + 12)
     return fact, it, trial
 
@@ -146,7 +150,7 @@ def main():
         achieved = flops / (k_ms * 1e-3) / 1e12
         roofline = {"kernel": "landing_ipm_kernel", "bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": achieved / FP64_PEAK_TFLOPS, "traffic": None, "launch_ms": k_ms, "flops_per_launch": flops,
-                    "note": "fp64; latency-bound persistent kernel (one workgroup per NLP): serial stage x pivot chain, v_mfma_f64_16x16x4 for the dense stage products only"}
+                    "note": "fp64; latency-bound persistent kernel (one workgroup per NLP, 3 per CU): serial chain of 40 stages x 6 block-pivot steps per factorisation; T^T P T, the blocked Gauss-Jordan elimination and the closed-loop map run on v_mfma_f64_16x16x4"}
         # ---- function-layer sweep kernel (HBM bound)
         Bs = 4096
         reps = (Bs + B - 1) // B
