@@ -103,6 +103,7 @@ inline hip_emu_f64x4 __builtin_amdgcn_mfma_f64_16x16x4f64(double a, double b, hi
   }
   return c;
 }
+inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
 inline double __builtin_amdgcn_rcp(double x) { return 1.0 / x; }
 inline void __builtin_amdgcn_sched_barrier(int) {}
 inline void __builtin_amdgcn_wave_barrier() { hip_emu::wave_barrier(); }
