@@ -124,6 +124,11 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     el = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    per_rank = None
+    if world > 1:      # per-GPU time spread (inter-GPU load imbalance is reported, not balanced)
+        allel = [torch.zeros_like(el) for _ in range(world)]
+        dist.all_gather(allel, el)
+        per_rank = [1e3 * float(t.item()) / a.steps for t in allel]
     conv = (st == 0).sum().to(torch.float64).reshape(1)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
@@ -181,7 +186,15 @@ def main():
             tc = time.perf_counter()
             r = orc.cpu_solve_batch(O, P[:ns], X0[:ns], threads=cores, max_iter=a.max_iter)
             tcpu = time.perf_counter() - tc
-            cpu = {"value": float((r["status"] == 0).sum() / tcpu), "unit": "NLPs/s", "cores": cores, "kind": "port",
+            # function layer on the host: full derivative sweeps/s of the CPU restatement, one core and all cores
+            nsw = int(min(B, 4 * cores))
+            lam_h = np.random.default_rng(0).normal(size=(nsw, lib.ng))
+            t1 = time.perf_counter(); orc.cpu_sweep_batch(O, X0[:16], P[:16], lam_h[:16], reps=4, threads=1); t1 = time.perf_counter() - t1
+            ta = time.perf_counter(); orc.cpu_sweep_batch(O, X0[:nsw], P[:nsw], lam_h, reps=4, threads=cores); ta = time.perf_counter() - ta
+            cpu_fn = {"unit": "derivative sweeps/s (278 288 algorithmic bytes each)", "one_core": 64 / t1, "all_cores": 4 * nsw / ta, "cores": cores,
+                      "kind": "port", "sample": f"64 sweeps on one core, {4 * nsw} sweeps on {cores} cores (oracle/landing_oracle.c, OpenMP over members)",
+                      "gpu_sweeps_per_s": Bs / (s_ms * 1e-3)}
+            cpu = {"value": float((r["status"] == 0).sum() / tcpu), "unit": "NLPs/s", "cores": cores, "kind": "port", "function_layer": cpu_fn,
                    "sample": f"first {ns} members of rank 0's batch (N=40), max_iter {a.max_iter}, OpenMP over members, {tcpu:.1f} s",
                    "converged": int((r["status"] == 0).sum()), "gpu_converged_same_members": int(ok[:ns].sum())}
         out = {
@@ -190,7 +203,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "3D-SRBM landing NLP, N=40 intervals, batch=%d random drop heights/attitudes per GPU, fp64 (BASELINE configs[1])" % B,
                        "global_batch": B * world, "max_iter": a.max_iter, "kkt_tol": 1e-6, "parallelism": "batch-sharded x%d, RCCL all-gather of x*" % world},
-            "solved_per_step": solved_per_step, "members_per_step": B * world,
+            "solved_per_step": solved_per_step, "members_per_step": B * world, "ms_per_step_by_rank": per_rank,
             "kkt_max_over_solved": kh[ok].max(axis=0).tolist() if ok.any() else None,
             "iters_median": float(np.median(ith)), "iters_mean": float(ith.mean()),
             "roofline": roofline, "sweep_roofline": sweep, "cpu_baseline": cpu,

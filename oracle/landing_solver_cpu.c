@@ -401,3 +401,37 @@ int lo_solve_batch(const lo_form* F, int B, const double* p, const double* x0, c
   if (counters) { counters[0] = c0; counters[1] = c1; }
   return 0;
 }
+
+/* Full derivative sweeps of a batch (g, grad f, Jacobian and Hessian nonzeros of every member; SURVEY 8d unit of work for
+ * the function layer), `reps` times, OpenMP over members: CPU timing leg of bench.py.  Outputs go to per-thread scratch. */
+int lo_sweep_batch(const lo_form* F, int B, const double* x, const double* p, const double* lam_g, int reps, int threads) {
+  const lo_int nx = lo_nx(F->N), ng = lo_ng(F->N), np = lo_np(F->N), nj = lo_nnz_jac(F->N), nh = lo_nnz_hess(F->N);
+  int bad = 0;
+#ifdef _OPENMP
+  if (threads > 0) omp_set_num_threads(threads);
+#else
+  (void)threads;
+#endif
+#pragma omp parallel reduction(+ : bad)
+  {
+    double* g = (double*)malloc(sizeof(double) * (size_t)(ng + nx + nj + nh));
+    double f;
+    int r, b;
+    if (!g) bad = 1;
+    else {
+      double *gf = g + ng, *J = gf + nx, *H = J + nj;
+      for (r = 0; r < reps; ++r) {
+#pragma omp for schedule(static) nowait
+        for (b = 0; b < B; ++b) {
+          const double* xb = x + (size_t)b * nx; const double* pb = p + (size_t)b * np;
+          lo_nlp_grad_f(F, xb, pb, &f, gf);
+          lo_nlp_jac_g(F, xb, pb, g, J);
+          lo_nlp_hess_l(F, xb, pb, 1.0, lam_g + (size_t)b * ng, H);
+          if (!(f == f)) bad += 1;
+        }
+      }
+      free(g);
+    }
+  }
+  return bad;
+}

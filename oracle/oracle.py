@@ -149,6 +149,12 @@ def cpu_solve_batch(O, P, X0, threads=0, max_iter=None, tol=None):
     return dict(x=x, lam_g=lam, status=st, iters=it, kkt=kkt, factorizations=int(cnt[0]), trials=int(cnt[1]))
 
 
+def cpu_sweep_batch(O, X, P, LAM, reps=1, threads=0):
+    """oracle/landing_solver_cpu.c: `reps` full derivative sweeps of the batch on the host (bench.py's CPU function-layer leg)."""
+    X = np.ascontiguousarray(X, float); P = np.ascontiguousarray(P, float); LAM = np.ascontiguousarray(LAM, float)
+    return int(O.lib.lo_sweep_batch(O._F, C.c_int(X.shape[0]), _p(X), _p(P), _p(LAM), C.c_int(reps), C.c_int(threads)))
+
+
 class RefOracle:
     """The reference's generated C through its CasADi external ABI (N=20: x[732], p[354])."""
     N, nx, np_, ng, nnz_jac, nnz_hess = 20, 732, 354, 2092, 7664, 3780
