@@ -55,6 +55,16 @@ typedef struct {
   double kin_z_off;   /* :155  0.05 */
   double comp_eps;    /* :140  1e-3 */
   double slip_eps;    /* :143-144  1e-2 */
+  /* running cost of the reference's N=41 script (generate_quadruped_SRBM_CCC.m:81-89); 0 = terminal cost only
+   * (generate_landingCtrller_IPOPT.m:83-87, the default):
+   *   sum_k dt_k ( |X_k - Xref_k|^2_QX + sum_legs |pos_k + p_hip - c_k|^2_Qc + sum_legs |f_k - f_ref|^2_Qf )
+   * QX, Qc, Qf are parameters of that script whose callers pass constants; here they are constants of the context.
+   * Supported by landing_solve_batch and by f / grad_f of landing_eval_batch; the Hessian nonzeros of
+   * landing_eval_batch keep the CCS pattern of the terminal-cost NLP and are refused with a running cost. */
+  int run_cost;
+  double QX[12], Qc[3], Qf[3];
+  double f_ref[3];    /* Uref(13:24,k) = f_ref per leg in the callers (test_loadCasadi_ws.m:68-72) */
+  double p_hip[12];   /* CCC :76-79 */
 } landing_form;
 
 /* Options of the interior-point solver; names follow the IPOPT options the reference sets

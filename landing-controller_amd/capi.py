@@ -18,7 +18,9 @@ _llp = C.POINTER(C.c_longlong)
 
 
 class LandingForm(C.Structure):
-    _fields_ = [("kin_box", C.c_double * 3), ("kin_z_off", C.c_double), ("comp_eps", C.c_double), ("slip_eps", C.c_double)]
+    _fields_ = [("kin_box", C.c_double * 3), ("kin_z_off", C.c_double), ("comp_eps", C.c_double), ("slip_eps", C.c_double),
+                ("run_cost", C.c_int), ("QX", C.c_double * 12), ("Qc", C.c_double * 3), ("Qf", C.c_double * 3),
+                ("f_ref", C.c_double * 3), ("p_hip", C.c_double * 12)]
 
 
 class SolverOpts(C.Structure):
@@ -72,7 +74,7 @@ def _p(a):
 class LandingLib:
     """Thin object wrapper: one context per (N, device)."""
 
-    def __init__(self, N, device=0, kin_box=None, lib_path=None):
+    def __init__(self, N, device=0, kin_box=None, lib_path=None, run_cost=None):
         self.lib = load(lib_path)
         self.N = N
         form = LandingForm()
@@ -80,6 +82,12 @@ class LandingLib:
         if kin_box is not None:
             for i in range(3):
                 form.kin_box[i] = kin_box[i]
+        if run_cost is not None:      # dict(QX=[12], Qc=[3], Qf=[3], f_ref=[3]): generate_quadruped_SRBM_CCC.m:81-89
+            form.run_cost = 1
+            for i in range(12):
+                form.QX[i] = run_cost["QX"][i]
+            for i in range(3):
+                form.Qc[i] = run_cost["Qc"][i]; form.Qf[i] = run_cost["Qf"][i]; form.f_ref[i] = run_cost.get("f_ref", (0, 0, 0))[i]
         self.ctx = self.lib.landing_create(N, device, C.byref(form))
         if not self.ctx:
             raise RuntimeError("landing_create failed: " + self.lib.landing_last_error().decode())

@@ -44,6 +44,10 @@ const char* landing_last_error(void) { return g_err.c_str(); }
 void landing_form_default(landing_form* f) {
   f->kin_box[0] = 0.15; f->kin_box[1] = 0.15; f->kin_box[2] = 0.30;
   f->kin_z_off = 0.05; f->comp_eps = 1e-3; f->slip_eps = 1e-2;
+  f->run_cost = 0;
+  { const landing::Layout d = landing::make_layout(3);
+    for (int i = 0; i < 12; ++i) { f->QX[i] = 0.0; f->p_hip[i] = d.p_hip[i]; }
+    for (int i = 0; i < 3; ++i) { f->Qc[i] = 0.0; f->Qf[i] = 0.0; f->f_ref[i] = 0.0; } }
 }
 
 void landing_solver_opts_default(landing_solver_opts* o) {
@@ -185,6 +189,9 @@ landing_ctx* landing_create(int N, int device, const landing_form* form) {
   if (form) {
     for (int i = 0; i < 3; ++i) c->L.kin_box[i] = form->kin_box[i];
     c->L.kin_z_off = form->kin_z_off; c->L.comp_eps = form->comp_eps; c->L.slip_eps = form->slip_eps;
+    c->L.run_cost = form->run_cost ? 1 : 0;
+    for (int i = 0; i < 12; ++i) { c->L.QX[i] = form->QX[i]; c->L.p_hip[i] = form->p_hip[i]; }
+    for (int i = 0; i < 3; ++i) { c->L.Qc[i] = form->Qc[i]; c->L.Qf[i] = form->Qf[i]; c->L.f_ref[i] = form->f_ref[i]; }
   }
   return c;
 }
@@ -204,6 +211,7 @@ int landing_eval_batch(landing_ctx* ctx, int B, const double* d_x, const double*
   if (ctx && B == 0) return 0;          // empty batch: nothing to do
   if (!ctx || B < 0 || !d_x || !d_p) return fail(LANDING_E_ARG, "landing_eval_batch: bad argument");
   if ((d_hess || d_ggx || d_ggp) && !d_lam_g) return fail(LANDING_E_ARG, "landing_eval_batch: lam_g required for hess/grad_gamma");
+  if (ctx->L.run_cost && (d_hess || d_ggx || d_ggp)) return fail(LANDING_E_ARG, "landing_eval_batch: hess / grad_gamma are not provided with a running cost (CCS pattern of the terminal-cost NLP)");
   HIP_TRY(hipSetDevice(ctx->device));
   landing::EvalArgs A{d_x, d_p, d_lam_f, d_lam_g, d_f, d_g, d_grad_f, d_jac, d_hess, d_ggx, d_ggp, ctx->d_edge_map, d_g ? 1 : 0};
   if (ctx->L.N < 3) return fail(LANDING_E_ARG, "landing_eval_batch: N >= 3 required");

@@ -24,6 +24,30 @@ __host__ __device__ __forceinline__ int dyn_row_of_state(int i) {  // state inde
   return i < 6 ? i : (i < 9 ? i + 3 : i - 3);
 }
 
+// Running cost of stage k (generate_quadruped_SRBM_CCC.m:81-89) and, optionally, its gradient added to gX / gc / gf.
+__device__ __forceinline__ double run_cost_stage(const Layout& L, const double* x, const double* p, int k, double* gX, double* gc, double* gf) {
+  const double* X = x + L.x_X(k); const double* U = x + L.x_U(k);
+  const double dt = p[L.o_dt + k];
+  double s = 0.0;
+#pragma unroll
+  for (int i = 0; i < 12; ++i) {
+    const double e = X[i] - p[12 * k + i];
+    s += L.QX[i] * e * e;
+    if (gX) gX[i] += 2.0 * dt * L.QX[i] * e;
+  }
+#pragma unroll
+  for (int l = 0; l < 4; ++l)
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const double r = X[a] + L.p_hip[3 * l + a] - U[3 * l + a], u = U[12 + 3 * l + a] - L.f_ref[a];
+      s += L.Qc[a] * r * r + L.Qf[a] * u * u;
+      if (gX) gX[a] += 2.0 * dt * L.Qc[a] * r;
+      if (gc) gc[3 * l + a] -= 2.0 * dt * L.Qc[a] * r;
+      if (gf) gf[3 * l + a] += 2.0 * dt * L.Qf[a] * u;
+    }
+  return dt * s;
+}
+
 __device__ __forceinline__ void load_stage(const Layout& L, const double* x, const double* p, int k,
                                            srbm::StageVars& z, srbm::StageParams& P) {
   const double* Xk = x + L.x_X(k);
@@ -209,6 +233,7 @@ __global__ void __launch_bounds__(64) landing_sweep_misc_kernel(Layout L, int B,
       const double d = x[12 * N + i] - p[12 * N + i];
       s += d * p[L.o_QN + i] * d;
     }
+    if (L.run_cost) for (int k = 0; k < N; ++k) s += run_cost_stage(L, x, p, k, nullptr, nullptr, nullptr);
     if (A.f) A.f[m] = s;
   }
   if (A.grad_f) {
@@ -216,6 +241,10 @@ __global__ void __launch_bounds__(64) landing_sweep_misc_kernel(Layout L, int B,
     for (int i = threadIdx.x; i < L.nx; i += blockDim.x) {
       const int t = i - 12 * N;
       gf[i] = (t >= 0 && t < 12) ? 2.0 * p[L.o_QN + t] * (x[i] - p[12 * N + t]) : 0.0;
+    }
+    if (L.run_cost) {
+      __builtin_amdgcn_wave_barrier();
+      for (int k = threadIdx.x; k < N; k += blockDim.x) { double* gU = gf + L.x_U(k); (void)run_cost_stage(L, x, p, k, gf + L.x_X(k), gU, gU + 12); }
     }
   }
   // ---- boundary rows (gen:90-97) ----

@@ -13,6 +13,9 @@ struct Layout {
       o_qd_term_min, o_qd_term_max, o_QN, o_mu, o_l_leg_max, o_f_max, o_mass, o_Ib, o_Ib_inv;
   // formulation constants
   double kin_box[3], kin_z_off, comp_eps, slip_eps;
+  // running cost of the N=41 script (generate_quadruped_SRBM_CCC.m:81-89), off by default
+  int run_cost;
+  double QX[12], Qc[3], Qf[3], f_ref[3], p_hip[12];
 
   __host__ __device__ int x_X(int k) const { return 12 * k; }
   __host__ __device__ int x_U(int k) const { return 12 * (N + 1) + 24 * k; }
@@ -38,6 +41,10 @@ inline Layout make_layout(int N) {
   L.o_q_term_min = b + 36; L.o_q_term_max = b + 42; L.o_qd_term_min = b + 48; L.o_qd_term_max = b + 54;
   L.o_QN = b + 60; L.o_mu = b + 72; L.o_l_leg_max = b + 73; L.o_f_max = b + 74; L.o_mass = b + 75; L.o_Ib = b + 76; L.o_Ib_inv = b + 79;
   L.kin_box[0] = 0.15; L.kin_box[1] = 0.15; L.kin_box[2] = 0.30; L.kin_z_off = 0.05; L.comp_eps = 1e-3; L.slip_eps = 1e-2;
+  L.run_cost = 0;
+  { const double ph[12] = {0.19, -0.1, -0.2, 0.19, 0.1, -0.2, -0.19, -0.1, -0.2, -0.19, 0.1, -0.2};
+    for (int i = 0; i < 12; ++i) { L.QX[i] = 0.0; L.p_hip[i] = ph[i]; }
+    for (int i = 0; i < 3; ++i) { L.Qc[i] = 0.0; L.Qf[i] = 0.0; L.f_ref[i] = 0.0; } }
   return L;
 }
 

@@ -34,13 +34,16 @@ constexpr int ES = 26;    // LDS row stride of the elimination side block [gamma
 constexpr int SOLVER_THREADS = 256;
 // condensed stage data (once per iteration): [G targets (table order) | gamma 48 | A^ values] per stage
 constexpr int COND_GAM = 480, COND_AH = 528, COND_STRIDE = 704;
+// constant Hessian entries of the running cost per stage, stored right behind the Hessian nonzeros so that the
+// condensation tables address them like any other entry of [J | H]: X diagonal (12) | (pos_a, c_leg,a) (12) | c diagonal (12) | f diagonal (12)
+constexpr int RUNC = 48;
 
 struct SolverWorkspace {
   double* buf = nullptr; size_t cap = 0;
   int* d_tab = nullptr; int* d_stage_tab = nullptr; int n_tab = 0;
   int *d_cterm = nullptr, *d_cstart = nullptr, *d_rterm = nullptr, *d_rstart = nullptr; int clen = 0, rlen = 0;
   static size_t member_stride(const Layout& L) {
-    return (size_t)4 * L.nx + (size_t)12 * L.ng + L.nnz_jac + L.nnz_hess + (size_t)(L.N + 1) * RIC_STRIDE + (size_t)L.N * COND_STRIDE;
+    return (size_t)4 * L.nx + (size_t)12 * L.ng + L.nnz_jac + L.nnz_hess + (size_t)L.N * RUNC + (size_t)(L.N + 1) * RIC_STRIDE + (size_t)L.N * COND_STRIDE;
   }
   int ensure(const Layout& L, int B);
   void release();
@@ -87,7 +90,7 @@ __device__ __forceinline__ double block_reduce1(double v, int op, double* red) {
 struct MemberMem {
   double *x, *xt, *dx, *gx;
   double *g, *gt, *s, *ds, *zL, *zU, *y, *yn, *lb, *ub, *sig, *rho;
-  double *J, *H, *ric, *cond;
+  double *J, *H, *Hc, *ric, *cond;
 };
 
 __device__ __forceinline__ MemberMem carve(const Layout& L, double* w) {
@@ -97,7 +100,7 @@ __device__ __forceinline__ MemberMem carve(const Layout& L, double* w) {
   M.zL = w; w += L.ng; M.zU = w; w += L.ng;
   M.y = w; w += L.ng; M.yn = w; w += L.ng; M.lb = w; w += L.ng; M.ub = w; w += L.ng;
   M.sig = w; w += L.ng; M.rho = w; w += L.ng;
-  M.J = w; w += L.nnz_jac; M.H = w; w += L.nnz_hess; M.ric = w; w += (size_t)(L.N + 1) * RIC_STRIDE; M.cond = w;
+  M.J = w; w += L.nnz_jac; M.H = w; w += L.nnz_hess; M.Hc = w; w += (size_t)L.N * RUNC; M.ric = w; w += (size_t)(L.N + 1) * RIC_STRIDE; M.cond = w;
   return M;
 }
 
@@ -690,6 +693,18 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
     M.x[i] = v;
   }
   for (int r = lane; r < ng; r += NT) { double lb, ub; bound_of(L, p, r, lb, ub); M.lb[r] = lb; M.ub[r] = ub; }
+  if (L.run_cost) {   // constant Hessian entries of the running cost (layout: RUNC)
+    for (int e = lane; e < N * RUNC; e += NT) {
+      const int k = e / RUNC, j = e % RUNC, a = j % 3;
+      const double dt2 = 2.0 * p[L.o_dt + k];
+      double v;
+      if (j < 12) v = dt2 * (L.QX[j] + (j < 3 ? 4.0 * L.Qc[j] : 0.0));
+      else if (j < 24) v = -dt2 * L.Qc[a];
+      else if (j < 36) v = dt2 * L.Qc[a];
+      else v = dt2 * L.Qf[a];
+      M.Hc[e] = v;
+    }
+  }
   __syncthreads();
   member_eval_g(L, M.x, p, M.g);
   __syncthreads();
@@ -752,6 +767,10 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
     if (A.prof) tp = (long long)wall_clock64();
     member_eval_jh(L, M.x, p, M.y, M.J, M.H, M.gx);
     __syncthreads();
+    if (L.run_cost) {   // objective gradient of the stage variables (the terminal part is in member_eval_jh)
+      for (int k = lane; k < N; k += NT) { double* gU = M.gx + L.x_U(k); (void)run_cost_stage(L, M.x, p, k, M.gx + L.x_X(k), gU, gU + 12); }
+      __syncthreads();
+    }
     PROF_ADD(PH_EVAL, tp);
     // ---------------------------------------------------------------- optimality error (unscaled)
     if (it == 0) point_pass(mu);
@@ -788,6 +807,18 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
     PROF_ADD(PH_ERR, tp);
 
     condense(A.cterm, A.clen);
+    if (L.run_cost) {   // ... and in the stage right-hand sides gamma_k (w order X, c, f)
+      for (int k = lane; k < N; k += NT) {
+        double gr[36];
+#pragma unroll
+        for (int a = 0; a < 36; ++a) gr[a] = 0.0;
+        (void)run_cost_stage(L, M.x, p, k, gr, gr + 12, gr + 24);
+        double* gm = M.cond + (size_t)k * COND_STRIDE + COND_GAM;
+#pragma unroll
+        for (int a = 0; a < 36; ++a) gm[a] += gr[a];
+      }
+      __syncthreads();
+    }
     PROF_ADD(PH_SIGRHO, tp);
     // ================================================================ Riccati factorisation with inertia correction
     // IPOPT's inertia-correction schedule (delta_w = 0 first, then max(1e-20, delta_last/3), then x8 / x100),
@@ -850,6 +881,17 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
       const double d = M.x[12 * N + lane] - p[12 * N + lane], qn = p[L.o_QN + lane];
       f0 = qn * d * d; dphi += 2.0 * qn * d * M.dx[12 * N + lane];
     }
+    if (L.run_cost) for (int k0 = 0; k0 < N; k0 += NT) {
+      const int k = k0 + lane;
+      if (k >= N) continue;
+      double gr[36];
+#pragma unroll
+      for (int a = 0; a < 36; ++a) gr[a] = 0.0;
+      f0 += run_cost_stage(L, M.x, p, k, gr, gr + 12, gr + 24);
+      const double* dX = M.dx + L.x_X(k); const double* dU = M.dx + L.x_U(k);
+#pragma unroll
+      for (int a = 0; a < 12; ++a) dphi += gr[a] * dX[a] + gr[12 + a] * dU[a] + gr[24 + a] * dU[12 + a];
+    }
     double a_pr, a_du;
     { double v[6] = {m_pr, m_du, th0, bar, dphi, f0}; const int op[6] = {RMAX, RMAX, RSUM, RSUM, RSUM, RSUM};
       block_reduce<6>(v, op, S.red); th0 = v[2]; bar = v[3]; dphi = v[4]; f0 = v[5];
@@ -878,6 +920,7 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
         bt -= log((lb > -INF ? s - lb : 1.0) * (ub < INF ? ub - s : 1.0));
       }
       if (lane < 12) { const double d = M.xt[12 * N + lane] - p[12 * N + lane]; ft = p[L.o_QN + lane] * d * d; }
+      if (L.run_cost) for (int k0 = 0; k0 < N; k0 += NT) { const int k = k0 + lane; if (k < N) ft += run_cost_stage(L, M.xt, p, k, nullptr, nullptr, nullptr); }
       { double v[3] = {tht, bt, ft}; const int op[3] = {RSUM, RSUM, RSUM}; block_reduce<3>(v, op, S.red); tht = v[0]; bt = v[1]; ft = v[2]; }
       const double pht = ft + mu * bt;
       bool ok_f = (tht <= th_max) && (pht < 1e300) && (pht > -1e300) && (tht < 1e300);
@@ -957,6 +1000,9 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
   // multipliers of the initial-state rows from stationarity of X(:,1): lam = -(grad f + J^T y)
   double fo = 0.0;
   if (lane < 12) { M.y[lane] = -M.gx[lane]; const double d = M.x[12 * N + lane] - p[12 * N + lane]; fo = p[L.o_QN + lane] * d * d; }
+  // (uniform trip count with a lane predicate: a loop whose trip count differs per lane right in front of the block
+  // reduction hung the kernel on gfx950 / ROCm 7.2 even with the branch not taken -- bisected, tools/dev)
+  if (L.run_cost) for (int k0 = 0; k0 < N; k0 += NT) { const int k = k0 + lane; if (k < N) fo += run_cost_stage(L, M.x, p, k, nullptr, nullptr, nullptr); }
   fo = block_reduce1(fo, RSUM, S.red);
   // reference-consistent KKT residual: max_viol(g), ||grad f + J^T lam||_inf, |lam * dist|
   double kp = 0.0, kc = 0.0;

@@ -24,6 +24,31 @@ void lo_form_default(lo_form* F, int N) {
   F->kin_z_off = 0.05;                                                /* gen:155 */
   F->comp_eps = 1e-3;                                                 /* gen:140 */
   F->slip_eps = 1e-2;                                                 /* gen:143-144 */
+  F->run_cost = 0;
+  { int i; static const double ph[12] = {0.19, -0.1, -0.2, 0.19, 0.1, -0.2, -0.19, -0.1, -0.2, -0.19, 0.1, -0.2};   /* CCC :76-79 */
+    for (i = 0; i < 12; i++) { F->QX[i] = 0.0; F->p_hip[i] = ph[i]; }
+    for (i = 0; i < 3; i++) { F->Qc[i] = 0.0; F->Qf[i] = 0.0; F->f_ref[i] = 0.0; } }
+}
+
+double lo_run_cost_stage(const lo_form* F, const double* x, const double* p, int k, double* gX, double* gc, double* gf) {
+  /* CCC :81-89 */
+  const int N = F->N; lo_poff o; int i, l, a; double s = 0.0, dt;
+  const double* X = x + 12 * k; const double* U = x + 12 * (N + 1) + 24 * k;
+  lo_param_offsets(N, &o);
+  dt = p[o.dt + k];
+  for (i = 0; i < 12; i++) {
+    const double e = X[i] - p[o.Xref + 12 * k + i];
+    s += F->QX[i] * e * e;
+    if (gX) gX[i] += 2.0 * dt * F->QX[i] * e;
+  }
+  for (l = 0; l < 4; l++) for (a = 0; a < 3; a++) {
+    const double r = X[a] + F->p_hip[3 * l + a] - U[3 * l + a], u = U[12 + 3 * l + a] - F->f_ref[a];
+    s += F->Qc[a] * r * r + F->Qf[a] * u * u;
+    if (gX) gX[a] += 2.0 * dt * F->Qc[a] * r;
+    if (gc) gc[3 * l + a] -= 2.0 * dt * F->Qc[a] * r;
+    if (gf) gf[3 * l + a] += 2.0 * dt * F->Qf[a] * u;
+  }
+  return dt * s;
 }
 
 void lo_param_offsets(int N, lo_poff* o) { /* gen:51-75, order of opti.parameter() calls */
@@ -535,6 +560,13 @@ void lo_nlp_grad_f(const lo_form* F, const double* x, const double* p, double* f
     double d = x[12 * N + i] - p[o.Xref + 12 * N + i];
     s += d * p[o.QN + i] * d;
     if (grad) grad[12 * N + i] = 2 * p[o.QN + i] * d;
+  }
+  if (F->run_cost) {
+    int k;
+    for (k = 0; k < N; k++) {
+      double* gX = grad ? grad + 12 * k : NULL; double* gU = grad ? grad + 12 * (N + 1) + 24 * k : NULL;
+      s += lo_run_cost_stage(F, x, p, k, gX, gU, gU ? gU + 12 : NULL);
+    }
   }
   if (f) *f = s;
 }

@@ -33,7 +33,17 @@ typedef struct {
   double kin_z_off;   /* 0.05, generate_landingCtrller_IPOPT.m:155                          */
   double comp_eps;    /* 1e-3, :140 */
   double slip_eps;    /* 1e-2, :143-144 */
+  /* running cost of the N=41 script (generate_quadruped_SRBM_CCC.m:81-89), off by default:
+   *   sum_k dt_k ( |X_k - Xref_k|^2_QX + |pos_k + p_hip - c_k|^2_Qc (per leg) + |f_k - f_ref|^2_Qf (per leg) )
+   * QX, Qc, Qf are parameters of that script; the callers pass constants, so they live here. */
+  int run_cost;
+  double QX[12], Qc[3], Qf[3];
+  double f_ref[3];    /* Uref(13:24,k) = f_ref per leg in the callers (test_loadCasadi_ws.m:68-72) */
+  double p_hip[12];   /* CCC :76-79 */
 } lo_form;
+
+/* running cost of stage k; gX/gc/gf (12 each, may be NULL) receive its gradient (added to) */
+double lo_run_cost_stage(const lo_form* F, const double* x, const double* p, int k, double* gX, double* gc, double* gf);
 
 void lo_form_default(lo_form* F, int N);
 

@@ -196,6 +196,17 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
       double lam[LO_NROW]; double* J = W->Jst + (size_t)k * 104 * 60;
       for (q = 0; q < LO_NROW; ++q) lam[q] = q < nr ? W->y[36 + 104 * k + q] : 0.0;
       lo_stage_eval(F, k, W->x, p, lam, NULL, J, W->Hst + (size_t)k * 3600);
+      if (F->run_cost) {   /* running cost of the stage: gradient into gx, constant Hessian entries into the dense stage block */
+        double* Hs = W->Hst + (size_t)k * 3600; const double dtk = p[o.dt + k]; int a, l2;
+        double* gU = gx + 12 * (N + 1) + 24 * k;
+        (void)lo_run_cost_stage(F, W->x, p, k, gx + 12 * k, gU, gU + 12);
+        for (c = 0; c < 12; ++c) Hs[c * 60 + c] += 2.0 * dtk * F->QX[c];
+        for (l2 = 0; l2 < 4; ++l2) for (a = 0; a < 3; ++a) {
+          const int ic = 12 + 3 * l2 + a, jf = 24 + 3 * l2 + a; const double hc = 2.0 * dtk * F->Qc[a];
+          Hs[a * 60 + a] += hc; Hs[ic * 60 + ic] += hc; Hs[a * 60 + ic] -= hc; Hs[ic * 60 + a] -= hc;
+          Hs[jf * 60 + jf] += 2.0 * dtk * F->Qf[a];
+        }
+      }
       for (q = 0; q < nr; ++q) for (c = 0; c < 60; ++c) if (J[q * 60 + c] != 0.0) {
         const lo_int gi = c < 12 ? 12 * k + c : (c < 36 ? 12 * (N + 1) + 24 * k + (c - 12) : (c < 48 ? 12 * (k + 1) + (c - 36) : 12 * (N + 1) + 24 * (k + 1) + (c - 48)));
         gx[gi] += lam[q] * J[q * 60 + c];
@@ -259,6 +270,11 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
         for (a = 0; a < n; ++a) { mk[idx[a]] += rh * val[a]; for (b = 0; b < n; ++b) Mk[idx[a] * NW + idx[b]] += sg * val[a] * val[b]; }
       }
       for (q = 0; q < 12; ++q) { for (a = 0; a < 36; ++a) Ah[ROW2STATE[q] * 36 + a] = -J[q * 60 + a]; W->bv[k * 12 + ROW2STATE[q]] = -W->g[g0 + q]; }
+      if (F->run_cost) {   /* objective gradient of the stage variables enters the stage right-hand side (w order: X, c, f) */
+        double gr[36]; for (a = 0; a < 36; ++a) gr[a] = 0.0;
+        (void)lo_run_cost_stage(F, W->x, p, k, gr, gr + 12, gr + 24);
+        for (a = 0; a < 36; ++a) mk[a] += gr[a];
+      }
     }
     /* factorisation with inertia correction (same schedule as the HIP kernel) */
     delta = (streak >= 2 && delta_last > 0.0) ? fmax(1e-20, delta_last * op->delta_dec) : 0.0;
@@ -322,6 +338,11 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
       W->yn[r] = yn;
     }
     for (i = 0; i < 12; ++i) { const double d = W->x[12 * N + i] - p[12 * N + i], qn = p[o.QN + i]; f0 += qn * d * d; dphi += 2.0 * qn * d * W->dx[12 * N + i]; }
+    if (F->run_cost) for (k = 0; k < N; ++k) {
+      double gX[12] = {0}, gc[12] = {0}, gf[12] = {0}; const double* dX = W->dx + 12 * k; const double* dU = W->dx + 12 * (N + 1) + 24 * k;
+      f0 += lo_run_cost_stage(F, W->x, p, k, gX, gc, gf);
+      for (i = 0; i < 12; ++i) dphi += gX[i] * dX[i] + gc[i] * dU[i] + gf[i] * dU[12 + i];
+    }
     ph0 = f0 + mu * bar;
     if (it == 0) th_max = 1e4 * fmax(1.0, th0);
     alpha = a_pr;
@@ -338,6 +359,7 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
         if (ub < INFINITY) bt -= log(ub - s);
       }
       for (i = 0; i < 12; ++i) { const double d = W->xt[12 * N + i] - p[12 * N + i]; ft += p[o.QN + i] * d * d; }
+      if (F->run_cost) for (k = 0; k < N; ++k) ft += lo_run_cost_stage(F, W->xt, p, k, NULL, NULL, NULL);
       pht = ft + mu * bt;
       ok_f = (tht <= th_max) && (pht < 1e300) && (pht > -1e300) && (tht < 1e300);
       for (e = 0; e < nfilt && ok_f; ++e) if (tht >= filt_th[e] && pht >= filt_ph[e]) ok_f = 0;

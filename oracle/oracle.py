@@ -29,7 +29,8 @@ def build(quiet=True):
 
 class _Form(C.Structure):
     _fields_ = [("N", C.c_int), ("kin_box", C.c_double * 3), ("kin_z_off", C.c_double),
-                ("comp_eps", C.c_double), ("slip_eps", C.c_double)]
+                ("comp_eps", C.c_double), ("slip_eps", C.c_double), ("run_cost", C.c_int), ("QX", C.c_double * 12),
+                ("Qc", C.c_double * 3), ("Qf", C.c_double * 3), ("f_ref", C.c_double * 3), ("p_hip", C.c_double * 12)]
 
 
 def _p(a):
@@ -37,7 +38,7 @@ def _p(a):
 
 
 class Oracle:
-    def __init__(self, N, kin_box=None):
+    def __init__(self, N, kin_box=None, run_cost=None):
         path = os.path.join(HERE, "liblanding_oracle.so")
         if not os.path.exists(path):
             build()
@@ -51,6 +52,12 @@ class Oracle:
         if kin_box is not None:
             for i in range(3):
                 self.form.kin_box[i] = kin_box[i]
+        if run_cost is not None:      # dict(QX=[12], Qc=[3], Qf=[3], f_ref=[3]): generate_quadruped_SRBM_CCC.m:81-89
+            self.form.run_cost = 1
+            for i in range(12):
+                self.form.QX[i] = run_cost["QX"][i]
+            for i in range(3):
+                self.form.Qc[i] = run_cost["Qc"][i]; self.form.Qf[i] = run_cost["Qf"][i]; self.form.f_ref[i] = run_cost.get("f_ref", (0, 0, 0))[i]
         self.nx, self.ng, self.np_ = lib.lo_nx(N), lib.lo_ng(N), lib.lo_np(N)
         self.nnz_jac, self.nnz_hess = lib.lo_nnz_jac(N), lib.lo_nnz_hess(N)
         self._F = C.byref(self.form)

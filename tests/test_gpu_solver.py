@@ -140,3 +140,28 @@ def test_solver_full_size_batch_properties(libs, oracle_mod):
     assert np.array_equal(xh[:, :6], P[:, po["q_init"]:po["q_init"] + 6]) and np.array_equal(xh[:, 6:12], P[:, po["qd_init"]:po["qd_init"] + 6])
     for b in np.nonzero(ok)[0][::97]:
         assert O.kkt(xh[b], P[b], lh[b]).max() <= KKT_TOL * 1.0001
+
+
+RUN_COST = dict(QX=[0, 0, 10, 1, 1, 0, .1, .1, .1, .1, .1, .1], Qc=[1.0, 1.0, 0.5], Qf=[1e-4, 1e-4, 1e-3], f_ref=[0, 0, 20.0])
+
+
+@pytest.mark.parametrize("N,B", [(20, 16), (40, 32)])
+def test_solver_with_running_cost(oracle_mod, N, B):
+    """objective of the reference's N=41 script (generate_quadruped_SRBM_CCC.m:81-89): KKT point certified by the oracle"""
+    O = oracle_mod.Oracle(N, run_cost=RUN_COST)
+    L = lc("capi").LandingLib(N, device=0, run_cost=RUN_COST)
+    P, X0, _, _ = lc("problem").make_batch(B, N, 0.6, seed=2)
+    r = L.solve_host(P, X0)
+    conv = r["status"] == 0
+    assert conv.mean() >= 0.85, f"only {conv.sum()}/{B} members converged"
+    for b in np.nonzero(conv)[0][:12]:
+        assert O.kkt(r["x"][b], P[b], r["lam_g"][b]).max() <= KKT_TOL * 1.0001
+        assert abs(O.f(r["x"][b], P[b]) - r["f"][b]) < 1e-9 * max(1.0, abs(r["f"][b]))
+    # function layer: f and grad_f carry the running cost, the Hessian of that variant is refused
+    x = X0 + 0.01 * np.random.default_rng(0).normal(size=X0.shape)
+    e = L.eval_host(x[:4], P[:4], want=("f", "grad_f"))
+    for b in range(4):
+        assert abs(e["f"][b] - O.f(x[b], P[b])) < 1e-10 * max(1.0, abs(e["f"][b]))
+        assert np.allclose(e["grad_f"][b], np.asarray(O.grad_f(x[b], P[b])[-1] if isinstance(O.grad_f(x[b], P[b]), tuple) else O.grad_f(x[b], P[b])).ravel(), rtol=1e-11, atol=1e-12)
+    with pytest.raises(RuntimeError):
+        L.eval_host(x[:1], P[:1], lam_g=np.zeros((1, L.ng)), want=("hess",))

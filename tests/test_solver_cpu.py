@@ -65,3 +65,38 @@ def test_emulated_kernel_follows_cpu_port(emu_lib, oracle_mod):
     assert np.max(np.abs(g["lam_g"][0] - c["lam_g"][0])) < 1e-6 * max(1.0, np.max(np.abs(c["lam_g"][0])))
     # the kernel's own KKT report is the reference-consistent residual
     assert np.allclose(g["kkt"][0], O.kkt(g["x"][0], P[0], g["lam_g"][0]), rtol=1e-6, atol=1e-12)
+
+
+RUN_COST = dict(QX=[0, 0, 10, 1, 1, 0, .1, .1, .1, .1, .1, .1], Qc=[1.0, 1.0, 0.5], Qf=[1e-4, 1e-4, 1e-3], f_ref=[0, 0, 20.0])
+
+
+def test_running_cost_oracle_gradient_and_port(oracle_mod):
+    """running cost of the reference's N=41 script (generate_quadruped_SRBM_CCC.m:81-89): the oracle's gradient against central
+    differences, and the CPU port converging to a KKT point of that objective"""
+    N = 20
+    O = oracle_mod.Oracle(N, run_cost=RUN_COST); O0 = oracle_mod.Oracle(N)
+    P, X0, _, _ = lc("problem").make_batch(2, N, 0.6, seed=1)
+    x = X0[0] + 0.01 * np.random.default_rng(0).normal(size=O.nx)
+    g = np.asarray(O.grad_f(x, P[0])[-1] if isinstance(O.grad_f(x, P[0]), tuple) else O.grad_f(x, P[0])).ravel()
+    assert O.f(x, P[0]) > O0.f(x, P[0])
+    for i in np.random.default_rng(1).choice(O.nx, 60, replace=False):
+        e = np.zeros(O.nx); e[i] = 1e-6
+        assert abs((O.f(x + e, P[0]) - O.f(x - e, P[0])) / 2e-6 - g[i]) < 1e-6 * max(1.0, abs(g[i]))
+    r = oracle_mod.cpu_solve_batch(O, P, X0, threads=2, max_iter=400)
+    assert (r["status"] == 0).all()
+    for b in range(2):
+        assert O.kkt(r["x"][b], P[b], r["lam_g"][b]).max() <= 1e-6 * 1.0001
+
+
+def test_emulated_kernel_follows_cpu_port_with_running_cost(emu_lib, oracle_mod):
+    N, K = 20, 6
+    O = oracle_mod.Oracle(N, run_cost=RUN_COST)
+    P, X0, _, _ = lc("problem").make_batch(1, N, 0.6, seed=1)
+    L = lc("capi").LandingLib(N, lib_path=emu_lib, run_cost=RUN_COST)
+    o = L.default_opts(); o.max_iter = K
+    g = L.solve_host(P, X0, o)
+    c = oracle_mod.cpu_solve_batch(O, P, X0, threads=1, max_iter=K)
+    assert g["iters"][0] == c["iters"][0] == K
+    assert np.max(np.abs(g["x"][0] - c["x"][0])) < 1e-7 * max(1.0, np.max(np.abs(c["x"][0])))
+    assert np.allclose(g["kkt"][0], O.kkt(g["x"][0], P[0], g["lam_g"][0]), rtol=1e-6, atol=1e-12)
+    assert abs(g["f"][0] - O.f(g["x"][0], P[0])) < 1e-10 * max(1.0, abs(g["f"][0]))
