@@ -155,6 +155,9 @@ int landing_solve_batch_host(landing_ctx* ctx, int B, const double* p, const dou
  * wall-clock ticks: eval, error, sigma/rho, backward, forward, dual, line search, accept; then counts of
  * factorisations, trial points, iterations); NULL disables. */
 int landing_set_profile_buffer(landing_ctx* ctx, double* d_prof);
+/* diagnostic: device pointer and per-member stride (doubles) of the solver workspace left by the last landing_solve_batch
+ * (layout: landing-controller_amd/csrc/solver_kernels.hip, carve()) */
+int landing_debug_workspace(landing_ctx* ctx, double** d_ws, unsigned long long* stride);
 
 /* name of the dominant kernels (for profilers) and per-launch algorithmic bytes of the sweep */
 const char* landing_kernel_name_sweep(void);

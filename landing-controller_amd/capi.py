@@ -35,7 +35,7 @@ EXPORTS = ["landing_last_error", "landing_form_default", "landing_solver_opts_de
            "landing_np", "landing_nnz_jac", "landing_nnz_hess", "landing_pattern_jac", "landing_pattern_hess",
            "landing_create", "landing_destroy", "landing_device_count", "landing_eval_batch", "landing_eval_batch_host",
            "landing_bounds_batch", "landing_solve_batch", "landing_solve_batch_host", "landing_kernel_name_sweep",
-           "landing_sweep_bytes_per_member", "landing_set_profile_buffer"]
+           "landing_sweep_bytes_per_member", "landing_set_profile_buffer", "landing_debug_workspace"]
 
 
 def load(path=None):

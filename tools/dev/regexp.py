@@ -31,14 +31,21 @@ def run(label, **kw):
 
 
 
-run('default')
-run('pivot fix floor 1e-4', stage_local_reg=1)
-run('pivot fix floor 1e-2', stage_local_reg=1, delta_init=1e-2)
-run('pivot fix floor 1', stage_local_reg=1, delta_init=1.0)
-run('pivot fix floor 1e-6', stage_local_reg=1, delta_init=1e-6)
-run('default (push .5)')
-run('push/frac .2', bound_push=0.2, bound_frac=0.2)
-run('push/frac .1', bound_push=0.1, bound_frac=0.1)
-run('push/frac .05', bound_push=0.05, bound_frac=0.05)
-run('push .1 frac .5', bound_push=0.1, bound_frac=0.5)
-run('push .5 frac .1', bound_push=0.5, bound_frac=0.1)
+for sd in (20211, 5150):
+    P, X0, q, qd = problem.make_batch(B, N, 0.6, seed=sd)
+    dP.copy_(torch.tensor(P)); dX0.copy_(torch.tensor(X0))
+    print('seed', sd)
+    run('default')
+    run('mu_init 0.03', mu_init=0.03)
+    run('mu_init 0.3', mu_init=0.3)
+    run('mu_init 1', mu_init=1.0)
+    run('kappa_mu 0.1', kappa_mu=0.1)
+    run('kappa_mu 0.3', kappa_mu=0.3)
+    run('theta_mu 1.8', theta_mu=1.8)
+    run('tau_min 0.95', tau_min=0.95)
+    run('tau_min 0.99', tau_min=0.99)
+    run('tau_min 0.8', tau_min=0.8)
+    run('bound_push 0.2', bound_push=0.2)
+    run('bound_push 1.0', bound_push=1.0)
+    run('kappa_eps 5', kappa_eps=5.0)
+    run('kappa_eps 20', kappa_eps=20.0)
