@@ -215,11 +215,9 @@ int landing_eval_batch(landing_ctx* ctx, int B, const double* d_x, const double*
   HIP_TRY(hipSetDevice(ctx->device));
   landing::EvalArgs A{d_x, d_p, d_lam_f, d_lam_g, d_f, d_g, d_grad_f, d_jac, d_hess, d_ggx, d_ggp, ctx->d_edge_map, d_g ? 1 : 0};
   if (ctx->L.N < 3) return fail(LANDING_E_ARG, "landing_eval_batch: N >= 3 required");
-  if ((long long)B * ctx->L.N * ctx->L.N >= (1LL << 32)) return fail(LANDING_E_ARG, "landing_eval_batch: B * N^2 must stay below 2^32 (split the batch)");
-  const unsigned sweep_waves = (unsigned)(((long long)B * ctx->L.N + 63) / 64);    // lane = one stage of one member, packed over the batch
-  if (d_jac) hipLaunchKernelGGL(landing::landing_sweep_kernel<0>, dim3(sweep_waves), dim3(64), 0, (hipStream_t)stream, ctx->L, B, A);
-  if (d_hess) hipLaunchKernelGGL(landing::landing_sweep_kernel<1>, dim3(sweep_waves), dim3(64), 0, (hipStream_t)stream, ctx->L, B, A);
-  if (d_g) hipLaunchKernelGGL(landing::landing_sweep_kernel<2>, dim3(sweep_waves), dim3(64), 0, (hipStream_t)stream, ctx->L, B, A);
+  if (d_jac) hipLaunchKernelGGL(landing::landing_sweep_kernel<0>, dim3(B), dim3(64), 0, (hipStream_t)stream, ctx->L, B, A);
+  if (d_hess) hipLaunchKernelGGL(landing::landing_sweep_kernel<1>, dim3(B), dim3(64), 0, (hipStream_t)stream, ctx->L, B, A);
+  if (d_g) hipLaunchKernelGGL(landing::landing_sweep_kernel<2>, dim3(B), dim3(64), 0, (hipStream_t)stream, ctx->L, B, A);
   hipLaunchKernelGGL(landing::landing_sweep_misc_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, ctx->L, B, A);
   HIP_TRY(hipGetLastError());
   return 0;

@@ -99,38 +99,30 @@ constexpr int TILE_LD = 17;
 // write-out of one tile.  Inlined (an out-of-line call makes every write-out wait for its stores at the return), but
 // the position counter is laundered through an empty asm so that the 25 call sites of a stage are not specialised
 // and hoisted into one giant live range (that version spilled 1.9 KB per lane).
-// flat stage index s = member * N + stage -> (member, stage) without a division (magic = 2^32 / N rounded up; exact for
-// s < 2^32 / N, i.e. for every batch that fits the device)
-struct StageDiv {
-  unsigned magic; int N;
-  __device__ __forceinline__ void split(unsigned s, int& m, int& k) const { m = (int)__umulhi(s, magic); k = (int)s - m * N; }
-};
-// Per-wave row directory in LDS, filled once by the lane that owns the row: stage index and the element offset of the
-// row's segment in the batch array (member * stride + segment start).  The write-out below then costs one LDS read
-// and one store per row; the edge-stage compaction is the only branch (2 stages of N).
-struct RowDir { int k[64]; long long off[2][64]; };
 template <int KIND>
-__device__ __forceinline__ void tile_flush(const double* tile, double* g0, const RowDir* dir, int which, int N, const int* map, int nrow, int cnt_, int n_) {
+__device__ __forceinline__ void tile_flush(const double* tile, double* gbase, const Layout* L, const int* map, int k0, int nrow, int cnt_, int n_) {
   int cnt = cnt_, n = n_;
   LANDING_OPAQUE_UNIFORM(cnt); LANDING_OPAQUE_UNIFORM(n);
   __builtin_amdgcn_wave_barrier();
-  const int lane = threadIdx.x & 63, c = lane & 15;
+  const int lane = threadIdx.x & 63, c = lane & 15, N = L->N;
   if (c < n) {
-    const int pos0 = cnt - n + c;
-#pragma unroll 4
+#pragma unroll 1
     for (int row = lane >> 4; row < nrow; row += 4) {
-      const int k = dir->k[row];
-      const long long off = dir->off[which][row];
-      int pos = pos0;
-      if (KIND == 1) { if (k == 0) pos = map[pos]; else if (k == N - 1) pos = map[228 + pos]; }
-      else if (KIND == 3) { if (k == 0) pos = (pos < 72) ? ((pos % 6 == 4) ? -1 : pos - (pos / 6) - (pos % 6 > 4 ? 1 : 0)) : pos - 12; }
-      else if (KIND == 4) {   // residual rows; the last stage has no no-slip rows (80 instead of 104 rows)
+      const int k = k0 + row;
+      int pos = cnt - n + c;
+      int seg;
+      if (KIND == 0) seg = L->jx(k);
+      else if (KIND == 1) { seg = L->ju(k); if (k == 0) pos = map[pos]; else if (k == N - 1) pos = map[228 + pos]; }
+      else if (KIND == 2) seg = L->hx(k);
+      else if (KIND == 3) { seg = L->hu(k); if (k == 0) pos = (pos < 72) ? ((pos % 6 == 4) ? -1 : pos - (pos / 6) - (pos % 6 > 4 ? 1 : 0)) : pos - 12; }
+      else {   // KIND 4: residual rows; the last stage has no no-slip rows (80 instead of 104 rows)
+        seg = L->g_stage(k);
         if (k == N - 1) {
           if (pos >= 64) pos -= 24;
           else if (pos >= 16) { const int l = (pos - 16) / 12, t = (pos - 16) % 12; pos = t < 2 ? 16 + 6 * l + t : (t < 8 ? -1 : 16 + 6 * l + t - 6); }
         }
       }
-      if (pos >= 0) g0[off + pos] = tile[row * TILE_LD + c];
+      if (pos >= 0) gbase[seg + pos] = tile[row * TILE_LD + c];
     }
   }
   __builtin_amdgcn_wave_barrier();
@@ -138,78 +130,68 @@ __device__ __forceinline__ void tile_flush(const double* tile, double* g0, const
 template <int KIND>   // 0: Jacobian X_k columns, 1: Jacobian U_k columns, 2: Hessian X_k columns, 3: Hessian U_k columns, 4: g rows
 struct TileStore {
   double* tile;          // LDS, 64 x TILE_LD
-  double* g0;            // J, H or g array of the batch
-  const RowDir* dir;     // LDS row directory of the wave
-  int which;             // which offset column of the directory
-  int N;
+  double* gbase;         // member's J or H array
+  const Layout* L;
   const int* map;        // edge_map (KIND 1) or nullptr
-  int nrow, cnt;         // rows really written
+  int k0, nrow, cnt;     // stage of tile row 0, rows really written
   __device__ __forceinline__ void col() {}
   __device__ __forceinline__ void put(int, double v) { put(v); }
   __device__ __forceinline__ void put(double v) {
     tile[(threadIdx.x & 63) * TILE_LD + (cnt & 15)] = v;
     ++cnt;
-    if ((cnt & 15) == 0) tile_flush<KIND>(tile, g0, dir, which, N, map, nrow, cnt, 16);
+    if ((cnt & 15) == 0) tile_flush<KIND>(tile, gbase, L, map, k0, nrow, cnt, 16);
   }
-  __device__ __forceinline__ void finish() { if (cnt & 15) tile_flush<KIND>(tile, g0, dir, which, N, map, nrow, cnt, cnt & 15); }
+  __device__ __forceinline__ void finish() { if (cnt & 15) tile_flush<KIND>(tile, gbase, L, map, k0, nrow, cnt, cnt & 15); }
 };
 
-// Jacobian (FAM 0), Hessian (FAM 1) nonzeros or residual rows (FAM 2) of every stage of the batch.  Lane = one stage of
-// one member, stages numbered flat over the batch (s = member * N + stage): a wavefront covers 64 consecutive stages
-// whatever N is, so no lane idles (one wave per member left 24 of 64 lanes idle at N = 40) and N > 64 needs no loop.
-// Every lane runs the middle-stage instruction stream (first = last = false) and the tile write-out drops the
+// Jacobian (FAM 0), Hessian (FAM 1) nonzeros or residual rows (FAM 2) of every stage of one member: one wavefront per member, lane = stage,
+// every lane runs the middle-stage instruction stream (first = last = false) and the tile write-out drops the
 // placeholders of the two edge stages.  Reported by landing_kernel_name_sweep() for profilers.
 // (register budget: the Jacobian stream fits 256 VGPRs -> 2 waves/SIMD; the Hessian stream needs the AGPR overflow
 // of the default bound, capping it costs 750 B of scratch per lane and doubles its time)
 template <int FAM>
 __global__ void __launch_bounds__(64, FAM == 1 ? 1 : 2) landing_sweep_kernel(Layout L, int B, EvalArgs A) {
+  const int m = blockIdx.x;
+  if (m >= B) return;
   const int N = L.N, ln = threadIdx.x;
-  const unsigned S = (unsigned)B * (unsigned)N, s0 = blockIdx.x * 64u;
-  if (s0 >= S) return;
-  const int rows_here = S - s0 < 64u ? (int)(S - s0) : 64;
-  StageDiv dv{(unsigned)(0xffffffffu / (unsigned)N) + 1u, N};
-  int m, k;
-  dv.split(s0 + (unsigned)ln < S ? s0 + (unsigned)ln : S - 1u, m, k);      // idle lanes of the last wave replay the last stage (never written out)
   const double* x = A.x + (size_t)m * L.nx;
   const double* p = A.p + (size_t)m * L.np;
   const double* lam_g = A.lam_g ? A.lam_g + (size_t)m * L.ng : nullptr;
   __shared__ double tileX[64 * TILE_LD], tileU[64 * TILE_LD];
-  __shared__ RowDir dir;
-  dir.k[ln] = k;
-  if (FAM == 0) { dir.off[0][ln] = (long long)m * L.nnz_jac + L.jx(k); dir.off[1][ln] = (long long)m * L.nnz_jac + L.ju(k); }
-  else if (FAM == 1) { dir.off[0][ln] = (long long)m * L.nnz_hess + L.hx(k); dir.off[1][ln] = (long long)m * L.nnz_hess + L.hu(k); }
-  else dir.off[0][ln] = (long long)m * L.ng + L.g_stage(k);
-  // compaction map of the two edge stages: LDS copy.  Read from global memory it put a load in front of every store
-  // of the write-out, and with the in-order memory counter each store then waited for the previous one to retire.
-  __shared__ int emap[FAM == 0 ? 456 : 1];
-  if (FAM == 0) for (int e = ln; e < 456; e += 64) emap[e] = A.edge_map[e];
-  srbm::StageVars z; srbm::StageParams P;
-  load_stage(L, x, p, k, z, P);
-  if (FAM == 0) {
-    double fz_prev[4] = {0, 0, 0, 0};
-    if (k > 0) { const double* Up = x + L.x_U(k - 1); for (int l = 0; l < 4; ++l) fz_prev[l] = Up[12 + 3 * l + 2]; }
-    TileStore<0> ex{tileX, A.jac, &dir, 0, N, nullptr, rows_here, 0};
-    TileStore<1> eu{tileU, A.jac, &dir, 1, N, emap, rows_here, 0};
-    srbm::stage_jac(z, P, false, false, fz_prev, ex, eu);
-    ex.finish(); eu.finish();
-  } else if (FAM == 2) {
-    TileStore<4> og{tileX, A.g, &dir, 0, N, nullptr, rows_here, 0};
-    srbm::stage_g(z, P, false, og);
-    og.finish();
-  } else {
-    double lps[12];
-    for (int i = 0; i < 12; ++i) lps[i] = 0.0;
-    if (k > 0) {
-      const double* lp = lam_g + L.g_stage(k - 1);
-      for (int l = 0; l < 4; ++l) for (int i = 0; i < 3; ++i) lps[3 * l + i] = lp[16 + 12 * l + 2 + i] + lp[16 + 12 * l + 5 + i];
+  for (int k0 = 0; k0 < N; k0 += 64) {
+    const int rows_here = N - k0 < 64 ? N - k0 : 64;
+    int k = k0 + ln;
+    if (k > N - 1) k = N - 1;                       // idle lanes replay the last stage (never written out)
+    srbm::StageVars z; srbm::StageParams P;
+    load_stage(L, x, p, k, z, P);
+    if (FAM == 0) {
+      double fz_prev[4] = {0, 0, 0, 0};
+      if (k > 0) { const double* Up = x + L.x_U(k - 1); for (int l = 0; l < 4; ++l) fz_prev[l] = Up[12 + 3 * l + 2]; }
+      double* J = A.jac + (size_t)m * L.nnz_jac;
+      TileStore<0> ex{tileX, J, &L, nullptr, k0, rows_here, 0};
+      TileStore<1> eu{tileU, J, &L, A.edge_map, k0, rows_here, 0};
+      srbm::stage_jac(z, P, false, false, fz_prev, ex, eu);
+      ex.finish(); eu.finish();
+    } else if (FAM == 2) {
+      TileStore<4> og{tileX, A.g + (size_t)m * L.ng, &L, nullptr, k0, rows_here, 0};
+      srbm::stage_g(z, P, false, og);
+      og.finish();
+    } else {
+      double* H = A.hess + (size_t)m * L.nnz_hess;
+      double lps[12];
+      for (int i = 0; i < 12; ++i) lps[i] = 0.0;
+      if (k > 0) {
+        const double* lp = lam_g + L.g_stage(k - 1);
+        for (int l = 0; l < 4; ++l) for (int i = 0; i < 3; ++i) lps[3 * l + i] = lp[16 + 12 * l + 2 + i] + lp[16 + 12 * l + 5 + i];
+      }
+      LamStage lam{lam_g + L.g_stage(k)};
+      TileStore<2> hx{tileX, H, &L, nullptr, k0, rows_here, 0};
+      TileStore<3> hu{tileU, H, &L, nullptr, k0, rows_here, 0};
+      // the last stage reads its multipliers through its own row numbering (80 rows); the emitted sequence is the same
+      // for every lane (runtime `last` only selects row offsets), so the tile write-outs stay convergent
+      srbm::stage_hess(z, P, false, k == N - 1, lam, lps, hx, hu);
+      hx.finish(); hu.finish();
     }
-    LamStage lam{lam_g + L.g_stage(k)};
-    TileStore<2> hx{tileX, A.hess, &dir, 0, N, nullptr, rows_here, 0};
-    TileStore<3> hu{tileU, A.hess, &dir, 1, N, nullptr, rows_here, 0};
-    // the last stage reads its multipliers through its own row numbering (80 rows); the emitted sequence is the same
-    // for every lane (runtime `last` only selects row offsets), so the tile write-outs stay convergent
-    srbm::stage_hess(z, P, false, k == N - 1, lam, lps, hx, hu);
-    hx.finish(); hu.finish();
   }
 }
 
