@@ -177,7 +177,7 @@ def main():
                  "frac": by / s_ms / 1e6 / HBM_PEAK_GBPS, "traffic": None, "launch_ms": s_ms, "members": Bs}
         # ---- CPU baseline (oracle port) on a bounded sample of the same workload
         cpu = None
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:      # CPU legs on rank 0 of the single-GPU run only
             from oracle import oracle as orc
             orc.build()
             O = orc.Oracle(N)
