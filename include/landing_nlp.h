@@ -85,7 +85,7 @@ typedef struct {
   int max_resets;        /* multiplier resets allowed per NLP (default 8), see reset_du          */
   double reset_du;       /* dual infeasibility above which slacks/multipliers/mu are re-initialised
                             at the current x (jammed iterate; IPOPT would enter restoration), 1e9  */
-  int stage_local_reg;   /* experimental: per-stage delta_w (one sweep, hurts convergence); default 0                       */
+  int stage_local_reg;   /* ignored (a per-stage delta_w was tried in round 1 and removed); kept for ABI stability            */
   int sticky_delta;      /* experimental: restart from delta_last when the previous first trial failed; default 0          */
   int restart_period;    /* re-initialise slacks/multipliers/filter at the current x when the first barrier problem (mu = mu_init)
                             is still not solved this many iterations after the last (re)start (crawling iterate; counts

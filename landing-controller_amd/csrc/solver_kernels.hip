@@ -125,7 +125,6 @@ struct Lds {
   double stg[COND_STRIDE + 12];
   int cab[COND_GAM]; int cat[COND_STRIDE - COND_AH]; int c_tab, c_nT, c_nA;
   MemberMem M; Layout L; const double* p; const int* tab; const int* stage_tab; int prof_on;
-  double d_init, d_incf, d_inc, d_dec, d_last, d_used; int d_local, n_stage_retry;
 };
 // One instance per workgroup (= per NLP).  Namespace scope keeps the LDS address space visible to every
 // phase function (ds_* instructions instead of flat_*).
@@ -158,23 +157,12 @@ __device__ __forceinline__ double lane_bcast(double v, int src) {
   return __hiloint2double(hi, lo);
 }
 
-// The same broadcast through the LDS crossbar (ds_bpermute_b32 x2): result in vector registers, issued on the LDS
-// pipe, so it runs beside the VALU stream instead of inside it.
-__device__ __forceinline__ double lane_bcast_xbar(double v, int src) {
-  const int hi = __builtin_amdgcn_ds_bpermute(src << 2, __double2hiint(v));
-  const int lo = __builtin_amdgcn_ds_bpermute(src << 2, __double2loint(v));
-  return __hiloint2double(hi, lo);
-}
-
 // Elimination of the controls of one stage by ONE wavefront, entirely in registers: Gauss-Jordan on
 // [G_uu | G_us | gamma_u], lane c owning column c (NU + 24 + 1 <= 49 lanes, NU values each).  The pivot of step j is
-// broadcast from lane j, the multipliers from lane j's column; no LDS traffic and no barrier inside the 24 steps
-// (the serial pivot chain is what bounds a Riccati stage).  On success Kl (LDS, NU x 24, row stride 24) holds
+// broadcast from lane j, the multipliers from lane j's column; no LDS traffic and no barrier inside the steps.
+// Used for the 12 x 12 block of the free feet of stage 0 only (the stages themselves go through block_eliminate).  On success Kl (LDS, NU x 24, row stride 24) holds
 // K = G_uu^-1 G_us and kl the vector kappa = G_uu^-1 gamma_u.  A non-positive / non-finite pivot (wrong inertia)
 // is reported through *flag = 0; the caller raises delta_w.
-#ifndef GJ_XBAR_ROWS
-#define GJ_XBAR_ROWS 0
-#endif
 template <int NU>
 __device__ __noinline__ void gauss_jordan_wave(const double* G, const double* gam, double* Kl, double* kl, int* flag) {
   const int lane = threadIdx.x;        // called by the first wave only (threadIdx.x < 64)
@@ -203,7 +191,7 @@ __device__ __noinline__ void gauss_jordan_wave(const double* G, const double* ga
     // multipliers first (independent scalar broadcasts, back to back), then the row updates
     double m[NU];
 #pragma unroll
-    for (int i = 1; i < NU; ++i) m[i] = (i >= NU - GJ_XBAR_ROWS) ? lane_bcast_xbar(col[i], j) : lane_bcast(col[i], j);
+    for (int i = 1; i < NU; ++i) m[i] = lane_bcast(col[i], j);
     __builtin_amdgcn_sched_barrier(0);      // all broadcasts in flight before the first update consumes one
 #pragma unroll
     for (int i = 1; i < NU; ++i) col[i - 1] = fma(-m[i], pj, col[i]);
@@ -561,7 +549,6 @@ __device__ __noinline__ bool riccati_backward(double delta) {
       __syncthreads();
     }
   }
-  if (lane == 0) S.d_used = delta;
   __syncthreads();
   return ok;
 }
@@ -693,8 +680,6 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
   double* __restrict__ r_zL = M.zL; double* __restrict__ r_zU = M.zU;
   double* __restrict__ r_y = M.y; double* __restrict__ r_yn = M.yn; double* __restrict__ r_sig = M.sig; double* __restrict__ r_rho = M.rho;
   S.M = M; S.L = L; S.p = p; S.tab = A.tab; S.stage_tab = A.stage_tab; S.prof_on = A.prof != nullptr;
-  S.d_init = o.delta_init; S.d_incf = o.delta_inc_first; S.d_inc = o.delta_inc; S.d_dec = o.delta_dec; S.d_last = 0.0; S.d_used = 0.0;
-  S.d_local = o.stage_local_reg; S.n_stage_retry = 0;
   if (lane < 16) S.prof[lane] = 0.0;
   {   // scatter codes of the table shared by the middle stages
     const int off = A.stage_tab[N / 2];
@@ -855,7 +840,7 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
         else delta *= (delta_last == 0.0 ? o.delta_inc_first : o.delta_inc);
         if (delta > 1e40) break;
       }
-      if (lane == 0) { S.prof[PH_NFACT] += 1.0; S.d_last = delta_last; }
+      if (lane == 0) S.prof[PH_NFACT] += 1.0;
       __syncthreads();
       const bool ok = riccati_backward(delta);
       fact_ok = ok;

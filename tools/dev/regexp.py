@@ -31,21 +31,14 @@ def run(label, **kw):
 
 
 
-for sd in (20211, 5150):
+for sd in (20211, 5150, 1, 99):
     P, X0, q, qd = problem.make_batch(B, N, 0.6, seed=sd)
     dP.copy_(torch.tensor(P)); dX0.copy_(torch.tensor(X0))
     print('seed', sd)
-    run('default')
-    run('mu_init 0.03', mu_init=0.03)
-    run('mu_init 0.3', mu_init=0.3)
-    run('mu_init 1', mu_init=1.0)
-    run('kappa_mu 0.1', kappa_mu=0.1)
-    run('kappa_mu 0.3', kappa_mu=0.3)
-    run('theta_mu 1.8', theta_mu=1.8)
-    run('tau_min 0.95', tau_min=0.95)
-    run('tau_min 0.99', tau_min=0.99)
-    run('tau_min 0.8', tau_min=0.8)
-    run('bound_push 0.2', bound_push=0.2)
-    run('bound_push 1.0', bound_push=1.0)
-    run('kappa_eps 5', kappa_eps=5.0)
-    run('kappa_eps 20', kappa_eps=20.0)
+    def run2(label, **kw):
+        run(label, **kw); its = it.cpu().numpy(); print('      max iters %d  p99 %d  top5 %s' % (its.max(), np.percentile(its, 99), np.sort(its)[-5:].tolist()))
+    run2('default (restart 80)')
+    run2('restart 0', restart_period=0)
+    run2('restart 40', restart_period=40)
+    run2('restart 60', restart_period=60)
+    run2('restart 120', restart_period=120)
