@@ -647,12 +647,26 @@ __device__ __noinline__ void row_products(const int4* __restrict__ rterm, int rl
   const double* __restrict__ Jn = M.J; const double* __restrict__ dxv = M.dx;
   const double* __restrict__ gv = M.g; const double* __restrict__ sv = M.s; double* __restrict__ dsv = M.ds;
   double acc = 0.0;
-#pragma unroll 4
-  for (int j = 0; j < rlen; ++j) {
-    const int4 t = rterm[(size_t)j * NT + tid];
-    const double v = Jn[t.x] * dxv[t.y];
-    acc += t.w ? v : 0.0;
-    if (t.z >= 0) { dsv[t.z] = acc + (gv[t.z] - sv[t.z]); acc = 0.0; }
+  // batches of 8 terms, the records of the next batch fetched under the gathers of this one (as in condense)
+  constexpr int BW = 8;
+  const int4 padterm = {0, 0, -1, 0};
+  int4 tn[BW];
+#pragma unroll
+  for (int u = 0; u < BW; ++u) tn[u] = (u < rlen) ? rterm[(size_t)u * NT + tid] : padterm;
+  for (int j0 = 0; j0 < rlen; j0 += BW) {
+    int4 t[BW];
+#pragma unroll
+    for (int u = 0; u < BW; ++u) t[u] = tn[u];
+#pragma unroll
+    for (int u = 0; u < BW; ++u) { const int j = j0 + BW + u; tn[u] = (j < rlen) ? rterm[(size_t)j * NT + tid] : padterm; }
+    double a[BW], b[BW], c[BW];
+#pragma unroll
+    for (int u = 0; u < BW; ++u) { a[u] = Jn[t[u].x]; b[u] = dxv[t[u].y]; c[u] = (t[u].z >= 0) ? gv[t[u].z] - sv[t[u].z] : 0.0; }
+#pragma unroll
+    for (int u = 0; u < BW; ++u) {
+      acc += t[u].w ? a[u] * b[u] : 0.0;
+      if (t[u].z >= 0) { dsv[t[u].z] = acc + c[u]; acc = 0.0; }
+    }
   }
   __syncthreads();
 }
