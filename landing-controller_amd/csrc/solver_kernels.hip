@@ -570,10 +570,10 @@ __device__ __noinline__ void forward_pass() {
   static_assert(24 * 65 + RIC_FWDN <= 48 * GS && RIC_FWDN <= XCH * 2, "forward scratch fits");
   auto slot = [&](int k) { return (k & 1) ? buf1 : buf; };
   auto fetch = [&](int k, double (&r)[3]) {
-    const double* rec = M.ric + (size_t)k * RIC_STRIDE + RIC_FWD0;
+    landing_gptr rec = (landing_gptr)(M.ric + (size_t)(k < N ? k : N - 1) * RIC_STRIDE + RIC_FWD0);   // global_load: a flat load would also tie up the LDS counter
 #pragma unroll
-    for (int j = 0; j < 3; ++j) { const int e = tid + j * 256; r[j] = (k < N && e < RIC_FWDN) ? rec[e] : 0.0; }
-  };
+    for (int j = 0; j < 3; ++j) { const int e = tid + j * 256; r[j] = rec[e < RIC_FWDN ? e : RIC_FWDN - 1]; }   // unconditional (clamped):
+  };                                                                                                     // the memory counter stays countable
   auto stash = [&](int k, const double (&r)[3]) {
     double* b = slot(k);
 #pragma unroll
@@ -615,13 +615,13 @@ __device__ __noinline__ void forward_pass() {
     const int k = e / 24, h = e % 24, i = h % 12;
     const double* sk = sg + 24 * (h < 12 ? k : k + 1);
     if (h < 12) {            // forces of stage k
-      const double* rec = M.ric + (size_t)k * RIC_STRIDE;
+      landing_gptr rec = (landing_gptr)(M.ric + (size_t)k * RIC_STRIDE);
       double acc = rec[RIC_KAP + i];
 #pragma unroll
       for (int t = 0; t < 24; ++t) acc += rec[RIC_K + i * 24 + t] * sk[t];
       M.dx[L.x_U(k) + 12 + i] = -acc;
     } else {                 // multipliers of the dynamics rows of stage k (state order -> row order)
-      const double* recn = M.ric + (size_t)(k + 1) * RIC_STRIDE;
+      landing_gptr recn = (landing_gptr)(M.ric + (size_t)(k + 1) * RIC_STRIDE);
       double acc = recn[RIC_PV + i];
 #pragma unroll
       for (int t = 0; t < 24; ++t) acc += recn[RIC_PX + i * 24 + t] * sk[t];
