@@ -37,8 +37,8 @@ for sd in (20211, 5150, 1, 99):
     print('seed', sd)
     def run2(label, **kw):
         run(label, **kw); its = it.cpu().numpy(); print('      max iters %d  p99 %d  top5 %s' % (its.max(), np.percentile(its, 99), np.sort(its)[-5:].tolist()))
-    run2('default (restart 80)')
-    run2('restart 0', restart_period=0)
-    run2('restart 40', restart_period=40)
-    run2('restart 60', restart_period=60)
-    run2('restart 120', restart_period=120)
+    run2('default')
+    run2('reset_du 1e5', reset_du=1e5)
+    run2('reset_du 1e6', reset_du=1e6)
+    run2('reset_du 1e7', reset_du=1e7)
+    run2('max_resets 16 reset_du 1e6', reset_du=1e6, max_resets=16)
