@@ -671,11 +671,12 @@ __device__ __noinline__ void row_products(const int4* __restrict__ rterm, int rl
   __syncthreads();
 }
 
-// Workgroups per CU the register budget is sized for.  Measured on MI355X (N = 40): 3 per CU (168 VGPRs) beats 4 (128)
-// at every batch size tried -- 1024: 2050 vs 1890 NLPs/s, 2048: 2810 vs 2730, 4096: 3500 vs 3420 -- the phases are
-// latency-bound, so the fourth resident workgroup mostly adds contention; 2 per CU is level at 1024 and worse beyond.
+// Workgroups per CU the register budget is sized for.  Measured on MI355X (N = 40, end of round 1, IPRA off): 2 per CU
+// (256 VGPRs) beats 3 (168) at batch 1024 -- 5220 vs 4760 NLPs/s -- and ties beyond (2048: 5410 vs 5330, 8192: 7080 vs
+// 7050); 4 per CU (128 VGPRs, and the 46 KB of LDS would only fit three) is far behind.  Every phase is latency-bound:
+// more resident workgroups mostly add contention, and the row passes / derivative phases spill less with 256 registers.
 #ifndef LANDING_MIN_WAVES
-#define LANDING_MIN_WAVES 3
+#define LANDING_MIN_WAVES 2
 #endif
 __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm_kernel(SolveArgs A) {
   const int m = blockIdx.x;
