@@ -3,23 +3,37 @@
 
 A "step" is one pass of the hot path over one batch: landing_solve_batch() on the rank's 1024 synthetic
 drop states (inputs already resident in HBM), followed -- for --gpus > 1 -- by the RCCL all-gather of the
-solved trajectories and status words (the only communication of the path).  One process per
-GPU; N>1 is launched by torch.distributed.run.  Rank 0 prints ONE JSON line.
+solved trajectories and status words (the only communication of the path).  One process per GPU.
+
+Launching.  `python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself:
+the parent -- BEFORE importing torch or touching HIP -- runs `python -m torch.distributed.run --nnodes=1
+--nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py <same flags>` as a child process, relays its
+output and exits with its code.  Under an external torchrun (RANK / LOCAL_RANK / WORLD_SIZE set) it runs as one rank.
+Rank 0 prints ONE JSON line.  `--backend gloo --dry` exercises exactly this multi-rank code path (rendezvous,
+sharding, gather, per-rank timing, reductions, JSON) on CPU with the solve replaced by a stub; the line then says
+"dry": true and carries no measurement (CPU test of the launcher, tests/test_bench_launcher_cpu.py).
 
   value            = NLPs that reached the KKT tolerance (status CONVERGED, unscaled pr/du/compl <= 1e-6)
-                     over all ranks and timed steps / wall time (barrier + synchronize on both sides, max over ranks)
-  roofline         = the dominant kernel (landing_ipm_kernel): algorithmic fp64 flops of the implemented
-                     recursion (counted per launch from the kernel's own iteration / factorisation / trial
-                     counters, model in DESIGN.md) / its HIP-event duration, against the fp64 matrix peak
-  sweep_roofline   = the function-layer sweep kernel (landing_sweep_kernel, HBM bound): algorithmic bytes
-                     (278 288 B per NLP at N=40) / HIP-event duration
+                     over all ranks and timed steps / wall time (barrier + synchronize on both sides, max over ranks);
+                     inputs resident in HBM.  `pcie_inclusive` repeats the measurement with H2D of p, x0 from pinned host
+                     memory and D2H of x*, status inside the timed step (SURVEY 8d's wording of the metric).
+  roofline         = the dominant kernel (landing_ipm_kernel): fp64 flops per launch / its HIP-event duration against the
+                     fp64 matrix peak, two ways: `frac` counts SURVEY 8(d)'s algorithmic figure (4.4 MFLOP per KKT solve +
+                     0.14 MFLOP of callbacks per iteration) x iterations; `frac_implemented` counts the flops of the
+                     implemented recursion (model in DESIGN.md) for the SUCCESSFUL stage eliminations only.
+                     `traffic` = HBM bytes per launch from the rocprofv3 --pmc passes committed under profiles/ (same
+                     command; bench.py cannot run the profiler on itself).
+  sweep_roofline   = the function-layer sweep kernel (HBM bound): algorithmic bytes (278 288 B per NLP at
+                     N=40) / HIP-event duration
   cpu_baseline     = oracle/landing_solver_cpu.c (scalar fp64 port of the same algorithm, OpenMP over
-                     members) on a bounded sample of the same workload, on this box's host cores (rank 0 only)
+                     members) on a bounded sample of the same workload, on this box's host cores (rank 0, N=1 only)
 """
 import argparse
 import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -30,11 +44,14 @@ N_INTERVALS = 40
 BATCH_PER_GPU = 1024
 FP64_PEAK_TFLOPS = 78.6      # MI355X fp64 vector = matrix peak (AMD datasheet)
 HBM_PEAK_GBPS = 8000.0       # MI355X_MICROARCH.md
+SURVEY_8D_KKT_FLOPS = 4.4e6  # block-tridiagonal factor+solve per interior-point iteration at N=40
+SURVEY_8D_CALLBACK_FLOPS = 0.14e6
+PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_ipm.json")
 
 
 def flop_model(N):
-    """fp64 flops of the implemented recursion (DESIGN.md 'flop model'), per factorisation / iteration / trial.
-    Algorithmic counts (no tile padding): multiply-add = 2."""
+    """fp64 flops of the implemented recursion (DESIGN.md 'flop model'): per stage elimination (middle / last stage),
+    per iteration outside the factorisation, per trial point.  Algorithmic counts (no tile padding): multiply-add = 2."""
     def stage(nu):
         nr, nc = nu + 24, nu + 25                      # rows (u, sigma) and columns (u, sigma, gamma) of the stage array
         y = 24 * 12 * 37 * 2                           # Y = P(:,0:12) [A^ | b]
@@ -42,13 +59,32 @@ def flop_model(N):
         gj = (nu // 4) * (nr * nc * 4 * 2 + nc * 28 + 60)   # blocked Gauss-Jordan: rank-4 updates, 4x4 solves, 4x4 LDL^T
         cl = 12 * 12 * 25 * 2 + 12 * 25                # closed-loop map Mt = A^_s - A^_f K_f, mv
         return y + tpt + gj + cl
-    fact = (N - 1) * stage(24) + stage(12) + 12 * 12 * 13 * 2 + 12 * 24 * 2      # + stage-0 foot block
+    foot = 12 * 12 * 13 * 2 + 12 * 24 * 2             # stage-0 foot block
     nnz_j = 36 + 385 * (N - 1) + 313
     n_terms = 1125 * N                                  # condensation terms per stage (tables in solver_capi.inc)
     it = (2 * 3500 * N          # Jacobian (twice: store + J^T y) and Hessian values, ~3.5 kflop per stage sweep each
           + 3 * n_terms + N * (24 * 24 * 2 * 2 + 12 * 24 * 2) + 2 * (nnz_j - 149 * N) + 40 * (104 * N + 12))
     trial = 360 * N + 12 * (104 * N + 12)
-    return fact, it, trial
+    return stage(24), stage(12), foot, it, trial
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(n, argv):
+    """Parent of a multi-GPU run: start n ranks through torch.distributed.run.  Nothing in this process has imported
+    torch or initialised HIP (an exec/fork after GPU initialisation is forbidden on this pool)."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -59,59 +95,93 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="NLPs per GPU (weak scaling)")
     ap.add_argument("--max-iter", type=int, default=300)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo only with --dry (CPU launcher test)")
+    ap.add_argument("--dry", action="store_true", help="no GPU work: exercise the multi-rank path with a stub solve")
     a = ap.parse_args()
+    if a.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if a.backend == "gloo" and not a.dry:
+        raise SystemExit("--backend gloo is the CPU launcher test and needs --dry: the product has no CPU path")
+
+    env_world = os.environ.get("WORLD_SIZE")
+    if a.gpus > 1 and env_world is None:
+        sys.exit(spawn_ranks(a.gpus, sys.argv[1:]))
+    world = int(env_world) if env_world is not None else 1
+    if world != a.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d -- launch with matching values" % (a.gpus, world))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
 
     import numpy as np
     import torch
     import torch.distributed as dist
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the product has no CPU path")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group(a.backend, rank=rank, world_size=world)
+    if a.dry:
+        dev = torch.device("cpu")
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
 
-    capi = importlib.import_module("landing-controller_amd.capi")
     problem = importlib.import_module("landing-controller_amd.problem")
     sharding = importlib.import_module("landing-controller_amd.sharding")
     N, B = N_INTERVALS, a.batch
-    lib = capi.LandingLib(N, device=local)
+    nx, ng = problem.nx(N), problem.ng(N)
+    lib = None
+    if not a.dry:
+        capi = importlib.import_module("landing-controller_amd.capi")
+        lib = capi.LandingLib(N, device=local)
 
     # synthetic drop states of SURVEY 8(d); every rank its own shard of the sweep (seed = 20211 + rank)
-    P, X0, _, _ = problem.make_batch(B, N, 0.6, seed=20211 + rank)
+    P, X0, _, _ = problem.make_batch(B if not a.dry else min(B, 8), N, 0.6, seed=20211 + rank)
+    if a.dry:
+        P = np.resize(P, (B, P.shape[1])); X0 = np.resize(X0, (B, X0.shape[1]))
     dP, dX0 = torch.tensor(P, device=dev), torch.tensor(X0, device=dev)
     mk = lambda *s, dt=torch.float64: torch.empty(*s, device=dev, dtype=dt)
-    x, f, lam, kkt = mk(B, lib.nx), mk(B), mk(B, lib.ng), mk(B, 3)
+    x, f, lam, kkt = mk(B, nx), mk(B), mk(B, ng), mk(B, 3)
     st, it = mk(B, dt=torch.int32), mk(B, dt=torch.int32)
+    xg = stg = None
     if world > 1:
-        xg, stg = mk(world * B, lib.nx), mk(world * B, dt=torch.int32)
-    opts = lib.default_opts()
-    opts.max_iter = a.max_iter
-    stream = torch.cuda.current_stream().cuda_stream
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        xg, stg = mk(world * B, nx), mk(world * B, dt=torch.int32)
+    if a.dry:
+        cuda_sync = lambda: None
+        ev0 = ev1 = None
+        opts = None
+        stream = 0
+    else:
+        cuda_sync = torch.cuda.synchronize
+        opts = lib.default_opts()
+        opts.max_iter = a.max_iter
+        stream = torch.cuda.current_stream().cuda_stream
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     kernel_ms = []
 
-    def step(timed):
-        if timed:
-            ev0.record()
-        lib.solve_device(B, dP.data_ptr(), dX0.data_ptr(), opts, x.data_ptr(), f.data_ptr(), lam.data_ptr(), st.data_ptr(),
+    def solve(dp, dx0):
+        if a.dry:     # stub: "solution" = the initial guess, everything converged
+            x.copy_(dx0); st.zero_(); it.fill_(1)
+            return
+        lib.solve_device(B, dp.data_ptr(), dx0.data_ptr(), opts, x.data_ptr(), f.data_ptr(), lam.data_ptr(), st.data_ptr(),
                          it.data_ptr(), kkt.data_ptr(), stream)
-        if timed:
+
+    def step(timed):
+        if timed and ev0 is not None:
+            ev0.record()
+        solve(dP, dX0)
+        if timed and ev1 is not None:
             ev1.record()
         if world > 1:   # collect the solved trajectories (RCCL over xGMI)
             sharding.gather_solutions(x, st, xg, stg)
-        return (ev0, ev1)
 
     def sync():
-        torch.cuda.synchronize()
+        cuda_sync()
         if world > 1:
             dist.barrier()
-            torch.cuda.synchronize()
+            cuda_sync()
 
     for _ in range(a.warmup):
         step(False)
@@ -119,8 +189,9 @@ def main():
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step(True)
-        torch.cuda.synchronize()            # events of this step are complete; the launch is asynchronous otherwise
-        kernel_ms.append(ev0.elapsed_time(ev1))
+        cuda_sync()                         # events of this step are complete; the launch is asynchronous otherwise
+        if ev0 is not None:
+            kernel_ms.append(ev0.elapsed_time(ev1))
     sync()
     elapsed = time.perf_counter() - t0
     el = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -135,83 +206,140 @@ def main():
         dist.all_reduce(conv, op=dist.ReduceOp.SUM)
     elapsed = float(el.item())
     solved_per_step = float(conv.item())
+    gathered_ok = None
+    if world > 1:      # the gathered block of this rank must be its own solution (cheap self-check of the collective)
+        gathered_ok = bool(torch.equal(xg[rank * B:(rank + 1) * B], x) and torch.equal(stg[rank * B:(rank + 1) * B], st))
 
-    out = None
+    # ---- the same step with the PCIe legs inside (SURVEY 8d wording): pinned host p, x0 -> HBM, x*, status -> host
+    pcie = None
+    if not a.dry:
+        hP, hX0 = torch.tensor(P).pin_memory(), torch.tensor(X0).pin_memory()
+        hx, hst = torch.empty(B, nx, dtype=torch.float64).pin_memory(), torch.empty(B, dtype=torch.int32).pin_memory()
+        dP2, dX02 = torch.empty_like(dP), torch.empty_like(dX0)
+
+        def step_pcie():
+            dP2.copy_(hP, non_blocking=True); dX02.copy_(hX0, non_blocking=True)
+            solve(dP2, dX02)
+            hx.copy_(x, non_blocking=True); hst.copy_(st, non_blocking=True)
+            if world > 1:
+                sharding.gather_solutions(x, st, xg, stg)
+        step_pcie(); sync()
+        tp = time.perf_counter()
+        for _ in range(a.steps):
+            step_pcie()
+            cuda_sync()
+        sync()
+        tp = time.perf_counter() - tp
+        tpe = torch.tensor([tp], device=dev, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(tpe, op=dist.ReduceOp.MAX)
+        tp = float(tpe.item())
+        pcie = {"value": solved_per_step * a.steps / tp, "unit": "NLPs/s", "ms_per_step": 1e3 * tp / a.steps,
+                "bytes_per_step_per_gpu": int(8 * B * (P.shape[1] + 2 * nx) + 4 * B),
+                "note": "H2D of p, x0 (pinned) and D2H of x*, status inside the timed step"}
+
     if rank == 0:
-        sth, ith, kh = st.cpu().numpy(), it.cpu().numpy(), kkt.cpu().numpy()
-        ok = sth == 0
-        # ---- roofline of the dominant kernel: counters from one extra (untimed) instrumented pass
-        prof = mk(B, 16)
-        prof.zero_()
-        lib.lib.landing_set_profile_buffer(lib.ctx, prof.data_ptr())
-        step(False)
-        torch.cuda.synchronize()
-        lib.lib.landing_set_profile_buffer(lib.ctx, None)
-        ph = prof.cpu().numpy()
-        n_fact, n_trial, n_iter = ph[:, 8].sum(), ph[:, 9].sum(), ph[:, 10].sum()
-        f_fact, f_it, f_trial = flop_model(N)
-        flops = n_fact * f_fact + n_iter * f_it + n_trial * f_trial
-        k_ms = float(np.mean(kernel_ms))
-        achieved = flops / (k_ms * 1e-3) / 1e12
-        roofline = {"kernel": "landing_ipm_kernel", "bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": achieved / FP64_PEAK_TFLOPS, "traffic": None, "launch_ms": k_ms, "flops_per_launch": flops,
-                    "note": "fp64; latency-bound persistent kernel (one workgroup per NLP, 3 per CU): serial chain of 40 stages x 6 block-pivot steps per factorisation; T^T P T, the blocked Gauss-Jordan elimination and the closed-loop map run on v_mfma_f64_16x16x4"}
-        # ---- function-layer sweep kernel (HBM bound)
-        Bs = 4096
-        reps = (Bs + B - 1) // B
-        sx = dX0.repeat(reps, 1)[:Bs].contiguous(); sp = dP.repeat(reps, 1)[:Bs].contiguous()
-        sl = torch.randn(Bs, lib.ng, device=dev, dtype=torch.float64)
-        sg, sgf, sj, sh = mk(Bs, lib.ng), mk(Bs, lib.nx), mk(Bs, lib.nnz_jac), mk(Bs, lib.nnz_hess)
-        run = lambda: lib.eval_device(Bs, sx.data_ptr(), sp.data_ptr(), 0, sl.data_ptr(), 0, sg.data_ptr(), sgf.data_ptr(), sj.data_ptr(), sh.data_ptr(), 0, 0, stream)
-        for _ in range(3):
-            run()
-        torch.cuda.synchronize()
-        ev0.record()
-        for _ in range(20):
-            run()
-        ev1.record()
-        torch.cuda.synchronize()
-        s_ms = ev0.elapsed_time(ev1) / 20
-        by = lib.lib.landing_sweep_bytes_per_member(N) * Bs
-        sweep = {"kernel": "landing_sweep_kernel<0>+<1>+<2>+landing_sweep_misc_kernel (one landing_eval_batch call)", "bound": "hbm", "achieved": by / s_ms / 1e6, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                 "frac": by / s_ms / 1e6 / HBM_PEAK_GBPS, "traffic": None, "launch_ms": s_ms, "members": Bs}
-        # ---- CPU baseline (oracle port) on a bounded sample of the same workload
-        cpu = None
-        if not a.no_cpu_baseline and world == 1:      # CPU legs on rank 0 of the single-GPU run only
-            from oracle import oracle as orc
-            orc.build()
-            O = orc.Oracle(N)
-            cores = os.cpu_count() or 1
-            ns = int(min(B, max(16, 4 * cores)))
-            tc = time.perf_counter()
-            r = orc.cpu_solve_batch(O, P[:ns], X0[:ns], threads=cores, max_iter=a.max_iter)
-            tcpu = time.perf_counter() - tc
-            # function layer on the host: full derivative sweeps/s of the CPU restatement, one core and all cores
-            nsw = int(min(B, 4 * cores))
-            lam_h = np.random.default_rng(0).normal(size=(nsw, lib.ng))
-            t1 = time.perf_counter(); orc.cpu_sweep_batch(O, X0[:16], P[:16], lam_h[:16], reps=4, threads=1); t1 = time.perf_counter() - t1
-            ta = time.perf_counter(); orc.cpu_sweep_batch(O, X0[:nsw], P[:nsw], lam_h, reps=4, threads=cores); ta = time.perf_counter() - ta
-            cpu_fn = {"unit": "derivative sweeps/s (278 288 algorithmic bytes each)", "one_core": 64 / t1, "all_cores": 4 * nsw / ta, "cores": cores,
-                      "kind": "port", "sample": f"64 sweeps on one core, {4 * nsw} sweeps on {cores} cores (oracle/landing_oracle.c, OpenMP over members)",
-                      "gpu_sweeps_per_s": Bs / (s_ms * 1e-3)}
-            cpu = {"value": float((r["status"] == 0).sum() / tcpu), "unit": "NLPs/s", "cores": cores, "kind": "port", "function_layer": cpu_fn,
-                   "sample": f"first {ns} members of rank 0's batch (N=40), max_iter {a.max_iter}, OpenMP over members, {tcpu:.1f} s",
-                   "converged": int((r["status"] == 0).sum()), "gpu_converged_same_members": int(ok[:ns].sum())}
-        out = {
-            "metric": "landing NLPs solved/sec (SRBM, N=40, batch)", "value": solved_per_step * a.steps / elapsed, "unit": "NLPs/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "3D-SRBM landing NLP, N=40 intervals, batch=%d random drop heights/attitudes per GPU, fp64 (BASELINE configs[1])" % B,
-                       "global_batch": B * world, "max_iter": a.max_iter, "kkt_tol": 1e-6, "parallelism": "batch-sharded x%d, RCCL all-gather of x*" % world},
-            "solved_per_step": solved_per_step, "members_per_step": B * world, "ms_per_step_by_rank": per_rank,
-            "kkt_max_over_solved": kh[ok].max(axis=0).tolist() if ok.any() else None,
-            "iters_median": float(np.median(ith)), "iters_mean": float(ith.mean()),
-            "roofline": roofline, "sweep_roofline": sweep, "cpu_baseline": cpu,
-        }
-        print(json.dumps(out))
+        cfg = {"workload": "3D-SRBM landing NLP, N=40 intervals, batch=%d random drop heights/attitudes per GPU, fp64 (BASELINE configs[1]%s)" % (B, "; x%d GPUs = configs[2]" % world if world > 1 else ""),
+               "global_batch": B * world, "max_iter": a.max_iter, "kkt_tol": 1e-6, "parallelism": "batch-sharded x%d, RCCL all-gather of x*" % world}
+        out = {"metric": "landing NLPs solved/sec (SRBM, N=40, batch)", "value": solved_per_step * a.steps / elapsed, "unit": "NLPs/s",
+               "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic", "config": cfg,
+               "solved_per_step": solved_per_step, "members_per_step": B * world, "ms_per_step_by_rank": per_rank, "gather_self_check": gathered_ok}
+        if a.dry:
+            out.update({"dry": True, "value": 0.0, "backend": a.backend, "note": "launcher dry run: stub solve, no measurement"})
+        else:
+            out.update(measure_details(a, lib, np, torch, dev, mk, B, N, P, X0, dP, dX0, st, it, kkt, kernel_ms, solve, world, stream, ev0, ev1))
+            out["pcie_inclusive"] = pcie
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def measure_details(a, lib, np, torch, dev, mk, B, N, P, X0, dP, dX0, st, it, kkt, kernel_ms, solve, world, stream, ev0, ev1):
+    """rank 0: roofline of the solver kernel, the sweep kernel, the CPU baseline"""
+    sth, ith, kh = st.cpu().numpy(), it.cpu().numpy(), kkt.cpu().numpy()
+    ok = sth == 0
+    # ---- roofline of the dominant kernel: counters from one extra (untimed) instrumented pass
+    prof = mk(B, 16)
+    prof.zero_()
+    lib.lib.landing_set_profile_buffer(lib.ctx, prof.data_ptr())
+    solve(dP, dX0)
+    torch.cuda.synchronize()
+    lib.lib.landing_set_profile_buffer(lib.ctx, None)
+    ph = prof.cpu().numpy()
+    n_fact, n_trial, n_iter = ph[:, 8].sum(), ph[:, 9].sum(), ph[:, 10].sum()
+    n_stage_ok, n_stage_all = ph[:, 11].sum(), ph[:, 13].sum()      # stage eliminations: successful / attempted
+    f_mid, f_last, f_foot, f_it, f_trial = flop_model(N)
+    # successful eliminations only: every iteration ends with exactly one complete sweep (N-1 middle stages, the last
+    # stage, the foot block); eliminations redone after an inertia failure are overhead, not useful work
+    flops_impl = n_iter * ((N - 1) * f_mid + f_last + f_foot) + n_iter * f_it + n_trial * f_trial
+    flops_8d = n_iter * (SURVEY_8D_KKT_FLOPS + SURVEY_8D_CALLBACK_FLOPS)
+    k_ms = float(np.mean(kernel_ms))
+    ach8d = flops_8d / (k_ms * 1e-3) / 1e12
+    achim = flops_impl / (k_ms * 1e-3) / 1e12
+    traffic = None
+    pmc_note = "no PMC file"
+    if os.path.exists(PMC_FILE):
+        try:
+            pm = json.load(open(PMC_FILE))
+            traffic = pm.get("traffic_bytes_per_launch")
+            pmc_note = pm.get("note", "")
+        except Exception as e:   # noqa: BLE001
+            pmc_note = "unreadable PMC file: %s" % e
+    roofline = {"kernel": "landing_ipm_kernel", "bound": "mfma", "achieved": ach8d, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": ach8d / FP64_PEAK_TFLOPS, "traffic": traffic, "launch_ms": k_ms,
+                "flops_per_launch": flops_8d, "basis": "SURVEY 8(d): (4.4 + 0.14) MFLOP x %d iterations" % int(n_iter),
+                "achieved_implemented": achim, "frac_implemented": achim / FP64_PEAK_TFLOPS, "flops_per_launch_implemented": flops_impl,
+                "iterations": int(n_iter), "sweeps_started": int(n_fact), "stage_eliminations_ok": int(n_stage_ok),
+                "stage_eliminations_attempted": int(n_stage_all),
+                "factorisation_equivalents_per_iteration": float(n_stage_all / max(1.0, n_iter * N)),
+                "trial_points": int(n_trial), "traffic_source": pmc_note,
+                "note": "fp64; latency-bound persistent kernel (one 256-thread workgroup per NLP, 2 per CU): serial chain of 40 stages x 6 block-pivot steps per sweep; T^T P T, the blocked Gauss-Jordan elimination and the closed-loop map run on v_mfma_f64_16x16x4"}
+    # ---- function-layer sweep kernel (HBM bound)
+    Bs = 4096
+    reps = (Bs + B - 1) // B
+    sx = dX0.repeat(reps, 1)[:Bs].contiguous(); sp = dP.repeat(reps, 1)[:Bs].contiguous()
+    sl = torch.randn(Bs, lib.ng, device=dev, dtype=torch.float64)
+    sg, sgf, sj, sh = mk(Bs, lib.ng), mk(Bs, lib.nx), mk(Bs, lib.nnz_jac), mk(Bs, lib.nnz_hess)
+    run = lambda: lib.eval_device(Bs, sx.data_ptr(), sp.data_ptr(), 0, sl.data_ptr(), 0, sg.data_ptr(), sgf.data_ptr(), sj.data_ptr(), sh.data_ptr(), 0, 0, stream)
+    for _ in range(3):
+        run()
+    torch.cuda.synchronize()
+    ev0.record()
+    for _ in range(20):
+        run()
+    ev1.record()
+    torch.cuda.synchronize()
+    s_ms = ev0.elapsed_time(ev1) / 20
+    by = lib.lib.landing_sweep_bytes_per_member(N) * Bs
+    sweep = {"kernel": "one landing_eval_batch call (g, grad f, Jacobian and Hessian nonzeros)", "bound": "hbm", "achieved": by / s_ms / 1e6, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+             "frac": by / s_ms / 1e6 / HBM_PEAK_GBPS, "traffic": None, "launch_ms": s_ms, "members": Bs}
+    # ---- CPU baseline (oracle port) on a bounded sample of the same workload
+    cpu = None
+    if not a.no_cpu_baseline and world == 1:      # CPU legs on rank 0 of the single-GPU run only
+        from oracle import oracle as orc
+        orc.build()
+        O = orc.Oracle(N)
+        cores = os.cpu_count() or 1
+        ns = int(min(B, max(16, 4 * cores)))
+        tc = time.perf_counter()
+        r = orc.cpu_solve_batch(O, P[:ns], X0[:ns], threads=cores, max_iter=a.max_iter)
+        tcpu = time.perf_counter() - tc
+        # function layer on the host (SURVEY 8d): full derivative sweeps/s of the CPU restatement, one core and all cores
+        nsw = int(min(B, 4 * cores))
+        lam_h = np.random.default_rng(0).normal(size=(nsw, lib.ng))
+        t1 = time.perf_counter(); orc.cpu_sweep_batch(O, X0[:16], P[:16], lam_h[:16], reps=4, threads=1); t1 = time.perf_counter() - t1
+        ta = time.perf_counter(); orc.cpu_sweep_batch(O, X0[:nsw], P[:nsw], lam_h, reps=4, threads=cores); ta = time.perf_counter() - ta
+        cpu_fn = {"unit": "derivative sweeps/s (278 288 algorithmic bytes each)", "one_core": 64 / t1, "all_cores": 4 * nsw / ta, "cores": cores,
+                  "kind": "port", "sample": f"64 sweeps on one core, {4 * nsw} sweeps on {cores} cores (oracle/landing_oracle.c, OpenMP over members)",
+                  "gpu_sweeps_per_s": Bs / (s_ms * 1e-3)}
+        cpu = {"value": float((r["status"] == 0).sum() / tcpu), "unit": "NLPs/s", "cores": cores, "kind": "port", "function_layer": cpu_fn,
+               "sample": f"first {ns} members of rank 0's batch (N=40), max_iter {a.max_iter}, OpenMP over members, {tcpu:.1f} s",
+               "converged": int((r["status"] == 0).sum()), "gpu_converged_same_members": int(ok[:ns].sum())}
+    return {"kkt_max_over_solved": kh[ok].max(axis=0).tolist() if ok.any() else None,
+            "iters_median": float(np.median(ith)), "iters_mean": float(ith.mean()), "iters_max": int(ith.max()),
+            "roofline": roofline, "sweep_roofline": sweep, "cpu_baseline": cpu}
 
 
 if __name__ == "__main__":

@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <array>
 #include <map>
+#include <mutex>
 #include <set>
 #include <string>
 #include <vector>
@@ -35,6 +36,7 @@ struct landing_ctx {
   int* d_edge_map = nullptr;
   landing::SolverWorkspace ws;
   double* d_prof = nullptr;
+  std::mutex mu;      // serialises landing_solve_batch calls on one context (the workspace belongs to the context)
 };
 
 extern "C" {

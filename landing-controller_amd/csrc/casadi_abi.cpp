@@ -47,7 +47,13 @@ landing_ctx* ctx() {
   }
   return g_ctx;
 }
-const double* in(const double** arg, int i) { return (arg && arg[i]) ? arg[i] : zeros.data(); }
+// arg[i] == NULL means "all zeros" (landingCtrller_IPOPT.c:69-70).  The zero vector is part of the lazily built tables, so
+// they are built HERE, before the pointer is taken (the arguments of eval() are evaluated before eval() itself runs).
+const double* in(const double** arg, int i) {
+  if (arg && arg[i]) return arg[i];
+  { std::lock_guard<std::mutex> lk(g_mu); build_sparsity(); }
+  return zeros.data();
+}
 
 // one evaluation; which outputs are wanted is decided by the caller's res[] pointers
 int eval(const double* x, const double* p, const double* lam_f, const double* lam_g, double* f, double* g,

@@ -40,12 +40,13 @@ constexpr int RUNC = 48;
 
 struct SolverWorkspace {
   double* buf = nullptr; size_t cap = 0;
+  hipEvent_t done = nullptr;     // recorded behind every solve launch: the next launch (any stream) and any re-allocation wait for it
   int* d_tab = nullptr; int* d_stage_tab = nullptr; int n_tab = 0;
   int *d_cterm = nullptr, *d_cstart = nullptr, *d_rterm = nullptr, *d_rstart = nullptr; int clen = 0, rlen = 0;
   static size_t member_stride(const Layout& L) {
     return (size_t)4 * L.nx + (size_t)12 * L.ng + L.nnz_jac + L.nnz_hess + (size_t)L.N * RUNC + (size_t)(L.N + 1) * RIC_STRIDE + (size_t)L.N * COND_STRIDE;
   }
-  int ensure(const Layout& L, int B);
+  int ensure(const Layout& L, int B, hipStream_t stream);
   void release();
 };
 

@@ -23,12 +23,25 @@ def training_pairs(N, q_init, qd_init, x_star, status=None, jpos_star=None):
 
 
 def append_shard(path, inp, out):
-    """append samples to an .npz shard (the reference re-saves a growing .mat after every sample)"""
-    try:
+    """append samples to an .npz shard (the reference re-saves a growing .mat after every sample,
+    generate_training_data_automated.m:214-219).  The shard is rewritten atomically: a crash mid-write leaves the
+    previous file intact."""
+    import os
+    import tempfile
+    path = str(path)
+    if not path.endswith(".npz"):
+        path += ".npz"            # numpy appends the suffix on save but not on load: normalise once for both
+    if os.path.exists(path):
         with np.load(path) as d:
             inp = np.concatenate([d["input"], inp], axis=1)
             out = np.concatenate([d["output"], out], axis=1)
-    except FileNotFoundError:
-        pass
-    np.savez_compressed(path, input=inp, output=out)
+    fd, tmp = tempfile.mkstemp(suffix=".npz", dir=os.path.dirname(os.path.abspath(path)))
+    try:
+        with os.fdopen(fd, "wb") as fh:
+            np.savez_compressed(fh, input=inp, output=out)
+        os.replace(tmp, path)
+    except BaseException:
+        if os.path.exists(tmp):
+            os.unlink(tmp)
+        raise
     return inp.shape[1]

@@ -64,14 +64,23 @@ void run_grid(dim3 grid, dim3 block, const std::function<void()>& body) {
     bool any = true;
     while (any) {
       any = false;
+      bool ran = false;
       for (unsigned t = 0; t < nthreads; ++t) {
         if (fibers[t].done) continue;
         any = true;
         if (fibers[t].wait_ptr) { if (*fibers[t].wait_ptr == fibers[t].wait_val) continue; fibers[t].wait_ptr = nullptr; }
+        ran = true;
         g_cur = (int)t;
         blockIdx = {bx, by, bz};
         threadIdx = {t % block.x, (t / block.x) % block.y, t / (block.x * block.y)};
         swapcontext(&g_sched, &fibers[t].ctx);
+      }
+      if (any && !ran) {   // every live fiber waits at a barrier that can no longer complete: a divergent __syncthreads()
+        unsigned waiting = 0, finished = 0;     // (some threads of the block left, or wait at another barrier) -- on the GPU this hangs
+        for (unsigned t = 0; t < nthreads; ++t) { if (fibers[t].done) ++finished; else ++waiting; }
+        std::fprintf(stderr, "hip_emu: barrier deadlock in block (%u,%u,%u): %u threads wait, %u have exited, block barrier %u/%u arrived\n",
+                     bx, by, bz, waiting, finished, g_block_arrived, g_block_size);
+        std::abort();
       }
     }
   }

@@ -46,6 +46,12 @@ inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int, hipStrea
 inline hipError_t hipMemset(void* d, int v, size_t n) { std::memset(d, v, n); return 0; }
 inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { std::memset(d, v, n); return 0; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
+#define hipEventDisableTiming 2
+inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = (hipEvent_t)1; return 0; }
+inline hipError_t hipEventDestroy(hipEvent_t) { return 0; }
+inline hipError_t hipEventSynchronize(hipEvent_t) { return 0; }
+inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return 0; }
+inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return 0; }
 inline hipError_t hipDeviceSynchronize() { return 0; }
 inline hipError_t hipGetLastError() { return 0; }
 inline hipError_t hipSetDevice(int) { return 0; }
@@ -109,7 +115,7 @@ inline void __builtin_amdgcn_sched_barrier(int) {}
 inline void __builtin_amdgcn_wave_barrier() { hip_emu::wave_barrier(); }
 inline int __double2hiint(double d) { long long b; std::memcpy(&b, &d, 8); return (int)(b >> 32); }
 inline int __double2loint(double d) { long long b; std::memcpy(&b, &d, 8); return (int)(b & 0xffffffffLL); }
-inline double __hiloint2double(int hi, int lo) { long long b = ((long long)hi << 32) | (unsigned int)lo; double d; std::memcpy(&d, &b, 8); return d; }
+inline double __hiloint2double(int hi, int lo) { long long b = (long long)(((unsigned long long)(unsigned int)hi << 32) | (unsigned int)lo); double d; std::memcpy(&d, &b, 8); return d; }
 
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
   hip_emu::run_grid(dim3(grid), dim3(block), [&]() { kernel(__VA_ARGS__); })

@@ -16,5 +16,9 @@ def test_training_pairs_layout(tmp_path):
     assert np.array_equal(Xs[:, 0], X0[4, :12]) and Us.shape == (24, N)
     f = tmp_path / "shard.npz"
     assert ds.append_shard(str(f), inp, out) == 3 and ds.append_shard(str(f), inp[:, :1], out[:, :1]) == 4
+    g = tmp_path / "noext"                                    # extension-less path: both appends must land in one file
+    assert ds.append_shard(str(g), inp[:, :2], out[:, :2]) == 2 and ds.append_shard(str(g), inp[:, 2:], out[:, 2:]) == 3
+    with np.load(str(g) + ".npz") as d:
+        assert np.array_equal(d["input"], inp) and np.array_equal(d["output"], out)
     jp = np.zeros((B, 12 * N))
     assert ds.training_pairs(N, q, qd, X0, status, jp)[1].shape[0] == P.nx(N) + 12 * N

@@ -48,6 +48,23 @@ def test_shard_and_gather_world2():
         assert r[5] == float((want_s == 0).sum())
 
 
+def test_shard_and_gather_world2_ragged():
+    """7 members over 2 ranks (4 + 3): the gather must pad, exchange once and drop the padding rows"""
+    world, total, nx = 2, 7, 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_worker, args=(r, world, port, total, nx, q)) for r in range(world)]
+    for p in ps: p.start()
+    res = [q.get(timeout=120) for _ in ps]
+    for p in ps: p.join(60)
+    want_x = np.arange(total, dtype=float)[:, None].repeat(nx, 1)
+    want_s = (np.arange(total) % 3).astype(np.int32)
+    assert sorted((r[1], r[2]) for r in res) == [(0, 4), (4, 7)]
+    for r in res:
+        assert np.array_equal(r[3], want_x) and np.array_equal(r[4], want_s)
+
+
 def test_shard_range_covers_ragged_totals():
     sh = lc("sharding")
     for total in (0, 1, 7, 8192, 1000):
