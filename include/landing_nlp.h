@@ -89,7 +89,8 @@ typedef struct {
   int sticky_delta;      /* experimental: restart from delta_last when the previous first trial failed; default 0          */
   int restart_period;    /* re-initialise slacks/multipliers/filter at the current x when the first barrier problem (mu = mu_init)
                             is still not solved this many iterations after the last (re)start (crawling iterate; counts
-                            against max_resets); 0 = never; default 80                                                      */
+                            against max_resets); 0 = never; default 60 (round 2, tests/dev/ipm_lab.py on four seeded
+                            batches: slowest member 149..160 iterations instead of 177..236 with 80, mean +1.3)                                                      */
   int reserved;
   double delta_init;     /* first trial regularisation when none was needed before (IPOPT first_hessian_perturbation, 1e-4) */
   double delta_inc_first;/* growth factor while no regularised iteration happened yet (IPOPT 100; default 10)            */
@@ -150,6 +151,34 @@ int landing_solve_batch(landing_ctx* ctx, int B, const double* d_p, const double
 int landing_solve_batch_host(landing_ctx* ctx, int B, const double* p, const double* x0,
                              const landing_solver_opts* opts,
                              double* x, double* f, double* lam_g, int* status, int* iters, double* kkt);
+
+/* ---- the reference's 21-argument solver function, batched ---------------------------------------
+ * [x*, f*] = landingCtrller_IPOPT(Xref, Uref, dt, q_min, q_max, qd_min, qd_max, q_init, qd_init, q_term_min, q_term_max,
+ *                                 qd_term_min, qd_term_max, QN, x0, mu, l_leg_max, f_max, mass, Ib, Ib_inv)
+ * (generate_solver/generate_landingCtrller_IPOPT.m:323-327; call sites main_scripts/landing_optimization.m:305-311,
+ * generate_data/generate_training_data_automated.m:130-136, generate_data/nn_warmstart.m:193-199).
+ * HOST pointers, column-major dense doubles exactly as MATLAB holds them, with a TRAILING batch dimension:
+ *   Xref 12 x (N+1) x B | Uref 24 x N x B | dt 1 x N x B | the ten 6-vectors 6 x B | QN 12 x B | x0 nx x B |
+ *   mu, l_leg_max, f_max, mass 1 x B | Ib, Ib_inv 3 x B
+ * i.e. member b of an argument with n values per member starts at arg + b*n.  Uref is an inactive Opti parameter in the
+ * terminal-cost NLP and may be NULL; it is not part of p.  Outputs (host): x_star [nx x B], f_star [B]
+ * (may be NULL), status / iters [B] (may be NULL), kkt [3 x B] (may be NULL).
+ * landing_pack_args21 only builds p [np x B] in Opti's active-parameter order (pure host code, no device needed). */
+typedef struct {
+  const double *Xref, *Uref, *dt, *q_min, *q_max, *qd_min, *qd_max, *q_init, *qd_init, *q_term_min, *q_term_max,
+      *qd_term_min, *qd_term_max, *QN, *x0, *mu, *l_leg_max, *f_max, *mass, *Ib, *Ib_inv;
+} landing_args21;
+int landing_pack_args21(int N, int B, const landing_args21* a, double* p);
+int landing_solve_args21(landing_ctx* ctx, int B, const landing_args21* a, const landing_solver_opts* opts,
+                         double* x_star, double* f_star, int* status, int* iters, double* kkt);
+/* the same with the 21 arguments spelled out in the reference's order (what a mex / FFI stub binds) */
+int landing_solve_21(landing_ctx* ctx, int B, const double* Xref, const double* Uref, const double* dt,
+                     const double* q_min, const double* q_max, const double* qd_min, const double* qd_max,
+                     const double* q_init, const double* qd_init, const double* q_term_min, const double* q_term_max,
+                     const double* qd_term_min, const double* qd_term_max, const double* QN, const double* x0,
+                     const double* mu, const double* l_leg_max, const double* f_max, const double* mass,
+                     const double* Ib, const double* Ib_inv, const landing_solver_opts* opts,
+                     double* x_star, double* f_star, int* status, int* iters, double* kkt);
 
 /* development aid: d_prof [B][16] doubles receives per-member phase timers of the next solves (100 MHz
  * wall-clock ticks: eval, error, sigma/rho, backward, forward, dual, line search, accept; then counts of

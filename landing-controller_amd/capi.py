@@ -31,11 +31,21 @@ class SolverOpts(C.Structure):
                 ("tau_min", C.c_double), ("alpha_fallback", C.c_double), ("reset_delta", C.c_double)]
 
 
+ARGS21 = ["Xref", "Uref", "dt", "q_min", "q_max", "qd_min", "qd_max", "q_init", "qd_init", "q_term_min", "q_term_max",
+          "qd_term_min", "qd_term_max", "QN", "x0", "mu", "l_leg_max", "f_max", "mass", "Ib", "Ib_inv"]
+
+
+class Args21(C.Structure):
+    """landing_args21: the reference's 21 solver-function arguments (generate_landingCtrller_IPOPT.m:323-327), host pointers"""
+    _fields_ = [(n, _dp) for n in ARGS21]
+
+
 EXPORTS = ["landing_last_error", "landing_form_default", "landing_solver_opts_default", "landing_nx", "landing_ng",
            "landing_np", "landing_nnz_jac", "landing_nnz_hess", "landing_pattern_jac", "landing_pattern_hess",
            "landing_create", "landing_destroy", "landing_device_count", "landing_eval_batch", "landing_eval_batch_host",
            "landing_bounds_batch", "landing_solve_batch", "landing_solve_batch_host", "landing_kernel_name_sweep",
-           "landing_sweep_bytes_per_member", "landing_set_profile_buffer", "landing_debug_workspace"]
+           "landing_sweep_bytes_per_member", "landing_set_profile_buffer", "landing_debug_workspace",
+           "landing_pack_args21", "landing_solve_args21", "landing_solve_21"]
 
 
 def load(path=None):
@@ -64,7 +74,27 @@ def load(path=None):
     lib.landing_solve_batch.argtypes = [vp, C.c_int, vp, vp, C.POINTER(SolverOpts), vp, vp, vp, vp, vp, vp, vp]
     lib.landing_set_profile_buffer.argtypes = [vp, vp]
     lib.landing_solve_batch_host.argtypes = [vp, C.c_int, _dp, _dp, C.POINTER(SolverOpts), _dp, _dp, _dp, _ip, _ip, _dp]
+    lib.landing_pack_args21.argtypes = [C.c_int, C.c_int, C.POINTER(Args21), _dp]
+    lib.landing_solve_args21.argtypes = [vp, C.c_int, C.POINTER(Args21), C.POINTER(SolverOpts), _dp, _dp, _ip, _ip, _dp]
+    lib.landing_solve_21.argtypes = [vp, C.c_int] + [_dp] * 21 + [C.POINTER(SolverOpts), _dp, _dp, _ip, _ip, _dp]
     return lib
+
+
+def matlab_args21(N, args):
+    """dict of the 21 arguments as MATLAB would hold them for a batch of B members -- arrays whose LAST axis is the batch
+    (Xref [12, N+1, B], dt [1, N, B], 6-vectors [6, B], x0 [nx, B], scalars [1, B] ...) -- flattened column-major into the
+    member-major host buffers the C ABI takes.  Returns (Args21, keep-alive list, B)."""
+    keep, a = [], Args21()
+    B = np.asarray(args["x0"]).shape[-1] if np.asarray(args["x0"]).ndim > 1 else 1
+    for n in ARGS21:
+        v = args.get(n)
+        if v is None:
+            setattr(a, n, None)
+            continue
+        buf = np.ascontiguousarray(np.asarray(v, float).reshape((-1, B), order="F").T)     # [B, n] member-major
+        keep.append(buf)
+        setattr(a, n, buf.ctypes.data_as(_dp))
+    return a, keep, B
 
 
 def _p(a):
@@ -151,6 +181,26 @@ class LandingLib:
                                                status.ctypes.data_as(_ip), iters.ctypes.data_as(_ip), _p(kkt))
         self._check(rc, "landing_solve_batch_host")
         return dict(x=x, f=f, lam_g=lam, status=status, iters=iters, kkt=kkt)
+
+    def pack_args21(self, args):
+        """p [B, np] from the 21 MATLAB-shaped arguments (landing_pack_args21; host only)"""
+        a, keep, B = matlab_args21(self.N, args)
+        p = np.zeros((B, self.np_))
+        self._check(self.lib.landing_pack_args21(self.N, B, C.byref(a), _p(p)), "landing_pack_args21")
+        return p
+
+    def solve_args21(self, args, opts=None, spelled_out=False):
+        """the reference's solver-function call, batched: args = dict of the 21 MATLAB-shaped arrays (batch = last axis)"""
+        a, keep, B = matlab_args21(self.N, args)
+        opts = opts or self.default_opts()
+        x = np.zeros((B, self.nx)); f = np.zeros(B); status = np.zeros(B, np.int32); iters = np.zeros(B, np.int32); kkt = np.zeros((B, 3))
+        outs = (_p(x), _p(f), status.ctypes.data_as(_ip), iters.ctypes.data_as(_ip), _p(kkt))
+        if spelled_out:
+            rc = self.lib.landing_solve_21(self.ctx, B, *[getattr(a, n) for n in ARGS21], C.byref(opts), *outs)
+        else:
+            rc = self.lib.landing_solve_args21(self.ctx, B, C.byref(a), C.byref(opts), *outs)
+        self._check(rc, "landing_solve_args21")
+        return dict(x=x, f=f, status=status, iters=iters, kkt=kkt)
 
     # ---- device-pointer entry points (integers = device addresses, e.g. torch tensor.data_ptr()) --
     def eval_device(self, B, d_x, d_p, d_lam_f=0, d_lam_g=0, d_f=0, d_g=0, d_grad_f=0, d_jac=0, d_hess=0, d_ggx=0, d_ggp=0, stream=0):

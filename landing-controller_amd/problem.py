@@ -160,6 +160,23 @@ def make_member(N, T, q_init, qd_init, consts=None):
     return p, x0, Xref, Uref
 
 
+def make_args21(B, N=40, T=0.6, seed=20211, consts=None):
+    """The 21 arguments of the solver function for B sampled drop states, shaped as the MATLAB callers hold them with a
+    trailing batch axis (generate_training_data_automated.m:62-136): dict name -> array."""
+    c = consts or CallerConstants()
+    mass, Ib, Ib_inv = robot_constants()
+    q, qd = sample_drop_states(B, seed, T / N, c)
+    Xref = np.zeros((12, N + 1, B)); Uref = np.zeros((24, N, B)); x0 = np.zeros((nx(N), B))
+    for b in range(B):
+        Xref[:, :, b], Uref[:, :, b] = reference_trajectories(N, q[b], qd[b], c)
+        x0[:, b] = np.concatenate([Xref[:, :, b].flatten(order="F"), Uref[:, :, b].flatten(order="F")])
+    rep = lambda v: np.repeat(np.asarray(v, float).reshape(-1, 1), B, axis=1)
+    return dict(Xref=Xref, Uref=Uref, dt=np.full((1, N, B), T / N), q_min=rep(c.q_min), q_max=rep(c.q_max), qd_min=rep(c.qd_min),
+                qd_max=rep(c.qd_max), q_init=q.T.copy(), qd_init=qd.T.copy(), q_term_min=rep(c.q_term_min), q_term_max=rep(c.q_term_max),
+                qd_term_min=rep(c.qd_term_min), qd_term_max=rep(c.qd_term_max), QN=rep(c.QN), x0=x0, mu=rep([c.mu]),
+                l_leg_max=rep([c.l_leg_max]), f_max=rep([c.f_max]), mass=rep([mass]), Ib=rep(Ib), Ib_inv=rep(Ib_inv))
+
+
 def make_batch(B, N=40, T=0.6, seed=20211, consts=None):
     """Synthetic drop-state batch of SURVEY 8(d): returns P[B,np], X0[B,nx], q_init, qd_init."""
     q, qd = sample_drop_states(B, seed, T / N, consts)

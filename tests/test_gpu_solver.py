@@ -142,6 +142,40 @@ def test_solver_full_size_batch_properties(libs, oracle_mod):
         assert O.kkt(xh[b], P[b], lh[b]).max() <= KKT_TOL * 1.0001
 
 
+def test_solver_config3_shard_size_on_one_gpu(libs, oracle_mod):
+    """BASELINE configs[2]'s total (B = 8192, N = 40) on ONE GPU: the workspace (9 GB of the 288 GB), the dispatch of 8192
+    workgroups over 512 resident slots and failure isolation at that size.  >= 99 % converge within 300 iterations; a sample of
+    the converged members is re-certified under the oracle's functions; member i equals member i of the 1024-batch with the
+    same seed (batch independence at full size)."""
+    import torch
+    N, B = 40, 8192
+    L = libs[N]
+    O = oracle_mod.Oracle(N)
+    Ps, X0s = [], []
+    for r in range(8):                                     # the eight rank shards of bench.py --gpus 8 (seed 20211 + rank)
+        Pr, Xr, _, _ = lc("problem").make_batch(1024, N, 0.6, seed=20211 + r)
+        Ps.append(Pr); X0s.append(Xr)
+    P, X0 = np.concatenate(Ps), np.concatenate(X0s)
+    dev = "cuda"
+    dP, dX0 = torch.tensor(P, device=dev), torch.tensor(X0, device=dev)
+    mk = lambda *s, dt=torch.float64: torch.empty(*s, device=dev, dtype=dt)
+    x, lam, kkt, st, it = mk(B, L.nx), mk(B, L.ng), mk(B, 3), mk(B, dt=torch.int32), mk(B, dt=torch.int32)
+    o = L.default_opts(); o.max_iter = 300
+    L.solve_device(B, dP.data_ptr(), dX0.data_ptr(), o, x.data_ptr(), 0, lam.data_ptr(), st.data_ptr(), it.data_ptr(), kkt.data_ptr(),
+                   torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    sth, kh, xh, lh = st.cpu().numpy(), kkt.cpu().numpy(), x.cpu().numpy(), lam.cpu().numpy()
+    ok = sth == 0
+    assert ok.mean() >= 0.99, f"{ok.sum()}/{B}"
+    assert kh[ok].max() <= KKT_TOL * 1.0001
+    for b in np.nonzero(ok)[0][::701]:
+        assert O.kkt(xh[b], P[b], lh[b]).max() <= KKT_TOL * 1.0001
+    x1 = mk(1024, L.nx)
+    L.solve_device(1024, dP.data_ptr(), dX0.data_ptr(), o, x1.data_ptr(), 0, 0, 0, 0, 0, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert torch.equal(x1, x[:1024])
+
+
 RUN_COST = dict(QX=[0, 0, 10, 1, 1, 0, .1, .1, .1, .1, .1, .1], Qc=[1.0, 1.0, 0.5], Qf=[1e-4, 1e-4, 1e-3], f_ref=[0, 0, 20.0])
 
 
