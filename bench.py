@@ -94,6 +94,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="NLPs per GPU (weak scaling)")
     ap.add_argument("--max-iter", type=int, default=300)
+    ap.add_argument("--distinct-batches", type=int, default=8, help="timed steps cycle through this many different synthetic batches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo only with --dry (CPU launcher test)")
     ap.add_argument("--dry", action="store_true", help="no GPU work: exercise the multi-rank path with a stub solve")
@@ -137,11 +138,19 @@ def main():
         capi = importlib.import_module("landing-controller_amd.capi")
         lib = capi.LandingLib(N, device=local)
 
-    # synthetic drop states of SURVEY 8(d); every rank its own shard of the sweep (seed = 20211 + rank)
-    P, X0, _, _ = problem.make_batch(B if not a.dry else min(B, 8), N, 0.6, seed=20211 + rank)
-    if a.dry:
-        P = np.resize(P, (B, P.shape[1])); X0 = np.resize(X0, (B, X0.shape[1]))
-    dP, dX0 = torch.tensor(P, device=dev), torch.tensor(X0, device=dev)
+    # synthetic drop states of SURVEY 8(d); every rank its own shard of the sweep (seed = 20211 + rank), and every timed
+    # step its own batch (seed + 1000 * step): the batch time is set by the slowest of the 1024 members, which varies by
+    # +-15 % from one random batch to the next -- the metric is the mean over the K batches, not one lucky or unlucky draw
+    def batch_of(step):
+        Pq, Xq, _, _ = problem.make_batch(B if not a.dry else min(B, 8), N, 0.6, seed=20211 + rank + 1000 * step)
+        if a.dry:
+            Pq = np.resize(Pq, (B, Pq.shape[1])); Xq = np.resize(Xq, (B, Xq.shape[1]))
+        return Pq, Xq
+    n_batches = max(1, min(a.steps, a.distinct_batches))
+    host_batches = [batch_of(i) for i in range(n_batches)]
+    dev_batches = [(torch.tensor(Pq, device=dev), torch.tensor(Xq, device=dev)) for Pq, Xq in host_batches]
+    P, X0 = host_batches[0]
+    dP, dX0 = dev_batches[0]
     mk = lambda *s, dt=torch.float64: torch.empty(*s, device=dev, dtype=dt)
     x, f, lam, kkt = mk(B, nx), mk(B), mk(B, ng), mk(B, 3)
     st, it = mk(B, dt=torch.int32), mk(B, dt=torch.int32)
@@ -168,10 +177,10 @@ def main():
         lib.solve_device(B, dp.data_ptr(), dx0.data_ptr(), opts, x.data_ptr(), f.data_ptr(), lam.data_ptr(), st.data_ptr(),
                          it.data_ptr(), kkt.data_ptr(), stream)
 
-    def step(timed):
+    def step(timed, i=0):
         if timed and ev0 is not None:
             ev0.record()
-        solve(dP, dX0)
+        solve(*dev_batches[i % n_batches])
         if timed and ev1 is not None:
             ev1.record()
         if world > 1:   # collect the solved trajectories (RCCL over xGMI)
@@ -187,9 +196,11 @@ def main():
         step(False)
     sync()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step(True)
+    n_conv = torch.zeros(1, device=dev, dtype=torch.float64)
+    for i in range(a.steps):
+        step(True, i)
         cuda_sync()                         # events of this step are complete; the launch is asynchronous otherwise
+        n_conv += (st == 0).sum()
         if ev0 is not None:
             kernel_ms.append(ev0.elapsed_time(ev1))
     sync()
@@ -200,7 +211,7 @@ def main():
         allel = [torch.zeros_like(el) for _ in range(world)]
         dist.all_gather(allel, el)
         per_rank = [1e3 * float(t.item()) / a.steps for t in allel]
-    conv = (st == 0).sum().to(torch.float64).reshape(1)
+    conv = n_conv / a.steps          # converged members per step, averaged over the timed steps
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         dist.all_reduce(conv, op=dist.ReduceOp.SUM)
@@ -213,11 +224,12 @@ def main():
     # ---- the same step with the PCIe legs inside (SURVEY 8d wording): pinned host p, x0 -> HBM, x*, status -> host
     pcie = None
     if not a.dry:
-        hP, hX0 = torch.tensor(P).pin_memory(), torch.tensor(X0).pin_memory()
+        pinned = [(torch.tensor(Pq).pin_memory(), torch.tensor(Xq).pin_memory()) for Pq, Xq in host_batches]
         hx, hst = torch.empty(B, nx, dtype=torch.float64).pin_memory(), torch.empty(B, dtype=torch.int32).pin_memory()
         dP2, dX02 = torch.empty_like(dP), torch.empty_like(dX0)
 
-        def step_pcie():
+        def step_pcie(i=0):
+            hP, hX0 = pinned[i % n_batches]
             dP2.copy_(hP, non_blocking=True); dX02.copy_(hX0, non_blocking=True)
             solve(dP2, dX02)
             hx.copy_(x, non_blocking=True); hst.copy_(st, non_blocking=True)
@@ -225,8 +237,8 @@ def main():
                 sharding.gather_solutions(x, st, xg, stg)
         step_pcie(); sync()
         tp = time.perf_counter()
-        for _ in range(a.steps):
-            step_pcie()
+        for i in range(a.steps):
+            step_pcie(i)
             cuda_sync()
         sync()
         tp = time.perf_counter() - tp
@@ -240,7 +252,7 @@ def main():
 
     if rank == 0:
         cfg = {"workload": "3D-SRBM landing NLP, N=40 intervals, batch=%d random drop heights/attitudes per GPU, fp64 (BASELINE configs[1]%s)" % (B, "; x%d GPUs = configs[2]" % world if world > 1 else ""),
-               "global_batch": B * world, "max_iter": a.max_iter, "kkt_tol": 1e-6, "parallelism": "batch-sharded x%d, RCCL all-gather of x*" % world}
+               "global_batch": B * world, "distinct_batches": n_batches, "max_iter": a.max_iter, "kkt_tol": 1e-6, "parallelism": "batch-sharded x%d, RCCL all-gather of x*" % world}
         out = {"metric": "landing NLPs solved/sec (SRBM, N=40, batch)", "value": solved_per_step * a.steps / elapsed, "unit": "NLPs/s",
                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic", "config": cfg,
@@ -248,7 +260,7 @@ def main():
         if a.dry:
             out.update({"dry": True, "value": 0.0, "backend": a.backend, "note": "launcher dry run: stub solve, no measurement"})
         else:
-            out.update(measure_details(a, lib, np, torch, dev, mk, B, N, P, X0, dP, dX0, st, it, kkt, kernel_ms, solve, world, stream, ev0, ev1))
+            out.update(measure_details(a, lib, np, torch, dev, mk, B, N, P, X0, dP, dX0, st, it, kkt, kernel_ms, solve, world, stream, ev0, ev1, dev_batches))
             out["pcie_inclusive"] = pcie
         print(json.dumps(out), flush=True)
     if world > 1:
@@ -256,26 +268,32 @@ def main():
         dist.destroy_process_group()
 
 
-def measure_details(a, lib, np, torch, dev, mk, B, N, P, X0, dP, dX0, st, it, kkt, kernel_ms, solve, world, stream, ev0, ev1):
+def measure_details(a, lib, np, torch, dev, mk, B, N, P, X0, dP, dX0, st, it, kkt, kernel_ms, solve, world, stream, ev0, ev1, dev_batches):
     """rank 0: roofline of the solver kernel, the sweep kernel, the CPU baseline"""
-    sth, ith, kh = st.cpu().numpy(), it.cpu().numpy(), kkt.cpu().numpy()
-    ok = sth == 0
-    # ---- roofline of the dominant kernel: counters from one extra (untimed) instrumented pass
+    # ---- roofline of the dominant kernel: counters from one extra (untimed) instrumented pass over the timed batches;
+    # per-launch figures = mean over those batches
+    nb = min(len(dev_batches), len(kernel_ms))
+    cnt = np.zeros(16)
+    ith_all, ok_all, kk_all = [], [], []
     prof = mk(B, 16)
-    prof.zero_()
-    lib.lib.landing_set_profile_buffer(lib.ctx, prof.data_ptr())
-    solve(dP, dX0)
-    torch.cuda.synchronize()
-    lib.lib.landing_set_profile_buffer(lib.ctx, None)
-    ph = prof.cpu().numpy()
-    n_fact, n_trial, n_iter = ph[:, 8].sum(), ph[:, 9].sum(), ph[:, 10].sum()
-    n_stage_ok, n_stage_all = ph[:, 11].sum(), ph[:, 13].sum()      # stage eliminations: successful / attempted
+    for b in range(nb):
+        prof.zero_()
+        lib.lib.landing_set_profile_buffer(lib.ctx, prof.data_ptr())
+        solve(*dev_batches[b])
+        torch.cuda.synchronize()
+        lib.lib.landing_set_profile_buffer(lib.ctx, None)
+        cnt += prof.cpu().numpy().sum(axis=0)
+        ith_all.append(it.cpu().numpy().copy()); ok_all.append(st.cpu().numpy() == 0); kk_all.append(kkt.cpu().numpy().copy())
+    cnt /= nb
+    ith, ok, kh = np.concatenate(ith_all), np.concatenate(ok_all), np.concatenate(kk_all)
+    n_fact, n_trial, n_iter = cnt[8], cnt[9], cnt[10]
+    n_stage_ok, n_stage_all = cnt[11], cnt[13]      # stage eliminations: successful / attempted
     f_mid, f_last, f_foot, f_it, f_trial = flop_model(N)
     # successful eliminations only: every iteration ends with exactly one complete sweep (N-1 middle stages, the last
     # stage, the foot block); eliminations redone after an inertia failure are overhead, not useful work
     flops_impl = n_iter * ((N - 1) * f_mid + f_last + f_foot) + n_iter * f_it + n_trial * f_trial
     flops_8d = n_iter * (SURVEY_8D_KKT_FLOPS + SURVEY_8D_CALLBACK_FLOPS)
-    k_ms = float(np.mean(kernel_ms))
+    k_ms = float(np.mean([np.mean(kernel_ms[b::len(dev_batches)]) for b in range(nb)]))
     ach8d = flops_8d / (k_ms * 1e-3) / 1e12
     achim = flops_impl / (k_ms * 1e-3) / 1e12
     traffic = None
@@ -336,7 +354,7 @@ def measure_details(a, lib, np, torch, dev, mk, B, N, P, X0, dP, dX0, st, it, kk
                   "gpu_sweeps_per_s": Bs / (s_ms * 1e-3)}
         cpu = {"value": float((r["status"] == 0).sum() / tcpu), "unit": "NLPs/s", "cores": cores, "kind": "port", "function_layer": cpu_fn,
                "sample": f"first {ns} members of rank 0's batch (N=40), max_iter {a.max_iter}, OpenMP over members, {tcpu:.1f} s",
-               "converged": int((r["status"] == 0).sum()), "gpu_converged_same_members": int(ok[:ns].sum())}
+               "converged": int((r["status"] == 0).sum()), "gpu_converged_same_members": int(ok_all[0][:ns].sum())}
     return {"kkt_max_over_solved": kh[ok].max(axis=0).tolist() if ok.any() else None,
             "iters_median": float(np.median(ith)), "iters_mean": float(ith.mean()), "iters_max": int(ith.max()),
             "roofline": roofline, "sweep_roofline": sweep, "cpu_baseline": cpu}

@@ -91,7 +91,9 @@ typedef struct {
                             is still not solved this many iterations after the last (re)start (crawling iterate; counts
                             against max_resets); 0 = never; default 60 (round 2, tests/dev/ipm_lab.py on four seeded
                             batches: slowest member 149..160 iterations instead of 177..236 with 80, mean +1.3)                                                      */
-  int reserved;
+  int dispatch_order;    /* 1 (default): members with a large initial body height are dispatched first (they tend to need the most
+                            iterations and would otherwise set the batch time from the second wave); 0: batch order.  Results do
+                            not depend on it (every member is solved independently)                                          */
   double delta_init;     /* first trial regularisation when none was needed before (IPOPT first_hessian_perturbation, 1e-4) */
   double delta_inc_first;/* growth factor while no regularised iteration happened yet (IPOPT 100; default 10)            */
   double delta_inc;      /* growth factor afterwards (IPOPT 8; default 4: finer steps over-regularise less, tools/strag.py) */

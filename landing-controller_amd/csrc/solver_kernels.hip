@@ -40,6 +40,7 @@ constexpr int RUNC = 48;
 
 struct SolverWorkspace {
   double* buf = nullptr; size_t cap = 0;
+  int* d_order = nullptr; int order_cap = 0;
   hipEvent_t done = nullptr;     // recorded behind every solve launch: the next launch (any stream) and any re-allocation wait for it
   int* d_tab = nullptr; int* d_stage_tab = nullptr; int n_tab = 0;
   int *d_cterm = nullptr, *d_cstart = nullptr, *d_rterm = nullptr, *d_rstart = nullptr; int clen = 0, rlen = 0;
@@ -51,7 +52,7 @@ struct SolverWorkspace {
 };
 
 // optional per-member phase timers (wall_clock64 ticks, 100 MHz) -- enabled when SolveArgs.prof != nullptr
-enum { PH_EVAL = 0, PH_ERR, PH_SIGRHO, PH_BACK, PH_FWD, PH_DUAL, PH_LS, PH_ACCEPT, PH_NFACT, PH_NTRIAL, PH_NITER, PH_B_LOAD, PH_B_ASM, PH_B_TPT, PH_B_ELIM, PH_B_POST, PH_COUNT = 16 };
+enum { PH_EVAL = 0, PH_ERR, PH_SIGRHO, PH_BACK, PH_FWD, PH_DUAL, PH_LS, PH_ACCEPT, PH_NFACT, PH_NTRIAL, PH_NITER, PH_NSTAGE_OK, PH_B_ASM, PH_NSTAGE, PH_B_ELIM, PH_B_POST, PH_COUNT = 16 };   // 11 / 13: stage eliminations that succeeded / were attempted (stage-0 foot block included)
 #define PROF_ADD(slot, tstart) do { if (SH.prof_on) { const long long n_ = (long long)wall_clock64(); if (threadIdx.x == 0) SH.prof[slot] += (double)(n_ - (tstart)); (tstart) = n_; } } while (0)
 
 struct SolveArgs {
@@ -61,6 +62,7 @@ struct SolveArgs {
   double* ws; size_t ws_stride;
   const int* tab; const int* stage_tab;
   const int4* cterm; int clen; const int4* rterm; int rlen;
+  const int* order;      // dispatch order: workgroup b solves member order[b] (hard-first, see landing_order_kernel); nullptr = identity
 };
 
 // ---- block-wide reductions through LDS (deterministic order), K values at once ----------------------
@@ -453,7 +455,10 @@ __device__ __noinline__ void condense(const int4* __restrict__ cterm, int clen) 
   double acc = 0.0;
   // batches of 8 terms: the records of the next batch are fetched while the 24 gathers of this one are in flight
   // (two dependent memory round trips per batch otherwise; the phase is pure latency)
-  constexpr int BW = 8;
+#ifndef LANDING_COND_BW
+#define LANDING_COND_BW 8
+#endif
+  constexpr int BW = LANDING_COND_BW;
   const int4 padterm = {-3, 0, -1, -1};
   int4 tn[BW];
 #pragma unroll
@@ -525,6 +530,7 @@ __device__ __noinline__ bool riccati_backward(double delta) {
     // ---- G + T^T P T, elimination of the controls: P_k, p_k, gains -> record k; stages the data of stage k-1
     double* rec = M.ric + (size_t)k * RIC_STRIDE;
     ok = last ? riccati_step<12>(rec, delta, k) : riccati_step<24>(rec, delta, k);
+    if (lane == 0) { S.prof[PH_NSTAGE] += 1.0; if (ok) S.prof[PH_NSTAGE_OK] += 1.0; }
     PROF_ADD(PH_B_ELIM, tb_);
   }
   if (ok) {
@@ -545,6 +551,7 @@ __device__ __noinline__ bool riccati_backward(double delta) {
     if (lane < 64) gauss_jordan_wave<12>(S.G, S.gam, S.A1, S.A1 + 24 * 24, &S.flag);
     __syncthreads();
     ok = S.flag != 0;
+    if (lane == 0) { S.prof[PH_NSTAGE] += 1.0; if (ok) S.prof[PH_NSTAGE_OK] += 1.0; }
     if (ok) {
       if (lane < 12) S.sig[12 + lane] = -S.A1[24 * 24 + lane];
       __syncthreads();
@@ -679,9 +686,31 @@ __device__ __noinline__ void row_products(const int4* __restrict__ rterm, int rl
 #ifndef LANDING_MIN_WAVES
 #define LANDING_MIN_WAVES 2
 #endif
+// Dispatch order of a batch: workgroups are handed to the CUs in blockIdx order and a batch larger than the resident
+// capacity (2 workgroups per CU) runs in waves, so the batch time is the finishing time of the slowest member -- which
+// is much later when that member only starts in the second wave.  Members likely to need many iterations go first.
+// Difficulty proxy = initial body height z0 = q_init(3) (it grows with |pitch| and the drop speed through the callers'
+// touch-down rule, generate_training_data_automated.m:52-60): correlation 0.65 with the iteration count on the bench
+// batches (tests/dev/ipm_lab.py), as good as what a 30-iteration probe predicts.  rank = number of members with a larger
+// key (ties: lower index first) -- O(B^2) comparisons, deterministic, no atomics.  NaN keys sort last.
+__global__ void landing_order_kernel(Layout L, int B, const double* __restrict__ p, int* __restrict__ order) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= B) return;
+  const int off = L.o_q_init + 2;
+  double key = p[(size_t)m * L.np + off];
+  if (!(key == key)) key = -INFINITY;
+  int rank = 0;
+  for (int j = 0; j < B; ++j) {
+    double kj = p[(size_t)j * L.np + off];
+    if (!(kj == kj)) kj = -INFINITY;
+    rank += (kj > key) || (kj == key && j < m);
+  }
+  order[rank] = m;
+}
+
 __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm_kernel(SolveArgs A) {
-  const int m = blockIdx.x;
-  if (m >= A.B) return;
+  if ((int)blockIdx.x >= A.B) return;
+  const int m = A.order ? A.order[blockIdx.x] : (int)blockIdx.x;
   const Layout& L = A.L;
   const int N = L.N, lane = threadIdx.x, NT = blockDim.x;
   const int nx = L.nx, ng = L.ng;
@@ -753,24 +782,35 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
   // rows; the accept pass below produces the same quantities for the next iterate, so this runs only at the start,
   // after a multiplier reset and when mu changes)
   double c_pr = 0.0, c_co = 0.0, c_cm = 0.0;
+  // Row passes: every thread owns the rows lane + NT j.  They are processed RB at a time with ALL loads of a batch issued
+  // up-front and unconditionally (every array is fully allocated; out-of-range rows re-read the last row and are masked):
+  // one memory round trip per batch instead of two or three dependent ones per row behind the bound-type branches.
+  constexpr int RB = 4;
   auto point_pass = [&](double mu_) {
     double pr = 0.0, co = 0.0, cm = 0.0;
-#pragma unroll 2
-    for (int r = lane; r < ng; r += NT) {
-      const double lb = r_lb[r], ub = r_ub[r];
-      double sg = 0.0, rh = 0.0;
-      if (r >= 12) {
-        const double g = r_g[r];
-        if (lb == ub) pr = fmax(pr, fabs(g - lb));
-        else {
-          const double s = r_s[r];
-          pr = fmax(pr, fabs(g - s));
-          if (lb > -INF) { const double d = s - lb, rd = fast_rcp(d), zl = r_zL[r]; co = fmax(co, d * zl); cm = fmax(cm, fabs(d * zl - mu_)); sg += zl * rd; rh -= mu_ * rd; }
-          if (ub < INF) { const double d = ub - s, rd = fast_rcp(d), zu = r_zU[r]; co = fmax(co, d * zu); cm = fmax(cm, fabs(d * zu - mu_)); sg += zu * rd; rh += mu_ * rd; }
-          rh += sg * (g - s);
+    for (int rb = lane; rb < ng; rb += NT * RB) {
+      double lbv[RB], ubv[RB], gv[RB], sv[RB], zlv[RB], zuv[RB];
+#pragma unroll
+      for (int j = 0; j < RB; ++j) { const int r = rb + j * NT, rr = r < ng ? r : ng - 1; lbv[j] = r_lb[rr]; ubv[j] = r_ub[rr]; gv[j] = r_g[rr]; sv[j] = r_s[rr]; zlv[j] = r_zL[rr]; zuv[j] = r_zU[rr]; }
+#pragma unroll
+      for (int j = 0; j < RB; ++j) {
+        const int r = rb + j * NT;
+        if (r >= ng) continue;
+        const double lb = lbv[j], ub = ubv[j];
+        double sg = 0.0, rh = 0.0;
+        if (r >= 12) {
+          const double g = gv[j];
+          if (lb == ub) pr = fmax(pr, fabs(g - lb));
+          else {
+            const double s = sv[j];
+            pr = fmax(pr, fabs(g - s));
+            if (lb > -INF) { const double d = s - lb, rd = fast_rcp(d), zl = zlv[j]; co = fmax(co, d * zl); cm = fmax(cm, fabs(d * zl - mu_)); sg += zl * rd; rh -= mu_ * rd; }
+            if (ub < INF) { const double d = ub - s, rd = fast_rcp(d), zu = zuv[j]; co = fmax(co, d * zu); cm = fmax(cm, fabs(d * zu - mu_)); sg += zu * rd; rh += mu_ * rd; }
+            rh += sg * (g - s);
+          }
         }
+        r_sig[r] = sg; r_rho[r] = rh;
       }
-      r_sig[r] = sg; r_rho[r] = rh;
     }
     double v[3] = {pr, co, cm}; const int op[3] = {RMAX, RMAX, RMAX};
     block_reduce<3>(v, op, S.red);
@@ -875,28 +915,34 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
     // fraction-to-the-boundary as tau / max(-ds/d), tau / max(-dz/z): reciprocals instead of divisions in the row
     // loop, one logarithm per row (log of the product of the two distances)
     double m_pr = 0.0, m_du = 0.0, th0 = 0.0, bar = 0.0, dphi = 0.0;
-#pragma unroll 2   // (unroll 4 of this loop hangs the kernel on gfx950 / ROCm 7.2 -- observed, not understood; keep 2)
-    for (int r = lane + 12; r < ng; r += NT) {
-      const double lb = r_lb[r], ub = r_ub[r], g = r_g[r];
-      if (lb == ub) { th0 += fabs(g - lb); continue; }
-      const double s = r_s[r], ds = r_ds[r];
-      th0 += fabs(g - s);
-      double dprod = 1.0;
-      if (lb > -INF) {
-        const double d = s - lb, rd = fast_rcp(d), zl = r_zL[r];
-        const double dz = fma(-zl * rd, ds, mu * rd - zl);
-        m_pr = fmax(m_pr, -ds * rd);
-        m_du = fmax(m_du, -dz * fast_rcp(zl));
-        dprod = d; dphi -= mu * ds * rd;
+    for (int rb = lane + 12; rb < ng; rb += NT * RB) {
+      double lbv[RB], ubv[RB], gv[RB], sv[RB], dsv[RB], zlv[RB], zuv[RB];
+#pragma unroll
+      for (int j = 0; j < RB; ++j) { const int r = rb + j * NT, rr = r < ng ? r : ng - 1; lbv[j] = r_lb[rr]; ubv[j] = r_ub[rr]; gv[j] = r_g[rr]; sv[j] = r_s[rr]; dsv[j] = r_ds[rr]; zlv[j] = r_zL[rr]; zuv[j] = r_zU[rr]; }
+#pragma unroll
+      for (int j = 0; j < RB; ++j) {
+        if (rb + j * NT >= ng) continue;
+        const double lb = lbv[j], ub = ubv[j], g = gv[j];
+        if (lb == ub) { th0 += fabs(g - lb); continue; }
+        const double s = sv[j], ds = dsv[j];
+        th0 += fabs(g - s);
+        double dprod = 1.0;
+        if (lb > -INF) {
+          const double d = s - lb, rd = fast_rcp(d), zl = zlv[j];
+          const double dz = fma(-zl * rd, ds, mu * rd - zl);
+          m_pr = fmax(m_pr, -ds * rd);
+          m_du = fmax(m_du, -dz * fast_rcp(zl));
+          dprod = d; dphi -= mu * ds * rd;
+        }
+        if (ub < INF) {
+          const double d = ub - s, rd = fast_rcp(d), zu = zuv[j];
+          const double dz = fma(zu * rd, ds, mu * rd - zu);
+          m_pr = fmax(m_pr, ds * rd);
+          m_du = fmax(m_du, -dz * fast_rcp(zu));
+          dprod *= d; dphi += mu * ds * rd;
+        }
+        bar -= log(dprod);
       }
-      if (ub < INF) {
-        const double d = ub - s, rd = fast_rcp(d), zu = r_zU[r];
-        const double dz = fma(zu * rd, ds, mu * rd - zu);
-        m_pr = fmax(m_pr, ds * rd);
-        m_du = fmax(m_du, -dz * fast_rcp(zu));
-        dprod *= d; dphi += mu * ds * rd;
-      }
-      bar -= log(dprod);
     }
     double f0 = 0.0;
     if (lane < 12) {
@@ -933,13 +979,19 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
       member_eval_g(L, M.xt, p, M.gt);
       __syncthreads();
       double tht = 0.0, bt = 0.0, ft = 0.0;
-  #pragma unroll 2
-    for (int r = lane + 12; r < ng; r += NT) {
-        const double lb = r_lb[r], ub = r_ub[r], g = r_gt[r];
-        if (lb == ub) { tht += fabs(g - lb); continue; }
-        const double s = r_s[r] + alpha * r_ds[r];
-        tht += fabs(g - s);
-        bt -= log((lb > -INF ? s - lb : 1.0) * (ub < INF ? ub - s : 1.0));
+      for (int rb = lane + 12; rb < ng; rb += NT * RB) {
+        double lbv[RB], ubv[RB], gv[RB], sv[RB], dsv[RB];
+#pragma unroll
+        for (int j = 0; j < RB; ++j) { const int r = rb + j * NT, rr = r < ng ? r : ng - 1; lbv[j] = r_lb[rr]; ubv[j] = r_ub[rr]; gv[j] = r_gt[rr]; sv[j] = r_s[rr]; dsv[j] = r_ds[rr]; }
+#pragma unroll
+        for (int j = 0; j < RB; ++j) {
+          if (rb + j * NT >= ng) continue;
+          const double lb = lbv[j], ub = ubv[j], g = gv[j];
+          if (lb == ub) { tht += fabs(g - lb); continue; }
+          const double s = sv[j] + alpha * dsv[j];
+          tht += fabs(g - s);
+          bt -= log((lb > -INF ? s - lb : 1.0) * (ub < INF ? ub - s : 1.0));
+        }
       }
       if (lane < 12) { const double d = M.xt[12 * N + lane] - p[12 * N + lane]; ft = p[L.o_QN + lane] * d * d; }
       if (L.run_cost) for (int k0 = 0; k0 < N; k0 += NT) { const int k = k0 + lane; if (k < N) ft += run_cost_stage(L, M.xt, p, k, nullptr, nullptr, nullptr); }
@@ -982,32 +1034,42 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
     for (int i = lane; i < nx; i += NT) M.x[i] = M.xt[i];
     {
       double npr = 0.0, nco = 0.0, ncm = 0.0;
-#pragma unroll 2
-      for (int r = lane; r < ng; r += NT) {
-        const double lb = r_lb[r], ub = r_ub[r], g = r_gt[r];
-        r_g[r] = g;
-        double sg = 0.0, rh = 0.0;
-        if (r >= 12) {
-          if (lb == ub) { r_y[r] += alpha * (r_yn[r] - r_y[r]); npr = fmax(npr, fabs(g - lb)); }
-          else {
-            const double so = r_s[r], ds = r_ds[r], s = so + alpha * ds;
-            double zl = 0.0, zu = 0.0;
-            if (lb > -INF) {
-              const double dold = so - lb, ro = fast_rcp(dold), zo = r_zL[r], dz = fma(-zo * ro, ds, mu * ro - zo), d = s - lb, rd = fast_rcp(d);
-              zl = fmin(fmax(zo + a_du * dz, 1e-10 * mu * rd), 1e10 * mu * rd);
-              nco = fmax(nco, d * zl); ncm = fmax(ncm, fabs(d * zl - mu)); sg += zl * rd; rh -= mu * rd;
-            }
-            if (ub < INF) {
-              const double dold = ub - so, ro = fast_rcp(dold), zo = r_zU[r], dz = fma(zo * ro, ds, mu * ro - zo), d = ub - s, rd = fast_rcp(d);
-              zu = fmin(fmax(zo + a_du * dz, 1e-10 * mu * rd), 1e10 * mu * rd);
-              nco = fmax(nco, d * zu); ncm = fmax(ncm, fabs(d * zu - mu)); sg += zu * rd; rh += mu * rd;
-            }
-            npr = fmax(npr, fabs(g - s));
-            rh += sg * (g - s);
-            r_s[r] = s; r_zL[r] = zl; r_zU[r] = zu; r_y[r] = zu - zl;
-          }
+      for (int rb = lane; rb < ng; rb += NT * RB) {
+        double lbv[RB], ubv[RB], gv[RB], sv[RB], dsv[RB], zlv[RB], zuv[RB], yv[RB], ynv[RB];
+#pragma unroll
+        for (int j = 0; j < RB; ++j) {
+          const int r = rb + j * NT, rr = r < ng ? r : ng - 1;
+          lbv[j] = r_lb[rr]; ubv[j] = r_ub[rr]; gv[j] = r_gt[rr]; sv[j] = r_s[rr]; dsv[j] = r_ds[rr]; zlv[j] = r_zL[rr]; zuv[j] = r_zU[rr]; yv[j] = r_y[rr]; ynv[j] = r_yn[rr];
         }
-        r_sig[r] = sg; r_rho[r] = rh;
+#pragma unroll
+        for (int j = 0; j < RB; ++j) {
+          const int r = rb + j * NT;
+          if (r >= ng) continue;
+          const double lb = lbv[j], ub = ubv[j], g = gv[j];
+          r_g[r] = g;
+          double sg = 0.0, rh = 0.0;
+          if (r >= 12) {
+            if (lb == ub) { r_y[r] = yv[j] + alpha * (ynv[j] - yv[j]); npr = fmax(npr, fabs(g - lb)); }
+            else {
+              const double so = sv[j], ds = dsv[j], s = so + alpha * ds;
+              double zl = 0.0, zu = 0.0;
+              if (lb > -INF) {
+                const double dold = so - lb, ro = fast_rcp(dold), zo = zlv[j], dz = fma(-zo * ro, ds, mu * ro - zo), d = s - lb, rd = fast_rcp(d);
+                zl = fmin(fmax(zo + a_du * dz, 1e-10 * mu * rd), 1e10 * mu * rd);
+                nco = fmax(nco, d * zl); ncm = fmax(ncm, fabs(d * zl - mu)); sg += zl * rd; rh -= mu * rd;
+              }
+              if (ub < INF) {
+                const double dold = ub - so, ro = fast_rcp(dold), zo = zuv[j], dz = fma(zo * ro, ds, mu * ro - zo), d = ub - s, rd = fast_rcp(d);
+                zu = fmin(fmax(zo + a_du * dz, 1e-10 * mu * rd), 1e10 * mu * rd);
+                nco = fmax(nco, d * zu); ncm = fmax(ncm, fabs(d * zu - mu)); sg += zu * rd; rh += mu * rd;
+              }
+              npr = fmax(npr, fabs(g - s));
+              rh += sg * (g - s);
+              r_s[r] = s; r_zL[r] = zl; r_zU[r] = zu; r_y[r] = zu - zl;
+            }
+          }
+          r_sig[r] = sg; r_rho[r] = rh;
+        }
       }
       double v[3] = {npr, nco, ncm}; const int op[3] = {RMAX, RMAX, RMAX};
       block_reduce<3>(v, op, S.red);

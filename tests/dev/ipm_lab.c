@@ -192,7 +192,7 @@ static void init_slacks(work_t* W, const lo_solver_opts* op0) {
 }
 
 
-typedef struct { int thmin_rel, max_soc, sticky, stall, probe, trace, clip; double clip_tau, mu_init, tau_min, bpush, bfrac, mehro_lo, mehro_hi, piv_jump, piv_keep; int zinit, mehro, zcomp; double stall_frac; int restart_period; double kappa_eps; } lab_t;
+typedef struct { int thmin_rel, max_soc, sticky, stall, probe, trace, clip; double clip_tau, mu_init, tau_min, bpush, bfrac, mehro_lo, mehro_hi, piv_jump, piv_keep; int zinit, mehro, zcomp; double thcap, thfloor; double stall_frac; int restart_period; double kappa_eps; } lab_t;
 static lab_t LAB;
 static void lab_init(void) {
   const char* e;
@@ -218,6 +218,8 @@ static void lab_init(void) {
   if ((e = getenv("LAB_PIVJUMP"))) LAB.piv_jump = atof(e);
   if ((e = getenv("LAB_PIVKEEP"))) LAB.piv_keep = atof(e);
   if ((e = getenv("LAB_ZCOMP"))) LAB.zcomp = atoi(e);
+  if ((e = getenv("LAB_THCAP"))) LAB.thcap = atof(e);
+  LAB.thfloor = 1e-3; if ((e = getenv("LAB_THFLOOR"))) LAB.thfloor = atof(e);
   LAB.trace = getenv("LO_TRACE") != NULL;
 }
 
@@ -517,6 +519,7 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
         counters[1]++;
         trial_point(F, p, W, &o, alpha, mu, &tht, &pht);
         ok_f = (tht <= th_max) && (pht < 1e300) && (pht > -1e300) && (tht < 1e300);
+        if (LAB.thcap > 0 && tht > fmax(LAB.thcap * th0, LAB.thfloor)) ok_f = 0;
         for (e = 0; e < nfilt && ok_f; ++e) if (tht >= filt_th[e] && pht >= filt_ph[e]) ok_f = 0;
         switching = (dphi < 0.0) && (th0 <= th_min) && (alpha * pow(-dphi, 2.3) > pow(th0, 1.1));
         if (ok_f) {

@@ -24,6 +24,8 @@ def solve(O, P, X0, threads=8, max_iter=300, tol=None, **kw):
     o = orc._SolverOpts(); O.lib.lo_solver_opts_default(C.byref(o)); o.max_iter = max_iter
     if tol: o.tol = tol
     for k, v in kw.items(): setattr(o, k, v)
+    if os.environ.get("LAB_RESETDU"): o.reset_du = float(os.environ["LAB_RESETDU"])
+    if os.environ.get("LAB_MAXRESETS"): o.max_resets = int(os.environ["LAB_MAXRESETS"])
     x = np.zeros((B, O.nx)); lam = np.zeros((B, O.ng)); st = np.zeros(B, np.int32); it = np.zeros(B, np.int32)
     kkt = np.zeros((B, 3)); cnt = np.zeros(5, np.int64)
     ip = C.POINTER(C.c_int)
@@ -43,7 +45,7 @@ if __name__ == "__main__":
     P, X0, q, qd = problem.make_batch(max(B, max(only) + 1 if only else 0), N, 0.6, seed=seed)
     if only: P, X0 = P[only], X0[only]
     else: P, X0 = P[:B], X0[:B]
-    t = time.time(); r = solve(O, P, X0, max_iter=int(os.environ.get("LAB_MAXIT", "300"))); dt = time.time() - t
+    t = time.time(); r = solve(O, P, X0, threads=int(os.environ.get("LAB_THREADS", "8")), max_iter=int(os.environ.get("LAB_MAXIT", "300"))); dt = time.time() - t
     it = r["iters"]; c = r["status"] == 0; cnt = r["cnt"]
     kk = r["kkt"][c].max() if c.any() else float("nan")
     tag = " ".join("%s=%s" % (k, v) for k, v in sorted(os.environ.items()) if k.startswith("LAB_"))
