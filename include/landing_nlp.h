@@ -182,6 +182,19 @@ int landing_solve_21(landing_ctx* ctx, int B, const double* Xref, const double* 
                      const double* Ib, const double* Ib_inv, const landing_solver_opts* opts,
                      double* x_star, double* f_star, int* status, int* iters, double* kkt);
 
+/* ---- tracking-controller synthesis along solved trajectories -------------------------------------
+ * SRBM variational linearisation A (24 x 24), B (24 x 12) (utilities_general/srbm-utilities/generateVariationalDynamics.m:29-62)
+ * and the Riccati differential equation Pdot = A'P + PA - P B R^-1 B'P + Q integrated backward along the sampled
+ * trajectory (generateRiccatiIntegrator.m:24-62, quadruped_SRBM_NLP.m:428-503), B trajectories at once.
+ *   d_xref [B][n][24] = [p rpy omega v pf(12)] and d_fref [B][n][12] at the n grid points (device);
+ *   Ib3x3: body inertia, row-major 3x3 (host); Q, F: 24 x 24 row-major (host); r_diag: diagonal of R (12, host);
+ *   rk4 = 0: the reference's backward step `P0 = Pf + dt*k1` (:47); 1: classical RK4 (:43-46)
+ * Outputs (device, any may be NULL): d_P [B][n][576] row-major with P[n-1] = F, d_K [B][n][12*24] = R^-1 B'P (tracking
+ * gains), d_A [B][n][576], d_B [B][n][288]. */
+int landing_riccati_gains_batch(landing_ctx* ctx, int B, int n, const double* d_xref, const double* d_fref,
+                                const double* Ib3x3, double mass, const double* Q, const double* r_diag, const double* F,
+                                double dt, int rk4, double* d_P, double* d_K, double* d_A, double* d_B, void* stream);
+
 /* development aid: d_prof [B][16] doubles receives per-member phase timers of the next solves (100 MHz
  * wall-clock ticks: eval, error, sigma/rho, backward, forward, dual, line search, accept; then counts of
  * factorisations, trial points, iterations); NULL disables. */

@@ -45,7 +45,7 @@ EXPORTS = ["landing_last_error", "landing_form_default", "landing_solver_opts_de
            "landing_create", "landing_destroy", "landing_device_count", "landing_eval_batch", "landing_eval_batch_host",
            "landing_bounds_batch", "landing_solve_batch", "landing_solve_batch_host", "landing_kernel_name_sweep",
            "landing_sweep_bytes_per_member", "landing_set_profile_buffer", "landing_debug_workspace",
-           "landing_pack_args21", "landing_solve_args21", "landing_solve_21"]
+           "landing_pack_args21", "landing_solve_args21", "landing_solve_21", "landing_riccati_gains_batch"]
 
 
 def load(path=None):
@@ -76,6 +76,8 @@ def load(path=None):
     lib.landing_solve_batch_host.argtypes = [vp, C.c_int, _dp, _dp, C.POINTER(SolverOpts), _dp, _dp, _dp, _ip, _ip, _dp]
     lib.landing_pack_args21.argtypes = [C.c_int, C.c_int, C.POINTER(Args21), _dp]
     lib.landing_solve_args21.argtypes = [vp, C.c_int, C.POINTER(Args21), C.POINTER(SolverOpts), _dp, _dp, _ip, _ip, _dp]
+    if hasattr(lib, "landing_riccati_gains_batch"):      # (older development builds used by tools/dev/variants.py lack it)
+        lib.landing_riccati_gains_batch.argtypes = [vp, C.c_int, C.c_int, vp, vp, _dp, C.c_double, _dp, _dp, _dp, C.c_double, C.c_int, vp, vp, vp, vp, vp]
     lib.landing_solve_21.argtypes = [vp, C.c_int] + [_dp] * 21 + [C.POINTER(SolverOpts), _dp, _dp, _ip, _ip, _dp]
     return lib
 
@@ -201,6 +203,13 @@ class LandingLib:
             rc = self.lib.landing_solve_args21(self.ctx, B, C.byref(a), C.byref(opts), *outs)
         self._check(rc, "landing_solve_args21")
         return dict(x=x, f=f, status=status, iters=iters, kkt=kkt)
+
+    def riccati_gains_device(self, B, n, d_xref, d_fref, Ib3x3, mass, Q, r_diag, F, dt, rk4=False, d_P=0, d_K=0, d_A=0, d_B=0, stream=0):
+        """landing_riccati_gains_batch: VBL linearisation + Riccati tracking gains along B sampled trajectories (device pointers)"""
+        Ib3x3 = np.ascontiguousarray(Ib3x3, float); Q = np.ascontiguousarray(Q, float); F = np.ascontiguousarray(F, float); r = np.ascontiguousarray(r_diag, float)
+        rc = self.lib.landing_riccati_gains_batch(self.ctx, B, n, d_xref, d_fref, _p(Ib3x3), float(mass), _p(Q), _p(r), _p(F), float(dt), int(bool(rk4)),
+                                                  d_P or None, d_K or None, d_A or None, d_B or None, stream or None)
+        self._check(rc, "landing_riccati_gains_batch")
 
     # ---- device-pointer entry points (integers = device addresses, e.g. torch tensor.data_ptr()) --
     def eval_device(self, B, d_x, d_p, d_lam_f=0, d_lam_g=0, d_f=0, d_g=0, d_grad_f=0, d_jac=0, d_hess=0, d_ggx=0, d_ggp=0, stream=0):

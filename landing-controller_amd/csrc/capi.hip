@@ -19,6 +19,7 @@
 #include "srbm_stage.hpp"
 #include "eval_kernels.hip"
 #include "solver_kernels.hip"
+#include "vbl_kernels.hip"
 
 using landing::Layout;
 
@@ -36,6 +37,7 @@ struct landing_ctx {
   int* d_edge_map = nullptr;
   landing::SolverWorkspace ws;
   double* d_prof = nullptr;
+  double* d_vbl = nullptr;      // Q (576) | F (576) | 1/diag(R) (12) of the last landing_riccati_gains_batch call
   std::mutex mu;      // serialises landing_solve_batch calls on one context (the workspace belongs to the context)
 };
 
@@ -203,6 +205,7 @@ void landing_destroy(landing_ctx* ctx) {
   hipSetDevice(ctx->device);
   ctx->ws.release();
   if (ctx->d_edge_map) (void)hipFree(ctx->d_edge_map);
+  if (ctx->d_vbl) (void)hipFree(ctx->d_vbl);
   delete ctx;
 }
 

@@ -38,12 +38,25 @@ constexpr int COND_GAM = 480, COND_AH = 528, COND_STRIDE = 704;
 // condensation tables address them like any other entry of [J | H]: X diagonal (12) | (pos_a, c_leg,a) (12) | c diagonal (12) | f diagonal (12)
 constexpr int RUNC = 48;
 
+// Packed condensation term (8 bytes), stage-local: value = JH[a] * (has_b ? JH[b] : 1) * coeff, coeff = sigma[row] (has_b) /
+// rho[row] (!has_b) for rtype 0, +1 / -1 / 0 for rtype 1 / 2 / 3; summed into the open destination, stored to
+// cond[stage][dst] when `closes`.  a, b = (segment, offset) into the member's [J | H | Hc] array:
+// segments 0..6 = J X_k | J U_k | J U_{k+1} | H X_k | H U_k | H U_{k+1} | running-cost constants of stage k.
+constexpr int CTAB_MLMAX = 6;
+__host__ __device__ inline unsigned long long cterm_pack(int sa, int oa, int sb, int ob, bool has_b, int rowq, int rtype, int dst, bool closes) {
+  const unsigned lo = (unsigned)oa | ((unsigned)sa << 8) | ((unsigned)ob << 11) | ((unsigned)sb << 19) | ((unsigned)(has_b ? 1 : 0) << 22) | ((unsigned)rowq << 23) | ((unsigned)rtype << 30);
+  const unsigned hi = (unsigned)dst | ((unsigned)(closes ? 1 : 0) << 10);
+  return (unsigned long long)lo | ((unsigned long long)hi << 32);
+}
+__host__ __device__ inline bool cterm_closes(unsigned long long t) { return ((t >> 42) & 1ull) != 0; }
+
 struct SolverWorkspace {
   double* buf = nullptr; size_t cap = 0;
   int* d_order = nullptr; int order_cap = 0;
   hipEvent_t done = nullptr;     // recorded behind every solve launch: the next launch (any stream) and any re-allocation wait for it
   int* d_tab = nullptr; int* d_stage_tab = nullptr; int n_tab = 0;
-  int *d_cterm = nullptr, *d_cstart = nullptr, *d_rterm = nullptr, *d_rstart = nullptr; int clen = 0, rlen = 0;
+  int* d_rterm = nullptr; int rlen = 0;
+  int *d_ctab = nullptr, *d_ctype = nullptr; int c_ml = 0, c_mid = 0;     // packed per-stage-type condensation tables
   static size_t member_stride(const Layout& L) {
     return (size_t)4 * L.nx + (size_t)12 * L.ng + L.nnz_jac + L.nnz_hess + (size_t)L.N * RUNC + (size_t)(L.N + 1) * RIC_STRIDE + (size_t)L.N * COND_STRIDE;
   }
@@ -61,7 +74,8 @@ struct SolveArgs {
   double* x_out; double* f_out; double* lam_out; int* status; int* iters; double* kkt;
   double* ws; size_t ws_stride;
   const int* tab; const int* stage_tab;
-  const int4* cterm; int clen; const int4* rterm; int rlen;
+  const unsigned long long* rterm; int rlen;                               // row-product records [rlen][256]
+  const unsigned long long* ctab; const int* ctype; int c_ml, c_mid;      // packed condensation tables [type][c_ml][256], type of every stage
   const int* order;      // dispatch order: workgroup b solves member order[b] (hard-first, see landing_order_kernel); nullptr = identity
 };
 
@@ -127,6 +141,11 @@ struct Lds {
   // the block steps) + the scatter codes of the most common stage table, cached once per launch
   double stg[COND_STRIDE + 12];
   int cab[COND_GAM]; int cat[COND_STRIDE - COND_AH]; int c_tab, c_nT, c_nA;
+  // condensation: packed term table of the most frequent stage type (the others are read from L2) and, per stage, the
+  // bases of the seven [J | H | Hc] segments + the type id (slot 7)
+  unsigned long long ctab_mid[CTAB_MLMAX * SOLVER_THREADS];
+  double carry[4 * SOLVER_THREADS];       // condensation carries: [batch parity][stage of the batch][thread]
+  int segb[64 * 8];
   MemberMem M; Layout L; const double* p; const int* tab; const int* stage_tab; int prof_on;
 };
 // One instance per workgroup (= per NLP).  Namespace scope keeps the LDS address space visible to every
@@ -443,45 +462,84 @@ __device__ __forceinline__ bool riccati_step(double* rec, double delta, int k) {
 }
 
 // Condensation (once per iteration): G targets = H + J_d^T Sigma J_d, gamma = J_d^T rho, A^ = -dg_dyn/d(X,c,f) of
-// every stage, straight from the CCS nonzeros.  Each thread owns a fixed list of terms (host-built, interleaved so
-// that the 16-byte records load coalesced; deterministic summation order).
-__device__ __noinline__ void condense(const int4* __restrict__ cterm, int clen) {
+// every stage, straight from the CCS nonzeros.  The work is described by packed 8-byte terms (cterm_pack) in
+// stage-LOCAL form: one table per stage type (first / middle / penultimate / last), the middle one cached in LDS -- the
+// round-1 version streamed a member-global list of 16-byte records (720 KB per member and iteration, four times the
+// J and H nonzeros themselves) from L2/HBM.  Thread t owns the terms [t*c_ml, (t+1)*c_ml) of every stage's list: perfectly
+// balanced (5 terms per thread and stage at N = 40).  A destination whose terms straddle chunk borders is finished by the
+// thread holding its closing term, which adds the carries of its `nprev` predecessors from LDS in thread order --
+// deterministic.  Two stages per batch: their gathers are issued together, one barrier per batch.
+__device__ __noinline__ void condense(const unsigned long long* __restrict__ ctab, int ML, int mid) {
   Lds& S = SH;
   const MemberMem& M = S.M;
-  const int ng = S.L.ng, tid = threadIdx.x, NT = blockDim.x;
-  const double* __restrict__ JH = M.J;       // [J | H] are contiguous
+  const int ng = S.L.ng, N = S.L.N, tid = threadIdx.x;
+  const double* __restrict__ JH = M.J;       // [J | H | Hc] are contiguous
   const double* __restrict__ SR = M.sig;     // [sigma | rho] are contiguous
   double* __restrict__ cond = M.cond;
-  double acc = 0.0;
-  // batches of 8 terms: the records of the next batch are fetched while the 24 gathers of this one are in flight
-  // (two dependent memory round trips per batch otherwise; the phase is pure latency)
-#ifndef LANDING_COND_BW
-#define LANDING_COND_BW 8
-#endif
-  constexpr int BW = LANDING_COND_BW;
-  const int4 padterm = {-3, 0, -1, -1};
-  int4 tn[BW];
+  constexpr int SB = 2;
+  const unsigned long long PAD = cterm_pack(0, 0, 0, 0, false, 0, 3, 0, false);
+  int batch = 0;
+  for (int k0 = 0; k0 < N; k0 += SB, ++batch) {
+    unsigned long long t[SB][CTAB_MLMAX];
+    double a[SB][CTAB_MLMAX], b[SB][CTAB_MLMAX], c[SB][CTAB_MLMAX];
 #pragma unroll
-  for (int u = 0; u < BW; ++u) tn[u] = (u < clen) ? cterm[(size_t)u * NT + tid] : padterm;
-  for (int j0 = 0; j0 < clen; j0 += BW) {
-    int4 t[BW];
+    for (int s = 0; s < SB; ++s) {
+      const int k = k0 + s < N ? k0 + s : N - 1;
+      const int tp = S.segb[k * 8 + 7];
+      const unsigned long long* gt = ctab + (size_t)tp * ML * SOLVER_THREADS;
 #pragma unroll
-    for (int u = 0; u < BW; ++u) t[u] = tn[u];
-#pragma unroll
-    for (int u = 0; u < BW; ++u) { const int j = j0 + BW + u; tn[u] = (j < clen) ? cterm[(size_t)j * NT + tid] : padterm; }
-    double a[BW], b[BW], c[BW];
-#pragma unroll
-    for (int u = 0; u < BW; ++u) {
-      a[u] = JH[t[u].y];
-      b[u] = JH[t[u].z >= 0 ? t[u].z : 0];
-      c[u] = SR[t[u].x >= 0 ? t[u].x + (t[u].z < 0 ? ng : 0) : 0];
+      for (int j = 0; j < CTAB_MLMAX; ++j) t[s][j] = j < ML ? (tp == mid ? S.ctab_mid[j * SOLVER_THREADS + tid] : gt[j * SOLVER_THREADS + tid]) : PAD;
     }
 #pragma unroll
-    for (int u = 0; u < BW; ++u) {
-      const double cc = t[u].x >= 0 ? c[u] : (t[u].x == -1 ? 1.0 : (t[u].x == -2 ? -1.0 : 0.0));
-      acc += a[u] * (t[u].z >= 0 ? b[u] : 1.0) * cc;
-      if (t[u].w >= 0) { cond[t[u].w] = acc; acc = 0.0; }
+    for (int s = 0; s < SB; ++s) {
+      const int k = k0 + s < N ? k0 + s : N - 1;
+      const int* sb = S.segb + k * 8;
+      const int g0 = S.L.g_stage(k);
+#pragma unroll
+      for (int j = 0; j < CTAB_MLMAX; ++j) {
+        const unsigned lo = (unsigned)t[s][j];
+        const int ia = sb[(lo >> 8) & 7] + (int)(lo & 255u), ib = sb[(lo >> 19) & 7] + (int)((lo >> 11) & 255u);
+        const bool has_b = (lo >> 22) & 1u;
+        const int rt = (int)(lo >> 30), row = g0 + (int)((lo >> 23) & 127u);
+        a[s][j] = JH[ia];
+        b[s][j] = JH[has_b ? ib : ia];
+        c[s][j] = SR[rt == 0 ? row + (has_b ? 0 : ng) : 0];
+      }
     }
+    double pend_acc[SB]; int pend_dst[SB], pend_n[SB];
+    double* carry = S.carry + (batch & 1) * SB * SOLVER_THREADS;
+#pragma unroll
+    for (int s = 0; s < SB; ++s) {
+      pend_acc[s] = 0.0; pend_dst[s] = 0; pend_n[s] = 0;
+      double* cd = cond + (size_t)(k0 + s < N ? k0 + s : N - 1) * COND_STRIDE;
+      const bool live = k0 + s < N;
+      double acc = 0.0;
+#pragma unroll
+      for (int j = 0; j < CTAB_MLMAX; ++j) {
+        const unsigned lo = (unsigned)t[s][j], hi = (unsigned)(t[s][j] >> 32);
+        const bool has_b = (lo >> 22) & 1u;
+        const int rt = (int)(lo >> 30);
+        const double cc = rt == 0 ? c[s][j] : (rt == 1 ? 1.0 : (rt == 2 ? -1.0 : 0.0));
+        acc += a[s][j] * (has_b ? b[s][j] : 1.0) * cc;
+        if ((hi >> 10) & 1u) {
+          const int np = (int)((hi >> 11) & 7u);
+          if (np > 0) { pend_acc[s] = acc; pend_dst[s] = (int)(hi & 1023u); pend_n[s] = np; }
+          else if (live) cd[hi & 1023u] = acc;
+          acc = 0.0;
+        }
+      }
+      carry[s * SOLVER_THREADS + tid] = acc;       // what the chunk contributes to a destination that closes in a later thread
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < SB; ++s) {
+      if (pend_n[s] > 0 && k0 + s < N) {
+        double tot = 0.0;
+        for (int i = pend_n[s]; i >= 1; --i) tot += carry[s * SOLVER_THREADS + tid - i];
+        cond[(size_t)(k0 + s) * COND_STRIDE + pend_dst[s]] = tot + pend_acc[s];
+      }
+    }
+    // (the next batch writes the other half of S.carry; the barrier of that batch orders it against these reads)
   }
   __syncthreads();
 }
@@ -647,33 +705,39 @@ __device__ __noinline__ void forward_pass() {
   __syncthreads();
 }
 
-// ds = J_d dx + (g - s) for every stage inequality row (fixed per-thread term lists, parallel over rows)
-__device__ __noinline__ void row_products(const int4* __restrict__ rterm, int rlen) {
+// ds = J_d dx + (g - s) for every stage inequality row: fixed per-thread term lists over the whole horizon (chunks cut at row
+// boundaries), 8-byte records {jac index (16 bits) | x index (16) | dst row (16) | closes (1) | valid (1)}, batches of 8 terms
+// with the records of the next batch fetched under the gathers of this one.  (Tried in round 2: the stage-local LDS
+// table scheme of condense() -- one term per thread and stage, carries through LDS, a barrier per 4 stages -- is slower
+// here, alone 0.065 vs 0.039 ms and under load 0.105 vs 0.091: the list is short, 15 k terms, and latency-bound.)
+__device__ __noinline__ void row_products(const unsigned long long* __restrict__ rterm, int rlen) {
   Lds& S = SH;
   const MemberMem& M = S.M;
   const int tid = threadIdx.x, NT = blockDim.x;
   const double* __restrict__ Jn = M.J; const double* __restrict__ dxv = M.dx;
   const double* __restrict__ gv = M.g; const double* __restrict__ sv = M.s; double* __restrict__ dsv = M.ds;
   double acc = 0.0;
-  // batches of 8 terms, the records of the next batch fetched under the gathers of this one (as in condense)
   constexpr int BW = 8;
-  const int4 padterm = {0, 0, -1, 0};
-  int4 tn[BW];
+  unsigned long long tn[BW];
 #pragma unroll
-  for (int u = 0; u < BW; ++u) tn[u] = (u < rlen) ? rterm[(size_t)u * NT + tid] : padterm;
+  for (int u = 0; u < BW; ++u) tn[u] = (u < rlen) ? rterm[(size_t)u * NT + tid] : 0ull;
   for (int j0 = 0; j0 < rlen; j0 += BW) {
-    int4 t[BW];
+    unsigned long long t[BW];
 #pragma unroll
     for (int u = 0; u < BW; ++u) t[u] = tn[u];
 #pragma unroll
-    for (int u = 0; u < BW; ++u) { const int j = j0 + BW + u; tn[u] = (j < rlen) ? rterm[(size_t)j * NT + tid] : padterm; }
+    for (int u = 0; u < BW; ++u) { const int j = j0 + BW + u; tn[u] = (j < rlen) ? rterm[(size_t)j * NT + tid] : 0ull; }
     double a[BW], b[BW], c[BW];
 #pragma unroll
-    for (int u = 0; u < BW; ++u) { a[u] = Jn[t[u].x]; b[u] = dxv[t[u].y]; c[u] = (t[u].z >= 0) ? gv[t[u].z] - sv[t[u].z] : 0.0; }
+    for (int u = 0; u < BW; ++u) {
+      const int ij = (int)(t[u] & 0xffffu), ix = (int)((t[u] >> 16) & 0xffffu), ir = (int)((t[u] >> 32) & 0xffffu);
+      a[u] = Jn[ij]; b[u] = dxv[ix]; c[u] = gv[ir] - sv[ir];
+    }
 #pragma unroll
     for (int u = 0; u < BW; ++u) {
-      acc += t[u].w ? a[u] * b[u] : 0.0;
-      if (t[u].z >= 0) { dsv[t[u].z] = acc + c[u]; acc = 0.0; }
+      const bool valid = (t[u] >> 49) & 1ull, closes = (t[u] >> 48) & 1ull;
+      acc += valid ? a[u] * b[u] : 0.0;
+      if (closes) { dsv[(int)((t[u] >> 32) & 0xffffu)] = acc + c[u]; acc = 0.0; }
     }
   }
   __syncthreads();
@@ -734,6 +798,17 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
     for (int e = lane; e < nT; e += NT) S.cab[e] = ab[e];
     for (int q = lane; q < nA; q += NT) S.cat[q] = at[3 * q + 1] * YS + at[3 * q + 2];
     if (lane == 0) { S.c_tab = off; S.c_nT = nT; S.c_nA = nA; }
+  }
+  {   // condensation: segment bases of every stage, packed term table of the most frequent stage type
+    const int nj = L.nnz_jac, nh = L.nnz_hess;
+    for (int k = lane; k < N; k += NT) {
+      int* sb = S.segb + k * 8;
+      sb[0] = L.jx(k); sb[1] = L.ju(k); sb[2] = k < N - 1 ? L.ju(k + 1) : 0;
+      sb[3] = nj + L.hx(k); sb[4] = nj + L.hu(k); sb[5] = k < N - 1 ? nj + L.hu(k + 1) : 0;
+      sb[6] = nj + nh + k * RUNC; sb[7] = A.ctype[k];
+    }
+    const unsigned long long* src = A.ctab + (size_t)A.c_mid * A.c_ml * SOLVER_THREADS;
+    for (int e = lane; e < A.c_ml * SOLVER_THREADS; e += NT) S.ctab_mid[e] = src[e];
   }
   __syncthreads();
 
@@ -868,7 +943,7 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
     const double tau = fmax(o.tau_min, 1.0 - mu);
     PROF_ADD(PH_ERR, tp);
 
-    condense(A.cterm, A.clen);
+    condense(A.ctab, A.c_ml, A.c_mid);
     if (L.run_cost) {   // ... and in the stage right-hand sides gamma_k (w order X, c, f)
       for (int k = lane; k < N; k += NT) {
         double gr[36];
