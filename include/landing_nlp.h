@@ -82,7 +82,9 @@ typedef struct {
   double kappa_mu;       /* 0.2                                                    */
   double theta_mu;       /* 1.5                                                    */
   int max_soc;           /* reserved                                               */
-  int max_resets;        /* multiplier resets allowed per NLP (default 8), see reset_du          */
+  int max_resets;        /* multiplier resets allowed per NLP (default 2: a member that jams a third time is reported as
+                            LANDING_NUMERICAL -- IPOPT would report local infeasibility / a failed restoration -- instead of
+                            cycling until max_iter; about 1 in 1000 synthetic drop states at N = 40), see reset_du */
   double reset_du;       /* dual infeasibility above which slacks/multipliers/mu are re-initialised
                             at the current x (jammed iterate; IPOPT would enter restoration), 1e9  */
   int stage_local_reg;   /* ignored (a per-stage delta_w was tried in round 1 and removed); kept for ABI stability            */
@@ -194,6 +196,17 @@ int landing_solve_21(landing_ctx* ctx, int B, const double* Xref, const double* 
 int landing_riccati_gains_batch(landing_ctx* ctx, int B, int n, const double* d_xref, const double* d_fref,
                                 const double* Ib3x3, double mass, const double* Q, const double* r_diag, const double* F,
                                 double dt, int rk4, double* d_P, double* d_K, double* d_A, double* d_B, void* stream);
+
+/* Receding-horizon loop (BASELINE configs[4]: 100 Hz warm-started re-solves).  One control tick =
+ *   landing_mpc_shift(previous solution, measured states) -> x0, p;  landing_solve_batch(p, x0, warm-start options).
+ * landing_mpc_shift: x0 = previous solution advanced by one stage (last column held) with d_state [B][12] = measured
+ * [q; qd] in X(:,0); q_init / qd_init of d_p [B][np] are overwritten in place.  d_x0 must not alias d_x_prev.
+ * Warm-start options: landing_solver_opts_warm() -- the reference's `_ws` variant sets bound_push = bound_frac = 5e-3
+ * (generate_landingCtrller_IPOPT_warmstart.m:246-247); with a shifted solution 1e-4 for both and mu_init = 1e-4 converge in
+ * 8 iterations instead of 27 (tests/dev, round 2), which is what fits a 10 ms tick; max_iter = 14 bounds the tick time
+ * (real-time iteration: an unconverged member keeps its iterate and continues at the next tick). */
+int landing_mpc_shift(landing_ctx* ctx, int B, const double* d_x_prev, const double* d_state, double* d_p, double* d_x0, void* stream);
+void landing_solver_opts_warm(landing_solver_opts* o);
 
 /* development aid: d_prof [B][16] doubles receives per-member phase timers of the next solves (100 MHz
  * wall-clock ticks: eval, error, sigma/rho, backward, forward, dual, line search, accept; then counts of

@@ -45,7 +45,7 @@ EXPORTS = ["landing_last_error", "landing_form_default", "landing_solver_opts_de
            "landing_create", "landing_destroy", "landing_device_count", "landing_eval_batch", "landing_eval_batch_host",
            "landing_bounds_batch", "landing_solve_batch", "landing_solve_batch_host", "landing_kernel_name_sweep",
            "landing_sweep_bytes_per_member", "landing_set_profile_buffer", "landing_debug_workspace",
-           "landing_pack_args21", "landing_solve_args21", "landing_solve_21", "landing_riccati_gains_batch"]
+           "landing_pack_args21", "landing_solve_args21", "landing_solve_21", "landing_riccati_gains_batch", "landing_mpc_shift", "landing_solver_opts_warm"]
 
 
 def load(path=None):
@@ -78,6 +78,8 @@ def load(path=None):
     lib.landing_solve_args21.argtypes = [vp, C.c_int, C.POINTER(Args21), C.POINTER(SolverOpts), _dp, _dp, _ip, _ip, _dp]
     if hasattr(lib, "landing_riccati_gains_batch"):      # (older development builds used by tools/dev/variants.py lack it)
         lib.landing_riccati_gains_batch.argtypes = [vp, C.c_int, C.c_int, vp, vp, _dp, C.c_double, _dp, _dp, _dp, C.c_double, C.c_int, vp, vp, vp, vp, vp]
+    if hasattr(lib, "landing_mpc_shift"):
+        lib.landing_mpc_shift.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp]
     lib.landing_solve_21.argtypes = [vp, C.c_int] + [_dp] * 21 + [C.POINTER(SolverOpts), _dp, _dp, _ip, _ip, _dp]
     return lib
 
@@ -145,6 +147,14 @@ class LandingLib:
         o = SolverOpts()
         self.lib.landing_solver_opts_default(C.byref(o))
         return o
+
+    def warm_opts(self):
+        o = SolverOpts()
+        self.lib.landing_solver_opts_warm(C.byref(o))
+        return o
+
+    def mpc_shift_device(self, B, d_x_prev, d_state, d_p, d_x0, stream=0):
+        self._check(self.lib.landing_mpc_shift(self.ctx, B, d_x_prev, d_state, d_p, d_x0, stream or None), "landing_mpc_shift")
 
     def pattern_jac(self):
         ci = np.zeros(self.nx + 1, np.int64); r = np.zeros(self.nnz_jac, np.int64)

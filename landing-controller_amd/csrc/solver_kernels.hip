@@ -750,6 +750,25 @@ __device__ __noinline__ void row_products(const unsigned long long* __restrict__
 #ifndef LANDING_MIN_WAVES
 #define LANDING_MIN_WAVES 2
 #endif
+// Receding-horizon shift (SURVEY 8f row N3 / BASELINE configs[4]): the initial guess of the next control tick is the previous
+// solution advanced by one stage -- X(:,k) <- X(:,k+1), U(:,k) <- U(:,k+1), the last column held -- with the measured state
+// in X(:,0); the parameter vector gets the new q_init / qd_init.  (The reference's warm-start variant re-solves from the stored
+// previous solution unshifted, codegen_casadi/test_loadCasadi_ws.m:73-88; the shift is what a 100 Hz loop adds.)
+__global__ void landing_mpc_shift_kernel(Layout L, int B, const double* __restrict__ x_prev, const double* __restrict__ state,
+                                         double* __restrict__ p, double* __restrict__ x0) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)B * L.nx) return;
+  const int m = (int)(idx / L.nx), i = (int)(idx % L.nx), N = L.N, nX = 12 * (N + 1);
+  const double* xp = x_prev + (size_t)m * L.nx;
+  double v;
+  if (i < 12) v = state[(size_t)m * 12 + i];
+  else if (i < nX) { const int k = i / 12, r = i % 12; v = xp[12 * (k < N ? k + 1 : N) + r]; }
+  else { const int j = i - nX, k = j / 24, r = j % 24; v = xp[nX + 24 * (k < N - 1 ? k + 1 : N - 1) + r]; }
+  x0[idx] = v;
+  if (i < 6) p[(size_t)m * L.np + L.o_q_init + i] = v;
+  else if (i < 12) p[(size_t)m * L.np + L.o_qd_init + (i - 6)] = v;
+}
+
 // Dispatch order of a batch: workgroups are handed to the CUs in blockIdx order and a batch larger than the resident
 // capacity (2 workgroups per CU) runs in waves, so the batch time is the finishing time of the slowest member -- which
 // is much later when that member only starts in the second wave.  Members likely to need many iterations go first.

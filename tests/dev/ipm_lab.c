@@ -168,6 +168,7 @@ static int riccati_backward(const lo_form* F, const double* p, work_t* W, double
   return 1;
 }
 
+static _Thread_local const double* t_lam0 = NULL;      /* warm-start multipliers (CasADi sign) or NULL */
 static void init_slacks(work_t* W, const lo_solver_opts* op0) {
   lo_int r; lo_solver_opts opl = *op0; const lo_solver_opts* op = &opl;
   const char* e_;
@@ -186,6 +187,11 @@ static void init_slacks(work_t* W, const lo_solver_opts* op0) {
       zl = hL ? 1.0 : 0.0; zu = hU ? 1.0 : 0.0;
       if ((e_ = getenv("LAB_ZINIT")) && atoi(e_)) { const double m0 = getenv("LAB_MUINIT") ? atof(getenv("LAB_MUINIT")) : op->mu_init;
         if (hL) zl = fmin(1.0, m0 / (sv - lb)); if (hU) zu = fmin(1.0, m0 / (ub - sv)); if (atoi(e_) == 2) { if (hL) zl = m0 / (sv - lb); if (hU) zu = m0 / (ub - sv); } }
+    }
+    if (t_lam0 && r >= 12) {
+      const double fl = getenv("LAB_ZFLOOR") ? atof(getenv("LAB_ZFLOOR")) : 1e-3;
+      if (lb == ub) { W->s[r] = sv; W->zL[r] = 0; W->zU[r] = 0; W->y[r] = t_lam0[r]; continue; }
+      if (lb > -INFINITY) zl = fmax(-t_lam0[r], fl); if (ub < INFINITY) zu = fmax(t_lam0[r], fl);
     }
     W->s[r] = sv; W->zL[r] = zl; W->zU[r] = zu; W->y[r] = zu - zl;
   }
@@ -355,7 +361,9 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
   }
   lo_bounds(F, p, W->lb, W->ub);
   eval_g(F, W->x, p, W->g);
+  t_lam0 = (getenv("LAB_LAMWS") && lam_out) ? lam_out : NULL;
   init_slacks(W, op);
+  t_lam0 = NULL;
   for (it = 0; it <= op->max_iter; ++it) {
     double du = 0, pr = 0, co = 0, tau, delta;
     int fact_ok = 0, attempt;

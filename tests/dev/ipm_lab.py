@@ -19,14 +19,14 @@ def build():
     return out
 
 
-def solve(O, P, X0, threads=8, max_iter=300, tol=None, **kw):
+def solve(O, P, X0, threads=8, max_iter=300, tol=None, lam0=None, **kw):
     B = P.shape[0]
     o = orc._SolverOpts(); O.lib.lo_solver_opts_default(C.byref(o)); o.max_iter = max_iter
     if tol: o.tol = tol
     for k, v in kw.items(): setattr(o, k, v)
     if os.environ.get("LAB_RESETDU"): o.reset_du = float(os.environ["LAB_RESETDU"])
     if os.environ.get("LAB_MAXRESETS"): o.max_resets = int(os.environ["LAB_MAXRESETS"])
-    x = np.zeros((B, O.nx)); lam = np.zeros((B, O.ng)); st = np.zeros(B, np.int32); it = np.zeros(B, np.int32)
+    x = np.zeros((B, O.nx)); lam = np.zeros((B, O.ng)) if lam0 is None else np.ascontiguousarray(lam0, float).copy(); st = np.zeros(B, np.int32); it = np.zeros(B, np.int32)
     kkt = np.zeros((B, 3)); cnt = np.zeros(5, np.int64)
     ip = C.POINTER(C.c_int)
     O.lib.lo_solve_batch(O._F, C.c_int(B), orc._p(np.ascontiguousarray(P)), orc._p(np.ascontiguousarray(X0)), C.byref(o), C.c_int(threads), orc._p(x), orc._p(lam),

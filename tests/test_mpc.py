@@ -1,0 +1,69 @@
+"""Receding-horizon loop (SURVEY 8f row N3 / BASELINE configs[4]): shift kernel + warm-started re-solves.
+CPU: the shift kernel through tests/emu against a numpy restatement.  GPU: a closed loop of several ticks at batch 64 --
+every tick's solution is a KKT point (<= 1e-6 under the oracle's functions on a sample) and warm ticks need far fewer
+iterations than the cold solve."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, lc
+
+PKG = os.path.join(ROOT, "landing-controller_amd")
+
+
+def _shift_ref(N, x, state, p, po):
+    X = x[:12 * (N + 1)].reshape(12, N + 1, order="F"); U = x[12 * (N + 1):].reshape(24, N, order="F")
+    Xn = np.concatenate([X[:, 1:], X[:, -1:]], axis=1); Un = np.concatenate([U[:, 1:], U[:, -1:]], axis=1)
+    Xn[:, 0] = state
+    pn = p.copy(); pn[po["q_init"]:po["q_init"] + 6] = state[:6]; pn[po["qd_init"]:po["qd_init"] + 6] = state[6:]
+    return np.concatenate([Xn.flatten(order="F"), Un.flatten(order="F")]), pn
+
+
+def test_mpc_shift_emulated():
+    subprocess.run(["make", "-C", os.path.join(PKG, "csrc"), "emu"], check=True, capture_output=True)
+    Pm = lc("problem")
+    N, B = 12, 3
+    L = lc("capi").LandingLib(N, lib_path=os.path.join(ROOT, "tests", "emu", "liblanding_emu.so"))
+    rng = np.random.default_rng(0)
+    P, X0, _, _ = Pm.make_batch(B, N, 0.6, seed=1)
+    x = rng.normal(size=X0.shape); state = rng.normal(size=(B, 12)); p = P.copy(); x0 = np.zeros_like(x)
+    L.mpc_shift_device(B, x.ctypes.data, state.ctypes.data, p.ctypes.data, x0.ctypes.data)
+    po = Pm.param_offsets(N)
+    for b in range(B):
+        xr, pr = _shift_ref(N, x[b], state[b], P[b], po)
+        assert np.array_equal(x0[b], xr) and np.array_equal(p[b], pr)
+    o = L.warm_opts()
+    assert o.bound_push == o.bound_frac == o.mu_init == 1e-4 and o.restart_period == 0 and o.max_iter == 14
+
+
+@pytest.mark.gpu
+def test_receding_horizon_closed_loop(oracle_mod):
+    import torch
+    capi, Pm, mpc = lc("capi"), lc("problem"), lc("mpc")
+    N, B, T = 40, 64, 6
+    L = capi.LandingLib(N, device=0)
+    O = oracle_mod.Oracle(N)
+    P, X0, _, _ = Pm.make_batch(B, N, 0.6, seed=12)
+    ctl = mpc.RecedingHorizon(L, P, X0)
+    torch.cuda.synchronize()
+    cold_it = ctl.iters.cpu().numpy().copy()
+    assert (ctl.status.cpu().numpy() == 0).all()
+    gen = torch.Generator(device="cuda"); gen.manual_seed(0)
+    warm_its = []
+    for t in range(T):
+        # plant = the NLP's own discretisation + a small state disturbance (measurement / model error)
+        state = ctl.predicted_next_state().clone()
+        state += 1e-3 * torch.randn(state.shape, device="cuda", dtype=torch.float64, generator=gen)
+        info = ctl.tick(state)
+        torch.cuda.synchronize()
+        st, it = info["status"].cpu().numpy(), info["iters"].cpu().numpy()
+        assert (st == 0).mean() >= 0.95 and (st <= 1).all(), (t, st)      # status 1 = iteration cap of the tick reached, continues next tick
+        warm_its.append(it[st == 0].mean())
+        kk = info["kkt"].cpu().numpy()
+        assert kk[st == 0].max() <= 1e-6 * 1.0001
+        xh, ph = ctl.x.cpu().numpy(), ctl.p.cpu().numpy()
+        assert np.array_equal(xh[:, :12], state.cpu().numpy())          # the measured state is the initial condition
+    assert np.mean(warm_its) < 0.35 * cold_it.mean(), (warm_its, cold_it.mean())
+    L.close()

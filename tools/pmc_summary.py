@@ -43,10 +43,10 @@ if __name__ == "__main__":
         cal = {}
         for name, d in (("FETCH_SIZE", sys.argv[6]), ("WRITE_SIZE", sys.argv[7])):
             acc, n = counters(d)
-            for sub, label, rd, wr in (("vectorized_elementwise", "stream8", 1, 1), ("index_select", "gather8", 1, 1), ("index", "gather8", 1, 1)):
+            for sub, label, rd, wr in (("AUnaryFunctor<double", "stream8", 1, 1), ("_scatter_gather_elementwise_kernel", "gather8", 2, 1)):
                 k = pick(acc, sub)
                 if k and (label + "_" + name) not in cal:
-                    true_kb = (1 << 27) * 8 / 1024.0
+                    true_kb = (1 << 27) * 8 / 1024.0 * (rd if name == "FETCH_SIZE" else wr)      # the gather also reads its 8-byte indices
                     cal[label + "_" + name] = {"counter_KB_per_launch": acc[k][name] / n[k], "true_KB": true_kb, "counter_over_true": acc[k][name] / n[k] / true_kb, "kernel": k[:60]}
         out["calibration"] = cal
     out.update(per)
