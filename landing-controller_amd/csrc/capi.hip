@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -37,7 +38,12 @@ struct landing_ctx {
   int* d_edge_map = nullptr;
   landing::SolverWorkspace ws;
   double* d_prof = nullptr;
-  double* d_vbl = nullptr;      // Q (576) | F (576) | 1/diag(R) (12) of the last landing_riccati_gains_batch call
+  double* d_vbl = nullptr;
+  // function layer: the Jacobian, Hessian and residual kernels of one landing_eval_batch call are independent; for large
+  // batches they run on two auxiliary streams forked from / joined to the caller's stream so that their ramps and tails overlap
+  hipStream_t aux[2] = {nullptr, nullptr};
+  hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
+  bool sweep_concurrent = true;      // Q (576) | F (576) | 1/diag(R) (12) of the last landing_riccati_gains_batch call
   std::mutex mu;      // serialises landing_solve_batch calls on one context (the workspace belongs to the context)
 };
 
@@ -176,6 +182,7 @@ landing_ctx* landing_create(int N, int device, const landing_form* form) {
   landing_ctx* c = new landing_ctx();
   c->L = landing::make_layout(N);
   c->device = device;
+  { const char* e = getenv("LANDING_SWEEP_SERIAL"); c->sweep_concurrent = !(e && e[0] == '1'); }
   {  // positions of the U_k Jacobian entries of stages 0 / N-1 inside the uniform (middle-stage) emission sequence
     struct RecCodes { std::vector<int>* v; void col() {} void put(int r, double) { v->push_back(r); } };
     std::vector<int> cx, cu;
@@ -214,6 +221,8 @@ void landing_destroy(landing_ctx* ctx) {
   ctx->ws.release();
   if (ctx->d_edge_map) (void)hipFree(ctx->d_edge_map);
   if (ctx->d_vbl) (void)hipFree(ctx->d_vbl);
+  for (int i = 0; i < 2; ++i) { if (ctx->aux[i]) (void)hipStreamDestroy(ctx->aux[i]); if (ctx->ev_join[i]) (void)hipEventDestroy(ctx->ev_join[i]); }
+  if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
   delete ctx;
 }
 
@@ -228,11 +237,28 @@ int landing_eval_batch(landing_ctx* ctx, int B, const double* d_x, const double*
   HIP_TRY(hipSetDevice(ctx->device));
   landing::EvalArgs A{d_x, d_p, d_lam_f, d_lam_g, d_f, d_g, d_grad_f, d_jac, d_hess, d_ggx, d_ggp, ctx->d_edge_map, d_g ? 1 : 0};
   if (ctx->L.N < 3) return fail(LANDING_E_ARG, "landing_eval_batch: N >= 3 required");
-  if (d_jac) hipLaunchKernelGGL(landing::landing_sweep_kernel<0>, dim3(B), dim3(64), 0, (hipStream_t)stream, ctx->L, B, A);
-  if (d_hess) hipLaunchKernelGGL(landing::landing_sweep_kernel<1>, dim3(B), dim3(64), 0, (hipStream_t)stream, ctx->L, B, A);
-  if (d_g) hipLaunchKernelGGL(landing::landing_sweep_kernel<2>, dim3(B), dim3(64), 0, (hipStream_t)stream, ctx->L, B, A);
-  hipLaunchKernelGGL(landing::landing_sweep_misc_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, ctx->L, B, A);
+  hipStream_t s0 = (hipStream_t)stream, sj = s0, sh = s0;
+  const bool fork = ctx->sweep_concurrent && B >= 512 && d_jac && d_hess;
+  if (fork) {
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    if (!ctx->aux[0]) {
+      HIP_TRY(hipStreamCreateWithFlags(&ctx->aux[0], hipStreamNonBlocking)); HIP_TRY(hipStreamCreateWithFlags(&ctx->aux[1], hipStreamNonBlocking));
+      HIP_TRY(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&ctx->ev_join[0], hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&ctx->ev_join[1], hipEventDisableTiming));
+    }
+    sj = ctx->aux[0]; sh = ctx->aux[1];
+    HIP_TRY(hipEventRecord(ctx->ev_fork, s0));
+    HIP_TRY(hipStreamWaitEvent(sj, ctx->ev_fork, 0)); HIP_TRY(hipStreamWaitEvent(sh, ctx->ev_fork, 0));
+  }
+  if (d_hess) hipLaunchKernelGGL(landing::landing_sweep_kernel<1>, dim3(B), dim3(64), 0, sh, ctx->L, B, A);
+  if (d_jac) hipLaunchKernelGGL(landing::landing_sweep_kernel<0>, dim3(B), dim3(64), 0, sj, ctx->L, B, A);
+  if (d_g) hipLaunchKernelGGL(landing::landing_sweep_kernel<2>, dim3(B), dim3(64), 0, s0, ctx->L, B, A);
+  hipLaunchKernelGGL(landing::landing_sweep_misc_kernel, dim3(B), dim3(64), 0, s0, ctx->L, B, A);
   HIP_TRY(hipGetLastError());
+  if (fork) {
+    HIP_TRY(hipEventRecord(ctx->ev_join[0], sj)); HIP_TRY(hipEventRecord(ctx->ev_join[1], sh));
+    HIP_TRY(hipStreamWaitEvent(s0, ctx->ev_join[0], 0)); HIP_TRY(hipStreamWaitEvent(s0, ctx->ev_join[1], 0));
+  }
   return 0;
 }
 

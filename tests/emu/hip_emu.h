@@ -47,6 +47,9 @@ inline hipError_t hipMemset(void* d, int v, size_t n) { std::memset(d, v, n); re
 inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { std::memset(d, v, n); return 0; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
 #define hipEventDisableTiming 2
+#define hipStreamNonBlocking 1
+inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = (hipStream_t)1; return 0; }
+inline hipError_t hipStreamDestroy(hipStream_t) { return 0; }
 inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = (hipEvent_t)1; return 0; }
 inline hipError_t hipEventDestroy(hipEvent_t) { return 0; }
 inline hipError_t hipEventSynchronize(hipEvent_t) { return 0; }
