@@ -250,6 +250,39 @@ def main():
                 "bytes_per_step_per_gpu": int(8 * B * (P.shape[1] + 2 * nx) + 4 * B),
                 "note": "H2D of p, x0 (pinned) and D2H of x*, status inside the timed step"}
 
+    # ---- the same K steps with two batches in flight (two contexts on two streams): the tail of one batch -- a handful of
+    # members that need 2-4x the mean iteration count while most CUs idle -- overlaps with the bulk of the next one.  What a
+    # data-generation job streaming batches through the GPU does; reported beside the one-batch-at-a-time `value`.
+    piped = None
+    if not a.dry and a.steps >= 2:
+        capi2 = importlib.import_module("landing-controller_amd.capi")
+        lanes = []
+        for i in range(2):
+            Lq = lib if i == 0 else capi2.LandingLib(N, device=local)
+            sq = torch.cuda.Stream()
+            lanes.append((Lq, sq, mk(B, nx), mk(B, dt=torch.int32), mk(B, dt=torch.int32)))
+        def pstep(i):
+            Lq, sq, xq, stq, itq = lanes[i % 2]
+            dPq, dXq = dev_batches[i % n_batches]
+            Lq.solve_device(B, dPq.data_ptr(), dXq.data_ptr(), opts, xq.data_ptr(), 0, 0, stq.data_ptr(), itq.data_ptr(), 0, sq.cuda_stream)
+        pstep(0); pstep(1); sync()
+        conv_p = torch.zeros(1, device=dev, dtype=torch.float64)
+        tq = time.perf_counter()
+        for i in range(a.steps):
+            if i >= 2:       # the lane's previous step must be read before its buffers are reused
+                lanes[i % 2][1].synchronize(); conv_p += (lanes[i % 2][3] == 0).sum()
+            pstep(i)
+        for i in range(min(2, a.steps)):
+            lanes[i][1].synchronize(); conv_p += (lanes[i][3] == 0).sum()
+        sync()
+        tq = time.perf_counter() - tq
+        tqe = torch.tensor([tq], device=dev, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(tqe, op=dist.ReduceOp.MAX); dist.all_reduce(conv_p, op=dist.ReduceOp.SUM)
+        piped = {"value": float(conv_p.item()) / float(tqe.item()), "unit": "NLPs/s", "batches_in_flight": 2, "ms_per_step": 1e3 * float(tqe.item()) / a.steps,
+                 "note": "same K steps, two contexts on two streams, no synchronisation between steps"}
+        lanes[1][0].close()
+
     if rank == 0:
         cfg = {"workload": "3D-SRBM landing NLP, N=40 intervals, batch=%d random drop heights/attitudes per GPU, fp64 (BASELINE configs[1]%s)" % (B, "; x%d GPUs = configs[2]" % world if world > 1 else ""),
                "global_batch": B * world, "distinct_batches": n_batches, "max_iter": a.max_iter, "kkt_tol": 1e-6, "parallelism": "batch-sharded x%d, RCCL all-gather of x*" % world}
@@ -262,6 +295,7 @@ def main():
         else:
             out.update(measure_details(a, lib, np, torch, dev, mk, B, N, P, X0, dP, dX0, st, it, kkt, kernel_ms, solve, world, stream, ev0, ev1, dev_batches))
             out["pcie_inclusive"] = pcie
+            out["two_batches_in_flight"] = piped
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -99,7 +99,8 @@ typedef struct {
   double delta_init;     /* first trial regularisation when none was needed before (IPOPT first_hessian_perturbation, 1e-4) */
   double delta_inc_first;/* growth factor while no regularised iteration happened yet (IPOPT 100; default 10)            */
   double delta_inc;      /* growth factor afterwards (IPOPT 8; default 4: finer steps over-regularise less, tools/strag.py) */
-  double delta_dec;      /* first trial = delta_last * delta_dec (IPOPT 1/3)                                             */
+  double delta_dec;      /* first trial = delta_last * delta_dec (IPOPT 1/3; default 1/2: 5 % fewer stage eliminations at unchanged
+                            iteration counts on three seeded batches, tests/dev/ipm_lab.py round 2)                        */
   double tau_min;        /* fraction-to-the-boundary floor (IPOPT 0.99; default 0.9)                                     */
   double alpha_fallback; /* step taken (and filter restarted) when the line search finds no acceptable point (1e-2)      */
   double reset_delta;    /* regularisation above which the iterate counts as jammed too (steps degenerate to damped
@@ -207,6 +208,31 @@ int landing_riccati_gains_batch(landing_ctx* ctx, int B, int n, const double* d_
  * (real-time iteration: an unconverged member keeps its iterate and continues at the next tick). */
 int landing_mpc_shift(landing_ctx* ctx, int B, const double* d_x_prev, const double* d_state, double* d_p, double* d_x0, void* stream);
 void landing_solver_opts_warm(landing_solver_opts* o);
+
+/* ---- floating-base rigid-body routines of the 18-body model ------------------------------------
+ * landing_rbd_model: the kinematic tree in compact form -- Xtree = plux(E, r) per body (get_robot_model.m:134-234), link
+ * inertias as (mass, m*com, rotational inertia about the link origin [xx xy xz yy yz zz]) -- built by the caller
+ * (landing-controller_amd/rbd.py restates the reference's 'quad3D' model) and uploaded once with landing_rbd_set_model.
+ * landing_fb_dynamics_batch: tau = H(q) qdd + C(q, qd, f_foot) at npts configurations (spatial_v2 HandC.m:14-62 with the
+ *   foot forces of casadi_compatible_dynamics.m:53-60; q, qd, tau [npts][18], f_foot [npts][12] world-frame forces or NULL);
+ *   outputs (device, any may be NULL): H [npts][18][18], C [npts][18], qdd [npts][18] (needs tau), the linearisation of the
+ *   forward dynamics A = d qdd / d [q; qd] [npts][18][36] by central differences of step fd_h (needs tau) and
+ *   Hinv = d qdd / d tau [npts][18][18].
+ * landing_kinodyn_rows_batch: the rows the kinodynamic refinement adds per stage (landing_optimization.m:152-189) at npts
+ *   (member, stage) points: q6 = [pos; rpy (XYZ convention)] [npts][6], c / f [npts][12] feet and forces, jpos [npts][12];
+ *   outputs fk [npts][12] (get_forward_kin_foot.m), fk_err = c - fk, tau = J_f'(-R_world_to_body f) (get_foot_jacobians_mc.m). */
+typedef struct {
+  int parent[18], jtype[18];            /* parent 1-based (0 = fixed base); joint 0..5 = Rx Ry Rz Px Py Pz */
+  double E[18][9], r[18][3];
+  double m[18], h[18][3], I[18][6];
+  int b_foot[4]; double foot_r[4][3];
+  double l1, l2, l3, l4;
+} landing_rbd_model;
+int landing_rbd_set_model(landing_ctx* ctx, const landing_rbd_model* model);
+int landing_fb_dynamics_batch(landing_ctx* ctx, int npts, const double* d_q, const double* d_qd, const double* d_tau, const double* d_f_foot,
+                              double* d_H, double* d_C, double* d_qdd, double* d_A, double* d_Hinv, double fd_h, void* stream);
+int landing_kinodyn_rows_batch(landing_ctx* ctx, int npts, const double* d_q6, const double* d_c, const double* d_f, const double* d_jpos,
+                               double* d_fk, double* d_fk_err, double* d_tau, void* stream);
 
 /* development aid: d_prof [B][16] doubles receives per-member phase timers of the next solves (100 MHz
  * wall-clock ticks: eval, error, sigma/rho, backward, forward, dual, line search, accept; then counts of

@@ -21,6 +21,7 @@
 #include "eval_kernels.hip"
 #include "solver_kernels.hip"
 #include "vbl_kernels.hip"
+#include "rbd_kernels.hip"
 
 using landing::Layout;
 
@@ -39,6 +40,7 @@ struct landing_ctx {
   landing::SolverWorkspace ws;
   double* d_prof = nullptr;
   double* d_vbl = nullptr;
+  landing::RbdModel* d_rbd = nullptr;     // uploaded by landing_rbd_set_model
   // function layer: the Jacobian, Hessian and residual kernels of one landing_eval_batch call are independent; for large
   // batches they run on two auxiliary streams forked from / joined to the caller's stream so that their ramps and tails overlap
   hipStream_t aux[2] = {nullptr, nullptr};
@@ -64,7 +66,7 @@ void landing_solver_opts_default(landing_solver_opts* o) {
   memset(o, 0, sizeof(*o));
   o->tol = 1e-6; o->max_iter = 3000; o->mu_init = 0.1; o->bound_push = 0.5; o->bound_frac = 0.1;
   o->kappa_eps = 10.0; o->kappa_mu = 0.2; o->theta_mu = 1.5; o->max_soc = 0; o->max_resets = 2; o->reset_du = 1e9;
-  o->delta_init = 1e-4; o->delta_inc_first = 10.0; o->delta_inc = 4.0; o->delta_dec = 1.0 / 3.0; o->tau_min = 0.9; o->alpha_fallback = 1e-2;
+  o->delta_init = 1e-4; o->delta_inc_first = 10.0; o->delta_inc = 4.0; o->delta_dec = 0.5; o->tau_min = 0.9; o->alpha_fallback = 1e-2;
   o->stage_local_reg = 0; o->sticky_delta = 0; o->restart_period = 60; o->reset_delta = 1e5; o->dispatch_order = 1;
 }
 
@@ -221,6 +223,7 @@ void landing_destroy(landing_ctx* ctx) {
   ctx->ws.release();
   if (ctx->d_edge_map) (void)hipFree(ctx->d_edge_map);
   if (ctx->d_vbl) (void)hipFree(ctx->d_vbl);
+  if (ctx->d_rbd) (void)hipFree(ctx->d_rbd);
   for (int i = 0; i < 2; ++i) { if (ctx->aux[i]) (void)hipStreamDestroy(ctx->aux[i]); if (ctx->ev_join[i]) (void)hipEventDestroy(ctx->ev_join[i]); }
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
   delete ctx;

@@ -1,0 +1,301 @@
+// rbd_kernels.hip -- batched floating-base rigid-body routines for the 18-body quadruped model (gfx950, fp64).
+// SURVEY section 8(f) rows N2 (BASELINE configs[3]: full 18-DoF dynamics and its linearisation at every knot of every
+// member) and N1 (the rows the kinodynamic refinement adds to a stage).
+//
+// What it computes follows
+//   utilities_general/spatial_v2/dynamics/HandC.m:14-62                       tau = H(q) qdd + C(q, qd, f_ext)
+//   utilities_general/dynamics-utilities/casadi_compatible_dynamics.m:12-143  the same recursion with foot forces (:53-60)
+//   utilities_general/dynamics-utilities/get_forward_kin_foot.m:4-25          foot positions
+//   utilities_general/dynamics-utilities/get_foot_jacobians_mc.m:12-24        closed-form leg Jacobians
+//   optimizations/landing/main_scripts/landing_optimization.m:152-189         torque rows J_f'(-R' f), FK-consistency rows
+// The reference evaluates them with 6 x 6 Pluecker matrices (and differentiates through CasADi).  Here every transform is
+// kept in its compact form plux(E, r) (12 numbers), every rigid-body inertia as (m, h = m c, Ibar) (10 numbers) -- both
+// closed under the operations of the recursions -- so one thread carries a whole 18-body evaluation in 5.8 KB of private
+// memory; the linearisation is a central-difference sweep of the forward dynamics with one thread per (knot, column).
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+namespace landing {
+
+constexpr int RB_NB = 18;
+struct RbdModel {                    // host-built (landing-controller_amd/rbd.py from constants.py), resident in HBM
+  int parent[RB_NB];                 // 1-based, 0 = fixed base
+  int jtype[RB_NB];                  // 0 Rx, 1 Ry, 2 Rz, 3 Px, 4 Py, 5 Pz
+  double E[RB_NB][9], r[RB_NB][3];   // Xtree = plux(E, r)
+  double m[RB_NB], h[RB_NB][3], I[RB_NB][6];   // link inertia: mass, m*com, rotational inertia about the link origin (xx xy xz yy yz zz)
+  int b_foot[4]; double foot_r[4][3];          // Xfoot = plux(1, foot_r) on body b_foot (1-based)
+  double l1, l2, l3, l4;             // leg lengths of get_foot_jacobians_mc.m:5-8
+};
+
+struct V3d { double x, y, z; };
+__device__ __forceinline__ V3d mk3(double x, double y, double z) { V3d v; v.x = x; v.y = y; v.z = z; return v; }
+__device__ __forceinline__ V3d add3(V3d a, V3d b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ V3d sub3(V3d a, V3d b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ V3d scl3(double s, V3d a) { return mk3(s * a.x, s * a.y, s * a.z); }
+__device__ __forceinline__ V3d crs3(V3d a, V3d b) { return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+__device__ __forceinline__ V3d mul3(const double* E, V3d v) { return mk3(E[0] * v.x + E[1] * v.y + E[2] * v.z, E[3] * v.x + E[4] * v.y + E[5] * v.z, E[6] * v.x + E[7] * v.y + E[8] * v.z); }
+__device__ __forceinline__ V3d mulT3(const double* E, V3d v) { return mk3(E[0] * v.x + E[3] * v.y + E[6] * v.z, E[1] * v.x + E[4] * v.y + E[7] * v.z, E[2] * v.x + E[5] * v.y + E[8] * v.z); }
+__device__ __forceinline__ V3d sym3(const double* I, V3d v) { return mk3(I[0] * v.x + I[1] * v.y + I[2] * v.z, I[1] * v.x + I[3] * v.y + I[4] * v.z, I[2] * v.x + I[4] * v.y + I[5] * v.z); }
+struct SV { V3d a, l; };             // spatial vector: angular / linear (motion) or moment / force
+
+// joint transform applied on top of Xtree: Xup = XJ * plux(E, r)   (jcalc.m:22-40, plux.m)
+__device__ __forceinline__ void joint_xform(int jt, double q, const double* Et, const double* rt, double* E, double* r) {
+  if (jt < 3) {
+    double s, c; sincos(q, &s, &c);
+    // rows of rx/ry/rz (coordinate transforms): rx = [1 0 0; 0 c s; 0 -s c], ry = [c 0 -s; 0 1 0; s 0 c], rz = [c s 0; -s c 0; 0 0 1]
+    const int a = jt, b = (jt + 1) % 3, d = (jt + 2) % 3;
+    for (int j = 0; j < 3; ++j) {
+      E[3 * a + j] = Et[3 * a + j];
+      E[3 * b + j] = c * Et[3 * b + j] + s * Et[3 * d + j];
+      E[3 * d + j] = -s * Et[3 * b + j] + c * Et[3 * d + j];
+    }
+    r[0] = rt[0]; r[1] = rt[1]; r[2] = rt[2];
+  } else {   // xlt(q e_a) * plux(E, r) = plux(E, r + E' (q e_a))
+    const int a = jt - 3;
+    for (int j = 0; j < 9; ++j) E[j] = Et[j];
+    r[0] = rt[0] + Et[3 * a] * q; r[1] = rt[1] + Et[3 * a + 1] * q; r[2] = rt[2] + Et[3 * a + 2] * q;
+  }
+}
+__device__ __forceinline__ SV xmotion(const double* E, const double* r, SV v) {      // X v
+  const V3d rr = mk3(r[0], r[1], r[2]);
+  SV o; o.a = mul3(E, v.a); o.l = mul3(E, sub3(v.l, crs3(rr, v.a))); return o;
+}
+__device__ __forceinline__ SV xforceT(const double* E, const double* r, SV f) {      // X' f  (child -> parent)
+  const V3d rr = mk3(r[0], r[1], r[2]);
+  SV o; o.l = mulT3(E, f.l); o.a = add3(mulT3(E, f.a), crs3(rr, o.l)); return o;
+}
+__device__ __forceinline__ SV crm_mul(SV v, SV w) { SV o; o.a = crs3(v.a, w.a); o.l = add3(crs3(v.a, w.l), crs3(v.l, w.a)); return o; }
+__device__ __forceinline__ SV crf_mul(SV v, SV f) { SV o; o.a = add3(crs3(v.a, f.a), crs3(v.l, f.l)); o.l = crs3(v.a, f.l); return o; }
+__device__ __forceinline__ SV inertia_mul(double m, const double* h, const double* I, SV v) {
+  const V3d hh = mk3(h[0], h[1], h[2]);
+  SV o; o.a = add3(sym3(I, v.a), crs3(hh, v.l)); o.l = sub3(scl3(m, v.l), crs3(hh, v.a)); return o;
+}
+__device__ __forceinline__ double sdot(int jt, SV f) { return jt == 0 ? f.a.x : (jt == 1 ? f.a.y : (jt == 2 ? f.a.z : (jt == 3 ? f.l.x : (jt == 4 ? f.l.y : f.l.z)))); }
+__device__ __forceinline__ SV sunit(int jt, double s) {
+  SV o; o.a = mk3(jt == 0 ? s : 0.0, jt == 1 ? s : 0.0, jt == 2 ? s : 0.0); o.l = mk3(jt == 3 ? s : 0.0, jt == 4 ? s : 0.0, jt == 5 ? s : 0.0); return o;
+}
+
+// H (row-major 18 x 18, may be null) and C (18) for one configuration; f_foot: 12 world-frame foot forces or null
+__device__ void hand_c(const RbdModel& M, const double* q, const double* qd, const double* f_foot, double* H, double* C) {
+  double E[RB_NB][9], r[RB_NB][3];
+  SV v[RB_NB], fvp[RB_NB];
+  double E0[9], r0[3];                       // transform from the world to the current chain body (only the 4 foot bodies need it)
+  double E0f[4][9], r0f[4][3];
+  {
+    SV avp[RB_NB];
+    for (int i = 0; i < RB_NB; ++i) {
+      joint_xform(M.jtype[i], q[i], M.E[i], M.r[i], E[i], r[i]);
+      const SV vJ = sunit(M.jtype[i], qd[i]);
+      const int pa = M.parent[i];
+      if (pa == 0) {
+        SV g; g.a = mk3(0, 0, 0); g.l = mk3(0, 0, 9.81);      // -a_grav
+        v[i] = vJ; avp[i] = xmotion(E[i], r[i], g);
+      } else {
+        const SV vp = xmotion(E[i], r[i], v[pa - 1]);
+        v[i].a = add3(vp.a, vJ.a); v[i].l = add3(vp.l, vJ.l);
+        const SV ap = xmotion(E[i], r[i], avp[pa - 1]), cv = crm_mul(v[i], vJ);
+        avp[i].a = add3(ap.a, cv.a); avp[i].l = add3(ap.l, cv.l);
+      }
+      const SV Ia = inertia_mul(M.m[i], M.h[i], M.I[i], avp[i]), Iv = inertia_mul(M.m[i], M.h[i], M.I[i], v[i]), cf = crf_mul(v[i], Iv);
+      fvp[i].a = add3(Ia.a, cf.a); fvp[i].l = add3(Ia.l, cf.l);
+    }
+  }
+  if (f_foot) {   // external forces at the feet, casadi_compatible_dynamics.m:53-60: fvp -= X0^{-T} f_world
+    // world transforms of the four foot bodies: the base chain (bodies 1..6) then the leg (3 bodies)
+    for (int j = 0; j < 9; ++j) E0[j] = (j % 4 == 0) ? 1.0 : 0.0;
+    r0[0] = r0[1] = r0[2] = 0.0;
+    auto compose = [](const double* Eu, const double* ru, double* Ea, double* ra) {   // (Ea, ra) <- plux(Eu, ru) * plux(Ea, ra)
+      const V3d t = mulT3(Ea, mk3(ru[0], ru[1], ru[2]));
+      double En[9];
+      for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) En[3 * a + b] = Eu[3 * a] * Ea[b] + Eu[3 * a + 1] * Ea[3 + b] + Eu[3 * a + 2] * Ea[6 + b];
+      for (int j = 0; j < 9; ++j) Ea[j] = En[j];
+      ra[0] += t.x; ra[1] += t.y; ra[2] += t.z;
+    };
+    for (int i = 0; i < 6; ++i) compose(E[i], r[i], E0, r0);
+    for (int leg = 0; leg < 4; ++leg) {
+      for (int j = 0; j < 9; ++j) E0f[leg][j] = E0[j];
+      for (int j = 0; j < 3; ++j) r0f[leg][j] = r0[j];
+      const int jb = M.b_foot[leg] - 1;
+      for (int i = jb - 2; i <= jb; ++i) compose(E[i], r[i], E0f[leg], r0f[leg]);
+      // foot point in world coordinates, spatial force about the world origin, moved into body coordinates: X0^* f = [E0 (n - r0 x f); E0 f]
+      const V3d pf = add3(mk3(r0f[leg][0], r0f[leg][1], r0f[leg][2]), mulT3(E0f[leg], mk3(M.foot_r[leg][0], M.foot_r[leg][1], M.foot_r[leg][2])));
+      const V3d fw = mk3(f_foot[3 * leg], f_foot[3 * leg + 1], f_foot[3 * leg + 2]);
+      const V3d nb = crs3(sub3(pf, mk3(r0f[leg][0], r0f[leg][1], r0f[leg][2])), fw);
+      fvp[jb].a = sub3(fvp[jb].a, mul3(E0f[leg], nb)); fvp[jb].l = sub3(fvp[jb].l, mul3(E0f[leg], fw));
+    }
+  }
+  for (int i = RB_NB - 1; i >= 0; --i) {
+    C[i] = sdot(M.jtype[i], fvp[i]);
+    const int pa = M.parent[i];
+    if (pa != 0) { const SV t = xforceT(E[i], r[i], fvp[i]); fvp[pa - 1].a = add3(fvp[pa - 1].a, t.a); fvp[pa - 1].l = add3(fvp[pa - 1].l, t.l); }
+  }
+  if (!H) return;
+  // composite rigid-body inertias in (m, h, Ibar) form: parent += X' I X with X = plux(E, r):
+  //   m' = m, h' = E'h + m r, Ibar' = E' Ibar E - skew(r) skew(E'h) - skew(E'h + m r) skew(r)
+  double cm[RB_NB], ch[RB_NB][3], cI[RB_NB][6];
+  for (int i = 0; i < RB_NB; ++i) { cm[i] = M.m[i]; for (int j = 0; j < 3; ++j) ch[i][j] = M.h[i][j]; for (int j = 0; j < 6; ++j) cI[i][j] = M.I[i][j]; }
+  for (int i = RB_NB - 1; i >= 0; --i) {
+    const int pa = M.parent[i];
+    if (pa == 0) continue;
+    const double* Ei = E[i];
+    const V3d hp = mulT3(Ei, mk3(ch[i][0], ch[i][1], ch[i][2])), rr = mk3(r[i][0], r[i][1], r[i][2]);
+    const V3d hn = add3(hp, scl3(cm[i], rr));
+    // E' Ibar E (symmetric)
+    double T[9];
+    { const double* I6 = cI[i];
+      const double Is[9] = {I6[0], I6[1], I6[2], I6[1], I6[3], I6[4], I6[2], I6[4], I6[5]};
+      double A[9];
+      for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) A[3 * a + b] = Is[3 * a] * Ei[b] + Is[3 * a + 1] * Ei[3 + b] + Is[3 * a + 2] * Ei[6 + b];     // Ibar E
+      for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) T[3 * a + b] = Ei[a] * A[b] + Ei[3 + a] * A[3 + b] + Ei[6 + a] * A[6 + b];                   // E' (Ibar E)
+    }
+    // - skew(r) skew(hp) - skew(hn) skew(r):  skew(a) skew(b) = b a' - (a.b) 1
+    auto add_ss = [&](V3d a, V3d b, double sgn) {
+      const double d = a.x * b.x + a.y * b.y + a.z * b.z;
+      const double av[3] = {a.x, a.y, a.z}, bv[3] = {b.x, b.y, b.z};
+      for (int x = 0; x < 3; ++x) for (int y = 0; y < 3; ++y) T[3 * x + y] += sgn * (bv[x] * av[y] - (x == y ? d : 0.0));
+    };
+    add_ss(rr, hp, -1.0); add_ss(hn, rr, -1.0);
+    double* Ip = cI[pa - 1];
+    Ip[0] += T[0]; Ip[1] += 0.5 * (T[1] + T[3]); Ip[2] += 0.5 * (T[2] + T[6]); Ip[3] += T[4]; Ip[4] += 0.5 * (T[5] + T[7]); Ip[5] += T[8];
+    cm[pa - 1] += cm[i]; ch[pa - 1][0] += hn.x; ch[pa - 1][1] += hn.y; ch[pa - 1][2] += hn.z;
+  }
+  for (int i = 0; i < RB_NB * RB_NB; ++i) H[i] = 0.0;
+  for (int i = 0; i < RB_NB; ++i) {
+    SV fh = inertia_mul(cm[i], ch[i], cI[i], sunit(M.jtype[i], 1.0));
+    H[i * RB_NB + i] = sdot(M.jtype[i], fh);
+    int j = i;
+    while (M.parent[j] > 0) {
+      fh = xforceT(E[j], r[j], fh);
+      j = M.parent[j] - 1;
+      const double hij = sdot(M.jtype[j], fh);
+      H[i * RB_NB + j] = hij; H[j * RB_NB + i] = hij;
+    }
+  }
+}
+
+// in-place Cholesky solve of the 18 x 18 system H x = b (H destroyed); returns false if H is not positive definite
+__device__ bool chol_solve18(double* H, double* b) {
+  for (int j = 0; j < RB_NB; ++j) {
+    double d = H[j * RB_NB + j];
+    for (int k = 0; k < j; ++k) d -= H[j * RB_NB + k] * H[j * RB_NB + k];
+    if (!(d > 0.0)) return false;
+    d = sqrt(d); H[j * RB_NB + j] = d;
+    for (int i = j + 1; i < RB_NB; ++i) {
+      double s = H[i * RB_NB + j];
+      for (int k = 0; k < j; ++k) s -= H[i * RB_NB + k] * H[j * RB_NB + k];
+      H[i * RB_NB + j] = s / d;
+    }
+  }
+  for (int i = 0; i < RB_NB; ++i) { double s = b[i]; for (int k = 0; k < i; ++k) s -= H[i * RB_NB + k] * b[k]; b[i] = s / H[i * RB_NB + i]; }
+  for (int i = RB_NB - 1; i >= 0; --i) { double s = b[i]; for (int k = i + 1; k < RB_NB; ++k) s -= H[k * RB_NB + i] * b[k]; b[i] = s / H[i * RB_NB + i]; }
+  return true;
+}
+
+struct FbArgs {
+  const RbdModel* model; int npts;
+  const double* q; const double* qd; const double* tau; const double* f_foot;   // [npts][18] x3, [npts][12] or null
+  double* H; double* C; double* qdd; double* A; double* Hinv;                  // [npts][324], [npts][18], [npts][18], [npts][18*36], [npts][324]; any may be null
+  double fd_h;
+};
+
+// one thread per knot: H, C (and qdd when tau is given)
+__global__ void __launch_bounds__(64) landing_fb_hc_kernel(FbArgs a) {
+  const int pt = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pt >= a.npts) return;
+  const RbdModel& M = *a.model;
+  double H[RB_NB * RB_NB], C[RB_NB];
+  hand_c(M, a.q + (size_t)pt * RB_NB, a.qd + (size_t)pt * RB_NB, a.f_foot ? a.f_foot + (size_t)pt * 12 : nullptr, H, C);
+  if (a.H) for (int i = 0; i < RB_NB * RB_NB; ++i) a.H[(size_t)pt * RB_NB * RB_NB + i] = H[i];
+  if (a.C) for (int i = 0; i < RB_NB; ++i) a.C[(size_t)pt * RB_NB + i] = C[i];
+  if (a.qdd && a.tau) {
+    double b[RB_NB];
+    for (int i = 0; i < RB_NB; ++i) b[i] = a.tau[(size_t)pt * RB_NB + i] - C[i];
+    const bool ok = chol_solve18(H, b);
+    for (int i = 0; i < RB_NB; ++i) a.qdd[(size_t)pt * RB_NB + i] = ok ? b[i] : NAN;
+  }
+}
+
+// linearisation of the forward dynamics qdd(q, qd, tau) = H^-1 (tau - C): one thread per (knot, column).
+// columns 0..35: d qdd / d [q; qd] by central differences with step fd_h (the reference differentiates the same recursion
+// through CasADi); columns 36..53: column of H^-1 = d qdd / d tau.
+__global__ void __launch_bounds__(64) landing_fb_lin_kernel(FbArgs a) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int pt = idx / 54, col = idx % 54;
+  if (pt >= a.npts) return;
+  const RbdModel& M = *a.model;
+  double q[RB_NB], qd[RB_NB], H[RB_NB * RB_NB], C[RB_NB], bp[RB_NB], bm[RB_NB];
+  for (int i = 0; i < RB_NB; ++i) { q[i] = a.q[(size_t)pt * RB_NB + i]; qd[i] = a.qd[(size_t)pt * RB_NB + i]; }
+  const double* ff = a.f_foot ? a.f_foot + (size_t)pt * 12 : nullptr;
+  if (col >= 36) {
+    if (!a.Hinv) return;
+    hand_c(M, q, qd, ff, H, C);
+    for (int i = 0; i < RB_NB; ++i) bp[i] = (i == col - 36) ? 1.0 : 0.0;
+    const bool ok = chol_solve18(H, bp);
+    for (int i = 0; i < RB_NB; ++i) a.Hinv[((size_t)pt * RB_NB + i) * RB_NB + (col - 36)] = ok ? bp[i] : NAN;
+    return;
+  }
+  if (!a.A) return;
+  double* var = col < RB_NB ? q : qd;
+  const int j = col % RB_NB;
+  const double x0 = var[j];
+  bool ok = true;
+  var[j] = x0 + a.fd_h;
+  hand_c(M, q, qd, ff, H, C);
+  for (int i = 0; i < RB_NB; ++i) bp[i] = a.tau[(size_t)pt * RB_NB + i] - C[i];
+  ok = chol_solve18(H, bp) && ok;
+  var[j] = x0 - a.fd_h;
+  hand_c(M, q, qd, ff, H, C);
+  for (int i = 0; i < RB_NB; ++i) bm[i] = a.tau[(size_t)pt * RB_NB + i] - C[i];
+  ok = chol_solve18(H, bm) && ok;
+  for (int i = 0; i < RB_NB; ++i) a.A[((size_t)pt * RB_NB + i) * 36 + col] = ok ? (bp[i] - bm[i]) / (2.0 * a.fd_h) : NAN;
+}
+
+// rows the kinodynamic refinement adds per stage (landing_optimization.m:152-189), one thread per (member, stage):
+// foot positions by forward kinematics of [q6; jpos] (get_forward_kin_foot.m), FK consistency c - FK, leg torques
+// tau = J_f' (-R_world_to_body f) with the closed-form Jacobian of get_foot_jacobians_mc.m:12-24 and rpyToRotMat_xyz.m:2
+struct KdArgs { const RbdModel* model; int npts; const double* q6; const double* c; const double* f; const double* jpos; double* fk; double* fk_err; double* tau; };
+__global__ void __launch_bounds__(64) landing_kinodyn_rows_kernel(KdArgs a) {
+  const int pt = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pt >= a.npts) return;
+  const RbdModel& M = *a.model;
+  const double* q6 = a.q6 + (size_t)pt * 6; const double* jp = a.jpos + (size_t)pt * 12;
+  double E0[9], r0[3];
+  for (int j = 0; j < 9; ++j) E0[j] = (j % 4 == 0) ? 1.0 : 0.0;
+  r0[0] = r0[1] = r0[2] = 0.0;
+  auto compose = [](const double* Eu, const double* ru, double* Ea, double* ra) {
+    const V3d t = mulT3(Ea, mk3(ru[0], ru[1], ru[2]));
+    double En[9];
+    for (int x = 0; x < 3; ++x) for (int y = 0; y < 3; ++y) En[3 * x + y] = Eu[3 * x] * Ea[y] + Eu[3 * x + 1] * Ea[3 + y] + Eu[3 * x + 2] * Ea[6 + y];
+    for (int j = 0; j < 9; ++j) Ea[j] = En[j];
+    ra[0] += t.x; ra[1] += t.y; ra[2] += t.z;
+  };
+  double E[9], r[3];
+  for (int i = 0; i < 6; ++i) { joint_xform(M.jtype[i], q6[i], M.E[i], M.r[i], E, r); compose(E, r, E0, r0); }
+  // R_world_to_body = E0 (the coordinate transform world -> body accumulated by the chain = (rx' ry' rz')')
+  for (int leg = 0; leg < 4; ++leg) {
+    double El[9], rl[3];
+    for (int j = 0; j < 9; ++j) El[j] = E0[j];
+    for (int j = 0; j < 3; ++j) rl[j] = r0[j];
+    const int jb = M.b_foot[leg] - 1;
+    for (int i = jb - 2; i <= jb; ++i) { joint_xform(M.jtype[i], jp[3 * leg + (i - (jb - 2))], M.E[i], M.r[i], E, r); compose(E, r, El, rl); }
+    const V3d pf = add3(mk3(rl[0], rl[1], rl[2]), mulT3(El, mk3(M.foot_r[leg][0], M.foot_r[leg][1], M.foot_r[leg][2])));
+    const double pfv[3] = {pf.x, pf.y, pf.z};
+    for (int j = 0; j < 3; ++j) {
+      if (a.fk) a.fk[(size_t)pt * 12 + 3 * leg + j] = pfv[j];
+      if (a.fk_err) a.fk_err[(size_t)pt * 12 + 3 * leg + j] = a.c[(size_t)pt * 12 + 3 * leg + j] - pfv[j];
+    }
+    if (a.tau) {
+      const double ss = (leg & 1) ? 1.0 : -1.0;            // sideSign = [-1, 1, -1, 1]
+      double s1, c1, s2, c2, s3, c3;
+      sincos(jp[3 * leg], &s1, &c1); sincos(jp[3 * leg + 1], &s2, &c2); sincos(jp[3 * leg + 2], &s3, &c3);
+      const double c23 = c2 * c3 - s2 * s3, s23 = s2 * c3 + c2 * s3, l14 = M.l1 + M.l4;
+      const double J[3][3] = {{0.0, M.l3 * c23 + M.l2 * c2, M.l3 * c23},
+                              {M.l3 * c1 * c23 + M.l2 * c1 * c2 - l14 * s1 * ss, -M.l3 * s1 * s23 - M.l2 * s1 * s2, -M.l3 * s1 * s23},
+                              {M.l3 * s1 * c23 + M.l2 * c2 * s1 + l14 * ss * c1, M.l3 * c1 * s23 + M.l2 * c1 * s2, M.l3 * c1 * s23}};
+      const V3d fb = mul3(E0, mk3(-a.f[(size_t)pt * 12 + 3 * leg], -a.f[(size_t)pt * 12 + 3 * leg + 1], -a.f[(size_t)pt * 12 + 3 * leg + 2]));
+      for (int j = 0; j < 3; ++j) a.tau[(size_t)pt * 12 + 3 * leg + j] = J[0][j] * fb.x + J[1][j] * fb.y + J[2][j] * fb.z;
+    }
+  }
+}
+
+}  // namespace landing

@@ -143,8 +143,6 @@ struct Lds {
   int cab[COND_GAM]; int cat[COND_STRIDE - COND_AH]; int c_tab, c_nT, c_nA;
   // condensation: packed term table of the most frequent stage type (the others are read from L2) and, per stage, the
   // bases of the seven [J | H | Hc] segments + the type id (slot 7)
-  unsigned long long ctab_mid[CTAB_MLMAX * SOLVER_THREADS];
-  double carry[4 * SOLVER_THREADS];       // condensation carries: [batch parity][stage of the batch][thread]
   int segb[64 * 8];
   MemberMem M; Layout L; const double* p; const int* tab; const int* stage_tab; int prof_on;
 };
@@ -473,6 +471,18 @@ __device__ __noinline__ void condense(const unsigned long long* __restrict__ cta
   Lds& S = SH;
   const MemberMem& M = S.M;
   const int ng = S.L.ng, N = S.L.N, tid = threadIdx.x;
+  // scratch of this phase lives in the Riccati arrays, which are dead here: the term table of the most frequent stage type in
+  // S.G (12 KB of 18.8, re-loaded from L2 on every call: 12 KB against the 720 KB the round-1 list streamed), the carries of
+  // even batches behind it, those of odd batches in S.A1
+  static_assert(CTAB_MLMAX * SOLVER_THREADS + 2 * SOLVER_THREADS <= 48 * GS && 2 * SOLVER_THREADS <= 2 * XCH, "condensation scratch fits");
+  unsigned long long* ctab_mid = reinterpret_cast<unsigned long long*>(S.G);
+  double* carry_even = S.G + CTAB_MLMAX * SOLVER_THREADS;
+  double* carry_odd = S.A1;
+  {
+    const unsigned long long* src = ctab + (size_t)mid * ML * SOLVER_THREADS;
+    for (int e = tid; e < ML * SOLVER_THREADS; e += SOLVER_THREADS) ctab_mid[e] = src[e];
+  }
+  __syncthreads();
   const double* __restrict__ JH = M.J;       // [J | H | Hc] are contiguous
   const double* __restrict__ SR = M.sig;     // [sigma | rho] are contiguous
   double* __restrict__ cond = M.cond;
@@ -488,7 +498,7 @@ __device__ __noinline__ void condense(const unsigned long long* __restrict__ cta
       const int tp = S.segb[k * 8 + 7];
       const unsigned long long* gt = ctab + (size_t)tp * ML * SOLVER_THREADS;
 #pragma unroll
-      for (int j = 0; j < CTAB_MLMAX; ++j) t[s][j] = j < ML ? (tp == mid ? S.ctab_mid[j * SOLVER_THREADS + tid] : gt[j * SOLVER_THREADS + tid]) : PAD;
+      for (int j = 0; j < CTAB_MLMAX; ++j) t[s][j] = j < ML ? (tp == mid ? ctab_mid[j * SOLVER_THREADS + tid] : gt[j * SOLVER_THREADS + tid]) : PAD;
     }
 #pragma unroll
     for (int s = 0; s < SB; ++s) {
@@ -507,7 +517,7 @@ __device__ __noinline__ void condense(const unsigned long long* __restrict__ cta
       }
     }
     double pend_acc[SB]; int pend_dst[SB], pend_n[SB];
-    double* carry = S.carry + (batch & 1) * SB * SOLVER_THREADS;
+    double* carry = (batch & 1) ? carry_odd : carry_even;
 #pragma unroll
     for (int s = 0; s < SB; ++s) {
       pend_acc[s] = 0.0; pend_dst[s] = 0; pend_n[s] = 0;
@@ -826,8 +836,6 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
       sb[3] = nj + L.hx(k); sb[4] = nj + L.hu(k); sb[5] = k < N - 1 ? nj + L.hu(k + 1) : 0;
       sb[6] = nj + nh + k * RUNC; sb[7] = A.ctype[k];
     }
-    const unsigned long long* src = A.ctab + (size_t)A.c_mid * A.c_ml * SOLVER_THREADS;
-    for (int e = lane; e < A.c_ml * SOLVER_THREADS; e += NT) S.ctab_mid[e] = src[e];
   }
   __syncthreads();
 

@@ -1,0 +1,87 @@
+"""Host side of the floating-base rigid-body routines: the reference's 'quad3D' Mini-Cheetah tree
+(utilities_general/dynamics-utilities/get_robot_model.m:134-234 with the 'mc3D' parameters of get_robot_params.m:50-115)
+in the compact form the HIP kernels use -- Xtree = plux(E, r), link inertia = (mass, m*com, rotational inertia about the
+link origin) -- and the ctypes binding of landing_rbd_set_model / landing_fb_dynamics_batch / landing_kinodyn_rows_batch."""
+import ctypes as C
+
+import numpy as np
+
+from . import constants as K
+
+
+class RbdModel(C.Structure):
+    _fields_ = [("parent", C.c_int * 18), ("jtype", C.c_int * 18), ("E", (C.c_double * 9) * 18), ("r", (C.c_double * 3) * 18),
+                ("m", C.c_double * 18), ("h", (C.c_double * 3) * 18), ("I", (C.c_double * 6) * 18),
+                ("b_foot", C.c_int * 4), ("foot_r", (C.c_double * 3) * 4), ("l1", C.c_double), ("l2", C.c_double), ("l3", C.c_double), ("l4", C.c_double)]
+
+
+def _rbi(m, com, rot):
+    """(m, h, Ibar about the origin): spatialInertia.m restated in compact form"""
+    com = np.asarray(com, float); c = K._skew(com)
+    Ibar = np.asarray(rot, float) + m * (c @ c.T)
+    return m, m * com, np.array([Ibar[0, 0], Ibar[0, 1], Ibar[0, 2], Ibar[1, 1], Ibar[1, 2], Ibar[2, 2]])
+
+
+def _flip_y_rbi(m, h, I6):
+    """flipAlongAxis(I, 'Y') (get_robot_model.m:852-889): mirror the link through the x-z plane"""
+    return m, h * np.array([1, -1, 1.0]), I6 * np.array([1, -1, 1, 1, -1, 1.0])
+
+
+def quad3d_model():
+    M = RbdModel()
+    abad = _rbi(0.54, [0, 0.036, 0], 1e-6 * np.array([[381, 58, 0.45], [58, 560, 0.95], [0.45, 0.95, 444]]))
+    hip = _rbi(0.634, [0, 0.016, -0.02], 1e-6 * np.array([[1983, 245, 13], [245, 2103, 1.5], [13, 1.5, 408]]))
+    knee = _rbi(0.064, [0, 0, -0.061], 1e-6 * np.array([[6, 0, 0], [0, 248, 0], [0, 0, 245.0]]))
+    body = _rbi(3.3, [0, 0, 0], 1e-6 * np.diag([11253.0, 36203.0, 42673.0]))
+    zero = (0.0, np.zeros(3), np.zeros(6))
+    abad_loc, hip_loc, knee_loc, foot_loc = np.array([0.19, 0.049, 0.0]), np.array([0, 0.062, 0.0]), np.array([0, 0, -0.209]), np.array([0, 0, -0.195])
+    side = np.array([[1, 1, -1, -1], [-1, 1, -1, 1], [1, 1, 1, 1]], float)
+    rzpi = np.array([[np.cos(np.pi), np.sin(np.pi), 0], [-np.sin(np.pi), np.cos(np.pi), 0], [0, 0, 1.0]])
+    bodies = [(i, t, np.eye(3), np.zeros(3), zero) for i, t in zip(range(6), (3, 4, 5, 0, 1, 2))]     # Px Py Pz Rx Ry Rz
+    bodies[5] = (5, 2, np.eye(3), np.zeros(3), body)
+    leg_side = -1
+    for leg in range(4):
+        s = side[:, leg]
+        links = [abad, hip, knee] if leg_side > 0 else [_flip_y_rbi(*abad), _flip_y_rbi(*hip), _flip_y_rbi(*knee)]
+        n0 = len(bodies)
+        bodies.append((6, 0, np.eye(3), s * abad_loc, links[0]))
+        bodies.append((n0 + 1, 1, rzpi, s * hip_loc, links[1]))           # plux(rz(pi), 0) * plux(1, r) = plux(rz(pi), r)
+        bodies.append((n0 + 2, 1, np.eye(3), s * knee_loc, links[2]))
+        M.b_foot[leg] = n0 + 3
+        for j in range(3):
+            M.foot_r[leg][j] = (s * foot_loc)[j]
+        leg_side = -leg_side
+    for i, (pa, jt, E, r, (m, h, I6)) in enumerate(bodies):
+        M.parent[i] = pa; M.jtype[i] = jt; M.m[i] = m
+        for j in range(9): M.E[i][j] = E.flatten()[j]
+        for j in range(3): M.r[i][j] = r[j]; M.h[i][j] = h[j]
+        for j in range(6): M.I[i][j] = I6[j]
+    M.l1, M.l2, M.l3, M.l4 = 0.062, 0.209, 0.195, 0.004                       # get_foot_jacobians_mc.m:5-8
+    return M
+
+
+TAU_MAX = np.tile(np.array([6.0, 6.0, 9.33]) * 3.0, 4)     # model.gr .* motorTauMax (get_robot_model.m:236-240, get_robot_params.m:103-108)
+JPOS_MIN = np.tile([-np.pi / 3, -np.pi / 2, 0.0], 4)       # landing_optimization.m:246-247
+JPOS_MAX = np.tile([np.pi / 3, np.pi / 2, 3 * np.pi / 4], 4)
+
+
+class Rbd:
+    """binds the three entry points on an existing LandingLib (its context owns the uploaded model)"""
+
+    def __init__(self, lib):
+        self.L = lib
+        vp = C.c_void_p
+        lib.lib.landing_rbd_set_model.argtypes = [vp, C.POINTER(RbdModel)]
+        lib.lib.landing_fb_dynamics_batch.argtypes = [vp, C.c_int] + [vp] * 9 + [C.c_double, vp]
+        lib.lib.landing_kinodyn_rows_batch.argtypes = [vp, C.c_int] + [vp] * 7 + [vp]
+        self.model = quad3d_model()
+        lib._check(lib.lib.landing_rbd_set_model(lib.ctx, C.byref(self.model)), "landing_rbd_set_model")
+
+    def fb_dynamics(self, npts, d_q, d_qd, d_tau=0, d_f_foot=0, d_H=0, d_C=0, d_qdd=0, d_A=0, d_Hinv=0, fd_h=1e-6, stream=0):
+        n = lambda v: v or None
+        self.L._check(self.L.lib.landing_fb_dynamics_batch(self.L.ctx, npts, d_q, d_qd, n(d_tau), n(d_f_foot), n(d_H), n(d_C), n(d_qdd), n(d_A), n(d_Hinv), fd_h, n(stream)),
+                      "landing_fb_dynamics_batch")
+
+    def kinodyn_rows(self, npts, d_q6, d_c, d_f, d_jpos, d_fk=0, d_fk_err=0, d_tau=0, stream=0):
+        n = lambda v: v or None
+        self.L._check(self.L.lib.landing_kinodyn_rows_batch(self.L.ctx, npts, d_q6, n(d_c), n(d_f), d_jpos, n(d_fk), n(d_fk_err), n(d_tau), n(stream)), "landing_kinodyn_rows_batch")

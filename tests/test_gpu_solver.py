@@ -25,10 +25,13 @@ def libs():
 @pytest.mark.parametrize("N,B", [(20, 24), (40, 32)])
 def test_solver_reaches_kkt_under_oracle_functions(libs, oracle_mod, N, B):
     O = oracle_mod.Oracle(N)
-    P, X0, _, _ = lc("problem").make_batch(B, N, 0.6, seed=1)
+    P, X0, _, qd = lc("problem").make_batch(B, N, 0.6, seed=1)
     r = libs[N].solve_host(P, X0)
     conv = r["status"] == 0
-    assert conv.mean() >= 0.9, f"only {conv.sum()}/{B} members converged"
+    # N = 40: every member converges.  N = 20 (dt = 30 ms): the drops faster than 4.4 m/s are infeasible at that resolution
+    # (tests/dev: the same states converge at N = 40) -- every slower one must converge (measured round 2: 100 %)
+    slow = qd[:, 5] > (-4.4 if N == 20 else -1e9)
+    assert conv[slow].all(), f"{(~conv & slow).sum()} members with |v_z| < 4.4 m/s failed: {np.nonzero(~conv & slow)[0]}"
     for b in np.nonzero(conv)[0]:
         k = O.kkt(r["x"][b], P[b], r["lam_g"][b])
         assert k.max() <= KKT_TOL * 1.0001, (b, k)
@@ -81,6 +84,9 @@ def test_warm_start_converges_faster(libs):
     warm = L.solve_host(P, cold["x"], o)
     ok = (cold["status"] == 0) & (warm["status"] == 0)
     assert ok.sum() >= 3 and warm["iters"][ok].sum() < cold["iters"][ok].sum()
+    w2 = L.solve_host(P, cold["x"], L.warm_opts())                    # the receding-horizon options: a handful of iterations from a solution
+    ok2 = (cold["status"] == 0)
+    assert (w2["iters"][ok2] <= 14).all() and (w2["status"][ok2] == 0).sum() >= ok2.sum() - 1
 
 
 def test_solver_other_horizons_and_limits(oracle_mod):
@@ -92,7 +98,7 @@ def test_solver_other_horizons_and_limits(oracle_mod):
         P, X0, _, _ = lc("problem").make_batch(6, N, 0.6, seed=4)
         r = L.solve_host(P, X0)
         ok = r["status"] == 0
-        assert ok.sum() >= (3 if N == 16 else 5)      # dt = 37.5 ms at N = 16: about a quarter of the drop states do not solve at that resolution
+        assert ok.sum() >= (3 if N == 16 else 6)      # dt = 37.5 ms at N = 16: about a quarter of the drop states (the fast drops) are infeasible at that resolution; N = 30: all solve
         for b in np.nonzero(ok)[0]:
             assert O.kkt(r["x"][b], P[b], r["lam_g"][b]).max() <= KKT_TOL * 1.0001
         L.close()
@@ -134,8 +140,10 @@ def test_solver_full_size_batch_properties(libs, oracle_mod):
     torch.cuda.synchronize()
     sth, kh, xh, lh = st.cpu().numpy(), kkt.cpu().numpy(), x.cpu().numpy(), lam.cpu().numpy()
     ok = sth == 0
-    assert ok.mean() >= 0.93
+    assert ok.sum() >= B - 1, f"{ok.sum()}/{B}"        # measured: 1024/1024 (rounds 1 and 2); one locally infeasible member is tolerated
     assert kh[ok].max() <= KKT_TOL * 1.0001
+    ith = it.cpu().numpy()
+    assert ith.mean() <= 70 and np.percentile(ith, 99) <= 140, (ith.mean(), np.percentile(ith, 99))     # measured: mean 63.9, p99 110
     po = O.param_offsets()
     assert np.array_equal(xh[:, :6], P[:, po["q_init"]:po["q_init"] + 6]) and np.array_equal(xh[:, 6:12], P[:, po["qd_init"]:po["qd_init"] + 6])
     for b in np.nonzero(ok)[0][::97]:
@@ -187,7 +195,7 @@ def test_solver_with_running_cost(oracle_mod, N, B):
     P, X0, _, _ = lc("problem").make_batch(B, N, 0.6, seed=2)
     r = L.solve_host(P, X0)
     conv = r["status"] == 0
-    assert conv.mean() >= 0.85, f"only {conv.sum()}/{B} members converged"
+    assert conv.mean() >= (0.85 if N == 20 else 0.96), f"only {conv.sum()}/{B} members converged"
     for b in np.nonzero(conv)[0][:12]:
         assert O.kkt(r["x"][b], P[b], r["lam_g"][b]).max() <= KKT_TOL * 1.0001
         assert abs(O.f(r["x"][b], P[b]) - r["f"][b]) < 1e-9 * max(1.0, abs(r["f"][b]))
@@ -241,3 +249,36 @@ def test_n40_reference_solutions_known_answer(oracle_mod):
         better += r["f"][b] <= f_ref * 1.001
     # measured in round 1: 6 of 17 coincide to <= 1e-4 relative, 8 are better, 3 end in another (worse) local minimum
     assert same >= 5 and better >= ok.sum() - 4, (same, better, ok.sum())
+
+
+def test_reference_bound_frac_is_a_supported_configuration(libs, oracle_mod):
+    """the reference's own slack initialisation, bound_push = bound_frac = 0.5 (generate_landingCtrller_IPOPT.m:241-242): slower
+    (every two-sided slack starts at its interval mid-point) but it must work: >= 95 % of a 256-member N=40 batch reach
+    KKT <= 1e-6 within 600 iterations (measured round 1: 97.6 % within 300)"""
+    N, B = 40, 256
+    L = libs[N]
+    P, X0, _, _ = lc("problem").make_batch(B, N, 0.6, seed=20211)
+    o = L.default_opts(); o.bound_frac = 0.5; o.max_iter = 600
+    r = L.solve_host(P, X0, o)
+    ok = r["status"] == 0
+    assert ok.mean() >= 0.95, ok.sum()
+    assert r["kkt"][ok].max() <= KKT_TOL * 1.0001
+
+
+def test_n20_failures_are_the_fast_drops(libs):
+    """N = 20, dt = 30 ms (the reference's generated horizon) over the full synthetic range of drop speeds: the members that do
+    not converge are the fastest drops (|v_z| > 4.4 m/s: the body covers 13 cm per stage -- locally infeasible NLPs, IPOPT would
+    report the same); every slower member converges, and every failing one converges when posed with N = 40."""
+    N, B = 20, 512
+    Pm = lc("problem")
+    P, X0, q, qd = Pm.make_batch(B, N, 0.6, seed=20211)
+    r = libs[20].solve_host(P, X0)
+    bad = r["status"] != 0
+    assert bad.mean() <= 0.10
+    assert (qd[bad, 5] < -4.4).all(), qd[bad, 5]
+    idx = np.nonzero(bad)[0]
+    P4 = np.zeros((len(idx), Pm.n_p(40))); X4 = np.zeros((len(idx), Pm.nx(40)))
+    for j, b in enumerate(idx):
+        P4[j], X4[j], _, _ = Pm.make_member(40, 0.6, q[b], qd[b])
+    r4 = libs[40].solve_host(P4, X4)
+    assert (r4["status"] == 0).all()
