@@ -82,9 +82,9 @@ typedef struct {
   double kappa_mu;       /* 0.2                                                    */
   double theta_mu;       /* 1.5                                                    */
   int max_soc;           /* reserved                                               */
-  int max_resets;        /* multiplier resets allowed per NLP (default 2: a member that jams a third time is reported as
-                            LANDING_NUMERICAL -- IPOPT would report local infeasibility / a failed restoration -- instead of
-                            cycling until max_iter; about 1 in 1000 synthetic drop states at N = 40), see reset_du */
+  int max_resets;        /* multiplier resets allowed per NLP (default 8), see reset_du.  (2 was tried in round 2: it stops the rare
+                            locally infeasible member ~130 iterations earlier, but the N=41-script formulation -- kin-box
+                            .05/.05/.27 with the running cost -- then loses 4 of its 17 stored reference cases.)            */
   double reset_du;       /* dual infeasibility above which slacks/multipliers/mu are re-initialised
                             at the current x (jammed iterate; IPOPT would enter restoration), 1e9  */
   int stage_local_reg;   /* ignored (a per-stage delta_w was tried in round 1 and removed); kept for ABI stability            */
