@@ -97,6 +97,7 @@ def main():
     ap.add_argument("--distinct-batches", type=int, default=8, help="timed steps cycle through this many different synthetic batches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo only with --dry (CPU launcher test)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the PCIe-inclusive and two-batches-in-flight legs (profiling runs: only the headline launches)")
     ap.add_argument("--dry", action="store_true", help="no GPU work: exercise the multi-rank path with a stub solve")
     a = ap.parse_args()
     if a.gpus < 1:
@@ -223,7 +224,7 @@ def main():
 
     # ---- the same step with the PCIe legs inside (SURVEY 8d wording): pinned host p, x0 -> HBM, x*, status -> host
     pcie = None
-    if not a.dry:
+    if not a.dry and not a.no_extras:
         pinned = [(torch.tensor(Pq).pin_memory(), torch.tensor(Xq).pin_memory()) for Pq, Xq in host_batches]
         hx, hst = torch.empty(B, nx, dtype=torch.float64).pin_memory(), torch.empty(B, dtype=torch.int32).pin_memory()
         dP2, dX02 = torch.empty_like(dP), torch.empty_like(dX0)
@@ -254,7 +255,7 @@ def main():
     # members that need 2-4x the mean iteration count while most CUs idle -- overlaps with the bulk of the next one.  What a
     # data-generation job streaming batches through the GPU does; reported beside the one-batch-at-a-time `value`.
     piped = None
-    if not a.dry and a.steps >= 2:
+    if not a.dry and a.steps >= 2 and not a.no_extras:
         capi2 = importlib.import_module("landing-controller_amd.capi")
         lanes = []
         for i in range(2):

@@ -330,6 +330,22 @@ __device__ __noinline__ void eval_task_jac(const Layout& L, const srbm::StageVar
   SeqStoreJ ex{J + L.jx(k)}, eu{J + L.ju(k)};
   srbm::stage_jac(z, P, k == 0, k == L.N - 1, fz_prev, ex, eu);
 }
+// Jacobian nonzeros of ALL stages by one wavefront with the coalesced tile write-out of landing_sweep_kernel<0> (every lane runs
+// the middle-stage instruction stream, the edge stages' placeholders are dropped through the compaction map): the solver's
+// per-lane sequential stores were 64 scattered 8-byte words per store instruction.  tileX / tileU: LDS, 64 x TILE_LD each.
+__device__ __noinline__ void eval_task_jac_tiled(const Layout& L, const double* x, const double* p, double* J, double* tileX, double* tileU, const int* edge_map) {
+  const int N = L.N, ln = threadIdx.x & 63;
+  int k = ln;
+  if (k > N - 1) k = N - 1;                       // idle lanes replay the last stage (never written out)
+  srbm::StageVars z; srbm::StageParams P;
+  load_stage(L, x, p, k, z, P);
+  double fz_prev[4] = {0, 0, 0, 0};
+  if (k > 0) { const double* Up = x + L.x_U(k - 1); for (int l = 0; l < 4; ++l) fz_prev[l] = Up[12 + 3 * l + 2]; }
+  TileStore<0> ex{tileX, J, &L, nullptr, 0, N, 0};
+  TileStore<1> eu{tileU, J, &L, edge_map, 0, N, 0};
+  srbm::stage_jac(z, P, false, false, fz_prev, ex, eu);
+  ex.finish(); eu.finish();
+}
 __device__ __noinline__ void eval_task_jty(const Layout& L, const srbm::StageVars& z, const srbm::StageParams& P, int k,
                                            const double* fz_prev, const double* y, double* gx) {
   const bool first = (k == 0);
@@ -355,7 +371,7 @@ __device__ __noinline__ void eval_task_hess(const Layout& L, const srbm::StageVa
 
 // Jacobian / Hessian nonzeros (CCS order) and gx = grad f + J^T y of one member.
 __device__ __noinline__ void member_eval_jh(const Layout& L, const double* x, const double* p, const double* y,
-                                            double* J, double* H, double* gx) {
+                                            double* J, double* H, double* gx, double* tiles = nullptr, const int* edge_map = nullptr) {
   const int N = L.N;
   for (int i = threadIdx.x; i < 36; i += blockDim.x) J[L.jx(N) + i] = 1.0;
   for (int i = threadIdx.x; i < 12; i += blockDim.x) {
@@ -369,8 +385,11 @@ __device__ __noinline__ void member_eval_jh(const Layout& L, const double* x, co
   // one wavefront per task (no divergent calls): wave 0 -> Jacobian, wave 1 -> J^T y, wave 2 -> Hessian; with fewer
   // than 3 waves the tasks are looped
   const int nwave = (blockDim.x + 63) >> 6, wave = threadIdx.x >> 6;
+  const bool tiled = tiles && edge_map && N <= 64 && N >= 3;
+  if (tiled && wave == 0) eval_task_jac_tiled(L, x, p, J, tiles, tiles + 64 * TILE_LD, edge_map);
   for (int task = wave; task < 3; task += nwave)
   for (int k = threadIdx.x & 63; k < N; k += 64) {
+    if (tiled && task == 0) break;
     const bool first = (k == 0);
     srbm::StageVars z; srbm::StageParams P;
     load_stage(L, x, p, k, z, P);

@@ -58,7 +58,7 @@ struct SolverWorkspace {
   int* d_rterm = nullptr; int rlen = 0;
   int *d_ctab = nullptr, *d_ctype = nullptr; int c_ml = 0, c_mid = 0;     // packed per-stage-type condensation tables
   static size_t member_stride(const Layout& L) {
-    return (size_t)4 * L.nx + (size_t)12 * L.ng + L.nnz_jac + L.nnz_hess + (size_t)L.N * RUNC + (size_t)(L.N + 1) * RIC_STRIDE + (size_t)L.N * COND_STRIDE;
+    return (size_t)4 * L.nx + (size_t)10 * L.ng + L.nnz_jac + L.nnz_hess + (size_t)L.N * RUNC + (size_t)(L.N + 1) * RIC_STRIDE + (size_t)L.N * COND_STRIDE;
   }
   int ensure(const Layout& L, int B, hipStream_t stream);
   void release();
@@ -76,6 +76,7 @@ struct SolveArgs {
   const int* tab; const int* stage_tab;
   const unsigned long long* rterm; int rlen;                               // row-product records [rlen][256]
   const unsigned long long* ctab; const int* ctype; int c_ml, c_mid;      // packed condensation tables [type][c_ml][256], type of every stage
+  const int* edge_map;   // compaction map of the tiled Jacobian write-out (landing_ctx::d_edge_map)
   const int* order;      // dispatch order: workgroup b solves member order[b] (hard-first, see landing_order_kernel); nullptr = identity
 };
 
@@ -106,7 +107,7 @@ __device__ __forceinline__ double block_reduce1(double v, int op, double* red) {
 
 struct MemberMem {
   double *x, *xt, *dx, *gx;
-  double *g, *gt, *s, *ds, *zL, *zU, *y, *yn, *lb, *ub, *sig, *rho;
+  double *g, *gt, *s, *ds, *zL, *zU, *y, *yn, *sig, *rho;
   double *J, *H, *Hc, *ric, *cond;
 };
 
@@ -115,7 +116,7 @@ __device__ __forceinline__ MemberMem carve(const Layout& L, double* w) {
   M.x = w; w += L.nx; M.xt = w; w += L.nx; M.dx = w; w += L.nx; M.gx = w; w += L.nx;
   M.g = w; w += L.ng; M.gt = w; w += L.ng; M.s = w; w += L.ng; M.ds = w; w += L.ng;
   M.zL = w; w += L.ng; M.zU = w; w += L.ng;
-  M.y = w; w += L.ng; M.yn = w; w += L.ng; M.lb = w; w += L.ng; M.ub = w; w += L.ng;
+  M.y = w; w += L.ng; M.yn = w; w += L.ng;
   M.sig = w; w += L.ng; M.rho = w; w += L.ng;
   M.J = w; w += L.nnz_jac; M.H = w; w += L.nnz_hess; M.Hc = w; w += (size_t)L.N * RUNC; M.ric = w; w += (size_t)(L.N + 1) * RIC_STRIDE; M.cond = w;
   return M;
@@ -144,6 +145,10 @@ struct Lds {
   // condensation: packed term table of the most frequent stage type (the others are read from L2) and, per stage, the
   // bases of the seven [J | H | Hc] segments + the type id (slot 7)
   int segb[64 * 8];
+  // bounds of the rows: lbg/ubg depend on the row's position inside its stage only (boundary rows | rows of a stage |
+  // rows of the last stage, which has another layout), so 244 (lb, ub) pairs in LDS replace two ng-long workspace arrays
+  // that every row pass used to stream (6 of ~30 array passes per iteration)
+  double bnd_lb[36 + 2 * 104], bnd_ub[36 + 2 * 104];
   MemberMem M; Layout L; const double* p; const int* tab; const int* stage_tab; int prof_on;
 };
 // One instance per workgroup (= per NLP).  Namespace scope keeps the LDS address space visible to every
@@ -813,7 +818,7 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
   Lds& S = SH;
   const double INF = INFINITY;
   // the workspace arrays never overlap: tell the compiler so that the row passes can batch their loads
-  const double* __restrict__ r_lb = M.lb; const double* __restrict__ r_ub = M.ub;
+  auto bidx = [N](int r) { if (r < 36) return r; const int k = (r - 36) / 104, q = (r - 36) - 104 * k; return 36 + (k == N - 1 ? 104 : 0) + q; };
   double* __restrict__ r_g = M.g; double* __restrict__ r_gt = M.gt; double* __restrict__ r_s = M.s; double* __restrict__ r_ds = M.ds;
   double* __restrict__ r_zL = M.zL; double* __restrict__ r_zU = M.zU;
   double* __restrict__ r_y = M.y; double* __restrict__ r_yn = M.yn; double* __restrict__ r_sig = M.sig; double* __restrict__ r_rho = M.rho;
@@ -845,7 +850,13 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
     if (i < 6) v = p[L.o_q_init + i]; else if (i < 12) v = p[L.o_qd_init + i - 6];   // X(:,1) is fixed (gen:90-91)
     M.x[i] = v;
   }
-  for (int r = lane; r < ng; r += NT) { double lb, ub; bound_of(L, p, r, lb, ub); M.lb[r] = lb; M.ub[r] = ub; }
+  for (int e = lane; e < 36 + 2 * 104; e += NT) {
+    const int r = e < 36 ? e : (e < 36 + 104 ? L.g_stage(0) + (e - 36) : L.g_stage(N - 1) + (e - 36 - 104));
+    double lb = 0.0, ub = 0.0;
+    if (r < ng) bound_of(L, p, r, lb, ub);          // (the last stage has 80 rows: the tail of its slot is never addressed)
+    S.bnd_lb[e] = lb; S.bnd_ub[e] = ub;
+  }
+  __syncthreads();
   if (L.run_cost) {   // constant Hessian entries of the running cost (layout: RUNC)
     for (int e = lane; e < N * RUNC; e += NT) {
       const int k = e / RUNC, j = e % RUNC, a = j % 3;
@@ -863,7 +874,7 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
   __syncthreads();
   auto init_slacks = [&]() {     // slack pushed into the interior (IPOPT bound_push/frac), z = 1, y = z_U - z_L, y_dyn = 0
     for (int r = lane; r < ng; r += NT) {
-      const double lb = M.lb[r], ub = M.ub[r];
+      const double lb = S.bnd_lb[bidx(r)], ub = S.bnd_ub[bidx(r)];
       double sv = 0.0, zl = 0.0, zu = 0.0;
       if (r >= 12 && lb != ub) {
         const bool hL = lb > -INF, hU = ub < INF;
@@ -893,7 +904,7 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
     for (int rb = lane; rb < ng; rb += NT * RB) {
       double lbv[RB], ubv[RB], gv[RB], sv[RB], zlv[RB], zuv[RB];
 #pragma unroll
-      for (int j = 0; j < RB; ++j) { const int r = rb + j * NT, rr = r < ng ? r : ng - 1; lbv[j] = r_lb[rr]; ubv[j] = r_ub[rr]; gv[j] = r_g[rr]; sv[j] = r_s[rr]; zlv[j] = r_zL[rr]; zuv[j] = r_zU[rr]; }
+      for (int j = 0; j < RB; ++j) { const int r = rb + j * NT, rr = r < ng ? r : ng - 1; lbv[j] = S.bnd_lb[bidx(rr)]; ubv[j] = S.bnd_ub[bidx(rr)]; gv[j] = r_g[rr]; sv[j] = r_s[rr]; zlv[j] = r_zL[rr]; zuv[j] = r_zU[rr]; }
 #pragma unroll
       for (int j = 0; j < RB; ++j) {
         const int r = rb + j * NT;
@@ -929,6 +940,10 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
   for (it = 0; it <= o.max_iter; ++it) {
     // ---------------------------------------------------------------- derivatives at (x, y)
     if (A.prof) tp = (long long)wall_clock64();
+    // (round 2: the coalesced tile write-out of landing_sweep_kernel<0> was tried here for the Jacobian task -- eval_task_jac_tiled,
+    // tiles in the dead G array -- and is slower: 0.049 vs 0.039 ms alone, 0.094 vs 0.085 under load; every lane then runs the
+    // full middle-stage stream and the wave serialises on 24 tile flushes, while the scattered stores of this version drain
+    // asynchronously behind the arithmetic of the other two waves)
     member_eval_jh(L, M.x, p, M.y, M.J, M.H, M.gx);
     __syncthreads();
     if (L.run_cost) {   // objective gradient of the stage variables (the terminal part is in member_eval_jh)
@@ -1020,7 +1035,7 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
     for (int rb = lane + 12; rb < ng; rb += NT * RB) {
       double lbv[RB], ubv[RB], gv[RB], sv[RB], dsv[RB], zlv[RB], zuv[RB];
 #pragma unroll
-      for (int j = 0; j < RB; ++j) { const int r = rb + j * NT, rr = r < ng ? r : ng - 1; lbv[j] = r_lb[rr]; ubv[j] = r_ub[rr]; gv[j] = r_g[rr]; sv[j] = r_s[rr]; dsv[j] = r_ds[rr]; zlv[j] = r_zL[rr]; zuv[j] = r_zU[rr]; }
+      for (int j = 0; j < RB; ++j) { const int r = rb + j * NT, rr = r < ng ? r : ng - 1; lbv[j] = S.bnd_lb[bidx(rr)]; ubv[j] = S.bnd_ub[bidx(rr)]; gv[j] = r_g[rr]; sv[j] = r_s[rr]; dsv[j] = r_ds[rr]; zlv[j] = r_zL[rr]; zuv[j] = r_zU[rr]; }
 #pragma unroll
       for (int j = 0; j < RB; ++j) {
         if (rb + j * NT >= ng) continue;
@@ -1084,7 +1099,7 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
       for (int rb = lane + 12; rb < ng; rb += NT * RB) {
         double lbv[RB], ubv[RB], gv[RB], sv[RB], dsv[RB];
 #pragma unroll
-        for (int j = 0; j < RB; ++j) { const int r = rb + j * NT, rr = r < ng ? r : ng - 1; lbv[j] = r_lb[rr]; ubv[j] = r_ub[rr]; gv[j] = r_gt[rr]; sv[j] = r_s[rr]; dsv[j] = r_ds[rr]; }
+        for (int j = 0; j < RB; ++j) { const int r = rb + j * NT, rr = r < ng ? r : ng - 1; lbv[j] = S.bnd_lb[bidx(rr)]; ubv[j] = S.bnd_ub[bidx(rr)]; gv[j] = r_gt[rr]; sv[j] = r_s[rr]; dsv[j] = r_ds[rr]; }
 #pragma unroll
         for (int j = 0; j < RB; ++j) {
           if (rb + j * NT >= ng) continue;
@@ -1141,7 +1156,7 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
 #pragma unroll
         for (int j = 0; j < RB; ++j) {
           const int r = rb + j * NT, rr = r < ng ? r : ng - 1;
-          lbv[j] = r_lb[rr]; ubv[j] = r_ub[rr]; gv[j] = r_gt[rr]; sv[j] = r_s[rr]; dsv[j] = r_ds[rr]; zlv[j] = r_zL[rr]; zuv[j] = r_zU[rr]; yv[j] = r_y[rr]; ynv[j] = r_yn[rr];
+          lbv[j] = S.bnd_lb[bidx(rr)]; ubv[j] = S.bnd_ub[bidx(rr)]; gv[j] = r_gt[rr]; sv[j] = r_s[rr]; dsv[j] = r_ds[rr]; zlv[j] = r_zL[rr]; zuv[j] = r_zU[rr]; yv[j] = r_y[rr]; ynv[j] = r_yn[rr];
         }
 #pragma unroll
         for (int j = 0; j < RB; ++j) {
@@ -1193,7 +1208,7 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
   // reference-consistent KKT residual: max_viol(g), ||grad f + J^T lam||_inf, |lam * dist|
   double kp = 0.0, kc = 0.0;
   for (int r = lane; r < ng; r += NT) {
-    const double lb = M.lb[r], ub = M.ub[r], g = M.g[r], lam = M.y[r];
+    const double lb = S.bnd_lb[bidx(r)], ub = S.bnd_ub[bidx(r)], g = M.g[r], lam = M.y[r];
     kp = fmax(kp, fmax(lb - g, fmax(g - ub, 0.0)));
     if (lb != ub) {
       const double dist = lam > 0.0 ? ub - g : g - lb;

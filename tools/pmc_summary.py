@@ -29,7 +29,7 @@ def stats(d, sub):
 
 if __name__ == "__main__":
     tag, d_stats, d_f, d_w, d_sq = sys.argv[1:6]
-    out = {"what": "rocprofv3 --kernel-trace --stats and separate --pmc passes of `python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline` (per-launch averages of landing_ipm_kernel)"}
+    out = {"what": "rocprofv3 --kernel-trace --stats and separate --pmc passes of `python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-extras` (per-launch averages of landing_ipm_kernel)"}
     out["kernel_stats"] = stats(d_stats, "landing_ipm_kernel")
     per = {}
     for name, d in (("FETCH_SIZE", d_f), ("WRITE_SIZE", d_w)):
