@@ -198,7 +198,7 @@ static void init_slacks(work_t* W, const lo_solver_opts* op0) {
 }
 
 
-typedef struct { int thmin_rel, max_soc, sticky, stall, probe, trace, clip; double clip_tau, mu_init, tau_min, bpush, bfrac, mehro_lo, mehro_hi, piv_jump, piv_keep; int zinit, mehro, zcomp; double thcap, thfloor; double stall_frac; int restart_period; double kappa_eps; } lab_t;
+typedef struct { int thmin_rel, max_soc, sticky, stall, probe, trace, clip; double clip_tau, mu_init, tau_min, bpush, bfrac, mehro_lo, mehro_hi, piv_jump, piv_keep; int zinit, mehro, zcomp, crawl2; double thcap, thfloor, crawl2_frac; double stall_frac; int restart_period; double kappa_eps; } lab_t;
 static lab_t LAB;
 static void lab_init(void) {
   const char* e;
@@ -226,6 +226,8 @@ static void lab_init(void) {
   if ((e = getenv("LAB_ZCOMP"))) LAB.zcomp = atoi(e);
   if ((e = getenv("LAB_THCAP"))) LAB.thcap = atof(e);
   LAB.thfloor = 1e-3; if ((e = getenv("LAB_THFLOOR"))) LAB.thfloor = atof(e);
+  if ((e = getenv("LAB_CRAWL2"))) LAB.crawl2 = atoi(e);
+  LAB.crawl2_frac = 0.125; if ((e = getenv("LAB_CRAWL2_FRAC"))) LAB.crawl2_frac = atof(e);
   LAB.trace = getenv("LO_TRACE") != NULL;
 }
 
@@ -338,7 +340,7 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
   double mu = LAB.mu_init > 0 ? LAB.mu_init : op->mu_init, delta_last = 0.0, th_max = 0.0, e_du = 0.0;
   double filt_th[64], filt_ph[64], th_min = 1e-4, delta_used = 0.0, minpiv_last = 1e300;
   double *gx, *cres, *rbar, *csoc, *dx0, *ds0, *yn0, *dzL0, *dzU0, *rbar2, *muL, *muU; long long ncorr = 0;
-  reg_t RG; long long nsoc_total = 0, soc_acc = 0;
+  reg_t RG; long long nsoc_total = 0, soc_acc = 0; int cutstreak = 0; double thhist[32]; int nth = 0;
   const double keps = LAB.kappa_eps > 0 ? LAB.kappa_eps : op->kappa_eps;
   const int rperiod = LAB.restart_period > 0 ? LAB.restart_period : op->restart_period;
   memset(&RG, 0, sizeof(RG)); RG.fail_stage = 99;
@@ -412,9 +414,19 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
     {
       int stalled = rperiod > 0 && it - last_reset_it >= rperiod && mu >= (LAB.mu_init > 0 ? LAB.mu_init : op->mu_init) && nreset < op->max_resets && ncrawl < 1;
       if (stalled && LAB.stall == 1 && pr <= 1e-2 && du <= 1e2 * keps * mu) stalled = 0;   /* the barrier problem is about to be solved */
+      if (LAB.stall == 2) {   /* progress-based crawl test: theta must have dropped by the factor stall_frac over the last `win` iterations */
+        const int win = getenv("LAB_WIN") ? atoi(getenv("LAB_WIN")) : 20; const double fr = getenv("LAB_FRAC") ? atof(getenv("LAB_FRAC")) : 0.5;
+        const int t0 = getenv("LAB_T0") ? atoi(getenv("LAB_T0")) : 40;
+        stalled = 0;
+        if (it - last_reset_it >= t0 && nth >= win + 1 && mu >= (LAB.mu_init > 0 ? LAB.mu_init : op->mu_init) && nreset < op->max_resets && ncrawl < 1 &&
+            thhist[(nth - 1) & 31] > fr * thhist[(nth - 1 - win) & 31]) stalled = 1;
+        if (it - last_reset_it >= 100 && mu >= (LAB.mu_init > 0 ? LAB.mu_init : op->mu_init) && nreset < op->max_resets && ncrawl < 1) stalled = 1;
+      }
+      if (LAB.crawl2 > 0 && cutstreak >= LAB.crawl2 && nreset < op->max_resets && ncrawl < 1 && it - last_reset_it >= 20) stalled = 1;
       if (stalled) ncrawl++;
       if (!((du > op->reset_du && nreset < op->max_resets) || stalled || (op->reset_delta > 0.0 && delta_last > op->reset_delta && nreset < op->max_resets))) goto no_reset;
       last_reset_it = it;
+      cutstreak = 0; nth = 0;
       nreset++; init_slacks(W, op); mu = LAB.mu_init > 0 ? LAB.mu_init : op->mu_init; nfilt = 0; delta_last = 0.0; streak = 0;
       continue;
     }
@@ -588,6 +600,8 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
       if (nfilt == 64) { memmove(filt_th, filt_th + 1, 63 * sizeof(double)); memmove(filt_ph, filt_ph + 1, 63 * sizeof(double)); nfilt = 63; }
       filt_th[nfilt] = (1.0 - 1e-5) * th0; filt_ph[nfilt] = ph0 - 1e-8 * th0; nfilt++;
     }
+    if (accepted && alpha <= LAB.crawl2_frac * a_pr) cutstreak++; else cutstreak = 0;
+    thhist[nth & 31] = th0; nth++;
     if (LAB.trace) fprintf(stderr, "      alpha %9.2e a_pr %9.2e a_du %9.2e delta %8.1e acc %d armijo %d th0 %9.2e dphi %9.2e failstage %d block row %d (stage %d type %d) s-dist %g\n", alpha, a_pr, a_du, delta, accepted, armijo, th0, dphi, RG.fail_stage, (int)g_block_row, g_block_row >= 36 ? (int)((g_block_row - 36) / 104) : -1, g_block_row >= 36 ? (int)((g_block_row - 36) % 104) : (int)g_block_row, g_block_row >= 0 ? fmin(W->s[g_block_row] - W->lb[g_block_row], W->ub[g_block_row] - W->s[g_block_row]) : 0.0);
     RG.fail_stage = 99;
     memcpy(W->x, W->xt, sizeof(double) * nx);
