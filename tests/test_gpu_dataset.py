@@ -34,3 +34,25 @@ def test_batched_data_generation_roundtrip(tmp_path):
             t0 = int(out_n[-4 + leg, e]) - 1
             assert np.allclose(U[12 + 3 * leg:15 + 3 * leg, t0:], Us[12 + 3 * leg:15 + 3 * leg, t0:], atol=1e-9)
     L.close()
+
+
+def test_two_batches_in_flight_give_the_same_results():
+    """pipeline.BatchPipeline: batches streamed through two contexts / two streams return, in order, exactly what one solve
+    at a time returns (every member is solved independently; nothing is shared between the lanes)"""
+    capi, P, pl = lc("capi"), lc("problem"), lc("pipeline")
+    N, B = 40, 256
+    batches = [P.make_batch(B, N, 0.6, seed=900 + i)[:2] for i in range(5)]
+    pipe = pl.BatchPipeline(N, depth=2)
+    got = []
+    for Pb, X0 in batches:
+        r = pipe.submit(Pb, X0)
+        if r is not None:
+            got.append(r)
+    got += pipe.drain()
+    pipe.close()
+    assert [g["tag"] for g in got] == list(range(5))
+    L = capi.LandingLib(N, device=0)
+    for (Pb, X0), g in zip(batches, got):
+        ref = L.solve_host(Pb, X0)
+        assert np.array_equal(ref["x"], g["x"]) and np.array_equal(ref["status"], g["status"]) and np.array_equal(ref["iters"], g["iters"])
+    L.close()
