@@ -231,6 +231,10 @@ typedef struct {
 int landing_rbd_set_model(landing_ctx* ctx, const landing_rbd_model* model);
 int landing_fb_dynamics_batch(landing_ctx* ctx, int npts, const double* d_q, const double* d_qd, const double* d_tau, const double* d_f_foot,
                               double* d_H, double* d_C, double* d_qdd, double* d_A, double* d_Hinv, double fd_h, void* stream);
+/* leg inverse kinematics (damped Newton on the tree FK, `iters` steps, clamped to jpos_min/max[3] per leg): joint angles
+ * d_jpos [npts][12] with FK([q6; jpos]) = d_c, residual |FK - c| per leg in d_res [npts][4] (may be NULL) */
+int landing_leg_ik_batch(landing_ctx* ctx, int npts, const double* d_q6, const double* d_c, const double* jpos_min3, const double* jpos_max3,
+                         int iters, double* d_jpos, double* d_res, void* stream);
 int landing_kinodyn_rows_batch(landing_ctx* ctx, int npts, const double* d_q6, const double* d_c, const double* d_f, const double* d_jpos,
                                double* d_fk, double* d_fk_err, double* d_tau, void* stream);
 

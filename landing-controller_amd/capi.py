@@ -46,7 +46,7 @@ EXPORTS = ["landing_last_error", "landing_form_default", "landing_solver_opts_de
            "landing_bounds_batch", "landing_solve_batch", "landing_solve_batch_host", "landing_kernel_name_sweep",
            "landing_sweep_bytes_per_member", "landing_set_profile_buffer", "landing_debug_workspace",
            "landing_pack_args21", "landing_solve_args21", "landing_solve_21", "landing_riccati_gains_batch", "landing_mpc_shift", "landing_solver_opts_warm", "landing_rbd_set_model", "landing_fb_dynamics_batch",
-           "landing_kinodyn_rows_batch"]
+           "landing_kinodyn_rows_batch", "landing_leg_ik_batch"]
 
 
 def load(path=None):

@@ -298,4 +298,74 @@ __global__ void __launch_bounds__(64) landing_kinodyn_rows_kernel(KdArgs a) {
   }
 }
 
+
+// Leg inverse kinematics for the kinodynamic screen: joint angles of every leg such that FK([q6; jpos]) = c (the foot positions of an
+// SRBM solution), by damped Newton steps on the tree FK with a central-difference 3 x 3 Jacobian, clamped to the joint limits of
+// landing_optimization.m:246-247 (the reference seeds its kinodynamic NLP the same way, through quadInverseKinematics / fsolve,
+// misc/inverse_kinematics.m:2).  One thread per (point, leg); res = |FK - c| after the last step.
+struct IkArgs { const RbdModel* model; int npts; const double* q6; const double* c; double* jpos; double* res; int iters; double jmin[3], jmax[3]; };
+__device__ __forceinline__ V3d leg_fk(const RbdModel& M, const double* E0, const double* r0, int leg, const double* q3) {
+  double El[9], rl[3], E[9], r[3];
+  for (int j = 0; j < 9; ++j) El[j] = E0[j];
+  for (int j = 0; j < 3; ++j) rl[j] = r0[j];
+  const int jb = M.b_foot[leg] - 1;
+  for (int i = jb - 2; i <= jb; ++i) {
+    joint_xform(M.jtype[i], q3[i - (jb - 2)], M.E[i], M.r[i], E, r);
+    const V3d t = mulT3(El, mk3(r[0], r[1], r[2]));
+    double En[9];
+    for (int x = 0; x < 3; ++x) for (int y = 0; y < 3; ++y) En[3 * x + y] = E[3 * x] * El[y] + E[3 * x + 1] * El[3 + y] + E[3 * x + 2] * El[6 + y];
+    for (int j = 0; j < 9; ++j) El[j] = En[j];
+    rl[0] += t.x; rl[1] += t.y; rl[2] += t.z;
+  }
+  return add3(mk3(rl[0], rl[1], rl[2]), mulT3(El, mk3(M.foot_r[leg][0], M.foot_r[leg][1], M.foot_r[leg][2])));
+}
+__global__ void __launch_bounds__(64) landing_leg_ik_kernel(IkArgs a) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int pt = idx >> 2, leg = idx & 3;
+  if (pt >= a.npts) return;
+  const RbdModel& M = *a.model;
+  const double* q6 = a.q6 + (size_t)pt * 6;
+  double E0[9], r0[3], E[9], r[3];
+  for (int j = 0; j < 9; ++j) E0[j] = (j % 4 == 0) ? 1.0 : 0.0;
+  r0[0] = r0[1] = r0[2] = 0.0;
+  for (int i = 0; i < 6; ++i) {
+    joint_xform(M.jtype[i], q6[i], M.E[i], M.r[i], E, r);
+    const V3d t = mulT3(E0, mk3(r[0], r[1], r[2]));
+    double En[9];
+    for (int x = 0; x < 3; ++x) for (int y = 0; y < 3; ++y) En[3 * x + y] = E[3 * x] * E0[y] + E[3 * x + 1] * E0[3 + y] + E[3 * x + 2] * E0[6 + y];
+    for (int j = 0; j < 9; ++j) E0[j] = En[j];
+    r0[0] += t.x; r0[1] += t.y; r0[2] += t.z;
+  }
+  const V3d target = mk3(a.c[(size_t)pt * 12 + 3 * leg], a.c[(size_t)pt * 12 + 3 * leg + 1], a.c[(size_t)pt * 12 + 3 * leg + 2]);
+  double q[3] = {0.0, -0.8, 1.6};
+  double err = 0.0;
+  for (int it = 0; it <= a.iters; ++it) {
+    const V3d e = sub3(leg_fk(M, E0, r0, leg, q), target);
+    err = sqrt(e.x * e.x + e.y * e.y + e.z * e.z);
+    if (it == a.iters || err < 1e-13) break;
+    double J[3][3];
+    const double h = 1e-6;
+    for (int j = 0; j < 3; ++j) {
+      const double qj = q[j];
+      q[j] = qj + h; const V3d fp = leg_fk(M, E0, r0, leg, q);
+      q[j] = qj - h; const V3d fm = leg_fk(M, E0, r0, leg, q);
+      q[j] = qj;
+      J[0][j] = (fp.x - fm.x) / (2 * h); J[1][j] = (fp.y - fm.y) / (2 * h); J[2][j] = (fp.z - fm.z) / (2 * h);
+    }
+    // dq = -(J'J + lam 1)^-1 J' e  (Levenberg damping keeps the step finite at the stretched-knee singularity)
+    double A[3][3], b[3];
+    const double ev[3] = {e.x, e.y, e.z};
+    for (int x = 0; x < 3; ++x) { b[x] = 0.0; for (int y = 0; y < 3; ++y) { A[x][y] = (x == y ? 1e-9 : 0.0); for (int t = 0; t < 3; ++t) A[x][y] += J[t][x] * J[t][y]; } for (int t = 0; t < 3; ++t) b[x] += J[t][x] * ev[t]; }
+    const double det = A[0][0] * (A[1][1] * A[2][2] - A[1][2] * A[2][1]) - A[0][1] * (A[1][0] * A[2][2] - A[1][2] * A[2][0]) + A[0][2] * (A[1][0] * A[2][1] - A[1][1] * A[2][0]);
+    if (!(fabs(det) > 0.0)) break;
+    const double dq0 = (b[0] * (A[1][1] * A[2][2] - A[1][2] * A[2][1]) - A[0][1] * (b[1] * A[2][2] - A[1][2] * b[2]) + A[0][2] * (b[1] * A[2][1] - A[1][1] * b[2])) / det;
+    const double dq1 = (A[0][0] * (b[1] * A[2][2] - A[1][2] * b[2]) - b[0] * (A[1][0] * A[2][2] - A[1][2] * A[2][0]) + A[0][2] * (A[1][0] * b[2] - b[1] * A[2][0])) / det;
+    const double dq2 = (A[0][0] * (A[1][1] * b[2] - b[1] * A[2][1]) - A[0][1] * (A[1][0] * b[2] - b[1] * A[2][0]) + b[0] * (A[1][0] * A[2][1] - A[1][1] * A[2][0])) / det;
+    const double dq[3] = {dq0, dq1, dq2};
+    for (int j = 0; j < 3; ++j) { const double step = fmax(-0.5, fmin(0.5, dq[j])); q[j] = fmax(a.jmin[j], fmin(a.jmax[j], q[j] - step)); }
+  }
+  for (int j = 0; j < 3; ++j) a.jpos[(size_t)pt * 12 + 3 * leg + j] = q[j];
+  if (a.res) a.res[(size_t)pt * 4 + leg] = err;
+}
+
 }  // namespace landing

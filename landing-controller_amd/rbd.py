@@ -74,6 +74,8 @@ class Rbd:
         lib.lib.landing_rbd_set_model.argtypes = [vp, C.POINTER(RbdModel)]
         lib.lib.landing_fb_dynamics_batch.argtypes = [vp, C.c_int] + [vp] * 9 + [C.c_double, vp]
         lib.lib.landing_kinodyn_rows_batch.argtypes = [vp, C.c_int] + [vp] * 7 + [vp]
+        dp = C.POINTER(C.c_double)
+        lib.lib.landing_leg_ik_batch.argtypes = [vp, C.c_int, vp, vp, dp, dp, C.c_int, vp, vp, vp]
         self.model = quad3d_model()
         lib._check(lib.lib.landing_rbd_set_model(lib.ctx, C.byref(self.model)), "landing_rbd_set_model")
 
@@ -85,3 +87,25 @@ class Rbd:
     def kinodyn_rows(self, npts, d_q6, d_c, d_f, d_jpos, d_fk=0, d_fk_err=0, d_tau=0, stream=0):
         n = lambda v: v or None
         self.L._check(self.L.lib.landing_kinodyn_rows_batch(self.L.ctx, npts, d_q6, n(d_c), n(d_f), d_jpos, n(d_fk), n(d_fk_err), n(d_tau), n(stream)), "landing_kinodyn_rows_batch")
+
+    def leg_ik(self, npts, d_q6, d_c, d_jpos, d_res=0, iters=12, jmin=None, jmax=None, stream=0):
+        jmin = np.ascontiguousarray(JPOS_MIN[:3] if jmin is None else jmin, float); jmax = np.ascontiguousarray(JPOS_MAX[:3] if jmax is None else jmax, float)
+        dp = C.POINTER(C.c_double)
+        self.L._check(self.L.lib.landing_leg_ik_batch(self.L.ctx, npts, d_q6, d_c, jmin.ctypes.data_as(dp), jmax.ctypes.data_as(dp), iters, d_jpos, d_res or None, stream or None),
+                      "landing_leg_ik_batch")
+
+    def kinodynamic_screen(self, N, x_star, kin_tol=0.01):
+        """SRBM solutions x* [B, nx] (device tensor) -> per member: worst FK residual after IK, worst torque ratio |tau| / tau_max and
+        whether every stage satisfies the FK band and the torque limits of landing_optimization.m:165-171,186-187"""
+        import torch
+        B = x_star.shape[0]; nX = 12 * (N + 1); n = B * N
+        X = x_star[:, :nX].reshape(B, N + 1, 12); U = x_star[:, nX:].reshape(B, N, 24)
+        q6 = X[:, :N, :6].reshape(n, 6).contiguous(); c = U[:, :, :12].reshape(n, 12).contiguous(); f = U[:, :, 12:].reshape(n, 12).contiguous()
+        mk = lambda *s: torch.zeros(*s, device=x_star.device, dtype=torch.float64)
+        jp, res, tau, err = mk(n, 12), mk(n, 4), mk(n, 12), mk(n, 12)
+        st = torch.cuda.current_stream().cuda_stream
+        self.leg_ik(n, q6.data_ptr(), c.data_ptr(), jp.data_ptr(), res.data_ptr(), stream=st)
+        self.kinodyn_rows(n, q6.data_ptr(), c.data_ptr(), f.data_ptr(), jp.data_ptr(), 0, err.data_ptr(), tau.data_ptr(), stream=st)
+        ratio = (tau.abs() / torch.as_tensor(TAU_MAX, device=x_star.device)).reshape(B, N * 12).max(dim=1).values
+        fk_bad = err.abs().reshape(B, N * 12).max(dim=1).values
+        return dict(jpos=jp.reshape(B, N, 12), fk_err_max=fk_bad, torque_ratio_max=ratio, feasible=(fk_bad <= kin_tol) & (ratio <= 1.0))

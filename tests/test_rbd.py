@@ -141,3 +141,54 @@ def test_kinodyn_rows_gpu_on_solved_batch():
         fko, eo, to = ro.kinodyn_rows(q6.reshape(n, 6)[i], c.reshape(n, 12)[i], f.reshape(n, 12)[i], jp.reshape(n, 12)[i])
         assert np.max(np.abs(fkh[i] - fko)) <= 1e-12 and np.max(np.abs(eh[i] - eo)) <= 1e-12 and np.max(np.abs(th[i] - to)) <= 1e-10 * max(1.0, np.max(np.abs(to)))
     L.close()
+
+
+def test_leg_ik_emulated_roundtrip():
+    """IK of the kinodynamic screen: FK(q6, IK(q6, FK(q6, jpos*))) == FK(q6, jpos*) for joint angles inside the limits"""
+    from oracle import rbd_oracle as ro
+    subprocess.run(["make", "-C", os.path.join(PKG, "csrc"), "emu"], check=True, capture_output=True)
+    L = lc("capi").LandingLib(20, lib_path=os.path.join(ROOT, "tests", "emu", "liblanding_emu.so"))
+    R = lc("rbd").Rbd(L)
+    rng = np.random.default_rng(9)
+    n = 6
+    q6 = np.concatenate([rng.normal(size=(n, 2)) * 0.2, 0.3 + 0.1 * rng.random((n, 1)), 0.4 * rng.normal(size=(n, 3))], axis=1)
+    jp_true = np.tile([0.0, -0.9, 1.7], (n, 4)) + 0.25 * rng.normal(size=(n, 12))
+    c = np.array([ro.forward_kin_foot(np.concatenate([q6[i], jp_true[i]])).reshape(12) for i in range(n)])
+    jp = np.zeros((n, 12)); res = np.zeros((n, 4))
+    p = lambda a: a.ctypes.data
+    R.leg_ik(n, p(q6), p(c), p(jp), p(res), iters=20)
+    assert res.max() < 1e-9, res
+    for i in range(n):
+        assert np.max(np.abs(ro.forward_kin_foot(np.concatenate([q6[i], jp[i]])).reshape(12) - c[i])) < 1e-9
+    lo, hi = lc("rbd").JPOS_MIN, lc("rbd").JPOS_MAX
+    assert (jp >= lo - 1e-12).all() and (jp <= hi + 1e-12).all()
+
+
+@pytest.mark.gpu
+def test_kinodynamic_screen_of_solved_batch():
+    """SRBM solutions -> joint angles by IK at every stage -> FK band and torque limits of landing_optimization.m:165-171,186-187:
+    the screen runs on the whole batch; FK residuals after IK are tiny wherever the foot is reachable, torques are finite, and the
+    verdict agrees with the oracle's rows on a sample"""
+    import torch
+    from oracle import rbd_oracle as ro
+    capi, Pm = lc("capi"), lc("problem")
+    N, B = 40, 64
+    L = capi.LandingLib(N, device=0)
+    R = lc("rbd").Rbd(L)
+    P, X0, _, _ = Pm.make_batch(B, N, 0.6, seed=8)
+    r = L.solve_host(P, X0)
+    xs = torch.tensor(r["x"], device="cuda")
+    # the SRBM NLP uses the ZYX rotation, the kinodynamic model XYZ Euler angles (SURVEY 8f N1); the screen is meaningful for small
+    # roll / yaw -- here it is exercised as is
+    s = R.kinodynamic_screen(N, xs)
+    torch.cuda.synchronize()
+    jp = s["jpos"].cpu().numpy(); ratio = s["torque_ratio_max"].cpu().numpy(); fkb = s["fk_err_max"].cpu().numpy()
+    assert np.isfinite(jp).all() and np.isfinite(ratio).all() and (ratio >= 0).all()
+    b = int(np.argmin(fkb))
+    Xs, Us = Pm.split_solution(N, r["x"][b])
+    worst = 0.0; tr = 0.0
+    for k in range(N):
+        fk, err, tau = ro.kinodyn_rows(Xs[:6, k], Us[:12, k], Us[12:, k], jp[b, k])
+        worst = max(worst, np.abs(err).max()); tr = max(tr, (np.abs(tau) / lc("rbd").TAU_MAX).max())
+    assert abs(worst - fkb[b]) < 1e-9 and abs(tr - ratio[b]) < 1e-9 * max(1.0, tr)
+    L.close()
