@@ -59,8 +59,9 @@ typedef struct {
    * (generate_landingCtrller_IPOPT.m:83-87, the default):
    *   sum_k dt_k ( |X_k - Xref_k|^2_QX + sum_legs |pos_k + p_hip - c_k|^2_Qc + sum_legs |f_k - f_ref|^2_Qf )
    * QX, Qc, Qf are parameters of that script whose callers pass constants; here they are constants of the context.
-   * Supported by landing_solve_batch and by f / grad_f of landing_eval_batch; the Hessian nonzeros of
-   * landing_eval_batch keep the CCS pattern of the terminal-cost NLP and are refused with a running cost. */
+   * Supported by landing_solve_batch and by every output of landing_eval_batch except d_hess: the running cost adds
+   * diagonal entries that casadi_s4 does not hold, so its Hessian is returned by landing_eval_hess_rc_batch in the
+   * extended pattern of landing_pattern_hess_rc. */
   int run_cost;
   double QX[12], Qc[3], Qf[3];
   double f_ref[3];    /* Uref(13:24,k) = f_ref per leg in the callers (test_loadCasadi_ws.m:68-72) */
@@ -137,6 +138,16 @@ int landing_eval_batch(landing_ctx* ctx, int B, const double* d_x, const double*
                        const double* d_lam_f, const double* d_lam_g,
                        double* d_f, double* d_g, double* d_grad_f, double* d_jac, double* d_hess,
                        double* d_grad_gamma_x, double* d_grad_gamma_p, void* stream);
+/* Hessian of the Lagrangian of the running-cost formulation (form.run_cost = 1; generate_quadruped_SRBM_CCC.m:81-99, for
+ * which the reference ships no generated C and hence no CCS pattern).  Pattern: casadi_s4 plus the 18 N diagonal entries
+ * (omega, omega), (v, v) of X_0..X_{N-1} and (f, f) of every stage -- upper triangular CCS, rows sorted inside a column.
+ * d_hess_rc: [B][landing_nnz_hess_rc(N)].  With run_cost = 0 the extra entries are zero.                                   */
+long long landing_nnz_hess_rc(int N);
+int landing_pattern_hess_rc(int N, long long* colind, long long* row);
+int landing_eval_hess_rc_batch(landing_ctx* ctx, int B, const double* d_x, const double* d_p, const double* d_lam_f,
+                               const double* d_lam_g, double* d_hess_rc, void* stream);
+int landing_eval_hess_rc_batch_host(landing_ctx* ctx, int B, const double* x, const double* p, const double* lam_f,
+                                    const double* lam_g, double* hess_rc);
 /* same, host pointers (copies in and out; used by the CasADi drop-in library) */
 int landing_eval_batch_host(landing_ctx* ctx, int B, const double* x, const double* p,
                             const double* lam_f, const double* lam_g,

@@ -46,7 +46,8 @@ EXPORTS = ["landing_last_error", "landing_form_default", "landing_solver_opts_de
            "landing_bounds_batch", "landing_solve_batch", "landing_solve_batch_host", "landing_kernel_name_sweep",
            "landing_sweep_bytes_per_member", "landing_set_profile_buffer", "landing_debug_workspace",
            "landing_pack_args21", "landing_solve_args21", "landing_solve_21", "landing_riccati_gains_batch", "landing_mpc_shift", "landing_solver_opts_warm", "landing_rbd_set_model", "landing_fb_dynamics_batch",
-           "landing_kinodyn_rows_batch", "landing_leg_ik_batch"]
+           "landing_kinodyn_rows_batch", "landing_leg_ik_batch", "landing_nnz_hess_rc", "landing_pattern_hess_rc",
+           "landing_eval_hess_rc_batch", "landing_eval_hess_rc_batch_host"]
 
 
 def load(path=None):
@@ -72,6 +73,11 @@ def load(path=None):
     lib.landing_eval_batch.argtypes = [vp, C.c_int] + [vp] * 11 + [vp]
     lib.landing_eval_batch_host.argtypes = [vp, C.c_int] + [_dp] * 11
     lib.landing_bounds_batch.argtypes = [vp, C.c_int, vp, vp, vp, vp]
+    if hasattr(lib, "landing_eval_hess_rc_batch"):
+        lib.landing_nnz_hess_rc.restype = C.c_longlong; lib.landing_nnz_hess_rc.argtypes = [C.c_int]
+        lib.landing_pattern_hess_rc.argtypes = [C.c_int, _llp, _llp]
+        lib.landing_eval_hess_rc_batch.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp]
+        lib.landing_eval_hess_rc_batch_host.argtypes = [vp, C.c_int, _dp, _dp, _dp, _dp, _dp]
     lib.landing_solve_batch.argtypes = [vp, C.c_int, vp, vp, C.POINTER(SolverOpts), vp, vp, vp, vp, vp, vp, vp]
     lib.landing_set_profile_buffer.argtypes = [vp, vp]
     lib.landing_solve_batch_host.argtypes = [vp, C.c_int, _dp, _dp, C.POINTER(SolverOpts), _dp, _dp, _dp, _ip, _ip, _dp]
@@ -166,6 +172,21 @@ class LandingLib:
         ci = np.zeros(self.nx + 1, np.int64); r = np.zeros(self.nnz_hess, np.int64)
         self._check(self.lib.landing_pattern_hess(self.N, ci.ctypes.data_as(_llp), r.ctypes.data_as(_llp)), "pattern_hess")
         return ci, r
+
+    def pattern_hess_rc(self):
+        """pattern of the Lagrangian Hessian of the running-cost formulation: casadi_s4 + 18 N diagonals"""
+        n = self.lib.landing_nnz_hess_rc(self.N)
+        ci = np.zeros(self.nx + 1, np.int64); r = np.zeros(n, np.int64)
+        self._check(self.lib.landing_pattern_hess_rc(self.N, ci.ctypes.data_as(_llp), r.ctypes.data_as(_llp)), "pattern_hess_rc")
+        return ci, r
+
+    def hess_rc_host(self, x, p, lam_f, lam_g):
+        x = np.ascontiguousarray(np.atleast_2d(x), float); p = np.ascontiguousarray(np.atleast_2d(p), float)
+        lam_g = np.ascontiguousarray(np.atleast_2d(lam_g), float)
+        lam_f = None if lam_f is None else np.ascontiguousarray(np.atleast_1d(lam_f), float)
+        h = np.full((x.shape[0], self.lib.landing_nnz_hess_rc(self.N)), np.nan)
+        self._check(self.lib.landing_eval_hess_rc_batch_host(self.ctx, x.shape[0], _p(x), _p(p), _p(lam_f), _p(lam_g), _p(h)), "landing_eval_hess_rc_batch_host")
+        return h
 
     # ---- host-pointer entry points (numpy in / numpy out) --------------------------------------
     def eval_host(self, x, p, lam_f=None, lam_g=None, want=("f", "g", "grad_f", "jac", "hess", "grad_gamma_x", "grad_gamma_p")):

@@ -41,6 +41,8 @@ struct landing_ctx {
   double* d_prof = nullptr;
   double* d_vbl = nullptr;
   landing::RbdModel* d_rbd = nullptr;     // uploaded by landing_rbd_set_model
+  int2* d_rc_map = nullptr;               // landing_eval_hess_rc_batch: source nonzero + running-cost code of every entry of the extended pattern
+  double* d_h4 = nullptr; size_t h4_cap = 0;   // ... and its scratch for the casadi_s4-pattern nonzeros
   // function layer: the Jacobian, Hessian and residual kernels of one landing_eval_batch call are independent; for large
   // batches they run on two auxiliary streams forked from / joined to the caller's stream so that their ramps and tails overlap
   hipStream_t aux[2] = {nullptr, nullptr};
@@ -174,6 +176,30 @@ int landing_pattern_hess(int N, long long* colind, long long* row) {
   return 0;
 }
 
+long long landing_nnz_hess_rc(int N) { return landing_nnz_hess(N) + 18LL * N; }
+
+// casadi_s4 plus the diagonals the running cost touches and s4 lacks: (omega, omega), (v, v) of X_0..X_{N-1} and (f, f) of every stage
+static bool rc_extra_diag(const Layout& L, long long col) {
+  if (col < L.x_X(L.N)) return (col % 12) >= 6;
+  if (col >= L.x_U(0)) return ((col - L.x_U(0)) % 24) >= 12;
+  return false;
+}
+int landing_pattern_hess_rc(int N, long long* colind, long long* row) {
+  if (N < 2 || !colind || !row) return fail(LANDING_E_ARG, "landing_pattern_hess_rc: bad argument");
+  const Layout L = landing::make_layout(N);
+  std::vector<long long> c4(L.nx + 1), r4(L.nnz_hess);
+  if (int e = landing_pattern_hess(N, c4.data(), r4.data())) return e;
+  long long n = 0;
+  for (long long c = 0; c < L.nx; ++c) {
+    colind[c] = n;
+    n = std::copy(r4.begin() + c4[c], r4.begin() + c4[c + 1], row + n) - row;
+    if (rc_extra_diag(L, c)) row[n++] = c;        // a diagonal: the largest row of an upper-triangular column
+  }
+  colind[L.nx] = n;
+  if (n != landing_nnz_hess_rc(N)) return fail(LANDING_E_ARG, "internal: hess_rc pattern size");
+  return 0;
+}
+
 // ---- context ----------------------------------------------------------------------------------
 landing_ctx* landing_create(int N, int device, const landing_form* form) {
   if (N < 2 || N > 256) { fail(LANDING_E_ARG, "landing_create: N must be in [2,256]"); return nullptr; }
@@ -224,6 +250,8 @@ void landing_destroy(landing_ctx* ctx) {
   if (ctx->d_edge_map) (void)hipFree(ctx->d_edge_map);
   if (ctx->d_vbl) (void)hipFree(ctx->d_vbl);
   if (ctx->d_rbd) (void)hipFree(ctx->d_rbd);
+  if (ctx->d_rc_map) (void)hipFree(ctx->d_rc_map);
+  if (ctx->d_h4) (void)hipFree(ctx->d_h4);
   for (int i = 0; i < 2; ++i) { if (ctx->aux[i]) (void)hipStreamDestroy(ctx->aux[i]); if (ctx->ev_join[i]) (void)hipEventDestroy(ctx->ev_join[i]); }
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
   delete ctx;
@@ -236,7 +264,7 @@ int landing_eval_batch(landing_ctx* ctx, int B, const double* d_x, const double*
   if (ctx && B == 0) return 0;          // empty batch: nothing to do
   if (!ctx || B < 0 || !d_x || !d_p) return fail(LANDING_E_ARG, "landing_eval_batch: bad argument");
   if ((d_hess || d_ggx || d_ggp) && !d_lam_g) return fail(LANDING_E_ARG, "landing_eval_batch: lam_g required for hess/grad_gamma");
-  if (ctx->L.run_cost && (d_hess || d_ggx || d_ggp)) return fail(LANDING_E_ARG, "landing_eval_batch: hess / grad_gamma are not provided with a running cost (CCS pattern of the terminal-cost NLP)");
+  if (ctx->L.run_cost && d_hess) return fail(LANDING_E_ARG, "landing_eval_batch: with a running cost the Hessian does not fit the CCS pattern of the terminal-cost NLP; use landing_eval_hess_rc_batch");
   HIP_TRY(hipSetDevice(ctx->device));
   landing::EvalArgs A{d_x, d_p, d_lam_f, d_lam_g, d_f, d_g, d_grad_f, d_jac, d_hess, d_ggx, d_ggp, ctx->d_edge_map, d_g ? 1 : 0};
   if (ctx->L.N < 3) return fail(LANDING_E_ARG, "landing_eval_batch: N >= 3 required");
@@ -262,6 +290,57 @@ int landing_eval_batch(landing_ctx* ctx, int B, const double* d_x, const double*
     HIP_TRY(hipEventRecord(ctx->ev_join[0], sj)); HIP_TRY(hipEventRecord(ctx->ev_join[1], sh));
     HIP_TRY(hipStreamWaitEvent(s0, ctx->ev_join[0], 0)); HIP_TRY(hipStreamWaitEvent(s0, ctx->ev_join[1], 0));
   }
+  return 0;
+}
+
+// Hessian of the Lagrangian including the running cost, nonzeros in the pattern of landing_pattern_hess_rc
+int landing_eval_hess_rc_batch(landing_ctx* ctx, int B, const double* d_x, const double* d_p, const double* d_lam_f,
+                               const double* d_lam_g, double* d_hess_rc, void* stream) {
+  if (ctx && B == 0) return 0;
+  if (!ctx || B < 0 || !d_x || !d_p || !d_lam_g || !d_hess_rc) return fail(LANDING_E_ARG, "landing_eval_hess_rc_batch: bad argument");
+  if (ctx->L.N < 3) return fail(LANDING_E_ARG, "landing_eval_hess_rc_batch: N >= 3 required");
+  HIP_TRY(hipSetDevice(ctx->device));
+  const Layout& L = ctx->L;
+  const int nrc = (int)landing_nnz_hess_rc(L.N);
+  std::lock_guard<std::mutex> lock(ctx->mu);      // the scratch belongs to the context
+  if (!ctx->d_rc_map) {
+    std::vector<long long> c4(L.nx + 1), r4(L.nnz_hess), cr(L.nx + 1), rr(nrc);
+    if (int e = landing_pattern_hess(L.N, c4.data(), r4.data())) return e;
+    if (int e = landing_pattern_hess_rc(L.N, cr.data(), rr.data())) return e;
+    std::vector<int2> map(nrc);
+    for (long long c = 0; c < L.nx; ++c) {
+      long long i4 = c4[c];
+      for (long long j = cr[c]; j < cr[c + 1]; ++j) {
+        const long long r = rr[j];
+        int src = -1, code = 0;
+        if (i4 < c4[c + 1] && r4[i4] == r) src = (int)i4++;
+        // which running-cost term lands on (r, c)?
+        if (r == c && c < L.x_X(L.N)) code = 1 | (int)(c % 12) << 4 | (int)(c / 12) << 8;
+        else if (c >= L.x_U(0)) {
+          const int k = (int)((c - L.x_U(0)) / 24), u = (int)((c - L.x_U(0)) % 24), a = u % 3;
+          if (r == c) code = (u < 12 ? 3 : 4) | a << 4 | k << 8;
+          else if (u < 12 && r == L.x_X(k) + a) code = 2 | a << 4 | k << 8;
+        }
+        map[j] = make_int2(src, code);
+      }
+      if (i4 != c4[c + 1]) return fail(LANDING_E_ARG, "internal: hess_rc pattern does not contain casadi_s4");
+    }
+    HIP_TRY(hipMalloc((void**)&ctx->d_rc_map, sizeof(int2) * (size_t)nrc));
+    HIP_TRY(hipMemcpy(ctx->d_rc_map, map.data(), sizeof(int2) * (size_t)nrc, hipMemcpyHostToDevice));
+  }
+  const size_t need = (size_t)B * L.nnz_hess;
+  if (ctx->h4_cap < need) {
+    if (ctx->d_h4) HIP_TRY(hipFree(ctx->d_h4));      // hipFree waits for the device: no launch still reads the old block
+    ctx->d_h4 = nullptr; ctx->h4_cap = 0;
+    HIP_TRY(hipMalloc((void**)&ctx->d_h4, need * sizeof(double)));
+    ctx->h4_cap = need;
+  }
+  hipStream_t s0 = (hipStream_t)stream;
+  landing::EvalArgs A{d_x, d_p, d_lam_f, d_lam_g, nullptr, nullptr, nullptr, nullptr, ctx->d_h4, nullptr, nullptr, ctx->d_edge_map, 0};
+  hipLaunchKernelGGL(landing::landing_sweep_kernel<1>, dim3(B), dim3(64), 0, s0, L, B, A);
+  hipLaunchKernelGGL(landing::landing_sweep_misc_kernel, dim3(B), dim3(64), 0, s0, L, B, A);     // terminal-cost block of the Hessian
+  hipLaunchKernelGGL(landing::landing_hess_rc_kernel, dim3((nrc + 255) / 256, B), dim3(256), 0, s0, L, B, nrc, ctx->d_rc_map, ctx->d_h4, d_p, d_lam_f, d_hess_rc);
+  HIP_TRY(hipGetLastError());
   return 0;
 }
 
@@ -303,6 +382,24 @@ int landing_eval_batch_host(landing_ctx* ctx, int B, const double* x, const doub
   if (hess) HIP_TRY(hipMemcpy(hess, dh.p, b * L.nnz_hess * 8, hipMemcpyDeviceToHost));
   if (ggx) HIP_TRY(hipMemcpy(ggx, dgx.p, b * L.nx * 8, hipMemcpyDeviceToHost));
   if (ggp) HIP_TRY(hipMemcpy(ggp, dgp.p, b * L.np * 8, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int landing_eval_hess_rc_batch_host(landing_ctx* ctx, int B, const double* x, const double* p, const double* lam_f,
+                                    const double* lam_g, double* hess_rc) {
+  if (!ctx || B <= 0 || !x || !p || !lam_g || !hess_rc) return fail(LANDING_E_ARG, "landing_eval_hess_rc_batch_host: bad argument");
+  const Layout& L = ctx->L;
+  HIP_TRY(hipSetDevice(ctx->device));
+  DevBuf dx, dp, dlf, dlg, dh;
+  const size_t b = (size_t)B, nrc = (size_t)landing_nnz_hess_rc(L.N);
+  HIP_TRY(dx.alloc(b * L.nx)); HIP_TRY(dp.alloc(b * L.np)); HIP_TRY(dlg.alloc(b * L.ng)); HIP_TRY(dh.alloc(b * nrc));
+  HIP_TRY(hipMemcpy(dx.p, x, b * L.nx * 8, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(dp.p, p, b * L.np * 8, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(dlg.p, lam_g, b * L.ng * 8, hipMemcpyHostToDevice));
+  if (lam_f) { HIP_TRY(dlf.alloc(b)); HIP_TRY(hipMemcpy(dlf.p, lam_f, b * 8, hipMemcpyHostToDevice)); }
+  if (int rc = landing_eval_hess_rc_batch(ctx, B, dx.p, dp.p, dlf.p, dlg.p, dh.p, nullptr)) return rc;
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(hess_rc, dh.p, b * nrc * 8, hipMemcpyDeviceToHost));
   return 0;
 }
 

@@ -288,6 +288,22 @@ __global__ void __launch_bounds__(64) landing_sweep_misc_kernel(Layout L, int B,
       for (int i = 1; i < 9; ++i) gp_acc[i] += o[i];
     }
   }
+  if (L.run_cost && A.ggx && lam_g) {   // lam_f * gradient of the running cost; stage k owns X_k and U_k (CCC :81-89)
+    __syncthreads();                   // the J^T lam sums above also write X_{k+1} of the neighbouring lane
+    double* gx = A.ggx + (size_t)m * L.nx;
+    for (int k = threadIdx.x; k < N; k += blockDim.x) {
+      double gX[12], gU[24];
+      for (int i = 0; i < 12; ++i) gX[i] = 0.0;
+      for (int i = 0; i < 24; ++i) gU[i] = 0.0;
+      (void)run_cost_stage(L, x, p, k, gX, gU, gU + 12);
+      for (int i = 0; i < 12; ++i) gx[L.x_X(k) + i] += lam_f * gX[i];
+      for (int i = 0; i < 24; ++i) gx[L.x_U(k) + i] += lam_f * gU[i];
+    }
+  }
+  if (L.run_cost && A.ggp && lam_g) {   // d/d dt_k of the running cost (the stage loop above wrote the constraint part)
+    for (int k = threadIdx.x; k < N; k += blockDim.x)
+      A.ggp[(size_t)m * L.np + L.o_dt + k] += lam_f * run_cost_stage(L, x, p, k, nullptr, nullptr, nullptr) / p[L.o_dt + k];
+  }
   if (A.ggp && lam_g) {   // uniform branch: reduce the shared-parameter sums over stages
     for (int i = 0; i < 9; ++i) red[threadIdx.x][i] = gp_acc[i];
     __syncthreads();
@@ -302,9 +318,29 @@ __global__ void __launch_bounds__(64) landing_sweep_misc_kernel(Layout L, int B,
       if (slot >= 0) { for (int t = 0; t < (int)blockDim.x; ++t) v += red[t][slot]; }
       else if (i >= 12 * N && i < 12 * N + 12) { const int t = i - 12 * N; v = -2.0 * lam_f * p[L.o_QN + t] * (x[12 * N + t] - p[12 * N + t]); }
       else if (i >= L.o_QN && i < L.o_QN + 12) { const int t = i - L.o_QN; const double d = x[12 * N + t] - p[12 * N + t]; v = lam_f * d * d; }
+      else if (L.run_cost && i < 12 * N) { const int k = i / 12; v = -2.0 * lam_f * p[L.o_dt + k] * L.QX[i - 12 * k] * (x[i] - p[i]); }   // Xref_k
       gp[i] = v;
     }
   }
+}
+
+// Hessian of the Lagrangian with the running cost, in the extended pattern (landing_pattern_hess_rc): entry j takes nonzero
+// map[j].x of the casadi_s4-pattern Hessian (or nothing) plus the constant second derivative of the running cost that
+// map[j].y encodes -- kind | axis << 4 | stage << 8, kind 1: QX[a] (+ 4 Qc[a] on pos), 2: -Qc[a], 3: Qc[a], 4: Qf[a] -- times
+// 2 lam_f dt_k (generate_quadruped_SRBM_CCC.m:81-89).
+__global__ void __launch_bounds__(256) landing_hess_rc_kernel(Layout L, int B, int nnz_rc, const int2* __restrict__ map, const double* __restrict__ h4,
+                                                              const double* __restrict__ p, const double* __restrict__ lam_f, double* __restrict__ out) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x, m = blockIdx.y;
+  if (j >= nnz_rc || m >= B) return;
+  const int2 e = map[j];
+  double v = e.x >= 0 ? h4[(size_t)m * L.nnz_hess + e.x] : 0.0;
+  const int kind = e.y & 15;
+  if (kind && L.run_cost) {
+    const int a = (e.y >> 4) & 15, k = e.y >> 8;
+    const double w = kind == 1 ? L.QX[a] + (a < 3 ? 4.0 * L.Qc[a] : 0.0) : kind == 2 ? -L.Qc[a] : kind == 3 ? L.Qc[a] : L.Qf[a];
+    v += 2.0 * (lam_f ? lam_f[m] : 1.0) * p[(size_t)m * L.np + L.o_dt + k] * w;
+  }
+  out[(size_t)m * nnz_rc + j] = v;
 }
 
 // ---- member-level device functions shared with the solver kernel (lane = stage) -------------------

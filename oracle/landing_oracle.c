@@ -634,6 +634,57 @@ void lo_nlp_hess_l(const lo_form* F, const double* x, const double* p, double la
   free(colind); free(row);
 }
 
+/* ---- Hessian of the Lagrangian WITH the running cost of the N=41 script (generate_quadruped_SRBM_CCC.m:81-89).  No generated C
+ * of that script exists in the reference, so the CCS pattern is this project's: casadi_s4 (landingCtrller_IPOPT.c:63) plus the
+ * diagonal entries the quadratic running cost adds and s4 lacks -- (omega, omega), (v, v), (f, f) of every stage:
+ * 18 more per stage.  The other running-cost entries -- (pos, pos), (rpy, rpy), (pos_a, c_leg_a), (c, c) -- are already
+ * structural nonzeros of s4.  Upper triangular, rows sorted inside a column (the new entries are diagonals: last in their column). */
+lo_int lo_nnz_hess_rc(int N) { return lo_nnz_hess(N) + 18 * (lo_int)N; }
+static int rc_new_diag(int N, lo_int c) {          /* is (c, c) one of the 18 N added diagonals? */
+  const lo_int nX = 12 * (lo_int)(N + 1);
+  if (c < 12 * (lo_int)N) return (c % 12) >= 6;                                  /* omega (6..8), v (9..11) of X_0..X_{N-1} */
+  if (c >= nX) { const lo_int j = (c - nX) % 24; return j >= 12; }                  /* f */
+  return 0;
+}
+void lo_pattern_hess_rc(int N, lo_int* colind, lo_int* row) {
+  const lo_int nx = lo_nx(N), nnz = lo_nnz_hess(N);
+  lo_int* ci = (lo_int*)malloc(sizeof(lo_int) * (size_t)(nx + 1));
+  lo_int* ro = (lo_int*)malloc(sizeof(lo_int) * (size_t)nnz);
+  lo_int c, i, n = 0;
+  lo_pattern_hess(N, ci, ro);
+  for (c = 0; c < nx; c++) {
+    colind[c] = n;
+    for (i = ci[c]; i < ci[c + 1]; i++) row[n++] = ro[i];
+    if (rc_new_diag(N, c)) row[n++] = c;
+  }
+  colind[nx] = n;
+  free(ci); free(ro);
+}
+void lo_nlp_hess_l_rc(const lo_form* F, const double* x, const double* p, double lam_f, const double* lam_g, double* hess) {
+  const int N = F->N; const lo_int nx = lo_nx(N), nnz = lo_nnz_hess(N), nrc = lo_nnz_hess_rc(N);
+  lo_int* ci = (lo_int*)malloc(sizeof(lo_int) * (size_t)(nx + 1)); lo_int* ro = (lo_int*)malloc(sizeof(lo_int) * (size_t)nrc);
+  lo_int* c4 = (lo_int*)malloc(sizeof(lo_int) * (size_t)(nx + 1)); lo_int* r4 = (lo_int*)malloc(sizeof(lo_int) * (size_t)nnz);
+  double* h4 = (double*)malloc(sizeof(double) * (size_t)nnz);
+  lo_poff o; lo_int c, i; int k, l, a;
+  (void)x;
+  lo_param_offsets(N, &o);
+  lo_pattern_hess_rc(N, ci, ro); lo_pattern_hess(N, c4, r4);
+  lo_nlp_hess_l(F, x, p, lam_f, lam_g, h4);
+  memset(hess, 0, sizeof(double) * (size_t)nrc);
+  for (c = 0; c < nx; c++) for (i = c4[c]; i < c4[c + 1]; i++) hess[ccs_find(ci, ro, r4[i], c)] = h4[i];
+  if (F->run_cost) for (k = 0; k < N; k++) {      /* second derivatives of dt_k (|X - Xref|^2_QX + sum_legs |pos + p_hip - c|^2_Qc + |f - f_ref|^2_Qf) */
+    const double d2 = 2.0 * lam_f * p[o.dt + k];
+    const lo_int X = 12 * (lo_int)k, U = 12 * (lo_int)(N + 1) + 24 * (lo_int)k;
+    for (a = 0; a < 12; a++) hess[ccs_find(ci, ro, X + a, X + a)] += d2 * (F->QX[a] + (a < 3 ? 4.0 * F->Qc[a] : 0.0));
+    for (l = 0; l < 4; l++) for (a = 0; a < 3; a++) {
+      hess[ccs_find(ci, ro, X + a, U + 3 * l + a)] += -d2 * F->Qc[a];
+      hess[ccs_find(ci, ro, U + 3 * l + a, U + 3 * l + a)] += d2 * F->Qc[a];
+      hess[ccs_find(ci, ro, U + 12 + 3 * l + a, U + 12 + 3 * l + a)] += d2 * F->Qf[a];
+    }
+  }
+  free(ci); free(ro); free(c4); free(r4); free(h4);
+}
+
 void lo_nlp_grad(const lo_form* F, const double* x, const double* p, double lam_f,
                  const double* lam_g, double* f, double* g, double* grad_x, double* grad_p) {
   const int N = F->N; const lo_int nx = lo_nx(N), ng = lo_ng(N);
@@ -692,6 +743,11 @@ void lo_nlp_grad(const lo_form* F, const double* x, const double* p, double lam_
     double d = x[12 * N + i] - p[o.Xref + 12 * N + i];
     grad_p[o.Xref + 12 * N + i] += -2 * lam_f * p[o.QN + i] * d;
     grad_p[o.QN + i] += lam_f * d * d;
+  }
+  if (grad_p && F->run_cost) for (k = 0; k < N; k++) {   /* running cost: d/dXref_k and d/ddt_k (the weights are constants of the form) */
+    const double dt = p[o.dt + k];
+    for (i = 0; i < 12; i++) grad_p[o.Xref + 12 * k + i] += -2.0 * lam_f * dt * F->QX[i] * (x[12 * k + i] - p[o.Xref + 12 * k + i]);
+    grad_p[o.dt + k] += lam_f * lo_run_cost_stage(F, x, p, k, NULL, NULL, NULL) / dt;
   }
   if (f) lo_nlp_f(F, x, p, f);
   if (g) memcpy(g, gg, sizeof(double) * (size_t)ng);

@@ -73,6 +73,10 @@ void lo_nlp_g(const lo_form* F, const double* x, const double* p, double* g);
 void lo_nlp_jac_g(const lo_form* F, const double* x, const double* p, double* g, double* jac_nz);
 void lo_nlp_hess_l(const lo_form* F, const double* x, const double* p, double lam_f,
                    const double* lam_g, double* hess_nz);
+/* Lagrangian Hessian including the running cost of the N=41 script, in this project's extended pattern (casadi_s4 + 18 N diagonals) */
+lo_int lo_nnz_hess_rc(int N);
+void lo_pattern_hess_rc(int N, lo_int* colind, lo_int* row);
+void lo_nlp_hess_l_rc(const lo_form* F, const double* x, const double* p, double lam_f, const double* lam_g, double* hess_nz);
 void lo_nlp_grad(const lo_form* F, const double* x, const double* p, double lam_f,
                  const double* lam_g, double* f, double* g, double* grad_x, double* grad_p);
 

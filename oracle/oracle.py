@@ -43,7 +43,7 @@ class Oracle:
         if not os.path.exists(path):
             build()
         self.lib = lib = C.CDLL(path)
-        for name in ("lo_nx", "lo_ng", "lo_np", "lo_nnz_jac", "lo_nnz_hess"):
+        for name in ("lo_nx", "lo_ng", "lo_np", "lo_nnz_jac", "lo_nnz_hess", "lo_nnz_hess_rc"):
             getattr(lib, name).restype = _ll
             getattr(lib, name).argtypes = [C.c_int]
         self.N = N
@@ -105,6 +105,17 @@ class Oracle:
     def hess_l(self, x, p, lam_f, lam_g):
         h = np.zeros(self.nnz_hess)
         self.lib.lo_nlp_hess_l(self._F, _p(x), _p(p), C.c_double(lam_f), _p(lam_g), _p(h))
+        return h
+
+    def pattern_hess_rc(self):
+        n = self.lib.lo_nnz_hess_rc(self.N)
+        ci = np.zeros(self.nx + 1, np.int64); r = np.zeros(n, np.int64)
+        self.lib.lo_pattern_hess_rc(C.c_int(self.N), ci.ctypes.data_as(C.POINTER(_ll)), r.ctypes.data_as(C.POINTER(_ll)))
+        return ci, r
+
+    def hess_l_rc(self, x, p, lam_f, lam_g):
+        h = np.zeros(self.lib.lo_nnz_hess_rc(self.N))
+        self.lib.lo_nlp_hess_l_rc(self._F, _p(np.ascontiguousarray(x, float)), _p(np.ascontiguousarray(p, float)), C.c_double(lam_f), _p(np.ascontiguousarray(lam_g, float)), _p(h))
         return h
 
     def grad(self, x, p, lam_f, lam_g):

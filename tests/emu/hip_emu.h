@@ -27,6 +27,8 @@
 
 struct dim3 { unsigned x, y, z; dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {} };
 struct int4 { int x, y, z, w; };
+struct int2 { int x, y; };
+inline int2 make_int2(int x, int y) { return int2{x, y}; }
 struct emu_idx { unsigned x, y, z; };
 extern emu_idx threadIdx, blockIdx;
 extern dim3 blockDim, gridDim;
