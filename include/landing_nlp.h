@@ -106,6 +106,18 @@ typedef struct {
   double alpha_fallback; /* step taken (and filter restarted) when the line search finds no acceptable point (1e-2)      */
   double reset_delta;    /* regularisation above which the iterate counts as jammed too (steps degenerate to damped
                             gradient steps); <= 0 disables; default 1e5                                                   */
+  int clip_k;            /* fraction-to-the-boundary rule of the primal step: the step length is set by the clip_k-th most blocking
+                            slack (1..4; default 4); the clip_k - 1 slacks that would limit it further stop at (1 - tau) of their
+                            current distance to the bound instead -- exactly where the rule would have left them had each been the
+                            only one -- and their row shows up in theta of the trial point, so the filter still decides.  Why: from
+                            the callers' straight-line guess the Newton step is long against the slack distances and ONE slack at a
+                            time cuts every step to 1..10 % for 3-4 iterations until its multiplier has grown (round-2 traces,
+                            DESIGN.md 4.2); letting the few worst jam together instead of one after the other: mean 63 -> 53
+                            iterations, slowest member of eight seeded batches 160..246 -> 100..133, inertia-failure retries
+                            1.28 -> 1.15 sweeps per iteration (tests/dev/ipm_lab.py).  0 / 1 = the classic rule (IPOPT)             */
+  double clip_until;     /* ... applied only while the primal infeasibility (max norm, slack rows included) is above this value
+                            (default 0.03): close to feasibility the classic rule is kept -- without the switch 1 member in 1000
+                            parks at pr ~ 2e-2 with diverging multipliers                                                     */
 } landing_solver_opts;
 
 /* status codes written per batch member by landing_solve_batch */

@@ -105,6 +105,29 @@ __device__ __forceinline__ double block_reduce1(double v, int op, double* red) {
   return a[0];
 }
 
+// The four largest of a set of values spread over the block (clip_k rule of the primal step length): every thread keeps
+// a sorted quadruple t[0] >= .. >= t[3]; the merge is a max-type operation, hence independent of the order.
+__device__ __forceinline__ void top4_push(double (&t)[4], double v) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { const double hi = fmax(t[i], v); v = fmin(t[i], v); t[i] = hi; }
+}
+__device__ __forceinline__ void block_top4(double (&t)[4], double* red) {
+  const int tid = threadIdx.x, nwave = (blockDim.x + 63) >> 6;
+#pragma unroll
+  for (int mask = 32; mask >= 1; mask >>= 1) {
+    double o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = __shfl_xor(t[i], mask);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) top4_push(t, o[i]);
+  }
+  if ((tid & 63) == 0) for (int i = 0; i < 4; ++i) red[(tid >> 6) * 4 + i] = t[i];
+  __syncthreads();
+  for (int i = 0; i < 4; ++i) t[i] = red[i];
+  for (int w = 1; w < nwave; ++w) for (int i = 0; i < 4; ++i) top4_push(t, red[w * 4 + i]);
+  __syncthreads();
+}
+
 struct MemberMem {
   double *x, *xt, *dx, *gx;
   double *g, *gt, *s, *ds, *zL, *zU, *y, *yn, *sig, *rho;
@@ -1031,6 +1054,11 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
     // ================================================================ dual steps, step bounds, merit data
     // fraction-to-the-boundary as tau / max(-ds/d), tau / max(-dz/z): reciprocals instead of divisions in the row
     // loop, one logarithm per row (log of the product of the two distances)
+    // clip_k rule (landing_nlp.h): while the point is far from feasible the step length comes from the clip_k-th largest
+    // ratio |ds| / distance; the slacks with a larger one stop at (1 - tau) of their distance (omt > 0 in the passes below)
+    const bool clip_now = o.clip_k > 1 && pr > o.clip_until;
+    const double omt = clip_now ? 1.0 - tau : -1.0;
+    double top[4] = {0.0, 0.0, 0.0, 0.0};
     double m_pr = 0.0, m_du = 0.0, th0 = 0.0, bar = 0.0, dphi = 0.0;
     for (int rb = lane + 12; rb < ng; rb += NT * RB) {
       double lbv[RB], ubv[RB], gv[RB], sv[RB], dsv[RB], zlv[RB], zuv[RB];
@@ -1047,14 +1075,14 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
         if (lb > -INF) {
           const double d = s - lb, rd = fast_rcp(d), zl = zlv[j];
           const double dz = fma(-zl * rd, ds, mu * rd - zl);
-          m_pr = fmax(m_pr, -ds * rd);
+          m_pr = fmax(m_pr, -ds * rd); top4_push(top, -ds * rd);
           m_du = fmax(m_du, -dz * fast_rcp(zl));
           dprod = d; dphi -= mu * ds * rd;
         }
         if (ub < INF) {
           const double d = ub - s, rd = fast_rcp(d), zu = zuv[j];
           const double dz = fma(zu * rd, ds, mu * rd - zu);
-          m_pr = fmax(m_pr, ds * rd);
+          m_pr = fmax(m_pr, ds * rd); top4_push(top, ds * rd);
           m_du = fmax(m_du, -dz * fast_rcp(zu));
           dprod *= d; dphi += mu * ds * rd;
         }
@@ -1081,6 +1109,11 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
     { double v[6] = {m_pr, m_du, th0, bar, dphi, f0}; const int op[6] = {RMAX, RMAX, RSUM, RSUM, RSUM, RSUM};
       block_reduce<6>(v, op, S.red); th0 = v[2]; bar = v[3]; dphi = v[4]; f0 = v[5];
       a_pr = (v[0] > tau) ? tau / v[0] : 1.0; a_du = (v[1] > tau) ? tau / v[1] : 1.0; }
+    if (clip_now) {
+      block_top4(top, S.red);
+      const double rk = top[(o.clip_k > 4 ? 4 : o.clip_k) - 1];
+      a_pr = (rk > tau) ? tau / rk : 1.0;
+    }
     const double ph0 = f0 + mu * bar;
     if (it == 0) th_max = 1e4 * fmax(1.0, th0);
     const double th_min = 1e-4;
@@ -1105,7 +1138,8 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
           if (rb + j * NT >= ng) continue;
           const double lb = lbv[j], ub = ubv[j], g = gv[j];
           if (lb == ub) { tht += fabs(g - lb); continue; }
-          const double s = sv[j] + alpha * dsv[j];
+          double s = sv[j] + alpha * dsv[j];
+          if (omt > 0.0) { if (lb > -INF) s = fmax(s, fma(omt, sv[j] - lb, lb)); if (ub < INF) s = fmin(s, fma(-omt, ub - sv[j], ub)); }
           tht += fabs(g - s);
           bt -= log((lb > -INF ? s - lb : 1.0) * (ub < INF ? ub - s : 1.0));
         }
@@ -1168,7 +1202,9 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
           if (r >= 12) {
             if (lb == ub) { r_y[r] = yv[j] + alpha * (ynv[j] - yv[j]); npr = fmax(npr, fabs(g - lb)); }
             else {
-              const double so = sv[j], ds = dsv[j], s = so + alpha * ds;
+              const double so = sv[j], ds = dsv[j];
+              double s = so + alpha * ds;
+              if (omt > 0.0) { if (lb > -INF) s = fmax(s, fma(omt, so - lb, lb)); if (ub < INF) s = fmin(s, fma(-omt, ub - so, ub)); }
               double zl = 0.0, zu = 0.0;
               if (lb > -INF) {
                 const double dold = so - lb, ro = fast_rcp(dold), zo = zlv[j], dz = fma(-zo * ro, ds, mu * ro - zo), d = s - lb, rd = fast_rcp(d);

@@ -29,12 +29,15 @@ typedef struct {
   double delta_init, delta_inc_first, delta_inc, delta_dec, tau_min, alpha_fallback;
   int restart_period;
   double reset_delta;
+  int clip_k;            /* the step to the boundary is set by the clip_k-th most blocking slack; the more blocking ones stop at    */
+  double clip_until;     /* (1 - tau) of their distance (include/landing_nlp.h); only while pr > clip_until                      */
 } lo_solver_opts;
 
 void lo_solver_opts_default(lo_solver_opts* o) {
   o->tol = 1e-6; o->max_iter = 3000; o->mu_init = 0.1; o->bound_push = 0.5; o->bound_frac = 0.1;
   o->kappa_eps = 10.0; o->kappa_mu = 0.2; o->theta_mu = 1.5; o->max_resets = 8; o->reset_du = 1e9;
   o->delta_init = 1e-4; o->delta_inc_first = 10.0; o->delta_inc = 4.0; o->delta_dec = 0.5; o->tau_min = 0.9; o->alpha_fallback = 1e-2; o->restart_period = 60; o->reset_delta = 1e5;
+  o->clip_k = 4; o->clip_until = 0.03;
 }
 
 #define NW 48
@@ -159,6 +162,22 @@ static void init_slacks(work_t* W, const lo_solver_opts* op) {
   }
 }
 
+/* sorted insert into the four largest values seen so far (t[0] >= t[1] >= t[2] >= t[3]) */
+static void top4_push(double t[4], double v) {
+  int i;
+  for (i = 0; i < 4; ++i) if (v > t[i]) { const double h = t[i]; t[i] = v; v = h; }
+}
+/* slack at step length alpha; with `clip` a slack does not pass (1 - tau) of its current distance to either bound (the
+ * componentwise fraction-to-the-boundary rule, applied to the few slacks that are more blocking than the one that set alpha) */
+static double slack_step(double s0, double ds, double alpha, double lb, double ub, int clip, double tau) {
+  double s = s0 + alpha * ds;
+  if (clip) {
+    if (lb > -INFINITY) s = fmax(s, lb + (1.0 - tau) * (s0 - lb));
+    if (ub < INFINITY) s = fmin(s, ub - (1.0 - tau) * (ub - s0));
+  }
+  return s;
+}
+
 /* one NLP; returns status (0 converged, 1 max_iter, 2 numerical) */
 static int solve_one(const lo_form* F, const double* p, const double* x0, const lo_solver_opts* op, double* x_out,
                      double* lam_out, int* iters_out, double kkt_out[3], long long counters[2]) {
@@ -183,7 +202,8 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
   init_slacks(W, op);
   for (it = 0; it <= op->max_iter; ++it) {
     double du = 0, pr = 0, co = 0, tau, delta;
-    int fact_ok = 0, attempt;
+    int fact_ok = 0, attempt, clip_now;
+    double top[4];
     double sig[24], w[NW], a_pr = 1.0, a_du = 1.0, th0 = 0, bar = 0, dphi = 0, f0 = 0, ph0, alpha;
     int accepted = 0, armijo = 0;
     /* derivatives per stage + gx = grad f + J^T y */
@@ -316,7 +336,10 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
       W->dx[12 * N + i] = sig[i];
       W->ds[ra] = sig[i] + (W->g[ra] - W->s[ra]); W->ds[rb] = sig[i] + (W->g[rb] - W->s[rb]);
     }
-    /* dual steps, step bounds, merit data */
+    /* dual steps, step bounds, merit data.  clip_now: the primal step length comes from the clip_k-th largest ratio
+     * |ds| / distance (top[] holds the four largest); the slacks with a larger ratio are clipped in slack_step(). */
+    clip_now = op->clip_k > 1 && pr > op->clip_until;
+    top[0] = top[1] = top[2] = top[3] = 0.0;
     for (r = 12; r < ng; ++r) {
       const double lb = W->lb[r], ub = W->ub[r], g = W->g[r]; double s, ds, yn;
       if (lb == ub) { th0 += fabs(g - lb); continue; }
@@ -324,14 +347,14 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
       if (lb > -INFINITY) {
         const double d = s - lb, zl = W->zL[r], dz = mu / d - zl - zl / d * ds;
         W->dzL[r] = dz; yn -= mu / d;
-        if (ds < 0.0) a_pr = fmin(a_pr, -tau * d / ds);
+        if (ds < 0.0) { a_pr = fmin(a_pr, -tau * d / ds); top4_push(top, -ds / d); }
         if (dz < 0.0) a_du = fmin(a_du, -tau * zl / dz);
         bar -= log(d); dphi -= mu * ds / d;
       } else W->dzL[r] = 0.0;
       if (ub < INFINITY) {
         const double d = ub - s, zu = W->zU[r], dz = mu / d - zu + zu / d * ds;
         W->dzU[r] = dz; yn += mu / d;
-        if (ds > 0.0) a_pr = fmin(a_pr, tau * d / ds);
+        if (ds > 0.0) { a_pr = fmin(a_pr, tau * d / ds); top4_push(top, ds / d); }
         if (dz < 0.0) a_du = fmin(a_du, -tau * zu / dz);
         bar -= log(d); dphi += mu * ds / d;
       } else W->dzU[r] = 0.0;
@@ -345,6 +368,7 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
     }
     ph0 = f0 + mu * bar;
     if (it == 0) th_max = 1e4 * fmax(1.0, th0);
+    if (clip_now) { const double rk = top[(op->clip_k > 4 ? 4 : op->clip_k) - 1]; a_pr = rk > tau ? tau / rk : 1.0; }
     alpha = a_pr;
     while (alpha > 1e-10) {
       double tht = 0, bt = 0, ft = 0, pht; int ok_f, e, switching;
@@ -354,7 +378,7 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
       for (r = 12; r < ng; ++r) {
         const double lb = W->lb[r], ub = W->ub[r], g = W->gt[r]; double s;
         if (lb == ub) { tht += fabs(g - lb); continue; }
-        s = W->s[r] + alpha * W->ds[r]; tht += fabs(g - s);
+        s = slack_step(W->s[r], W->ds[r], alpha, lb, ub, clip_now, tau); tht += fabs(g - s);
         if (lb > -INFINITY) bt -= log(s - lb);
         if (ub < INFINITY) bt -= log(ub - s);
       }
@@ -385,7 +409,7 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
       W->g[r] = W->gt[r];
       if (r < 12) continue;
       if (lb == ub) { W->y[r] += alpha * (W->yn[r] - W->y[r]); continue; }
-      s = W->s[r] + alpha * W->ds[r];
+      s = slack_step(W->s[r], W->ds[r], alpha, lb, ub, clip_now, tau);
       if (lb > -INFINITY) { const double d = s - lb; zl = W->zL[r] + a_du * W->dzL[r]; zl = fmin(fmax(zl, mu / (1e10 * d)), 1e10 * mu / d); }
       if (ub < INFINITY) { const double d = ub - s; zu = W->zU[r] + a_du * W->dzU[r]; zu = fmin(fmax(zu, mu / (1e10 * d)), 1e10 * mu / d); }
       W->s[r] = s; W->zL[r] = zl; W->zU[r] = zu; W->y[r] = zu - zl;

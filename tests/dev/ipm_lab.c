@@ -198,7 +198,7 @@ static void init_slacks(work_t* W, const lo_solver_opts* op0) {
 }
 
 
-typedef struct { int thmin_rel, max_soc, sticky, stall, probe, trace, clip; double clip_tau, mu_init, tau_min, bpush, bfrac, mehro_lo, mehro_hi, piv_jump, piv_keep; int zinit, mehro, zcomp, crawl2; double thcap, thfloor, crawl2_frac; double stall_frac; int restart_period; double kappa_eps; } lab_t;
+typedef struct { int thmin_rel, max_soc, sticky, stall, probe, trace, clip; double clip_tau, mu_init, tau_min, bpush, bfrac, mehro_lo, mehro_hi, piv_jump, piv_keep; int zinit, mehro, zcomp, crawl2; double thcap, thfloor, crawl2_frac; double stall_frac; int restart_period; double kappa_eps; int adapt; double sig_max, mono_fact; int adapt_glob; int clipk; double clipk_until; } lab_t;
 static lab_t LAB;
 static void lab_init(void) {
   const char* e;
@@ -228,6 +228,12 @@ static void lab_init(void) {
   LAB.thfloor = 1e-3; if ((e = getenv("LAB_THFLOOR"))) LAB.thfloor = atof(e);
   if ((e = getenv("LAB_CRAWL2"))) LAB.crawl2 = atoi(e);
   LAB.crawl2_frac = 0.125; if ((e = getenv("LAB_CRAWL2_FRAC"))) LAB.crawl2_frac = atof(e);
+  if ((e = getenv("LAB_CLIPK"))) LAB.clipk = atoi(e);
+  LAB.clipk_until = 0.0; if ((e = getenv("LAB_CLIPK_UNTIL"))) LAB.clipk_until = atof(e);
+  if ((e = getenv("LAB_ADAPT"))) LAB.adapt = atoi(e);
+  LAB.sig_max = 100.0; if ((e = getenv("LAB_SIGMAX"))) LAB.sig_max = atof(e);
+  LAB.mono_fact = 0.8; if ((e = getenv("LAB_MONOFACT"))) LAB.mono_fact = atof(e);
+  LAB.adapt_glob = 1; if ((e = getenv("LAB_ADAPTGLOB"))) LAB.adapt_glob = atoi(e);
   LAB.trace = getenv("LO_TRACE") != NULL;
 }
 
@@ -279,8 +285,10 @@ static void forward_sweep(const lo_form* F, work_t* W, const double* sig0, const
 /* dual steps + fraction-to-the-boundary bounds for the current ds; mu_c = centering parameter used in dz */
 static lo_int g_block_row = -1;
 static const double *g_muL = NULL, *g_muU = NULL;     /* per-row centering targets (corrector), NULL = scalar mu */
+static _Thread_local int t_clip_now = 0;
 static void dual_steps(work_t* W, double mu_s, double tau, double* a_pr, double* a_du) {
-  lo_int r; double ap = 1.0, ad = 1.0; g_block_row = -1;
+  lo_int r; double ap = 1.0, ad = 1.0; double small[64]; int ns = 0, kk = LAB.clipk > 64 ? 64 : LAB.clipk; g_block_row = -1;
+#define PUSH_RATIO(v) do { if (kk > 0) { double v_ = (v); int q_; if (ns < kk) { small[ns++] = v_; } else { int im = 0; for (q_ = 1; q_ < kk; ++q_) if (small[q_] > small[im]) im = q_; if (v_ < small[im]) small[im] = v_; } } } while (0)
   for (r = 12; r < W->ng; ++r) {
     const double lb = W->lb[r], ub = W->ub[r]; double s, ds, yn;
     if (lb == ub) continue;
@@ -289,6 +297,7 @@ static void dual_steps(work_t* W, double mu_s, double tau, double* a_pr, double*
       const double mu_c = g_muL ? g_muL[r] : mu_s;
       const double d = s - lb, zl = W->zL[r], dz = mu_c / d - zl - zl / d * ds;
       W->dzL[r] = dz; yn -= mu_c / d;
+      if (ds < 0.0) PUSH_RATIO(-tau * d / ds);
       if (ds < 0.0 && -tau * d / ds < ap) { ap = -tau * d / ds; g_block_row = r; }
       if (dz < 0.0) ad = fmin(ad, -tau * zl / dz);
     } else W->dzL[r] = 0.0;
@@ -296,11 +305,13 @@ static void dual_steps(work_t* W, double mu_s, double tau, double* a_pr, double*
       const double mu_c = g_muU ? g_muU[r] : mu_s;
       const double d = ub - s, zu = W->zU[r], dz = mu_c / d - zu + zu / d * ds;
       W->dzU[r] = dz; yn += mu_c / d;
+      if (ds > 0.0) PUSH_RATIO(tau * d / ds);
       if (ds > 0.0 && tau * d / ds < ap) { ap = tau * d / ds; g_block_row = r; }
       if (dz < 0.0) ad = fmin(ad, -tau * zu / dz);
     } else W->dzU[r] = 0.0;
     W->yn[r] = yn;
   }
+  if (kk > 0 && t_clip_now && ns == kk) { int q_, im = 0; for (q_ = 1; q_ < kk; ++q_) if (small[q_] > small[im]) im = q_; ap = fmin(1.0, small[im]); }
   *a_pr = ap; *a_du = ad;
 }
 
@@ -308,7 +319,7 @@ static void dual_steps(work_t* W, double mu_s, double tau, double* a_pr, double*
  * limiting the step of every other variable (componentwise fraction-to-the-boundary rule) */
 static double slack_at(const work_t* W, lo_int r, double alpha) {
   double s = W->s[r] + alpha * W->ds[r];
-  if (LAB.clip) {
+  if (LAB.clip || t_clip_now) {
     const double lb = W->lb[r], ub = W->ub[r], t = 1.0 - LAB.clip_tau;
     if (lb > -INFINITY) s = fmax(s, lb + t * (W->s[r] - lb));
     if (ub < INFINITY) s = fmin(s, ub - t * (ub - W->s[r]));
@@ -340,6 +351,7 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
   double mu = LAB.mu_init > 0 ? LAB.mu_init : op->mu_init, delta_last = 0.0, th_max = 0.0, e_du = 0.0;
   double filt_th[64], filt_ph[64], th_min = 1e-4, delta_used = 0.0, minpiv_last = 1e300;
   double *gx, *cres, *rbar, *csoc, *dx0, *ds0, *yn0, *dzL0, *dzU0, *rbar2, *muL, *muU; long long ncorr = 0;
+  int afree = 1, nref = 0; double refs[4], mu_max_ad = -1.0; long long nfixed = 0;
   reg_t RG; long long nsoc_total = 0, soc_acc = 0; int cutstreak = 0; double thhist[32]; int nth = 0;
   const double keps = LAB.kappa_eps > 0 ? LAB.kappa_eps : op->kappa_eps;
   const int rperiod = LAB.restart_period > 0 ? LAB.restart_period : op->restart_period;
@@ -431,7 +443,29 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
       continue;
     }
     no_reset:;
-    for (;;) {
+    if (LAB.adapt) {   /* IPOPT's adaptive barrier strategy, kkt-error globalisation (IpAdaptiveMuUpdate.cpp) */
+      double du1 = 0, pr1 = 0, co1 = 0, E; long long nc = 0; int suff = (nref == 0), e2;
+      for (i = 12; i < nx; ++i) du1 += fabs(gx[i]);
+      for (r = 12; r < ng; ++r) {
+        const double lb = W->lb[r], ub = W->ub[r];
+        if (lb == ub) { pr1 += fabs(W->g[r] - lb); continue; }
+        pr1 += fabs(W->g[r] - W->s[r]);
+        if (lb > -INFINITY) { co1 += (W->s[r] - lb) * W->zL[r]; nc++; }
+        if (ub < INFINITY) { co1 += (ub - W->s[r]) * W->zU[r]; nc++; }
+      }
+      E = du1 / (double)(nx - 12) + pr1 / (double)(ng - 12) + co1 / (double)nc;
+      for (e2 = 0; e2 < nref; ++e2) if (E <= 0.9999 * refs[e2]) suff = 1;
+      if (!LAB.adapt_glob) suff = 1;
+      if (suff) {
+        if (!afree) { afree = 1; }
+        if (nref == 4) { memmove(refs, refs + 1, 3 * sizeof(double)); nref = 3; }
+        refs[nref++] = E;
+      } else if (afree) {
+        afree = 0; mu = fmax(op->tol / 10.0, LAB.mono_fact * co1 / (double)nc); nfilt = 0;
+      }
+      if (!afree) nfixed++;
+    }
+    if (!LAB.adapt || !afree) for (;;) {
       double cm = 0;
       for (r = 12; r < ng; ++r) {
         const double lb = W->lb[r], ub = W->ub[r];
@@ -492,8 +526,53 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
     minpiv_last = t_minpiv;
     if (delta > 0.0) { delta_last = delta; streak++; } else streak = 0;
     if (streak > 8) streak = 0;
+    if (LAB.adapt && afree) {
+      double avg = 0, minc = 1e300, sigma, d_io = delta_used, sg2[24]; long long nc = 0;
+      for (r = 12; r < ng; ++r) {
+        const double lb = W->lb[r], ub = W->ub[r];
+        if (lb == ub) continue;
+        if (lb > -INFINITY) { const double c = (W->s[r] - lb) * W->zL[r]; avg += c; if (c < minc) minc = c; nc++; }
+        if (ub < INFINITY) { const double c = (ub - W->s[r]) * W->zU[r]; avg += c; if (c < minc) minc = c; nc++; }
+      }
+      avg /= (double)nc;
+      if (mu_max_ad < 0.0) mu_max_ad = 1e3 * avg;
+      if (LAB.adapt == 1) {   /* LOQO rule */
+        const double xi = minc / avg; sigma = 0.1 * pow(fmin(0.05 * (1.0 - xi) / xi, 2.0), 3.0);
+      } else {                /* Mehrotra probing: affine-scaling step with the factorisation at hand */
+        double ap, ad, maff = 0;
+        for (r = 0; r < ng; ++r) rbar2[r] = 0.0;
+        build_vectors(F, p, W, cres, rbar2);
+        RG.sticky = 1;
+        if (!riccati_backward(F, p, W, &d_io, &o, sg2, &RG)) { status = 2; break; }
+        RG.sticky = LAB.sticky; ncorr++;
+        forward_sweep(F, W, sg2, cres);
+        dual_steps(W, 0.0, 1.0, &ap, &ad);
+        for (r = 12; r < ng; ++r) {
+          const double lb = W->lb[r], ub = W->ub[r];
+          if (lb == ub) continue;
+          if (lb > -INFINITY) maff += (W->s[r] + ap * W->ds[r] - lb) * (W->zL[r] + ad * W->dzL[r]);
+          if (ub < INFINITY) maff += (ub - W->s[r] - ap * W->ds[r]) * (W->zU[r] + ad * W->dzU[r]);
+        }
+        maff /= (double)nc;
+        sigma = fmin(pow(maff / avg, 3.0), LAB.sig_max);
+      }
+      mu = fmin(fmax(sigma * avg, op->tol / 10.0), mu_max_ad);
+      tau = fmax(LAB.tau_min > 0 ? LAB.tau_min : op->tau_min, 1.0 - mu);
+      for (r = 12; r < ng; ++r) {
+        const double lb = W->lb[r], ub = W->ub[r]; double rh = 0;
+        if (lb != ub) { if (lb > -INFINITY) rh -= mu / (W->s[r] - lb); if (ub < INFINITY) rh += mu / (ub - W->s[r]); }
+        rbar[r] = rh;
+      }
+      build_vectors(F, p, W, cres, rbar);
+      RG.sticky = 1; d_io = delta_used;
+      if (!riccati_backward(F, p, W, &d_io, &o, sig, &RG)) { status = 2; break; }
+      RG.sticky = LAB.sticky; ncorr++;
+      nfilt = 0;
+      if (LAB.trace) fprintf(stderr, "      adaptive: avg %9.2e sigma %9.2e mu %9.2e\n", avg, sigma, mu);
+    }
     forward_sweep(F, W, sig, cres);
     /* dual steps, step bounds, merit data */
+    t_clip_now = LAB.clipk > 0 && pr > LAB.clipk_until;
     dual_steps(W, mu, tau, &a_pr, &a_du);
     if (LAB.mehro && (LAB.mehro == 1 || a_pr < 0.5)) {   /* corrector: second-order complementarity term of the predictor step */
       double sg2[24]; double d_io = delta_used; const double sc = (LAB.mehro == 3) ? a_pr * a_du : 1.0;
