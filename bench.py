@@ -193,17 +193,28 @@ def main():
             dist.barrier()
             cuda_sync()
 
-    for _ in range(a.warmup):
-        step(False)
-    sync()
-    t0 = time.perf_counter()
+    # warm-up steps are the timed step verbatim (events, the count of solved members, the event read-back): the first use of
+    # every torch kernel loads its code object, ~0.2 s in total that otherwise lands in the first timed steps
     n_conv = torch.zeros(1, device=dev, dtype=torch.float64)
+    for _ in range(a.warmup):
+        step(True)
+        cuda_sync()
+        n_conv += (st == 0).sum()
+        if ev0 is not None:
+            ev0.elapsed_time(ev1)
+    sync()
+    n_conv.zero_()
+    sync()
+    step_ms = []
+    t0 = time.perf_counter()
     for i in range(a.steps):
+        ts = time.perf_counter()
         step(True, i)
         cuda_sync()                         # events of this step are complete; the launch is asynchronous otherwise
         n_conv += (st == 0).sum()
         if ev0 is not None:
             kernel_ms.append(ev0.elapsed_time(ev1))
+        step_ms.append(1e3 * (time.perf_counter() - ts))
     sync()
     elapsed = time.perf_counter() - t0
     el = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -290,7 +301,8 @@ def main():
         out = {"metric": "landing NLPs solved/sec (SRBM, N=40, batch)", "value": solved_per_step * a.steps / elapsed, "unit": "NLPs/s",
                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic", "config": cfg,
-               "solved_per_step": solved_per_step, "members_per_step": B * world, "ms_per_step_by_rank": per_rank, "gather_self_check": gathered_ok}
+               "solved_per_step": solved_per_step, "members_per_step": B * world, "ms_per_step_by_rank": per_rank, "gather_self_check": gathered_ok,
+               "ms_by_step_rank0": [round(v, 2) for v in step_ms]}
         if a.dry:
             out.update({"dry": True, "value": 0.0, "backend": a.backend, "note": "launcher dry run: stub solve, no measurement"})
         else:

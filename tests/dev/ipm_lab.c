@@ -198,7 +198,7 @@ static void init_slacks(work_t* W, const lo_solver_opts* op0) {
 }
 
 
-typedef struct { int thmin_rel, max_soc, sticky, stall, probe, trace, clip; double clip_tau, mu_init, tau_min, bpush, bfrac, mehro_lo, mehro_hi, piv_jump, piv_keep; int zinit, mehro, zcomp, crawl2; double thcap, thfloor, crawl2_frac; double stall_frac; int restart_period; double kappa_eps; int adapt; double sig_max, mono_fact; int adapt_glob; int clipk; double clipk_until; } lab_t;
+typedef struct { int thmin_rel, max_soc, sticky, stall, probe, trace, clip; double clip_tau, mu_init, tau_min, bpush, bfrac, mehro_lo, mehro_hi, piv_jump, piv_keep; int zinit, mehro, zcomp, crawl2; double thcap, thfloor, crawl2_frac; double stall_frac; int restart_period; double kappa_eps; int adapt; double sig_max, mono_fact; int adapt_glob; int clipk; double clipk_until; int full0; double full0_alpha; } lab_t;
 static lab_t LAB;
 static void lab_init(void) {
   const char* e;
@@ -230,6 +230,8 @@ static void lab_init(void) {
   LAB.crawl2_frac = 0.125; if ((e = getenv("LAB_CRAWL2_FRAC"))) LAB.crawl2_frac = atof(e);
   if ((e = getenv("LAB_CLIPK"))) LAB.clipk = atoi(e);
   LAB.clipk_until = 0.0; if ((e = getenv("LAB_CLIPK_UNTIL"))) LAB.clipk_until = atof(e);
+  if ((e = getenv("LAB_FULL0"))) LAB.full0 = atoi(e);
+  LAB.full0_alpha = 1.0; if ((e = getenv("LAB_FULL0_ALPHA"))) LAB.full0_alpha = atof(e);
   if ((e = getenv("LAB_ADAPT"))) LAB.adapt = atoi(e);
   LAB.sig_max = 100.0; if ((e = getenv("LAB_SIGMAX"))) LAB.sig_max = atof(e);
   LAB.mono_fact = 0.8; if ((e = getenv("LAB_MONOFACT"))) LAB.mono_fact = atof(e);
@@ -571,6 +573,13 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
       if (LAB.trace) fprintf(stderr, "      adaptive: avg %9.2e sigma %9.2e mu %9.2e\n", avg, sigma, mu);
     }
     forward_sweep(F, W, sig, cres);
+    if (it < LAB.full0) {   /* warm-up: full Newton step in x, slacks / multipliers re-initialised at the new point */
+      for (i = 0; i < nx; ++i) W->x[i] += LAB.full0_alpha * W->dx[i];
+      eval_g(F, W->x, p, W->g);
+      for (r = 12; r < ng; ++r) if (W->lb[r] == W->ub[r]) W->y[r] += LAB.full0_alpha * (W->yn[r] - W->y[r]);
+      init_slacks(W, op); nfilt = 0; delta_last = 0.0; streak = 0;
+      continue;
+    }
     /* dual steps, step bounds, merit data */
     t_clip_now = LAB.clipk > 0 && pr > LAB.clipk_until;
     dual_steps(W, mu, tau, &a_pr, &a_du);
@@ -609,7 +618,7 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
       for (i = 0; i < 12; ++i) dphi += gX[i] * dX[i] + gc[i] * dU[i] + gf[i] * dU[12 + i];
     }
     ph0 = f0 + mu * bar;
-    if (it == 0) { th_max = 1e4 * fmax(1.0, th0); th_min = LAB.thmin_rel ? 1e-4 * fmax(1.0, th0) : 1e-4; }
+    if (th_max == 0.0) { th_max = 1e4 * fmax(1.0, th0); th_min = LAB.thmin_rel ? 1e-4 * fmax(1.0, th0) : 1e-4; }
     alpha = LAB.clip ? 1.0 : a_pr;
     {
       int first = 1, nsoc_done = 0;

@@ -26,7 +26,7 @@ def solve(O, P, X0, threads=8, max_iter=300, tol=None, lam0=None, **kw):
     for k, v in kw.items(): setattr(o, k, v)
     if os.environ.get("LAB_RESETDU"): o.reset_du = float(os.environ["LAB_RESETDU"])
     if os.environ.get("LAB_MAXRESETS"): o.max_resets = int(os.environ["LAB_MAXRESETS"])
-    for nm in ("delta_dec", "delta_inc", "delta_inc_first", "delta_init"):
+    for nm in ("delta_dec", "delta_inc", "delta_inc_first", "delta_init", "theta_mu", "kappa_mu", "kappa_eps", "bound_push", "bound_frac", "mu_init", "tau_min"):
         if os.environ.get("LAB_" + nm.upper()): setattr(o, nm, float(os.environ["LAB_" + nm.upper()]))
     x = np.zeros((B, O.nx)); lam = np.zeros((B, O.ng)) if lam0 is None else np.ascontiguousarray(lam0, float).copy(); st = np.zeros(B, np.int32); it = np.zeros(B, np.int32)
     kkt = np.zeros((B, 3)); cnt = np.zeros(5, np.int64)
