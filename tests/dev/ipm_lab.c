@@ -78,6 +78,34 @@ static int spd_solve(double* A, int lda, int n, double* B, int ldb, int m) {
   return 1;
 }
 
+/* LAB_FP32: the stage elimination in single precision (BASELINE configs[4] names an fp32 matrix-core KKT factor): G, gamma, the
+ * cost-to-go P, p and the gains are rounded to float, the products T^T P T accumulate in float, the LDL^T runs in float.  Everything
+ * outside the factorisation (residuals, right-hand sides, forward sweep) stays fp64: inexact Newton with exact residuals. */
+static int lab_fp32(void);
+#define F32(v) ((double)(float)(v))
+static int spd_solve_f(double* A, int lda, int n, double* B, int ldb, int m) {
+  int i, j, c;
+  for (j = 0; j < n; ++j) {
+    const float d = (float)A[j * lda + j];
+    if (!(d > 0.0f) || !(d < 1e30f)) { t_failpiv = d; return 0; }
+    if (d < t_minpiv) t_minpiv = d;
+    for (i = j + 1; i < n; ++i) {
+      const float l = (float)A[i * lda + j] / d;
+      if (l == 0.0f) continue;
+      for (c = j + 1; c < n; ++c) A[i * lda + c] = (float)A[i * lda + c] - l * (float)A[j * lda + c];
+      for (c = 0; c < m; ++c) B[i * ldb + c] = (float)B[i * ldb + c] - l * (float)B[j * ldb + c];
+      A[i * lda + j] = l;
+    }
+  }
+  for (j = n - 1; j >= 0; --j) {
+    for (c = 0; c < m; ++c) {
+      float v = (float)B[j * ldb + c] / (float)A[j * lda + j];
+      for (i = j + 1; i < n; ++i) v -= (float)A[i * lda + j] * (float)B[i * ldb + c];
+      B[j * ldb + c] = v;
+    }
+  }
+  return 1;
+}
 /* backward Riccati sweep; returns 1 on success */
 typedef struct { int sticky; double delta_last, delta_init, inc_first, inc, dec; long long nstage; int fail_stage; } reg_t;
 static double next_delta(double delta, const reg_t* R) {
@@ -120,13 +148,14 @@ static int riccati_backward(const lo_form* F, const double* p, work_t* W, double
         gam[36 + i] += q[12 + i];
       }
     }
+    if (lab_fp32()) { for (i = 0; i < NW * NW; ++i) G[i] = F32(G[i]); for (i = 0; i < NW; ++i) gam[i] = F32(gam[i]); }
     /* K = Guu^-1 [Gus | gam_u] */
     for (i = 0; i < nu; ++i) {
       for (j = 0; j < nu; ++j) Guu[i * 24 + j] = G[(24 + i) * NW + 24 + j];
       for (j = 0; j < 24; ++j) R[i * 25 + j] = G[(24 + i) * NW + j];
       R[i * 25 + 24] = gam[24 + i];
     }
-    if (!spd_solve(Guu, 24, nu, R, 25, 25)) {
+    if (!(lab_fp32() ? spd_solve_f(Guu, 24, nu, R, 25, 25) : spd_solve(Guu, 24, nu, R, 25, 25))) {
       RG->fail_stage = k;
       if (!RG->sticky) return 0;
       delta = next_delta(delta, RG);
@@ -138,6 +167,7 @@ static int riccati_backward(const lo_form* F, const double* p, work_t* W, double
       for (j = 0; j < 24; ++j) { double a = G[i * NW + j]; for (t = 0; t < nu; ++t) a -= G[(24 + t) * NW + i] * R[t * 25 + j]; P[i * 24 + j] = a; }
       { double a = gam[i]; for (t = 0; t < nu; ++t) a -= G[(24 + t) * NW + i] * R[t * 25 + 24]; pv[i] = a; }
     }
+    if (lab_fp32()) { for (i = 0; i < 576; ++i) P[i] = F32(P[i]); for (i = 0; i < 24; ++i) pv[i] = F32(pv[i]); }
     for (i = 0; i < 12; ++i) { for (j = 0; j < 24; ++j) W->Px[(size_t)k * 288 + i * 24 + j] = P[i * 24 + j]; W->pvx[k * 12 + i] = pv[i]; }
   }
   {  /* stage 0: X_0 fixed, c_0 free */
@@ -198,8 +228,9 @@ static void init_slacks(work_t* W, const lo_solver_opts* op0) {
 }
 
 
-typedef struct { int thmin_rel, max_soc, sticky, stall, probe, trace, clip; double clip_tau, mu_init, tau_min, bpush, bfrac, mehro_lo, mehro_hi, piv_jump, piv_keep; int zinit, mehro, zcomp, crawl2; double thcap, thfloor, crawl2_frac; double stall_frac; int restart_period; double kappa_eps; int adapt; double sig_max, mono_fact; int adapt_glob; int clipk; double clipk_until; int full0; double full0_alpha; } lab_t;
+typedef struct { int thmin_rel, max_soc, sticky, stall, probe, trace, clip; double clip_tau, mu_init, tau_min, bpush, bfrac, mehro_lo, mehro_hi, piv_jump, piv_keep; int zinit, mehro, zcomp, crawl2; double thcap, thfloor, crawl2_frac; double stall_frac; int restart_period; double kappa_eps; int adapt; double sig_max, mono_fact; int adapt_glob; int clipk; double clipk_until; int full0; double full0_alpha; int clipkd; int fp32; int scaled; int stallany; } lab_t;
 static lab_t LAB;
+static int lab_fp32(void) { return LAB.fp32; }
 static void lab_init(void) {
   const char* e;
   memset(&LAB, 0, sizeof(LAB));
@@ -230,6 +261,10 @@ static void lab_init(void) {
   LAB.crawl2_frac = 0.125; if ((e = getenv("LAB_CRAWL2_FRAC"))) LAB.crawl2_frac = atof(e);
   if ((e = getenv("LAB_CLIPK"))) LAB.clipk = atoi(e);
   LAB.clipk_until = 0.0; if ((e = getenv("LAB_CLIPK_UNTIL"))) LAB.clipk_until = atof(e);
+  if ((e = getenv("LAB_SCALED"))) LAB.scaled = atoi(e);
+  if ((e = getenv("LAB_STALLANY"))) LAB.stallany = atoi(e);
+  if ((e = getenv("LAB_FP32"))) LAB.fp32 = atoi(e);
+  if ((e = getenv("LAB_CLIPKD"))) LAB.clipkd = atoi(e);
   if ((e = getenv("LAB_FULL0"))) LAB.full0 = atoi(e);
   LAB.full0_alpha = 1.0; if ((e = getenv("LAB_FULL0_ALPHA"))) LAB.full0_alpha = atof(e);
   if ((e = getenv("LAB_ADAPT"))) LAB.adapt = atoi(e);
@@ -290,6 +325,8 @@ static const double *g_muL = NULL, *g_muU = NULL;     /* per-row centering targe
 static _Thread_local int t_clip_now = 0;
 static void dual_steps(work_t* W, double mu_s, double tau, double* a_pr, double* a_du) {
   lo_int r; double ap = 1.0, ad = 1.0; double small[64]; int ns = 0, kk = LAB.clipk > 64 ? 64 : LAB.clipk; g_block_row = -1;
+  double smalld[64]; int nsd = 0, kd = LAB.clipkd > 64 ? 64 : LAB.clipkd;
+#define PUSH_RATIOD(v) do { if (kd > 0) { double v_ = (v); int q_; if (nsd < kd) { smalld[nsd++] = v_; } else { int im = 0; for (q_ = 1; q_ < kd; ++q_) if (smalld[q_] > smalld[im]) im = q_; if (v_ < smalld[im]) smalld[im] = v_; } } } while (0)
 #define PUSH_RATIO(v) do { if (kk > 0) { double v_ = (v); int q_; if (ns < kk) { small[ns++] = v_; } else { int im = 0; for (q_ = 1; q_ < kk; ++q_) if (small[q_] > small[im]) im = q_; if (v_ < small[im]) small[im] = v_; } } } while (0)
   for (r = 12; r < W->ng; ++r) {
     const double lb = W->lb[r], ub = W->ub[r]; double s, ds, yn;
@@ -301,7 +338,7 @@ static void dual_steps(work_t* W, double mu_s, double tau, double* a_pr, double*
       W->dzL[r] = dz; yn -= mu_c / d;
       if (ds < 0.0) PUSH_RATIO(-tau * d / ds);
       if (ds < 0.0 && -tau * d / ds < ap) { ap = -tau * d / ds; g_block_row = r; }
-      if (dz < 0.0) ad = fmin(ad, -tau * zl / dz);
+      if (dz < 0.0) { ad = fmin(ad, -tau * zl / dz); PUSH_RATIOD(-tau * zl / dz); }
     } else W->dzL[r] = 0.0;
     if (ub < INFINITY) {
       const double mu_c = g_muU ? g_muU[r] : mu_s;
@@ -309,10 +346,11 @@ static void dual_steps(work_t* W, double mu_s, double tau, double* a_pr, double*
       W->dzU[r] = dz; yn += mu_c / d;
       if (ds > 0.0) PUSH_RATIO(tau * d / ds);
       if (ds > 0.0 && tau * d / ds < ap) { ap = tau * d / ds; g_block_row = r; }
-      if (dz < 0.0) ad = fmin(ad, -tau * zu / dz);
+      if (dz < 0.0) { ad = fmin(ad, -tau * zu / dz); PUSH_RATIOD(-tau * zu / dz); }
     } else W->dzU[r] = 0.0;
     W->yn[r] = yn;
   }
+  if (kd > 0 && t_clip_now && nsd == kd) { int q_, im = 0; for (q_ = 1; q_ < kd; ++q_) if (smalld[q_] > smalld[im]) im = q_; ad = fmin(1.0, smalld[im]); }
   if (kk > 0 && t_clip_now && ns == kk) { int q_, im = 0; for (q_ = 1; q_ < kk; ++q_) if (small[q_] > small[im]) im = q_; ap = fmin(1.0, small[im]); }
   *a_pr = ap; *a_du = ad;
 }
@@ -353,6 +391,7 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
   double mu = LAB.mu_init > 0 ? LAB.mu_init : op->mu_init, delta_last = 0.0, th_max = 0.0, e_du = 0.0;
   double filt_th[64], filt_ph[64], th_min = 1e-4, delta_used = 0.0, minpiv_last = 1e300;
   double *gx, *cres, *rbar, *csoc, *dx0, *ds0, *yn0, *dzL0, *dzU0, *rbar2, *muL, *muU; long long ncorr = 0;
+  int last_mu_it = 0;
   int afree = 1, nref = 0; double refs[4], mu_max_ad = -1.0; long long nfixed = 0;
   reg_t RG; long long nsoc_total = 0, soc_acc = 0; int cutstreak = 0; double thhist[32]; int nth = 0;
   const double keps = LAB.kappa_eps > 0 ? LAB.kappa_eps : op->kappa_eps;
@@ -436,6 +475,7 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
             thhist[(nth - 1) & 31] > fr * thhist[(nth - 1 - win) & 31]) stalled = 1;
         if (it - last_reset_it >= 100 && mu >= (LAB.mu_init > 0 ? LAB.mu_init : op->mu_init) && nreset < op->max_resets && ncrawl < 1) stalled = 1;
       }
+      if (LAB.stallany > 0 && mu < (LAB.mu_init > 0 ? LAB.mu_init : op->mu_init) && it - last_mu_it >= LAB.stallany && it - last_reset_it >= LAB.stallany && nreset < op->max_resets) stalled = 1;
       if (LAB.crawl2 > 0 && cutstreak >= LAB.crawl2 && nreset < op->max_resets && ncrawl < 1 && it - last_reset_it >= 20) stalled = 1;
       if (stalled) ncrawl++;
       if (!((du > op->reset_du && nreset < op->max_resets) || stalled || (op->reset_delta > 0.0 && delta_last > op->reset_delta && nreset < op->max_resets))) goto no_reset;
@@ -475,7 +515,14 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
         if (lb > -INFINITY) cm = fmax(cm, fabs((W->s[r] - lb) * W->zL[r] - mu));
         if (ub < INFINITY) cm = fmax(cm, fabs((ub - W->s[r]) * W->zU[r] - mu));
       }
-      if (fmax(du, fmax(pr, cm)) <= keps * mu && mu > op->tol / 10.0) { mu = fmax(op->tol / 10.0, fmin(op->kappa_mu * mu, pow(mu, op->theta_mu))); nfilt = 0; }
+      double sd = 1.0, sc = 1.0;
+      if (LAB.scaled) {   /* IPOPT's scaling of the optimality error (eq. 5 of Waechter & Biegler): s_d = max(s_max, (|y|_1 + |z|_1) / (m + n)) / s_max, s_c likewise */
+        double ys = 0, zs = 0; long long nz = 0;
+        for (r = 12; r < ng; ++r) { ys += fabs(W->y[r]); if (W->lb[r] != W->ub[r]) { if (W->lb[r] > -INFINITY) { zs += W->zL[r]; nz++; } if (W->ub[r] < INFINITY) { zs += W->zU[r]; nz++; } } }
+        sd = fmax(100.0, (ys + zs) / (double)(ng - 12 + nz)) / 100.0; sc = fmax(100.0, zs / (double)nz) / 100.0;
+        if (LAB.scaled == 2) { sd = fmax(1.0, (ys + zs) / (double)(ng - 12 + nz)); sc = fmax(1.0, zs / (double)nz); }
+      }
+      if (fmax(du / sd, fmax(pr, cm / sc)) <= keps * mu && mu > op->tol / 10.0) { mu = fmax(op->tol / 10.0, fmin(op->kappa_mu * mu, pow(mu, op->theta_mu))); nfilt = 0; last_mu_it = it; }
       else break;
     }
     tau = fmax(LAB.tau_min > 0 ? LAB.tau_min : op->tau_min, 1.0 - mu);
@@ -706,8 +753,8 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
         W->s[r] = s; W->zL[r] = zl; W->zU[r] = zu; W->y[r] = zu - zl;
         continue;
       }
-      if (lb > -INFINITY) { const double d = s - lb; zl = W->zL[r] + a_du * W->dzL[r]; zl = fmin(fmax(zl, mu / (1e10 * d)), 1e10 * mu / d); }
-      if (ub < INFINITY) { const double d = ub - s; zu = W->zU[r] + a_du * W->dzU[r]; zu = fmin(fmax(zu, mu / (1e10 * d)), 1e10 * mu / d); }
+      if (lb > -INFINITY) { const double d = s - lb; zl = W->zL[r] + a_du * W->dzL[r]; if (LAB.clipkd && t_clip_now) zl = fmax(zl, (1.0 - tau) * W->zL[r]); zl = fmin(fmax(zl, mu / (1e10 * d)), 1e10 * mu / d); }
+      if (ub < INFINITY) { const double d = ub - s; zu = W->zU[r] + a_du * W->dzU[r]; if (LAB.clipkd && t_clip_now) zu = fmax(zu, (1.0 - tau) * W->zU[r]); zu = fmin(fmax(zu, mu / (1e10 * d)), 1e10 * mu / d); }
       W->s[r] = s; W->zL[r] = zl; W->zU[r] = zu; W->y[r] = zu - zl;
     }
   }
