@@ -118,6 +118,16 @@ typedef struct {
   double clip_until;     /* ... applied only while the primal infeasibility (max norm, slack rows included) is above this value
                             (default 0.03): close to feasibility the classic rule is kept -- without the switch 1 member in 1000
                             parks at pr ~ 2e-2 with diverging multipliers                                                     */
+  int factor_fp32;       /* 1: the stage eliminations of the Riccati factorisation (T^T P T, blocked LDL^T, gains, cost-to-go) run in
+                            single precision on v_mfma_f32_16x16x4_f32 -- BASELINE configs[4]'s "fp32 MFMA KKT factor".  Residuals,
+                            right-hand sides, forward sweep, line search and the convergence test stay fp64: the step becomes an
+                            inexact Newton step and the interior-point iteration itself is the refinement loop (KKT <= tol is the
+                            fp64 residual, as always).  Default 0, also in landing_solver_opts_warm(): measured on MI355X (round 2) the
+                            variant converges like the fp64 one from a cold start (1024 / 1024 members, mean 53.0 vs 53.3 iterations)
+                            and needs 9.3 instead of 8.1 iterations per warm-started tick, but a stage elimination is 11 % SLOWER
+                            (0.325 vs 0.292 ms of backward sweep per iteration with a CU to itself): the operands are still staged in
+                            the fp64 LDS arrays and converted at fetch, and the sweep is latency-bound, not matrix-core-bound
+                                                                                                                    */
 } landing_solver_opts;
 
 /* status codes written per batch member by landing_solve_batch */

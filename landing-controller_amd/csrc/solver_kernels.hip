@@ -172,7 +172,7 @@ struct Lds {
   // rows of the last stage, which has another layout), so 244 (lb, ub) pairs in LDS replace two ng-long workspace arrays
   // that every row pass used to stream (6 of ~30 array passes per iteration)
   double bnd_lb[36 + 2 * 104], bnd_ub[36 + 2 * 104];
-  MemberMem M; Layout L; const double* p; const int* tab; const int* stage_tab; int prof_on;
+  MemberMem M; Layout L; const double* p; const int* tab; const int* stage_tab; int prof_on; int fp32;
 };
 // One instance per workgroup (= per NLP).  Namespace scope keeps the LDS address space visible to every
 // phase function (ds_* instructions instead of flat_*).
@@ -476,12 +476,178 @@ __device__ __noinline__ bool block_eliminate(double* __restrict__ rec, double de
   return true;
 }
 
+// The same elimination in SINGLE precision on v_mfma_f32_16x16x4_f32 (BASELINE configs[4] / SURVEY 8f row N3: "fp32 MFMA KKT
+// factor"; landing_solver_opts::factor_fp32).  G, gamma, A^, b and the cost-to-go are rounded to float as they are fetched from
+// LDS, T^T P T, the 4 x 4 LDL^T, the triangular solves and the rank-4 updates run in float, the gains / cost-to-go / closed-loop
+// map go back to the (double) stage record and LDS arrays.  Nothing else changes precision: the residuals, the right-hand sides,
+// the forward sweep and the line search stay fp64, so the factor only makes the Newton step inexact (relative error ~1e-6) and the
+// outer interior-point iteration is the refinement loop -- the KKT residual that decides convergence is the fp64 one.
+// The f32 accumulator layout differs from the f64 one (row = 4 (l>>4) + r instead of (l>>4) + 4 r, cdna_hip_programming.md
+// section 3): lane group lk holds FOUR CONSECUTIVE rows, so the four pivot rows of a block step sit in the registers of ONE lane
+// group (lk = b & 3) and the contraction index of the products that consume an accumulator as B operand is (k-step kt, lane
+// group lk) <-> row 4 lk + kt.
+typedef float f32x4 __attribute__((vector_size(16)));
+template <int NU>
+__device__ __noinline__ bool block_eliminate_f32(double* __restrict__ rec, double delta, int k) {
+  Lds& S = SH;
+  constexpr int NR = NU + 24;
+  const int tid = threadIdx.x, ct = tid >> 6, l = tid & 63, lj = l & 15, lk = l >> 4;
+  const int c = 16 * ct + lj;
+  const bool isg = (c == NR), live = (c <= NR);
+  const int bcol = c < NU ? 24 + c : (c < NR ? c - NU : 0);
+  f32x4 T[3];
+  {
+    const double* src = isg ? S.gam : S.G + bcol;
+    const int stride = isg ? 1 : GS;
+#pragma unroll
+    for (int rt = 0; rt < 3; ++rt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int rho = 16 * rt + 4 * lk + r;
+        const int a = rho < NU ? 24 + rho : (rho < NR ? rho - NU : 0);
+        const double v = src[a * stride] + (rho == c ? delta : 0.0);
+        T[rt][r] = (live && rho < NR) ? (float)v : 0.0f;
+      }
+  }
+  {
+    const bool cplus = live && !isg && bcol >= 36;
+    const int pcol = cplus ? 12 + bcol - 36 : 0;
+    float be[3];
+#pragma unroll
+    for (int kt = 0; kt < 3; ++kt) {
+      const double va = S.Ah[(4 * kt + lk) * YS + (bcol < 36 ? bcol : 0)], vb = S.bv[4 * kt + lk];
+      be[kt] = isg ? (float)vb : ((live && bcol < 36) ? (float)va : 0.0f);
+    }
+    f32x4 Y1 = {0.0f, 0.0f, 0.0f, 0.0f};              // rows 0..15 of P(:,0:12) [A^ | b] (+ P(:,c+), p): lane group lk, register r <-> row 4 lk + r
+#pragma unroll
+    for (int kt = 0; kt < 3; ++kt) Y1 = __builtin_amdgcn_mfma_f32_16x16x4f32((float)S.P[lj * PS + 4 * kt + lk], be[kt], Y1, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 4 * lk + r;                    // (rows 12..15 are never consumed)
+      const double dp = S.P[row * PS + pcol], dv = S.pv[row];
+      Y1[r] += cplus ? (float)dp : (isg ? (float)dv : 0.0f);
+    }
+#pragma unroll
+    for (int rt = 0; rt < 3; ++rt) {
+      const int rho = 16 * rt + lj;
+      const int a = rho < NU ? 24 + rho : (rho < NR ? rho - NU : 99);
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) {               // contraction row 4 lk + kt (< 12: lane group 3 supplies zeros)
+        const double av = S.Ah[(lk < 3 ? 4 * lk + kt : 0) * YS + (a < 36 ? a : 0)];
+        T[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32((a < 36 && lk < 3) ? (float)av : 0.0f, Y1[kt], T[rt], 0, 0, 0);
+      }
+    }
+    if (NU == 24) {   // rows of c+ (control rows 12..23 = tile 0 rows 12..15, tile 1 rows 0..7): + rows 12..23 of P T, accumulated in place
+#pragma unroll
+      for (int kt = 0; kt < 3; ++kt) {
+        const double p0 = S.P[(lj >= 12 ? lj : 12) * PS + 4 * kt + lk], p1 = S.P[(lj < 8 ? 16 + lj : 16) * PS + 4 * kt + lk];
+        T[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(lj >= 12 ? (float)p0 : 0.0f, be[kt], T[0], 0, 0, 0);
+        T[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(lj < 8 ? (float)p1 : 0.0f, be[kt], T[1], 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int r0 = 12 + r, r1 = 16 + 4 * (lk < 2 ? lk : 0) + r;
+        const double d0 = cplus ? S.P[r0 * PS + pcol] : (isg ? S.pv[r0] : 0.0);
+        const double d1 = cplus ? S.P[r1 * PS + pcol] : (isg ? S.pv[r1] : 0.0);
+        if (lk == 3) T[0][r] += (float)d0;
+        if (lk < 2) T[1][r] += (float)d1;
+      }
+    }
+  }
+  StageCopy nxt;
+  float* XB = reinterpret_cast<float*>(S.A1);
+#pragma unroll
+  for (int b = 0; b < NU / 4; ++b) {
+    const int rtb = b >> 2, lb = b & 3;
+    float* W = XB + (b & 1) * XCH;
+    float* C = W + 256;
+    if (lk == lb) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) W[c * 4 + r] = T[rtb][r];
+    }
+    if (ct == rtb && (lj >> 2) == lb) {
+#pragma unroll
+      for (int rt = 0; rt < 3; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) C[(16 * rt + 4 * lk + r) * 4 + (lj & 3)] = T[rt][r];
+    }
+    __syncthreads();
+    if (b == 0) stage_copy_load(k - 1, nxt);
+    const float* Dp = C + 16 * b;
+    const float a00 = Dp[0], a10 = Dp[4], a11 = Dp[5], a20 = Dp[8], a21 = Dp[9], a22 = Dp[10], a30 = Dp[12], a31 = Dp[13], a32 = Dp[14], a33 = Dp[15];
+    const float w0 = W[c * 4 + 0], w1 = W[c * 4 + 1], w2 = W[c * 4 + 2], w3 = W[c * 4 + 3];
+    float am[3];
+#pragma unroll
+    for (int rt = 0; rt < 3; ++rt) { const float cv = C[(16 * rt + lj) * 4 + lk]; am[rt] = ((16 * rt + lj) >> 2 == b) ? 0.0f : cv; }
+    const float d0 = a00, i0 = __builtin_amdgcn_rcpf(d0);
+    const float l10 = a10 * i0, l20 = a20 * i0, l30 = a30 * i0;
+    const float d1 = fmaf(-l10, a10, a11), i1 = __builtin_amdgcn_rcpf(d1);
+    const float t21 = fmaf(-l20, a10, a21), t31 = fmaf(-l30, a10, a31);
+    const float l21 = t21 * i1, l31 = t31 * i1;
+    const float d2 = fmaf(-l21, t21, fmaf(-l20, a20, a22)), i2 = __builtin_amdgcn_rcpf(d2);
+    const float t32 = fmaf(-l31, t21, fmaf(-l30, a20, a32));
+    const float l32 = t32 * i2;
+    const float d3 = fmaf(-l32, t32, fmaf(-l31, t31, fmaf(-l30, a30, a33))), i3 = __builtin_amdgcn_rcpf(d3);
+    const float dmin = fminf(fminf(d0, d1), fminf(d2, d3)), dmax = fmaxf(fmaxf(d0, d1), fmaxf(d2, d3));
+    const bool ok = (dmin > 1e-30f) && (dmax < 1e30f) && (d0 == d0) && (d1 == d1) && (d2 == d2) && (d3 == d3);
+    const float y1 = fmaf(-l10, w0, w1);
+    const float y2 = fmaf(-l21, y1, fmaf(-l20, w0, w2));
+    const float y3 = fmaf(-l32, y2, fmaf(-l31, y1, fmaf(-l30, w0, w3)));
+    const float r3 = y3 * i3;
+    const float r2 = fmaf(-l32, r3, y2 * i2);
+    const float r1 = fmaf(-l31, r3, fmaf(-l21, r2, y1 * i1));
+    const float r0 = fmaf(-l30, r3, fmaf(-l20, r2, fmaf(-l10, r1, w0 * i0)));
+    const float R = lk == 0 ? r0 : (lk == 1 ? r1 : (lk == 2 ? r2 : r3));
+    if (16 * ct + 16 > 4 * b) {
+#pragma unroll
+      for (int rt = 0; rt < 3; ++rt) T[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(am[rt], -R, T[rt], 0, 0, 0);
+      if (lk == lb) { T[rtb][0] = r0; T[rtb][1] = r1; T[rtb][2] = r2; T[rtb][3] = r3; }
+    }
+    if (!ok) return false;
+  }
+  stage_copy_store(nxt);
+  {
+    f32x4 Mq = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      const double af = S.Ah[(lj < 12 ? lj : 0) * YS + 24 + (lk < 3 ? 4 * lk + kt : 0)];
+      Mq = __builtin_amdgcn_mfma_f32_16x16x4f32((lj < 12 && lk < 3) ? (float)af : 0.0f, T[0][kt], Mq, 0, 0, 0);
+    }
+    if (c >= NU && c <= NR && lk < 3) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = 4 * lk + r;
+        if (c < NR) rec[RIC_MT + i * 24 + (c - NU)] = S.Ah[i * YS + (c - NU)] - (double)Mq[r];
+        else rec[RIC_MV + i] = S.bv[i] - (double)Mq[r];
+      }
+    }
+  }
+  if (c >= NU && c <= NR) {
+    const int sj = c - NU;
+#pragma unroll
+    for (int rt = 0; rt < 3; ++rt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int rho = 16 * rt + 4 * lk + r;
+        const double v = (double)T[rt][r];
+        if (rho < NU) {
+          if (c < NR) rec[RIC_K + rho * 24 + sj] = v; else rec[RIC_KAP + rho] = v;
+        } else if (rho < NR) {
+          const int i = rho - NU;
+          if (c < NR) { S.P[i * PS + sj] = v; if (i < 12) rec[RIC_PX + i * 24 + sj] = v; }
+          else { S.pv[i] = v; if (i < 12) rec[RIC_PV + i] = v; }
+        }
+      }
+  }
+  return true;
+}
+
 // Everything of one backward Riccati step that follows the assembly of G, gamma (templated on the control
 // dimension: 24 = (f_k, c_{k+1}), 12 = last stage).  Writes P_k, p_k into S and the stage record.
 template <int NU>
 __device__ __forceinline__ bool riccati_step(double* rec, double delta, int k) {
   Lds& S = SH;
-  const bool ok = block_eliminate<NU>(rec, delta, k);
+  const bool ok = S.fp32 ? block_eliminate_f32<NU>(rec, delta, k) : block_eliminate<NU>(rec, delta, k);
   if (!ok) { __syncthreads(); return false; }
   __syncthreads();
   return true;
@@ -845,7 +1011,7 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
   double* __restrict__ r_g = M.g; double* __restrict__ r_gt = M.gt; double* __restrict__ r_s = M.s; double* __restrict__ r_ds = M.ds;
   double* __restrict__ r_zL = M.zL; double* __restrict__ r_zU = M.zU;
   double* __restrict__ r_y = M.y; double* __restrict__ r_yn = M.yn; double* __restrict__ r_sig = M.sig; double* __restrict__ r_rho = M.rho;
-  S.M = M; S.L = L; S.p = p; S.tab = A.tab; S.stage_tab = A.stage_tab; S.prof_on = A.prof != nullptr;
+  S.M = M; S.L = L; S.p = p; S.tab = A.tab; S.stage_tab = A.stage_tab; S.prof_on = A.prof != nullptr; S.fp32 = o.factor_fp32;
   if (lane < 16) S.prof[lane] = 0.0;
   {   // scatter codes of the table shared by the middle stages
     const int off = A.stage_tab[N / 2];

@@ -114,6 +114,24 @@ inline hip_emu_f64x4 __builtin_amdgcn_mfma_f64_16x16x4f64(double a, double b, hi
   }
   return c;
 }
+typedef float hip_emu_f32x4 __attribute__((vector_size(16)));
+// v_mfma_f32_16x16x4_f32: A / B as above (one float per lane), D[4 (l>>4) + r][l&15] -- NOT the f64 row map
+inline hip_emu_f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, hip_emu_f32x4 c, int, int, int) {
+  static float bufA[2][1024], bufB[2][1024];
+  static unsigned cnt[1024];
+  const unsigned p = cnt[threadIdx.x]++ & 1u, base = threadIdx.x & ~63u, l = threadIdx.x & 63u;
+  bufA[p][threadIdx.x] = a; bufB[p][threadIdx.x] = b;
+  hip_emu::wave_barrier();
+  const unsigned col = l & 15u;
+  for (unsigned r = 0; r < 4; ++r) {
+    const unsigned row = 4 * (l >> 4) + r;
+    float acc = c[r];
+    for (unsigned k = 0; k < 4; ++k) acc = std::fmaf(bufA[p][base + k * 16 + row], bufB[p][base + k * 16 + col], acc);
+    c[r] = acc;
+  }
+  return c;
+}
+inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
 inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
 inline double __builtin_amdgcn_rcp(double x) { return 1.0 / x; }
 inline void __builtin_amdgcn_sched_barrier(int) {}

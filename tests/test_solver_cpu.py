@@ -100,3 +100,24 @@ def test_emulated_kernel_follows_cpu_port_with_running_cost(emu_lib, oracle_mod)
     assert np.max(np.abs(g["x"][0] - c["x"][0])) < 1e-7 * max(1.0, np.max(np.abs(c["x"][0])))
     assert np.allclose(g["kkt"][0], O.kkt(g["x"][0], P[0], g["lam_g"][0]), rtol=1e-6, atol=1e-12)
     assert abs(g["f"][0] - O.f(g["x"][0], P[0])) < 1e-10 * max(1.0, abs(g["f"][0]))
+
+
+def test_emulated_fp32_factor_follows_and_converges(emu_lib, oracle_mod):
+    """landing_solver_opts::factor_fp32 (BASELINE configs[4]'s fp32 matrix-core KKT factor): the single-precision stage elimination
+    follows the fp64 one to single-precision accuracy over the first iterations, and the solve still ends at an fp64 KKT point
+    (the interior-point iteration is the refinement loop) -- certified by the oracle's residual"""
+    N = 20
+    O = oracle_mod.Oracle(N)
+    P, X0, _, _ = lc("problem").make_batch(1, N, 0.6, seed=1)
+    L = lc("capi").LandingLib(N, lib_path=emu_lib)
+    o = L.default_opts(); o.max_iter = 5
+    a = L.solve_host(P, X0, o)
+    o.factor_fp32 = 1
+    b = L.solve_host(P, X0, o)
+    assert a["iters"][0] == b["iters"][0] == 5
+    d = np.max(np.abs(a["x"][0] - b["x"][0]))
+    assert 0.0 < d < 1e-4 * max(1.0, np.max(np.abs(a["x"][0])))        # different arithmetic, same path
+    o.max_iter = 400
+    r = L.solve_host(P, X0, o)
+    assert r["status"][0] == 0
+    assert O.kkt(r["x"][0], P[0], r["lam_g"][0]).max() <= 1e-6 * 1.0001
