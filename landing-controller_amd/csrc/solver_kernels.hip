@@ -311,6 +311,15 @@ __device__ __forceinline__ void stage_copy_store(const StageCopy& R) {
 // own columns, and ONE rank-4 MFMA per tile:  T -= C R  (C = pivot columns with the pivot rows blanked; the pivot
 // rows are then overwritten by R itself -- forming them as W - (D - I) R would cancel at the scale of W).  The pivots of the 4 x 4 LDL^T are the scalar pivots of the unblocked
 // elimination, so the inertia test (all pivots positive) is unchanged.  Returns false on a non-positive pivot.
+// development sub-timers of the elimination (tools/dev/backprof.py): -DLANDING_ELIM_PROF=n accumulates the time from the start of
+// block_eliminate to point n (1 tile fetch, 2 prologue, 3 block steps, 4 end) into the PH_B_POST slot; off in the product build
+#ifdef LANDING_ELIM_PROF
+#define ELIM_T0() const long long et0_ = SH.prof_on ? (long long)wall_clock64() : 0
+#define ELIM_T(n) do { if ((n) == LANDING_ELIM_PROF && SH.prof_on) { __syncthreads(); if (threadIdx.x == 0) SH.prof[PH_B_POST] += (double)((long long)wall_clock64() - et0_); } } while (0)
+#else
+#define ELIM_T0() do { } while (0)
+#define ELIM_T(n) do { } while (0)
+#endif
 template <int NU>
 __device__ __noinline__ bool block_eliminate(double* __restrict__ rec, double delta, int k) {
   Lds& S = SH;
@@ -319,6 +328,7 @@ __device__ __noinline__ bool block_eliminate(double* __restrict__ rec, double de
   const int c = 16 * ct + lj;
   const bool isg = (c == NR), live = (c <= NR);
   const int bcol = c < NU ? 24 + c : (c < NR ? c - NU : 0);        // position of the own column in the (sigma, f, c+) order of G
+  ELIM_T0();
   f64x4 T[3];
   {   // tile fetch: every lane walks its own column (base, stride) of the condensed G / of gamma; delta_w on the diagonal
     const double* src = isg ? S.gam : S.G + bcol;
@@ -333,6 +343,7 @@ __device__ __noinline__ bool block_eliminate(double* __restrict__ rec, double de
         T[rt][r] = (live && rho < NR) ? v : 0.0;
       }
   }
+  ELIM_T(1);
   {   // + T^T P T and T^T (P b + p) of the next stage's cost-to-go, formed where it is consumed.  With
       // A_ext = [A^ | b] (12 rows) the own column of Y = P(:,0:12) A_ext comes out of the matrix cores in accumulator
       // layout, which IS the B-operand layout of the next product (row 4kt+k of k-step kt sits in lane group k):
@@ -379,6 +390,7 @@ __device__ __noinline__ bool block_eliminate(double* __restrict__ rec, double de
       T[0][3] += Y2[0]; T[1][0] += Y2[1]; T[1][1] += Y2[2];
     }
   }
+  ELIM_T(2);
   StageCopy nxt;
 #pragma unroll
   for (int b = 0; b < NU / 4; ++b) {
@@ -436,6 +448,7 @@ __device__ __noinline__ bool block_eliminate(double* __restrict__ rec, double de
     if (!ok) return false;                               // identical in every lane of the workgroup (tested after the
                                                          // update so that the operand fetches are not held behind it)
   }
+  ELIM_T(3);
   stage_copy_store(nxt);                                 // before the record stores below (in-order memory counter)
   {   // closed-loop state map for the forward sweep: X+ = A^_sigma sigma + A^_f f + b with f = -(K_f sigma + kappa_f), i.e.
       // Mt = A^_sigma - A^_f K_f, mv = b - A^_f kappa_f.  K_f / kappa_f are rows 0..11 of the first row tile, already in
@@ -473,6 +486,7 @@ __device__ __noinline__ bool block_eliminate(double* __restrict__ rec, double de
         }
       }
   }
+  ELIM_T(4);
   return true;
 }
 
