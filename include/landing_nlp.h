@@ -118,6 +118,12 @@ typedef struct {
   double clip_until;     /* ... applied only while the primal infeasibility (max norm, slack rows included) is above this value
                             (default 0.03): close to feasibility the classic rule is kept -- without the switch 1 member in 1000
                             parks at pr ~ 2e-2 with diverging multipliers                                                     */
+  double theta_floor;    /* filter line search: constraint violations (theta, 1-norm over the rows) below theta_floor * tol count as
+                            equal -- a trial point that stays below is never rejected for its theta.  Default 1.  At the last barrier
+                            problems theta sits at ~1e-7, far below the tolerance, while the dual infeasibility still needs full
+                            Newton steps whose second-order terms raise theta a little; the relative-decrease test alone then cuts
+                            every step to 1/64 (IPOPT gets past this with second-order corrections / its acceptable-point stop).
+                            One member of the eight bench batches: 212 -> 99 iterations, nothing else changes.  0 = off          */
   int factor_fp32;       /* 1: the stage eliminations of the Riccati factorisation (T^T P T, blocked LDL^T, gains, cost-to-go) run in
                             single precision on v_mfma_f32_16x16x4_f32 -- BASELINE configs[4]'s "fp32 MFMA KKT factor".  Residuals,
                             right-hand sides, forward sweep, line search and the convergence test stay fp64: the step becomes an

@@ -1296,7 +1296,7 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
     }
     const double ph0 = f0 + mu * bar;
     if (it == 0) th_max = 1e4 * fmax(1.0, th0);
-    const double th_min = 1e-4;
+    const double th_min = 1e-4, th_floor = o.theta_floor * o.tol;     // violations below the tolerance count as equal (landing_nlp.h)
 
     PROF_ADD(PH_DUAL, tp);
     // ================================================================ filter line search
@@ -1329,12 +1329,12 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
       { double v[3] = {tht, bt, ft}; const int op[3] = {RSUM, RSUM, RSUM}; block_reduce<3>(v, op, S.red); tht = v[0]; bt = v[1]; ft = v[2]; }
       const double pht = ft + mu * bt;
       bool ok_f = (tht <= th_max) && (pht < 1e300) && (pht > -1e300) && (tht < 1e300);
-      for (int e = 0; e < nfilt && ok_f; ++e) if (tht >= S.filt_th[e] && pht >= S.filt_ph[e]) ok_f = false;
+      for (int e = 0; e < nfilt && ok_f; ++e) if (tht >= fmax(S.filt_th[e], th_floor) && pht >= S.filt_ph[e]) ok_f = false;
       const bool switching = (dphi < 0.0) && (th0 <= th_min) && (alpha * pow(-dphi, 2.3) > 1.0 * pow(th0, 1.1));
       if (ok_f) {
         if (switching) {
           if (pht <= ph0 + 1e-8 * alpha * dphi) { accepted = true; armijo_step = true; }
-        } else if (tht <= (1.0 - 1e-5) * th0 || pht <= ph0 - 1e-8 * th0) {
+        } else if (tht <= fmax((1.0 - 1e-5) * th0, th_floor) || pht <= ph0 - 1e-8 * th0) {
           accepted = true;
         }
       }

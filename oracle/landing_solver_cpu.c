@@ -29,6 +29,7 @@ typedef struct {
   double delta_init, delta_inc_first, delta_inc, delta_dec, tau_min, alpha_fallback;
   int restart_period;
   double reset_delta;
+  double theta_floor;    /* constraint violations (1-norm theta) below theta_floor * tol count as equal in the filter tests              */
   int clip_k;            /* the step to the boundary is set by the clip_k-th most blocking slack; the more blocking ones stop at    */
   double clip_until;     /* (1 - tau) of their distance (include/landing_nlp.h); only while pr > clip_until                      */
 } lo_solver_opts;
@@ -37,7 +38,7 @@ void lo_solver_opts_default(lo_solver_opts* o) {
   o->tol = 1e-6; o->max_iter = 3000; o->mu_init = 0.1; o->bound_push = 0.5; o->bound_frac = 0.1;
   o->kappa_eps = 10.0; o->kappa_mu = 0.2; o->theta_mu = 1.5; o->max_resets = 8; o->reset_du = 1e9;
   o->delta_init = 1e-4; o->delta_inc_first = 10.0; o->delta_inc = 4.0; o->delta_dec = 0.5; o->tau_min = 0.9; o->alpha_fallback = 1e-2; o->restart_period = 60; o->reset_delta = 1e5;
-  o->clip_k = 4; o->clip_until = 0.03;
+  o->theta_floor = 1.0; o->clip_k = 4; o->clip_until = 0.03;
 }
 
 #define NW 48
@@ -203,7 +204,7 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
   for (it = 0; it <= op->max_iter; ++it) {
     double du = 0, pr = 0, co = 0, tau, delta;
     int fact_ok = 0, attempt, clip_now;
-    double top[4];
+    double top[4]; const double th_floor = op->theta_floor * op->tol;
     double sig[24], w[NW], a_pr = 1.0, a_du = 1.0, th0 = 0, bar = 0, dphi = 0, f0 = 0, ph0, alpha;
     int accepted = 0, armijo = 0;
     /* derivatives per stage + gx = grad f + J^T y */
@@ -386,11 +387,15 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
       if (F->run_cost) for (k = 0; k < N; ++k) ft += lo_run_cost_stage(F, W->xt, p, k, NULL, NULL, NULL);
       pht = ft + mu * bt;
       ok_f = (tht <= th_max) && (pht < 1e300) && (pht > -1e300) && (tht < 1e300);
-      for (e = 0; e < nfilt && ok_f; ++e) if (tht >= filt_th[e] && pht >= filt_ph[e]) ok_f = 0;
+      for (e = 0; e < nfilt && ok_f; ++e) if (tht >= fmax(filt_th[e], th_floor) && pht >= filt_ph[e]) ok_f = 0;
       switching = (dphi < 0.0) && (th0 <= 1e-4) && (alpha * pow(-dphi, 2.3) > pow(th0, 1.1));
       if (ok_f) {
+        /* th_floor: constraint violations below the convergence tolerance count as equal (trial points that stay below it are
+         * never rejected for their theta): at the last barrier problems theta sits at 1e-7 while the dual infeasibility still needs
+         * full Newton steps, and the relative-decrease test alone cuts those to 1/64 (212 instead of 99 iterations on one member
+         * of the bench batches) */
         if (switching) { if (pht <= ph0 + 1e-8 * alpha * dphi) { accepted = 1; armijo = 1; } }
-        else if (tht <= (1.0 - 1e-5) * th0 || pht <= ph0 - 1e-8 * th0) accepted = 1;
+        else if (tht <= fmax((1.0 - 1e-5) * th0, th_floor) || pht <= ph0 - 1e-8 * th0) accepted = 1;
       }
       if (accepted) break;
       alpha *= 0.5;
@@ -403,6 +408,7 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
       if (nfilt == 64) { memmove(filt_th, filt_th + 1, 63 * sizeof(double)); memmove(filt_ph, filt_ph + 1, 63 * sizeof(double)); nfilt = 63; }
       filt_th[nfilt] = (1.0 - 1e-5) * th0; filt_ph[nfilt] = ph0 - 1e-8 * th0; nfilt++;
     }
+    if (getenv("LO_TRACE")) fprintf(stderr, "      alpha %9.2e a_pr %9.2e a_du %9.2e delta %8.1e acc %d armijo %d th0 %9.2e dphi %9.2e clip %d\n", alpha, a_pr, a_du, delta, accepted, armijo, th0, dphi, clip_now);
     memcpy(W->x, W->xt, sizeof(double) * nx);
     for (r = 0; r < ng; ++r) {
       const double lb = W->lb[r], ub = W->ub[r]; double s, zl = 0, zu = 0;
