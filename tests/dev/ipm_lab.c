@@ -391,7 +391,7 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
   double mu = LAB.mu_init > 0 ? LAB.mu_init : op->mu_init, delta_last = 0.0, th_max = 0.0, e_du = 0.0;
   double filt_th[64], filt_ph[64], th_min = 1e-4, delta_used = 0.0, minpiv_last = 1e300;
   double *gx, *cres, *rbar, *csoc, *dx0, *ds0, *yn0, *dzL0, *dzU0, *rbar2, *muL, *muU; long long ncorr = 0;
-  int last_mu_it = 0;
+  int last_mu_it = 0, first_mu_it = -1;
   int afree = 1, nref = 0; double refs[4], mu_max_ad = -1.0; long long nfixed = 0;
   reg_t RG; long long nsoc_total = 0, soc_acc = 0; int cutstreak = 0; double thhist[32]; int nth = 0;
   const double keps = LAB.kappa_eps > 0 ? LAB.kappa_eps : op->kappa_eps;
@@ -522,7 +522,7 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
         sd = fmax(100.0, (ys + zs) / (double)(ng - 12 + nz)) / 100.0; sc = fmax(100.0, zs / (double)nz) / 100.0;
         if (LAB.scaled == 2) { sd = fmax(1.0, (ys + zs) / (double)(ng - 12 + nz)); sc = fmax(1.0, zs / (double)nz); }
       }
-      if (fmax(du / sd, fmax(pr, cm / sc)) <= keps * mu && mu > op->tol / 10.0) { mu = fmax(op->tol / 10.0, fmin(op->kappa_mu * mu, pow(mu, op->theta_mu))); nfilt = 0; last_mu_it = it; }
+      if (fmax(du / sd, fmax(pr, cm / sc)) <= keps * mu && mu > op->tol / 10.0) { mu = fmax(op->tol / 10.0, fmin(op->kappa_mu * mu, pow(mu, op->theta_mu))); nfilt = 0; last_mu_it = it; if (first_mu_it < 0) first_mu_it = it; }
       else break;
     }
     tau = fmax(LAB.tau_min > 0 ? LAB.tau_min : op->tau_min, 1.0 - mu);
@@ -762,7 +762,7 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
   for (i = 0; i < 12; ++i) W->y[i] = -gx[i];
   memcpy(x_out, W->x, sizeof(double) * nx);
   if (lam_out) memcpy(lam_out, W->y, sizeof(double) * ng);
-  if (iters_out) *iters_out = it;
+  if (iters_out) *iters_out = getenv("LAB_ENCODE_T1") ? it + 1000 * (first_mu_it < 0 ? it : first_mu_it) : it;
   if (kkt_out) { lo_kkt(F, W->x, p, W->y, kkt_out); (void)e_du; }
   free(W->x); free(W->xt); free(W->dx); free(gx); free(W->g); free(W->gt); free(W->s); free(W->ds); free(W->zL); free(W->zU);
   free(W->dzL); free(W->dzU); free(W->y); free(W->yn); free(W->lb); free(W->ub); free(W->sig); free(W->rho); free(W->Jst); free(W->Hst);
