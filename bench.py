@@ -99,6 +99,7 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo only with --dry (CPU launcher test)")
     ap.add_argument("--no-extras", action="store_true", help="skip the PCIe-inclusive and two-batches-in-flight legs (profiling runs: only the headline launches)")
     ap.add_argument("--dry", action="store_true", help="no GPU work: exercise the multi-rank path with a stub solve")
+    ap.add_argument("--force-dist", action="store_true", help="run the collective path (process group, RCCL gather, reductions) at world size 1 too: GPU smoke test of the multi-GPU code on a 1-GPU box")
     a = ap.parse_args()
     if a.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
@@ -111,6 +112,7 @@ def main():
     world = int(env_world) if env_world is not None else 1
     if world != a.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d -- launch with matching values" % (a.gpus, world))
+    multi = world > 1 or a.force_dist
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
 
@@ -118,7 +120,7 @@ def main():
     import torch
     import torch.distributed as dist
 
-    if world > 1:
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group(a.backend, rank=rank, world_size=world)
@@ -156,7 +158,7 @@ def main():
     x, f, lam, kkt = mk(B, nx), mk(B), mk(B, ng), mk(B, 3)
     st, it = mk(B, dt=torch.int32), mk(B, dt=torch.int32)
     xg = stg = None
-    if world > 1:
+    if multi:
         xg, stg = mk(world * B, nx), mk(world * B, dt=torch.int32)
     if a.dry:
         cuda_sync = lambda: None
@@ -184,12 +186,12 @@ def main():
         solve(*dev_batches[i % n_batches])
         if timed and ev1 is not None:
             ev1.record()
-        if world > 1:   # collect the solved trajectories (RCCL over xGMI)
+        if multi:   # collect the solved trajectories (RCCL over xGMI)
             sharding.gather_solutions(x, st, xg, stg)
 
     def sync():
         cuda_sync()
-        if world > 1:
+        if multi:
             dist.barrier()
             cuda_sync()
 
@@ -219,18 +221,18 @@ def main():
     elapsed = time.perf_counter() - t0
     el = torch.tensor([elapsed], device=dev, dtype=torch.float64)
     per_rank = None
-    if world > 1:      # per-GPU time spread (inter-GPU load imbalance is reported, not balanced)
+    if multi:      # per-GPU time spread (inter-GPU load imbalance is reported, not balanced)
         allel = [torch.zeros_like(el) for _ in range(world)]
         dist.all_gather(allel, el)
         per_rank = [1e3 * float(t.item()) / a.steps for t in allel]
     conv = n_conv / a.steps          # converged members per step, averaged over the timed steps
-    if world > 1:
+    if multi:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         dist.all_reduce(conv, op=dist.ReduceOp.SUM)
     elapsed = float(el.item())
     solved_per_step = float(conv.item())
     gathered_ok = None
-    if world > 1:      # the gathered block of this rank must be its own solution (cheap self-check of the collective)
+    if multi:      # the gathered block of this rank must be its own solution (cheap self-check of the collective)
         gathered_ok = bool(torch.equal(xg[rank * B:(rank + 1) * B], x) and torch.equal(stg[rank * B:(rank + 1) * B], st))
 
     # ---- the same step with the PCIe legs inside (SURVEY 8d wording): pinned host p, x0 -> HBM, x*, status -> host
@@ -245,7 +247,7 @@ def main():
             dP2.copy_(hP, non_blocking=True); dX02.copy_(hX0, non_blocking=True)
             solve(dP2, dX02)
             hx.copy_(x, non_blocking=True); hst.copy_(st, non_blocking=True)
-            if world > 1:
+            if multi:
                 sharding.gather_solutions(x, st, xg, stg)
         step_pcie(); sync()
         tp = time.perf_counter()
@@ -255,7 +257,7 @@ def main():
         sync()
         tp = time.perf_counter() - tp
         tpe = torch.tensor([tp], device=dev, dtype=torch.float64)
-        if world > 1:
+        if multi:
             dist.all_reduce(tpe, op=dist.ReduceOp.MAX)
         tp = float(tpe.item())
         pcie = {"value": solved_per_step * a.steps / tp, "unit": "NLPs/s", "ms_per_step": 1e3 * tp / a.steps,
@@ -289,7 +291,7 @@ def main():
         sync()
         tq = time.perf_counter() - tq
         tqe = torch.tensor([tq], device=dev, dtype=torch.float64)
-        if world > 1:
+        if multi:
             dist.all_reduce(tqe, op=dist.ReduceOp.MAX); dist.all_reduce(conv_p, op=dist.ReduceOp.SUM)
         piped = {"value": float(conv_p.item()) / float(tqe.item()), "unit": "NLPs/s", "batches_in_flight": 2, "ms_per_step": 1e3 * float(tqe.item()) / a.steps,
                  "note": "same K steps, two contexts on two streams, no synchronisation between steps"}
@@ -310,7 +312,7 @@ def main():
             out["pcie_inclusive"] = pcie
             out["two_batches_in_flight"] = piped
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -24,8 +24,10 @@ def gather_solutions(x_local, status_local, out_x=None, out_status=None, equal_s
     ``equal_shards=True`` promises equal sizes and skips the size exchange (bench.py: 1024 members per GPU);
     otherwise the sizes are all-gathered first, every shard is padded to the largest one for the single
     all_gather_into_tensor, and the padding rows are dropped afterwards."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return x_local, status_local
+    if dist.get_world_size() == 1 and out_x is None:      # (with output buffers a single rank still goes through the collective:
+        return x_local, status_local                       # bench.py --force-dist, the 1-GPU smoke test of the RCCL path)
     world = dist.get_world_size()
     b = x_local.shape[0]
     if equal_shards is None:
