@@ -255,8 +255,11 @@ void landing_solver_opts_warm(landing_solver_opts* o);
  * landing_fb_dynamics_batch: tau = H(q) qdd + C(q, qd, f_foot) at npts configurations (spatial_v2 HandC.m:14-62 with the
  *   foot forces of casadi_compatible_dynamics.m:53-60; q, qd, tau [npts][18], f_foot [npts][12] world-frame forces or NULL);
  *   outputs (device, any may be NULL): H [npts][18][18], C [npts][18], qdd [npts][18] (needs tau), the linearisation of the
- *   forward dynamics A = d qdd / d [q; qd] [npts][18][36] by central differences of step fd_h (needs tau) and
- *   Hinv = d qdd / d tau [npts][18][18].
+ *   forward dynamics A = d qdd / d [q; qd] [npts][18][36] (needs tau) and Hinv = d qdd / d tau [npts][18][18].
+ *   fd_h <= 0: A is EXACT -- -H^-1 d ID(q, qd, qdd, f) / d [q; qd] with the 36 tangent directions pushed through the
+ *   inverse-dynamics recursion in forward mode (dual numbers), what the reference obtains from CasADi's algorithmic
+ *   differentiation of casadi_compatible_dynamics.m; fd_h > 0: central differences of the forward dynamics with that step
+ *   (round-2 first half; kept as a cross-check).
  * landing_kinodyn_rows_batch: the rows the kinodynamic refinement adds per stage (landing_optimization.m:152-189) at npts
  *   (member, stage) points: q6 = [pos; rpy (XYZ convention)] [npts][6], c / f [npts][12] feet and forces, jpos [npts][12];
  *   outputs fk [npts][12] (get_forward_kin_foot.m), fk_err = c - fk, tau = J_f'(-R_world_to_body f) (get_foot_jacobians_mc.m). */

@@ -42,6 +42,7 @@ struct landing_ctx {
   double* d_vbl = nullptr;
   landing::RbdModel* d_rbd = nullptr;     // uploaded by landing_rbd_set_model
   int2* d_rc_map = nullptr;               // landing_eval_hess_rc_batch: source nonzero + running-cost code of every entry of the extended pattern
+  double* d_fb_scratch = nullptr; size_t fb_scratch_n = 0;   // qdd and H^-1 per knot of the exact floating-base linearisation
   double* d_h4 = nullptr; size_t h4_cap = 0;   // ... and its scratch for the casadi_s4-pattern nonzeros
   // function layer: the Jacobian, Hessian and residual kernels of one landing_eval_batch call are independent; for large
   // batches they run on two auxiliary streams forked from / joined to the caller's stream so that their ramps and tails overlap
@@ -254,6 +255,7 @@ void landing_destroy(landing_ctx* ctx) {
   if (ctx->d_rbd) (void)hipFree(ctx->d_rbd);
   if (ctx->d_rc_map) (void)hipFree(ctx->d_rc_map);
   if (ctx->d_h4) (void)hipFree(ctx->d_h4);
+  if (ctx->d_fb_scratch) (void)hipFree(ctx->d_fb_scratch);
   for (int i = 0; i < 2; ++i) { if (ctx->aux[i]) (void)hipStreamDestroy(ctx->aux[i]); if (ctx->ev_join[i]) (void)hipEventDestroy(ctx->ev_join[i]); }
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
   delete ctx;

@@ -250,6 +250,164 @@ __global__ void __launch_bounds__(64) landing_fb_lin_kernel(FbArgs a) {
   for (int i = 0; i < RB_NB; ++i) a.A[((size_t)pt * RB_NB + i) * 36 + col] = ok ? (bp[i] - bm[i]) / (2.0 * a.fd_h) : NAN;
 }
 
+// ---- exact linearisation (forward mode) ------------------------------------------------------------------------------------------
+// d qdd / d z = -H^-1 d ID(q, qd, qdd, f) / d z at fixed qdd, z in [q; qd], with ID = H qdd + C the inverse dynamics (the recursion of
+// hand_c with the joint accelerations S qdd added, ID.m:20-40).  The reference gets these derivatives from CasADi's algorithmic
+// differentiation of the same recursion (casadi_compatible_dynamics.m is called on SX symbols); here every thread pushes ONE tangent
+// direction through the recursion with dual numbers (value, derivative) -- exact to rounding, one O(n) pass per column instead of the
+// two O(n^2..n^3) forward-dynamics evaluations of the central-difference kernel above.
+struct Dual { double v, d; };
+__device__ __forceinline__ Dual D_(double v, double d = 0.0) { Dual o; o.v = v; o.d = d; return o; }
+__device__ __forceinline__ Dual operator+(Dual a, Dual b) { return D_(a.v + b.v, a.d + b.d); }
+__device__ __forceinline__ Dual operator-(Dual a, Dual b) { return D_(a.v - b.v, a.d - b.d); }
+__device__ __forceinline__ Dual operator-(Dual a) { return D_(-a.v, -a.d); }
+__device__ __forceinline__ Dual operator*(Dual a, Dual b) { return D_(a.v * b.v, fma(a.v, b.d, a.d * b.v)); }
+__device__ __forceinline__ Dual operator*(double a, Dual b) { return D_(a * b.v, a * b.d); }
+struct V3D { Dual x, y, z; };
+__device__ __forceinline__ V3D mk3D(Dual x, Dual y, Dual z) { V3D v; v.x = x; v.y = y; v.z = z; return v; }
+__device__ __forceinline__ V3D mk3D(double x, double y, double z) { return mk3D(D_(x), D_(y), D_(z)); }
+__device__ __forceinline__ V3D add3(V3D a, V3D b) { return mk3D(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ V3D sub3(V3D a, V3D b) { return mk3D(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ V3D scl3(double s, V3D a) { return mk3D(s * a.x, s * a.y, s * a.z); }
+__device__ __forceinline__ V3D crs3(V3D a, V3D b) { return mk3D(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+__device__ __forceinline__ V3D mul3(const Dual* E, V3D v) { return mk3D(E[0] * v.x + E[1] * v.y + E[2] * v.z, E[3] * v.x + E[4] * v.y + E[5] * v.z, E[6] * v.x + E[7] * v.y + E[8] * v.z); }
+__device__ __forceinline__ V3D mulT3(const Dual* E, V3D v) { return mk3D(E[0] * v.x + E[3] * v.y + E[6] * v.z, E[1] * v.x + E[4] * v.y + E[7] * v.z, E[2] * v.x + E[5] * v.y + E[8] * v.z); }
+__device__ __forceinline__ V3D sym3(const double* I, V3D v) { return mk3D(I[0] * v.x + I[1] * v.y + I[2] * v.z, I[1] * v.x + I[3] * v.y + I[4] * v.z, I[2] * v.x + I[4] * v.y + I[5] * v.z); }
+struct SVD { V3D a, l; };
+__device__ __forceinline__ SVD addS(SVD p, SVD q) { SVD o; o.a = add3(p.a, q.a); o.l = add3(p.l, q.l); return o; }
+__device__ __forceinline__ void joint_xform(int jt, Dual q, const double* Et, const double* rt, Dual* E, Dual* r) {
+  if (jt < 3) {
+    double s, c; sincos(q.v, &s, &c);
+    const Dual S = D_(s, c * q.d), Cc = D_(c, -s * q.d);
+    const int a = jt, b = (jt + 1) % 3, d = (jt + 2) % 3;
+    for (int j = 0; j < 3; ++j) {
+      E[3 * a + j] = D_(Et[3 * a + j]);
+      E[3 * b + j] = Et[3 * b + j] * Cc + Et[3 * d + j] * S;
+      E[3 * d + j] = Et[3 * d + j] * Cc - Et[3 * b + j] * S;
+    }
+    r[0] = D_(rt[0]); r[1] = D_(rt[1]); r[2] = D_(rt[2]);
+  } else {
+    const int a = jt - 3;
+    for (int j = 0; j < 9; ++j) E[j] = D_(Et[j]);
+    r[0] = D_(rt[0]) + Et[3 * a] * q; r[1] = D_(rt[1]) + Et[3 * a + 1] * q; r[2] = D_(rt[2]) + Et[3 * a + 2] * q;
+  }
+}
+__device__ __forceinline__ SVD xmotion(const Dual* E, const Dual* r, SVD v) {
+  const V3D rr = mk3D(r[0], r[1], r[2]);
+  SVD o; o.a = mul3(E, v.a); o.l = mul3(E, sub3(v.l, crs3(rr, v.a))); return o;
+}
+__device__ __forceinline__ SVD xforceT(const Dual* E, const Dual* r, SVD f) {
+  const V3D rr = mk3D(r[0], r[1], r[2]);
+  SVD o; o.l = mulT3(E, f.l); o.a = add3(mulT3(E, f.a), crs3(rr, o.l)); return o;
+}
+__device__ __forceinline__ SVD crm_mul(SVD v, SVD w) { SVD o; o.a = crs3(v.a, w.a); o.l = add3(crs3(v.a, w.l), crs3(v.l, w.a)); return o; }
+__device__ __forceinline__ SVD crf_mul(SVD v, SVD f) { SVD o; o.a = add3(crs3(v.a, f.a), crs3(v.l, f.l)); o.l = crs3(v.a, f.l); return o; }
+__device__ __forceinline__ SVD inertia_mul(double m, const double* h, const double* I, SVD v) {
+  const V3D hh = mk3D(h[0], h[1], h[2]);
+  SVD o; o.a = add3(sym3(I, v.a), crs3(hh, v.l)); o.l = sub3(scl3(m, v.l), crs3(hh, v.a)); return o;
+}
+__device__ __forceinline__ Dual sdot(int jt, SVD f) { return jt == 0 ? f.a.x : (jt == 1 ? f.a.y : (jt == 2 ? f.a.z : (jt == 3 ? f.l.x : (jt == 4 ? f.l.y : f.l.z)))); }
+__device__ __forceinline__ SVD sunit(int jt, Dual s) {
+  const Dual z = D_(0.0);
+  SVD o; o.a = mk3D(jt == 0 ? s : z, jt == 1 ? s : z, jt == 2 ? s : z); o.l = mk3D(jt == 3 ? s : z, jt == 4 ? s : z, jt == 5 ? s : z); return o;
+}
+// derivative of tau = ID(q, qd, qdd, f_foot) along the direction (dir < 18: q_dir, else qd_{dir-18}); dtau[18]
+__device__ void rnea_tangent(const RbdModel& M, const double* q, const double* qd, const double* qdd, const double* f_foot, int dir, double* dtau) {
+  Dual E[RB_NB][9], r[RB_NB][3];
+  SVD v[RB_NB], fvp[RB_NB], avp[RB_NB];
+  for (int i = 0; i < RB_NB; ++i) {
+    const Dual qi = D_(q[i], dir == i ? 1.0 : 0.0), qdi = D_(qd[i], dir == RB_NB + i ? 1.0 : 0.0);
+    joint_xform(M.jtype[i], qi, M.E[i], M.r[i], E[i], r[i]);
+    const SVD vJ = sunit(M.jtype[i], qdi), aJ = sunit(M.jtype[i], D_(qdd[i]));
+    const int pa = M.parent[i];
+    if (pa == 0) {
+      SVD g; g.a = mk3D(0.0, 0.0, 0.0); g.l = mk3D(0.0, 0.0, 9.81);
+      v[i] = vJ; avp[i] = addS(xmotion(E[i], r[i], g), aJ);
+    } else {
+      v[i] = addS(xmotion(E[i], r[i], v[pa - 1]), vJ);
+      avp[i] = addS(addS(xmotion(E[i], r[i], avp[pa - 1]), crm_mul(v[i], vJ)), aJ);
+    }
+    fvp[i] = addS(inertia_mul(M.m[i], M.h[i], M.I[i], avp[i]), crf_mul(v[i], inertia_mul(M.m[i], M.h[i], M.I[i], v[i])));
+  }
+  if (f_foot) {
+    Dual E0[9], r0[3];
+    for (int j = 0; j < 9; ++j) E0[j] = D_((j % 4 == 0) ? 1.0 : 0.0);
+    r0[0] = r0[1] = r0[2] = D_(0.0);
+    auto compose = [](const Dual* Eu, const Dual* ru, Dual* Ea, Dual* ra) {
+      const V3D t = mulT3(Ea, mk3D(ru[0], ru[1], ru[2]));
+      Dual En[9];
+      for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) En[3 * a + b] = Eu[3 * a] * Ea[b] + Eu[3 * a + 1] * Ea[3 + b] + Eu[3 * a + 2] * Ea[6 + b];
+      for (int j = 0; j < 9; ++j) Ea[j] = En[j];
+      ra[0] = ra[0] + t.x; ra[1] = ra[1] + t.y; ra[2] = ra[2] + t.z;
+    };
+    for (int i = 0; i < 6; ++i) compose(E[i], r[i], E0, r0);
+    for (int leg = 0; leg < 4; ++leg) {
+      Dual Ef[9], rf[3];
+      for (int j = 0; j < 9; ++j) Ef[j] = E0[j];
+      for (int j = 0; j < 3; ++j) rf[j] = r0[j];
+      const int jb = M.b_foot[leg] - 1;
+      for (int i = jb - 2; i <= jb; ++i) compose(E[i], r[i], Ef, rf);
+      const V3D rb = mk3D(rf[0], rf[1], rf[2]);
+      const V3D pf = add3(rb, mulT3(Ef, mk3D(M.foot_r[leg][0], M.foot_r[leg][1], M.foot_r[leg][2])));
+      const V3D fw = mk3D(f_foot[3 * leg], f_foot[3 * leg + 1], f_foot[3 * leg + 2]);
+      const V3D nb = crs3(sub3(pf, rb), fw);
+      fvp[jb].a = sub3(fvp[jb].a, mul3(Ef, nb)); fvp[jb].l = sub3(fvp[jb].l, mul3(Ef, fw));
+    }
+  }
+  for (int i = RB_NB - 1; i >= 0; --i) {
+    dtau[i] = sdot(M.jtype[i], fvp[i]).d;
+    const int pa = M.parent[i];
+    if (pa != 0) fvp[pa - 1] = addS(fvp[pa - 1], xforceT(E[i], r[i], fvp[i]));
+  }
+}
+// pass 1 (one thread per knot): H, C, qdd and H^-1 (scratch or caller buffers); pass 2 (one thread per (knot, column)): A(:, col) = -H^-1 dtau
+__global__ void __launch_bounds__(64) landing_fb_lin_exact_prep_kernel(FbArgs a, double* qdd_out, double* hinv_out) {
+  const int pt = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pt >= a.npts) return;
+  const RbdModel& M = *a.model;
+  double H[RB_NB * RB_NB], C[RB_NB], b[RB_NB];
+  hand_c(M, a.q + (size_t)pt * RB_NB, a.qd + (size_t)pt * RB_NB, a.f_foot ? a.f_foot + (size_t)pt * 12 : nullptr, H, C);
+  for (int i = 0; i < RB_NB; ++i) b[i] = a.tau[(size_t)pt * RB_NB + i] - C[i];
+  bool ok = true;     // Cholesky factor in place, then qdd and the 18 columns of the inverse by substitution
+  for (int j = 0; j < RB_NB && ok; ++j) {
+    double d = H[j * RB_NB + j];
+    for (int k = 0; k < j; ++k) d -= H[j * RB_NB + k] * H[j * RB_NB + k];
+    if (!(d > 0.0)) { ok = false; break; }
+    d = sqrt(d); H[j * RB_NB + j] = d;
+    for (int i = j + 1; i < RB_NB; ++i) {
+      double s = H[i * RB_NB + j];
+      for (int k = 0; k < j; ++k) s -= H[i * RB_NB + k] * H[j * RB_NB + k];
+      H[i * RB_NB + j] = s / d;
+    }
+  }
+  auto subst = [&](double* x) {
+    for (int i = 0; i < RB_NB; ++i) { double s = x[i]; for (int k = 0; k < i; ++k) s -= H[i * RB_NB + k] * x[k]; x[i] = s / H[i * RB_NB + i]; }
+    for (int i = RB_NB - 1; i >= 0; --i) { double s = x[i]; for (int k = i + 1; k < RB_NB; ++k) s -= H[k * RB_NB + i] * x[k]; x[i] = s / H[i * RB_NB + i]; }
+  };
+  subst(b);
+  for (int i = 0; i < RB_NB; ++i) qdd_out[(size_t)pt * RB_NB + i] = ok ? b[i] : NAN;
+  for (int c = 0; c < RB_NB; ++c) {
+    double e[RB_NB];
+    for (int i = 0; i < RB_NB; ++i) e[i] = (i == c) ? 1.0 : 0.0;
+    subst(e);
+    for (int i = 0; i < RB_NB; ++i) hinv_out[((size_t)pt * RB_NB + i) * RB_NB + c] = ok ? e[i] : NAN;
+  }
+}
+__global__ void __launch_bounds__(64) landing_fb_lin_exact_kernel(FbArgs a, const double* qdd_in, const double* hinv_in) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int pt = idx / 36, col = idx % 36;
+  if (pt >= a.npts) return;
+  const RbdModel& M = *a.model;
+  double dtau[RB_NB];
+  rnea_tangent(M, a.q + (size_t)pt * RB_NB, a.qd + (size_t)pt * RB_NB, qdd_in + (size_t)pt * RB_NB, a.f_foot ? a.f_foot + (size_t)pt * 12 : nullptr, col, dtau);
+  const double* Hi = hinv_in + (size_t)pt * RB_NB * RB_NB;
+  for (int i = 0; i < RB_NB; ++i) {
+    double s = 0.0;
+    for (int k = 0; k < RB_NB; ++k) s -= Hi[i * RB_NB + k] * dtau[k];
+    a.A[((size_t)pt * RB_NB + i) * 36 + col] = s;
+  }
+}
+
 // rows the kinodynamic refinement adds per stage (landing_optimization.m:152-189), one thread per (member, stage):
 // foot positions by forward kinematics of [q6; jpos] (get_forward_kin_foot.m), FK consistency c - FK, leg torques
 // tau = J_f' (-R_world_to_body f) with the closed-form Jacobian of get_foot_jacobians_mc.m:12-24 and rpyToRotMat_xyz.m:2

@@ -79,7 +79,8 @@ class Rbd:
         self.model = quad3d_model()
         lib._check(lib.lib.landing_rbd_set_model(lib.ctx, C.byref(self.model)), "landing_rbd_set_model")
 
-    def fb_dynamics(self, npts, d_q, d_qd, d_tau=0, d_f_foot=0, d_H=0, d_C=0, d_qdd=0, d_A=0, d_Hinv=0, fd_h=1e-6, stream=0):
+    def fb_dynamics(self, npts, d_q, d_qd, d_tau=0, d_f_foot=0, d_H=0, d_C=0, d_qdd=0, d_A=0, d_Hinv=0, fd_h=0.0, stream=0):
+        """fd_h = 0: exact linearisation (forward-mode tangents of the inverse dynamics); fd_h > 0: central differences with that step"""
         n = lambda v: v or None
         self.L._check(self.L.lib.landing_fb_dynamics_batch(self.L.ctx, npts, d_q, d_qd, n(d_tau), n(d_f_foot), n(d_H), n(d_C), n(d_qdd), n(d_A), n(d_Hinv), fd_h, n(stream)),
                       "landing_fb_dynamics_batch")

@@ -198,3 +198,11 @@ def fd_linearisation(q, qd, tau, f_foot_world=None, h=1e-6):
         A[:, NB + i] = (forward_dynamics(q, qd + e, tau, f_foot_world) - forward_dynamics(q, qd - e, tau, f_foot_world)) / (2 * h)
     H, C = hand_c(q, qd, f_foot_world)
     return np.linalg.solve(H, tau - C), A, np.linalg.inv(H)
+
+
+def richardson_linearisation(q, qd, tau, f_foot_world=None, h=2e-3):
+    """d(qdd)/d[q; qd] to ~1e-9: Richardson extrapolation of the central differences at steps h and h/2 (error O(h^4)); the
+    independent reference for the kernels' exact (forward-mode) linearisation"""
+    _, A1, _ = fd_linearisation(q, qd, tau, f_foot_world, h=h)
+    _, A2, _ = fd_linearisation(q, qd, tau, f_foot_world, h=0.5 * h)
+    return (4.0 * A2 - A1) / 3.0

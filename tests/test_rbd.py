@@ -53,6 +53,31 @@ def test_fb_dynamics_emulated(with_f):
     _check_dynamics(ro, q, qd, tau, f, H, Cb, qdd, A, Hinv, 1e-6, with_f)
 
 
+@pytest.mark.parametrize("with_f", [False, True])
+def test_fb_exact_linearisation_emulated(with_f):
+    """fd_h = 0: the exact linearisation (forward-mode tangents of the inverse dynamics, -H^-1 dID/dz) against the oracle's
+    Richardson-extrapolated central differences (1e-8 relative; the central-difference kernel only reaches 1e-5), with and without
+    caller buffers for qdd / H^-1 (the context scratch path)"""
+    from oracle import rbd_oracle as ro
+    subprocess.run(["make", "-C", os.path.join(PKG, "csrc"), "emu"], check=True, capture_output=True)
+    L = lc("capi").LandingLib(20, lib_path=os.path.join(ROOT, "tests", "emu", "liblanding_emu.so"))
+    R = lc("rbd").Rbd(L)
+    n = 2
+    q, qd, tau, f = _points(np.random.default_rng(7), n)
+    p = lambda a: a.ctypes.data
+    A = np.zeros((n, 18, 36)); A2 = np.zeros((n, 18, 36)); qdd = np.zeros((n, 18)); Hinv = np.zeros((n, 18, 18))
+    R.fb_dynamics(n, p(q), p(qd), p(tau), p(f) if with_f else 0, d_qdd=p(qdd), d_A=p(A), d_Hinv=p(Hinv), fd_h=0.0)
+    R.fb_dynamics(n, p(q), p(qd), p(tau), p(f) if with_f else 0, d_A=p(A2), fd_h=0.0)          # scratch for qdd / H^-1
+    assert np.array_equal(A, A2)
+    for i in range(n):
+        ff = f[i].reshape(4, 3) if with_f else None
+        Ao = ro.richardson_linearisation(q[i], qd[i], tau[i], ff)
+        assert np.max(np.abs(A[i] - Ao)) <= 1e-8 * max(1.0, np.max(np.abs(Ao))), np.max(np.abs(A[i] - Ao))
+        Ho, Co = ro.hand_c(q[i], qd[i], ff)
+        assert np.max(np.abs(qdd[i] - np.linalg.solve(Ho, tau[i] - Co))) <= 1e-9 * max(1.0, np.max(np.abs(qdd[i])))
+        assert np.max(np.abs(Hinv[i] - np.linalg.inv(Ho))) <= 1e-9 * np.max(np.abs(np.linalg.inv(Ho)))
+
+
 def test_model_matches_reference_constants():
     """the compact model reproduces the reference's composite inertia at the home pose"""
     from oracle import rbd_oracle as ro
@@ -109,6 +134,16 @@ def test_fb_dynamics_gpu_config4_shape():
     assert np.isfinite(Ah).all() and np.abs(Hh - np.swapaxes(Hh, 1, 2)).max() == 0.0
     E = torch.matmul(H, Hinv) - torch.eye(18, device=dev, dtype=torch.float64)
     assert E.abs().max().item() < 1e-8
+    # exact linearisation at the same shape: equals the central differences to their accuracy everywhere, the oracle's Richardson
+    # extrapolation to 1e-8 on a sample
+    Ax = mk(n, 18, 36)
+    R.fb_dynamics(n, dq.data_ptr(), dqd.data_ptr(), dtau.data_ptr(), df.data_ptr(), d_A=Ax.data_ptr(), fd_h=0.0, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    Axh = Ax.cpu().numpy()
+    assert np.isfinite(Axh).all() and np.abs(Axh - Ah).max() <= 2e-5 * max(1.0, np.abs(Ah).max())
+    for i in idx[:3]:
+        Ao = ro.richardson_linearisation(Q[i], QD[i], TAU[i], F[i].reshape(4, 3))
+        assert np.max(np.abs(Axh[i] - Ao)) <= 1e-8 * max(1.0, np.max(np.abs(Ao)))
     L.close()
 
 
