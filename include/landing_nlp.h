@@ -280,6 +280,28 @@ int landing_leg_ik_batch(landing_ctx* ctx, int npts, const double* d_q6, const d
 int landing_kinodyn_rows_batch(landing_ctx* ctx, int npts, const double* d_q6, const double* d_c, const double* d_f, const double* d_jpos,
                                double* d_fk, double* d_fk_err, double* d_tau, void* stream);
 
+/* ---- SQP (Gauss-Newton / iLQR) loop on the 18-DoF model (BASELINE configs[3]) --------------------------------
+ * Trajectory-tracking problem per member: state x = [q; qd] (36), control u = the 12 joint torques (base unactuated), known foot
+ * forces f_k, explicit Euler  q+ = q + dt qd, qd+ = qd + dt qdd(q, qd, [0; u], f)  (the discretisation of the SRBM NLP,
+ * generate_landingCtrller_IPOPT.m:127-130), cost  sum_k 1/2 |x_k - xref_k|^2_Q + 1/2 |u_k|^2_R + 1/2 |x_N - xref_N|^2_QN  with
+ * diagonal weights.  The reference has the dynamics (casadi_compatible_dynamics.m) but no loop around them; one iteration here is
+ *   landing_fb_dynamics_batch(npts = B N, q/qd/tau = knots of (x, u), ..., d_A, d_Hinv, fd_h = 0)   exact linearisation,
+ *   landing_wb_backward     LQ subproblem by a Riccati recursion (one wavefront per member, 36 x 36 value function in LDS):
+ *                           feedback gains d_K [B][N][12][36], feed-forward d_kff [B][N][12], expected decrease d_dV [B][2]
+ *                           (cost change ~ alpha dV[0] + alpha^2 dV[1]), d_ok [B] = 0 where a stage Hessian was not positive definite
+ *                           (raise reg), and
+ *   landing_wb_rollout      the nonlinear dynamics under u = u_k + alpha kff_k + K_k (x - x_k) for nalpha step lengths, one thread
+ *                           per (step length, member): trajectories d_xnew [nalpha][B][N+1][36], d_unew [nalpha][B][N][12] and their
+ *                           costs d_cost [nalpha][B] (inf where the dynamics failed); d_K = d_kff = NULL rolls out u open loop
+ *                           (initialisation: a dynamically consistent trajectory and its cost).
+ * The host keeps the best step length per member and adapts reg (landing-controller_amd/wb.py). */
+int landing_wb_backward(landing_ctx* ctx, int B, int N, double dt, double reg, const double* d_x, const double* d_u, const double* d_xref,
+                        const double* d_A, const double* d_Hinv, const double* Q36, const double* R12, const double* QN36,
+                        double* d_K, double* d_kff, double* d_dV, int* d_ok, void* stream);
+int landing_wb_rollout(landing_ctx* ctx, int B, int N, int nalpha, const double* d_alphas, double dt, const double* d_x, const double* d_u,
+                       const double* d_xref, const double* d_f_foot, const double* d_K, const double* d_kff, const double* Q36, const double* R12,
+                       const double* QN36, double* d_xnew, double* d_unew, double* d_cost, void* stream);
+
 /* development aid: d_prof [B][16] doubles receives per-member phase timers of the next solves (100 MHz
  * wall-clock ticks: eval, error, sigma/rho, backward, forward, dual, line search, accept; then counts of
  * factorisations, trial points, iterations); NULL disables. */

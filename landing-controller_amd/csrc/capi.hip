@@ -22,6 +22,7 @@
 #include "solver_kernels.hip"
 #include "vbl_kernels.hip"
 #include "rbd_kernels.hip"
+#include "wb_kernels.hip"
 
 using landing::Layout;
 

@@ -1,0 +1,73 @@
+"""TEST INFRASTRUCTURE -- numpy restatement of the Gauss-Newton / iLQR loop on the 18-DoF model for ONE member (oracle of
+landing-controller_amd/wb.py and csrc/wb_kernels.hip).  Dynamics and their linearisation come from
+oracle/rbd_oracle.py (6 x 6 Pluecker matrices as spatial_v2 HandC.m / casadi_compatible_dynamics.m; Richardson-extrapolated central
+differences), the LQ pass is written with dense numpy algebra in the textbook order (no shared code with the kernels).
+parity unpinned by the reference: it has the dynamics but no loop around them."""
+import numpy as np
+
+from oracle import rbd_oracle as ro
+
+
+def step(x, u, f, dt):
+    q, qd = x[:18], x[18:]
+    qdd = ro.forward_dynamics(q, qd, np.concatenate([np.zeros(6), u]), None if f is None else f.reshape(4, 3))
+    return np.concatenate([q + dt * qd, qd + dt * qdd])
+
+
+def cost_of(xs, us, xref, Q, R, QN):
+    c = 0.5 * np.sum(QN * (xs[-1] - xref[-1]) ** 2)
+    for k in range(us.shape[0]):
+        c += 0.5 * np.sum(Q * (xs[k] - xref[k]) ** 2) + 0.5 * np.sum(R * us[k] ** 2)
+    return c
+
+
+def rollout(x0, us, xs_nom, K, kff, alpha, f_foot, dt):
+    N = us.shape[0]
+    xs = np.zeros((N + 1, 36)); un = np.zeros((N, 12)); xs[0] = x0
+    for k in range(N):
+        un[k] = us[k] if K is None else us[k] + alpha * kff[k] + K[k] @ (xs[k] - xs_nom[k])
+        xs[k + 1] = step(xs[k], un[k], None if f_foot is None else f_foot[k], dt)
+    return xs, un
+
+
+def backward(xs, us, xref, f_foot, dt, Q, R, QN, reg=0.0):
+    N = us.shape[0]
+    V = np.diag(QN).astype(float); v = QN * (xs[N] - xref[N])
+    K = np.zeros((N, 12, 36)); kff = np.zeros((N, 12)); d1 = 0.0
+    for k in range(N - 1, -1, -1):
+        q, qd = xs[k, :18], xs[k, 18:]
+        tau = np.concatenate([np.zeros(6), us[k]])
+        ff = None if f_foot is None else f_foot[k].reshape(4, 3)
+        Ad = ro.richardson_linearisation(q, qd, tau, ff)
+        H, _ = ro.hand_c(q, qd, ff)
+        Hinv = np.linalg.inv(H)
+        A = np.eye(36); A[:18, 18:] += dt * np.eye(18); A[18:, :] += dt * Ad
+        Bm = np.zeros((36, 12)); Bm[18:, :] = dt * Hinv[:, 6:]
+        Qx = Q * (xs[k] - xref[k]) + A.T @ v; Qu = R * us[k] + Bm.T @ v
+        Qxx = np.diag(Q) + A.T @ V @ A; Quu = np.diag(R) + Bm.T @ V @ Bm + reg * np.eye(12); Qux = Bm.T @ V @ A
+        K[k] = -np.linalg.solve(Quu, Qux); kff[k] = -np.linalg.solve(Quu, Qu)
+        d1 += kff[k] @ Qu
+        V = Qxx + Qux.T @ K[k]; V = 0.5 * (V + V.T)
+        v = Qx + Qux.T @ kff[k]
+    return K, kff, np.array([d1, -0.5 * d1])
+
+
+def solve(x0, u_init, xref, f_foot, dt, Q, R, QN, iters, alphas=(1.0, 0.5, 0.25, 0.1, 0.03), K_init=None):
+    if K_init is None:
+        xs, us = rollout(x0, u_init, None, None, None, 0.0, f_foot, dt)
+    else:       # initial rollout under u = u_init + K_init (x - xref)
+        nom = xref.copy(); nom[0] = x0
+        xs, us = rollout(x0, u_init, nom, np.broadcast_to(K_init, (u_init.shape[0], 12, 36)), np.zeros_like(u_init), 0.0, f_foot, dt)
+    cost = cost_of(xs, us, xref, Q, R, QN); hist = [cost]
+    for _ in range(iters):
+        K, kff, dV = backward(xs, us, xref, f_foot, dt, Q, R, QN)
+        best = None
+        for a in alphas:
+            xn, un = rollout(x0, us, xs, K, kff, a, f_foot, dt)
+            c = cost_of(xn, un, xref, Q, R, QN)
+            if np.isfinite(c) and (best is None or c < best[0]):
+                best = (c, xn, un)
+        if best is not None and best[0] < cost:
+            cost, xs, us = best
+        hist.append(cost)
+    return xs, us, np.array(hist)

@@ -1,0 +1,42 @@
+"""BASELINE configs[3]: full 18-DoF floating-base dynamics linearisation in the SQP loop, N = 40, batch = 1024.
+Times the Gauss-Newton / iLQR iteration of landing-controller_amd/wb.py (exact linearisation of 40 960 knots, LQ backward pass, five
+nonlinear rollouts per member) with HIP events and reports the cost history.    python tools/bench_wb.py [--members 1024] [--iters 6]"""
+import argparse, importlib, json, os, sys, time
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+capi = importlib.import_module("landing-controller_amd.capi"); rbd = importlib.import_module("landing-controller_amd.rbd"); wb = importlib.import_module("landing-controller_amd.wb")
+import test_wb as T
+ap = argparse.ArgumentParser(); ap.add_argument("--members", type=int, default=1024); ap.add_argument("--iters", type=int, default=6); a = ap.parse_args()
+N, B = 40, a.members
+L = capi.LandingLib(N, 0); R = rbd.Rbd(L)
+S = wb.WholeBodySQP(L, R, N, T.DT, T.Q, T.R, T.QN, device="cuda")
+nb = min(B, 64)
+x0, u0, xref, f = T._problem(np.random.default_rng(5), nb, N)
+rep = (B + nb - 1) // nb
+tile = lambda v: np.tile(v, (rep,) + (1,) * (v.ndim - 1))[:B]
+rng = np.random.default_rng(1)
+x0 = tile(x0) + 1e-3 * rng.normal(size=(B, 36)); u0, xref, f = tile(u0), tile(xref), tile(f)
+t = lambda v: torch.tensor(v, dtype=torch.float64, device="cuda")
+dx0, du0, dxr, df = t(x0), t(u0), t(xref), t(f)
+S.solve(dx0, du0, dxr, df, iters=1, K_init=T.KPD); torch.cuda.synchronize()          # warm-up (code objects, allocator)
+t0 = time.perf_counter(); out = S.solve(dx0, du0, dxr, df, iters=a.iters, K_init=T.KPD); torch.cuda.synchronize(); wall = time.perf_counter() - t0
+# phase times of one iteration on the final trajectory
+x, u = out["x"], out["u"]
+def timed(fn, reps=5):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps): r = fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps, r
+t_lin, (A, Hinv) = timed(lambda: S.linearise(x, u, df))
+t_back, (K, kff, dV, ok) = timed(lambda: S.backward(x, u, dxr, A, Hinv))
+t_roll, _ = timed(lambda: S.rollout(x, u, dxr, df, K, kff))
+cost = out["cost"].cpu().numpy()
+print(json.dumps({"workload": "SQP (Gauss-Newton / iLQR) on the 18-DoF floating-base model, N=40, batch=%d, fp64 (BASELINE configs[3])" % B,
+                  "iterations": a.iters, "wall_ms_per_iteration_incl_host": 1e3 * wall / (a.iters + 1),
+                  "linearise_ms": t_lin, "backward_ms": t_back, "rollouts_ms": t_roll, "kernel_ms_per_iteration": t_lin + t_back + t_roll,
+                  "sqp_iterations_per_s_whole_batch": B / ((t_lin + t_back + t_roll) * 1e-3),
+                  "cost_mean_by_iteration": [float(v) for v in cost.mean(axis=1)], "cost_decreased_members": int((cost[-1] < cost[0]).sum()),
+                  "step_lengths_tried": [float(v) for v in S.alphas.cpu()]}))
