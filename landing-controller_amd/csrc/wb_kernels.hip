@@ -9,7 +9,7 @@
 // One SQP iteration = (1) exact linearisation of the dynamics at every knot (rbd_kernels.hip, one thread per (knot, tangent)),
 // (2) landing_wb_backward_kernel: the LQ subproblem by a Riccati recursion, one wavefront per member, the 36 x 36 value function and
 // the stage matrices in LDS, (3) landing_wb_rollout_kernel: the nonlinear dynamics rolled out under the feedback policy for a set
-// of step lengths, one thread per (step length, member); the host keeps the best one per member (landing-controller_amd/wb.py).
+// of step lengths, one thread per (step length, member); the host backtracks over them (landing-controller_amd/wb.py).
 #include <hip/hip_runtime.h>
 #include <math.h>
 

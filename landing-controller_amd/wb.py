@@ -2,7 +2,7 @@
 
 Host side of include/landing_nlp.h's landing_wb_* entry points: per iteration one exact linearisation of the dynamics at every knot
 (landing_fb_dynamics_batch, fd_h = 0), one LQ backward pass (landing_wb_backward) and one set of nonlinear rollouts
-(landing_wb_rollout); the best step length per member is kept.  Tensors live where `device` says ("cuda" for the product library,
+(landing_wb_rollout) per step length of a backtracking search; a member keeps the first step length that lowers its cost.  Tensors live where `device` says ("cuda" for the product library,
 "cpu" for the host emulation of tests/emu -- the C ABI only sees pointers).
 
     sqp = WholeBodySQP(lib, rbd, N=40, dt=0.015, Q=..., R=..., QN=...)
@@ -58,7 +58,7 @@ class WholeBodySQP:
                       "landing_wb_backward")
         return K, kff, dV, ok
 
-    def solve(self, x0, u_init, xref, f_foot=None, iters=5, reg=0.0, K_init=None):
+    def solve(self, x0, u_init, xref, f_foot=None, iters=5, reg=0.0, K_init=None, rel_tol=0.0):
         """x0 [B, 36], u_init [B, N, 12], xref [B, N+1, 36], f_foot [B, N, 12] or None (tensors on self.dev).  K_init [12, 36]: feedback
         gain of the initial rollout, u = u_init + K_init (x - xref) -- e.g. a joint PD law; an open-loop rollout of constant torques
         over the whole horizon does not stay near the reference"""
@@ -73,15 +73,22 @@ class WholeBodySQP:
             xn, un, c0 = self.rollout(nom.contiguous(), u, xref, f_foot, K0, self._mk(B, self.N, 12), alphas=self._mk(1))
         x, u, cost = xn[0].contiguous(), un[0].contiguous(), c0[0].clone()
         hist, steps = [cost.clone()], []
-        ar = torch.arange(B, device=self.dev)
         for _ in range(iters):
             A, Hinv = self.linearise(x, u, f_foot)
             K, kff, dV, ok = self.backward(x, u, xref, A, Hinv, reg)
-            xn, un, cn = self.rollout(x, u, xref, f_foot, K, kff)
-            cn = torch.where(ok.bool()[None, :], cn, torch.full_like(cn, float("inf")))
-            best = cn.argmin(dim=0); cb = cn[best, ar]
-            acc = cb < cost
-            x = torch.where(acc[:, None, None], xn[best, ar], x).contiguous(); u = torch.where(acc[:, None, None], un[best, ar], u).contiguous()
-            cost = torch.where(acc, cb, cost)
-            hist.append(cost.clone()); steps.append(torch.where(acc, self.alphas[best], torch.zeros_like(cost)))
+            # backtracking: the step lengths in decreasing order, one rollout launch each, a member keeps the FIRST one that lowers its
+            # cost; the loop ends as soon as every member has one (normally after alpha = 1)
+            x_old, u_old = x, u
+            done = ~ok.bool(); step = torch.zeros_like(cost)
+            for ia in range(self.alphas.shape[0]):
+                xn, un, cn = self.rollout(x_old, u_old, xref, f_foot, K, kff, alphas=self.alphas[ia:ia + 1])
+                acc = (~done) & (cn[0] < cost)
+                x = torch.where(acc[:, None, None], xn[0], x).contiguous(); u = torch.where(acc[:, None, None], un[0], u).contiguous()
+                cost = torch.where(acc, cn[0], cost); step = torch.where(acc, self.alphas[ia], step)
+                done = done | acc
+                if bool(done.all()):
+                    break
+            hist.append(cost.clone()); steps.append(step)
+            if float(((hist[-2] - hist[-1]) / hist[-1].clamp_min(1e-300)).max()) <= rel_tol:      # no member improved any more
+                break
         return dict(x=x, u=u, cost=torch.stack(hist), alpha=torch.stack(steps) if steps else None, expected=dV)

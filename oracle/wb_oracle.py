@@ -61,13 +61,11 @@ def solve(x0, u_init, xref, f_foot, dt, Q, R, QN, iters, alphas=(1.0, 0.5, 0.25,
     cost = cost_of(xs, us, xref, Q, R, QN); hist = [cost]
     for _ in range(iters):
         K, kff, dV = backward(xs, us, xref, f_foot, dt, Q, R, QN)
-        best = None
-        for a in alphas:
+        for a in alphas:          # backtracking: the first step length that lowers the cost
             xn, un = rollout(x0, us, xs, K, kff, a, f_foot, dt)
             c = cost_of(xn, un, xref, Q, R, QN)
-            if np.isfinite(c) and (best is None or c < best[0]):
-                best = (c, xn, un)
-        if best is not None and best[0] < cost:
-            cost, xs, us = best
+            if np.isfinite(c) and c < cost:
+                cost, xs, us = c, xn, un
+                break
         hist.append(cost)
     return xs, us, np.array(hist)

@@ -1,6 +1,6 @@
 """BASELINE configs[3]: full 18-DoF floating-base dynamics linearisation in the SQP loop, N = 40, batch = 1024.
-Times the Gauss-Newton / iLQR iteration of landing-controller_amd/wb.py (exact linearisation of 40 960 knots, LQ backward pass, five
-nonlinear rollouts per member) with HIP events and reports the cost history.    python tools/bench_wb.py [--members 1024] [--iters 6]"""
+Times the Gauss-Newton / iLQR iteration of landing-controller_amd/wb.py (exact linearisation of 40 960 knots, LQ backward pass, one
+nonlinear rollout per member and step length tried) with HIP events and reports the cost history.    python tools/bench_wb.py [--members 1024] [--iters 6]"""
 import argparse, importlib, json, os, sys, time
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -32,11 +32,11 @@ def timed(fn, reps=5):
     return e0.elapsed_time(e1) / reps, r
 t_lin, (A, Hinv) = timed(lambda: S.linearise(x, u, df))
 t_back, (K, kff, dV, ok) = timed(lambda: S.backward(x, u, dxr, A, Hinv))
-t_roll, _ = timed(lambda: S.rollout(x, u, dxr, df, K, kff))
+t_roll, _ = timed(lambda: S.rollout(x, u, dxr, df, K, kff, alphas=S.alphas[:1]))
 cost = out["cost"].cpu().numpy()
 print(json.dumps({"workload": "SQP (Gauss-Newton / iLQR) on the 18-DoF floating-base model, N=40, batch=%d, fp64 (BASELINE configs[3])" % B,
                   "iterations": a.iters, "wall_ms_per_iteration_incl_host": 1e3 * wall / (a.iters + 1),
                   "linearise_ms": t_lin, "backward_ms": t_back, "rollouts_ms": t_roll, "kernel_ms_per_iteration": t_lin + t_back + t_roll,
                   "sqp_iterations_per_s_whole_batch": B / ((t_lin + t_back + t_roll) * 1e-3),
                   "cost_mean_by_iteration": [float(v) for v in cost.mean(axis=1)], "cost_decreased_members": int((cost[-1] < cost[0]).sum()),
-                  "step_lengths_tried": [float(v) for v in S.alphas.cpu()]}))
+                  "rollout_launches_per_iteration": "one per step length tried (backtracking 1, 0.5, 0.25, 0.1, 0.03); normally one", "alpha_mean_by_iteration": [float(v) for v in out["alpha"].mean(dim=1).cpu()]}))
