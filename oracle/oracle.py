@@ -149,7 +149,7 @@ class _SolverOpts(C.Structure):
                 ("restart_period", C.c_int), ("reset_delta", C.c_double), ("theta_floor", C.c_double), ("clip_k", C.c_int), ("clip_until", C.c_double)]
 
 
-def cpu_solve_batch(O, P, X0, threads=0, max_iter=None, tol=None):
+def cpu_solve_batch(O, P, X0, threads=0, max_iter=None, tol=None, **opts):
     """oracle/landing_solver_cpu.c: scalar CPU port of the interior-point algorithm (cpu_baseline / cross-check)."""
     P = np.ascontiguousarray(np.atleast_2d(P), float); X0 = np.ascontiguousarray(np.atleast_2d(X0), float)
     B = P.shape[0]
@@ -159,6 +159,8 @@ def cpu_solve_batch(O, P, X0, threads=0, max_iter=None, tol=None):
         o.max_iter = max_iter
     if tol is not None:
         o.tol = tol
+    for k_, v_ in opts.items():          # any other field of lo_solver_opts (clip_k, theta_floor, ...)
+        setattr(o, k_, v_)
     x = np.zeros((B, O.nx)); lam = np.zeros((B, O.ng)); st = np.zeros(B, np.int32); it = np.zeros(B, np.int32)
     kkt = np.zeros((B, 3)); cnt = np.zeros(2, np.int64)
     ip = C.POINTER(C.c_int)

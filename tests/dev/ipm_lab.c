@@ -554,7 +554,7 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
     }
     build_vectors(F, p, W, cres, rbar);
     /* factorisation with inertia correction */
-    delta = (streak >= 2 && delta_last > 0.0) ? fmax(1e-20, delta_last * op->delta_dec) : 0.0;
+    delta = (streak >= (getenv("LAB_STREAKMIN") ? atoi(getenv("LAB_STREAKMIN")) : 2) && delta_last > 0.0) ? fmax(1e-20, delta_last * op->delta_dec) : 0.0;
     if (LAB.piv_keep > 0 && delta_last > 0.0 && streak >= 1) {   /* below delta_last - minpiv the last matrix was certainly indefinite */
       const double lbd = delta_last - LAB.piv_keep * minpiv_last;
       if (lbd > delta) delta = lbd;
