@@ -240,7 +240,7 @@ def test_n40_reference_solutions_known_answer(oracle_mod):
     Ps, X0s = np.array(Ps), np.array(X0s)
     r = L.solve_host(Ps, X0s)
     ok = r["status"] == 0
-    assert ok.sum() >= len(Ps) - 2, r["status"]        # measured: 17/17 (round 1), 16/17 (round 2 defaults)
+    assert ok.sum() >= len(Ps) - 1, r["status"]        # measured: 17/17 (round 1), 16/17 (first half of round 2), 17/17 (final)
     same = better = 0
     for b in np.nonzero(ok)[0]:
         assert O.kkt(r["x"][b], Ps[b], r["lam_g"][b]).max() <= KKT_TOL * 1.0001
@@ -249,8 +249,10 @@ def test_n40_reference_solutions_known_answer(oracle_mod):
         better += r["f"][b] <= f_ref * 1.001
     # measured in round 1: 6 of 17 coincide to <= 1e-4 relative, 8 are better, 3 end in another (worse) local minimum;
     # round 2 (restart_period 60, delta_dec 0.5): 5 coincide, 6 are better, 5 end in a worse local minimum, 1 does not converge
+    # round 2, final (clip_k, theta_floor): 17 of 17 converge, 7 coincide, 12 have the same or a better objective, 5 a worse local minimum
     # (non-convex NLP: which KKT point a run reaches depends on the regularisation path; every returned point is certified above)
-    assert same >= 4 and better >= 10, (same, better, ok.sum())
+    print("N=40 stored reference solutions: converged %d of %d, same local minimum %d, same or better objective %d" % (ok.sum(), len(Ps), same, better))
+    assert same >= 6 and better >= 11, (same, better, ok.sum())
 
 
 def test_reference_bound_frac_is_a_supported_configuration(libs, oracle_mod):
