@@ -431,9 +431,16 @@ __device__ __noinline__ void member_eval_jh(const Layout& L, const double* x, co
     load_stage(L, x, p, k, z, P);
     double fz_prev[4] = {0, 0, 0, 0};
     if (!first) { const double* Up = x + L.x_U(k - 1); for (int l = 0; l < 4; ++l) fz_prev[l] = Up[12 + 3 * l + 2]; }
+#ifdef LANDING_DEV_SKIP_TASK
+    if (task == LANDING_DEV_SKIP_TASK) continue;
+#endif
     if (task == 0) eval_task_jac(L, z, P, k, fz_prev, J);
     else if (task == 1) eval_task_jty(L, z, P, k, fz_prev, y, gx);
+#ifdef LANDING_DEV_SKIP_TASK          // development probe (tools/dev): which task bounds the derivative phase
+    else if (LANDING_DEV_SKIP_TASK != 2) eval_task_hess(L, z, P, k, y, H);
+#else
     else eval_task_hess(L, z, P, k, y, H);
+#endif
   }
 }
 
