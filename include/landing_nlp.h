@@ -124,6 +124,18 @@ typedef struct {
                             Newton steps whose second-order terms raise theta a little; the relative-decrease test alone then cuts
                             every step to 1/64 (IPOPT gets past this with second-order corrections / its acceptable-point stop).
                             One member of the eight bench batches: 212 -> 99 iterations, nothing else changes.  0 = off          */
+  int fresh_restart;     /* 1 (default): restarts do not all happen in place.  (a) A restart that follows a JAM (dual infeasibility above
+                            reset_du, regularisation above reset_delta) and every member's SECOND restart go back to the caller's initial
+                            guess with clip_k = 2 instead of re-initialising slacks and multipliers at the current x; (b) the crawl
+                            detector may fire twice; (c) a LATER barrier problem (mu < mu_init) that is still unsolved 2 restart_period
+                            iterations after it began with a primal infeasibility above 1e-3 has wandered off and is restarted in place
+                            (nothing else catches that case).  Why: over 65 536 fresh drop states (tools/soak.py) 12 members did not
+                            converge within 300 iterations -- none infeasible or unusual: each solves in 50..100 iterations from the same
+                            guess with clip_k = 2 or with the classic rule, but a restart in place repeats the failure from a bad x (8
+                            members), or no restart ever fired (3).  Such a member sets the time of its batch (250 instead of 105 ms, one
+                            batch in six).  With the rule 65 536 of 65 536 converge (worst 272 iterations) and the mean batch time over
+                            the 64 batches is 126.8 instead of 133.2 ms; the eight bench batches (no such member) lose 2 %: 9180 instead
+                            of 9400 NLPs/s, because a handful of slow-but-converging members now restart.  0 = restarts in place only    */
   int factor_fp32;       /* 1: the stage eliminations of the Riccati factorisation (T^T P T, blocked LDL^T, gains, cost-to-go) run in
                             single precision on v_mfma_f32_16x16x4_f32 -- BASELINE configs[4]'s "fp32 MFMA KKT factor".  Residuals,
                             right-hand sides, forward sweep, line search and the convergence test stay fp64: the step becomes an

@@ -72,13 +72,14 @@ void landing_solver_opts_default(landing_solver_opts* o) {
   o->kappa_eps = 10.0; o->kappa_mu = 0.2; o->theta_mu = 1.5; o->max_soc = 0; o->max_resets = 8; o->reset_du = 1e9;
   o->delta_init = 1e-4; o->delta_inc_first = 10.0; o->delta_inc = 4.0; o->delta_dec = 0.5; o->tau_min = 0.9; o->alpha_fallback = 1e-2;
   o->stage_local_reg = 0; o->sticky_delta = 0; o->restart_period = 60; o->reset_delta = 1e5; o->dispatch_order = 1;
-  o->clip_k = 4; o->clip_until = 0.03; o->theta_floor = 1.0; o->factor_fp32 = 0;
+  o->clip_k = 4; o->clip_until = 0.03; o->theta_floor = 1.0; o->fresh_restart = 1; o->factor_fp32 = 0;
 }
 
 void landing_solver_opts_warm(landing_solver_opts* o) {
   landing_solver_opts_default(o);
   o->bound_push = 1e-4; o->bound_frac = 1e-4; o->mu_init = 1e-4;
   o->clip_k = 0;                 // a shifted plan starts next to the boundary of many rows: classic rule
+  o->fresh_restart = 0;          // the initial guess of a tick IS the previous plan
   o->restart_period = 0;         // the crawl detector is tied to mu_init; a warm start is not expected to crawl
   o->max_iter = 14;              // real-time iteration cap: a tick never runs longer than ~14 x 0.56 ms at one NLP per CU; a member
                                  // that needs more keeps its improved iterate and continues at the next tick (status 1)

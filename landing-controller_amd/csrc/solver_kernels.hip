@@ -1137,7 +1137,7 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
   double mu = o.mu_init, delta_last = 0.0, th_max = 0.0;
   int nfilt = 0, it = 0, status = LANDING_MAX_ITER, need_reg_streak = 0, nreset = 0;
   bool first_failed = false;
-  int last_reset_it = 0, ncrawl = 0;
+  int last_reset_it = 0, ncrawl = 0, clip_k_cur = o.clip_k, last_mu_it = 0;
   double e_pr = 0, e_du = 0, e_co = 0;
 
   for (it = 0; it <= o.max_iter; ++it) {
@@ -1166,14 +1166,31 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
     if (it == o.max_iter) break;
     if (du > o.reset_du && nreset >= o.max_resets && o.max_resets > 0) { status = LANDING_NUMERICAL; break; }   // jammed again: give up
     // crawling: still in the first barrier problem (mu never decreased) restart_period iterations after the last (re)start
-    const bool stalled = o.restart_period > 0 && it - last_reset_it >= o.restart_period && mu >= o.mu_init && nreset < o.max_resets && ncrawl < 1;
+    const bool stalled = o.restart_period > 0 && it - last_reset_it >= o.restart_period && mu >= o.mu_init && nreset < o.max_resets && ncrawl < (o.fresh_restart ? 2 : 1);
     const bool overreg = o.reset_delta > 0.0 && delta_last > o.reset_delta && nreset < o.max_resets;
-    if ((du > o.reset_du && nreset < o.max_resets) || stalled || overreg) {
+    // a LATER barrier problem not solved 2 restart_period iterations after it began has wandered off (the dual infeasibility stays
+    // far below reset_du, nothing else catches it): restarted in place like a crawling iterate
+    const bool lost = o.fresh_restart && o.restart_period > 0 && mu < o.mu_init && pr > 1e-3 && it - last_mu_it >= 2 * o.restart_period && it - last_reset_it >= o.restart_period && nreset < o.max_resets;
+    if ((du > o.reset_du && nreset < o.max_resets) || stalled || overreg || lost) {
       last_reset_it = it;
       if (stalled) ncrawl++;
       // jammed iterate (multipliers blown up): keep x, re-initialise slacks, multipliers, barrier parameter and
       // filter -- the role IPOPT's restoration phase plays on this problem class
       nreset++;
+      if (o.fresh_restart && (nreset == 2 || (nreset == 1 && !stalled && !lost))) {
+        // the restart in place did not help (second restart) or the iterate is jammed: back to the caller's initial guess with
+        // another step rule (landing_nlp.h: the members that fail from it with clip_k = 4 solve with clip_k = 2)
+        for (int i = lane; i < nx; i += NT) {
+          double v = A.x0[(size_t)m * nx + i];
+          if (i < 6) v = p[L.o_q_init + i]; else if (i < 12) v = p[L.o_qd_init + i - 6];
+          M.x[i] = v;
+        }
+        __syncthreads();
+        member_eval_g(L, M.x, p, M.g);
+        __syncthreads();
+        if (clip_k_cur > 1) clip_k_cur = 2;
+        th_max = 0.0;
+      }
       init_slacks();
       mu = o.mu_init; nfilt = 0; delta_last = 0.0; need_reg_streak = 0;
       point_pass(mu);
@@ -1182,7 +1199,7 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
     // ---------------------------------------------------------------- barrier parameter (monotone)
     while (fmax(du, fmax(pr, c_cm)) <= o.kappa_eps * mu && mu > o.tol / 10.0) {
       mu = fmax(o.tol / 10.0, fmin(o.kappa_mu * mu, pow(mu, o.theta_mu)));
-      nfilt = 0;
+      nfilt = 0; last_mu_it = it;
       point_pass(mu);                     // complementarity error, Sigma, rho for the new mu
     }
     const double tau = fmax(o.tau_min, 1.0 - mu);
@@ -1236,7 +1253,7 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
     // loop, one logarithm per row (log of the product of the two distances)
     // clip_k rule (landing_nlp.h): while the point is far from feasible the step length comes from the clip_k-th largest
     // ratio |ds| / distance; the slacks with a larger one stop at (1 - tau) of their distance (omt > 0 in the passes below)
-    const bool clip_now = o.clip_k > 1 && pr > o.clip_until;
+    const bool clip_now = clip_k_cur > 1 && pr > o.clip_until;
     const double omt = clip_now ? 1.0 - tau : -1.0;
     double top[4] = {0.0, 0.0, 0.0, 0.0};
     double m_pr = 0.0, m_du = 0.0, th0 = 0.0, bar = 0.0, dphi = 0.0;
@@ -1291,11 +1308,11 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
       a_pr = (v[0] > tau) ? tau / v[0] : 1.0; a_du = (v[1] > tau) ? tau / v[1] : 1.0; }
     if (clip_now) {
       block_top4(top, S.red);
-      const double rk = top[(o.clip_k > 4 ? 4 : o.clip_k) - 1];
+      const double rk = top[(clip_k_cur > 4 ? 4 : clip_k_cur) - 1];
       a_pr = (rk > tau) ? tau / rk : 1.0;
     }
     const double ph0 = f0 + mu * bar;
-    if (it == 0) th_max = 1e4 * fmax(1.0, th0);
+    if (th_max == 0.0) th_max = 1e4 * fmax(1.0, th0);
     const double th_min = 1e-4, th_floor = o.theta_floor * o.tol;     // violations below the tolerance count as equal (landing_nlp.h)
 
     PROF_ADD(PH_DUAL, tp);

@@ -29,6 +29,7 @@ typedef struct {
   double delta_init, delta_inc_first, delta_inc, delta_dec, tau_min, alpha_fallback;
   int restart_period;
   double reset_delta;
+  int fresh_restart;     /* 1: a restart that follows a jam (or any second restart) goes back to the caller's initial guess with clip_k = 2 */
   double theta_floor;    /* constraint violations (1-norm theta) below theta_floor * tol count as equal in the filter tests              */
   int clip_k;            /* the step to the boundary is set by the clip_k-th most blocking slack; the more blocking ones stop at    */
   double clip_until;     /* (1 - tau) of their distance (include/landing_nlp.h); only while pr > clip_until                      */
@@ -38,7 +39,7 @@ void lo_solver_opts_default(lo_solver_opts* o) {
   o->tol = 1e-6; o->max_iter = 3000; o->mu_init = 0.1; o->bound_push = 0.5; o->bound_frac = 0.1;
   o->kappa_eps = 10.0; o->kappa_mu = 0.2; o->theta_mu = 1.5; o->max_resets = 8; o->reset_du = 1e9;
   o->delta_init = 1e-4; o->delta_inc_first = 10.0; o->delta_inc = 4.0; o->delta_dec = 0.5; o->tau_min = 0.9; o->alpha_fallback = 1e-2; o->restart_period = 60; o->reset_delta = 1e5;
-  o->theta_floor = 1.0; o->clip_k = 4; o->clip_until = 0.03;
+  o->fresh_restart = 1; o->theta_floor = 1.0; o->clip_k = 4; o->clip_until = 0.03;
 }
 
 #define NW 48
@@ -183,8 +184,8 @@ static double slack_step(double s0, double ds, double alpha, double lb, double u
 static int solve_one(const lo_form* F, const double* p, const double* x0, const lo_solver_opts* op, double* x_out,
                      double* lam_out, int* iters_out, double kkt_out[3], long long counters[2]) {
   const int N = F->N; const lo_int nx = lo_nx(N), ng = lo_ng(N);
-  lo_poff o; work_t Wk, *W = &Wk; lo_int i, r; int k, it, status = 1, nfilt = 0, streak = 0, nreset = 0, last_reset_it = 0, ncrawl = 0;
-  double mu = op->mu_init, delta_last = 0.0, th_max = 0.0, e_du = 0.0;
+  lo_poff o; work_t Wk, *W = &Wk; lo_int i, r; int k, it, status = 1, nfilt = 0, streak = 0, nreset = 0, last_reset_it = 0, ncrawl = 0, last_mu_it = 0;
+  double mu = op->mu_init, delta_last = 0.0, th_max = 0.0, e_du = 0.0; int clip_k_cur = op->clip_k;
   double filt_th[64], filt_ph[64];
   double* gx;
   lo_param_offsets(N, &o);
@@ -248,11 +249,23 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
     if (it == op->max_iter) break;
     if (du > op->reset_du && nreset >= op->max_resets && op->max_resets > 0) { status = 2; break; }
     {
-      const int stalled = op->restart_period > 0 && it - last_reset_it >= op->restart_period && mu >= op->mu_init && nreset < op->max_resets && ncrawl < 1;
+      const int stalled = op->restart_period > 0 && it - last_reset_it >= op->restart_period && mu >= op->mu_init && nreset < op->max_resets && ncrawl < (op->fresh_restart ? 2 : 1);
+      /* ... and a LATER barrier problem that is not solved 2 restart_period iterations after it began has wandered off (nothing else
+       * catches that case: the dual infeasibility stays far below reset_du) -- restarted in place like a crawling iterate */
+      const int lost = op->fresh_restart && op->restart_period > 0 && mu < op->mu_init && pr > 1e-3 && it - last_mu_it >= 2 * op->restart_period && it - last_reset_it >= op->restart_period && nreset < op->max_resets;
       if (stalled) ncrawl++;
-      if (!((du > op->reset_du && nreset < op->max_resets) || stalled || (op->reset_delta > 0.0 && delta_last > op->reset_delta && nreset < op->max_resets))) goto no_reset;
+      if (!((du > op->reset_du && nreset < op->max_resets) || stalled || lost || (op->reset_delta > 0.0 && delta_last > op->reset_delta && nreset < op->max_resets))) goto no_reset;
       last_reset_it = it;
-      nreset++; init_slacks(W, op); mu = op->mu_init; nfilt = 0; delta_last = 0.0; streak = 0;
+      nreset++;
+      if (op->fresh_restart && (nreset == 2 || (nreset == 1 && !stalled && !lost))) {
+        /* the restart in place did not help (second restart) or the iterate is jammed (multipliers blown up): back to the caller's
+         * initial guess with another step rule -- the members that fail from it with clip_k = 4 solve with clip_k = 2 */
+        memcpy(W->x, x0, sizeof(double) * nx);
+        for (i = 0; i < 6; ++i) { W->x[i] = p[o.q_init + i]; W->x[6 + i] = p[o.qd_init + i]; }
+        eval_g(F, W->x, p, W->g);
+        clip_k_cur = clip_k_cur > 1 ? 2 : clip_k_cur; th_max = 0.0;
+      }
+      init_slacks(W, op); mu = op->mu_init; nfilt = 0; delta_last = 0.0; streak = 0;
       continue;
     }
     no_reset:;
@@ -264,7 +277,7 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
         if (lb > -INFINITY) cm = fmax(cm, fabs((W->s[r] - lb) * W->zL[r] - mu));
         if (ub < INFINITY) cm = fmax(cm, fabs((ub - W->s[r]) * W->zU[r] - mu));
       }
-      if (fmax(du, fmax(pr, cm)) <= op->kappa_eps * mu && mu > op->tol / 10.0) { mu = fmax(op->tol / 10.0, fmin(op->kappa_mu * mu, pow(mu, op->theta_mu))); nfilt = 0; }
+      if (fmax(du, fmax(pr, cm)) <= op->kappa_eps * mu && mu > op->tol / 10.0) { mu = fmax(op->tol / 10.0, fmin(op->kappa_mu * mu, pow(mu, op->theta_mu))); nfilt = 0; last_mu_it = it; }
       else break;
     }
     tau = fmax(op->tau_min, 1.0 - mu);
@@ -339,7 +352,7 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
     }
     /* dual steps, step bounds, merit data.  clip_now: the primal step length comes from the clip_k-th largest ratio
      * |ds| / distance (top[] holds the four largest); the slacks with a larger ratio are clipped in slack_step(). */
-    clip_now = op->clip_k > 1 && pr > op->clip_until;
+    clip_now = clip_k_cur > 1 && pr > op->clip_until;
     top[0] = top[1] = top[2] = top[3] = 0.0;
     for (r = 12; r < ng; ++r) {
       const double lb = W->lb[r], ub = W->ub[r], g = W->g[r]; double s, ds, yn;
@@ -368,8 +381,8 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
       for (i = 0; i < 12; ++i) dphi += gX[i] * dX[i] + gc[i] * dU[i] + gf[i] * dU[12 + i];
     }
     ph0 = f0 + mu * bar;
-    if (it == 0) th_max = 1e4 * fmax(1.0, th0);
-    if (clip_now) { const double rk = top[(op->clip_k > 4 ? 4 : op->clip_k) - 1]; a_pr = rk > tau ? tau / rk : 1.0; }
+    if (th_max == 0.0) th_max = 1e4 * fmax(1.0, th0);
+    if (clip_now) { const double rk = top[(clip_k_cur > 4 ? 4 : clip_k_cur) - 1]; a_pr = rk > tau ? tau / rk : 1.0; }
     alpha = a_pr;
     while (alpha > 1e-10) {
       double tht = 0, bt = 0, ft = 0, pht; int ok_f, e, switching;

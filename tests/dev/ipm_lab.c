@@ -322,9 +322,9 @@ static void forward_sweep(const lo_form* F, work_t* W, const double* sig0, const
 /* dual steps + fraction-to-the-boundary bounds for the current ds; mu_c = centering parameter used in dz */
 static lo_int g_block_row = -1;
 static const double *g_muL = NULL, *g_muU = NULL;     /* per-row centering targets (corrector), NULL = scalar mu */
-static _Thread_local int t_clip_now = 0;
+static _Thread_local int t_clip_now = 0, t_clipk_cur = -1;
 static void dual_steps(work_t* W, double mu_s, double tau, double* a_pr, double* a_du) {
-  lo_int r; double ap = 1.0, ad = 1.0; double small[64]; int ns = 0, kk = LAB.clipk > 64 ? 64 : LAB.clipk; g_block_row = -1;
+  lo_int r; double ap = 1.0, ad = 1.0; double small[64]; int ns = 0, kk = (t_clipk_cur >= 0 ? t_clipk_cur : LAB.clipk) > 64 ? 64 : (t_clipk_cur >= 0 ? t_clipk_cur : LAB.clipk); g_block_row = -1;
   double smalld[64]; int nsd = 0, kd = LAB.clipkd > 64 ? 64 : LAB.clipkd;
 #define PUSH_RATIOD(v) do { if (kd > 0) { double v_ = (v); int q_; if (nsd < kd) { smalld[nsd++] = v_; } else { int im = 0; for (q_ = 1; q_ < kd; ++q_) if (smalld[q_] > smalld[im]) im = q_; if (v_ < smalld[im]) smalld[im] = v_; } } } while (0)
 #define PUSH_RATIO(v) do { if (kk > 0) { double v_ = (v); int q_; if (ns < kk) { small[ns++] = v_; } else { int im = 0; for (q_ = 1; q_ < kk; ++q_) if (small[q_] > small[im]) im = q_; if (v_ < small[im]) small[im] = v_; } } } while (0)
@@ -396,7 +396,7 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
   reg_t RG; long long nsoc_total = 0, soc_acc = 0; int cutstreak = 0; double thhist[32]; int nth = 0;
   const double keps = LAB.kappa_eps > 0 ? LAB.kappa_eps : op->kappa_eps;
   const int rperiod = LAB.restart_period > 0 ? LAB.restart_period : op->restart_period;
-  memset(&RG, 0, sizeof(RG)); RG.fail_stage = 99;
+  memset(&RG, 0, sizeof(RG)); RG.fail_stage = 99; t_clipk_cur = -1;
   lo_param_offsets(N, &o);
   W->N = N; W->nx = nx; W->ng = ng;
   W->x = dalloc(nx); W->xt = dalloc(nx); W->dx = dalloc(nx); gx = dalloc(nx);
@@ -465,7 +465,7 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
     if (it == op->max_iter) break;
     if (du > op->reset_du && nreset >= op->max_resets && op->max_resets > 0) { status = 2; break; }
     {
-      int stalled = rperiod > 0 && it - last_reset_it >= rperiod && mu >= (LAB.mu_init > 0 ? LAB.mu_init : op->mu_init) && nreset < op->max_resets && ncrawl < 1;
+      int stalled = rperiod > 0 && it - last_reset_it >= rperiod && mu >= (LAB.mu_init > 0 ? LAB.mu_init : op->mu_init) && nreset < op->max_resets && ncrawl < (getenv("LAB_CRAWLMAX") ? atoi(getenv("LAB_CRAWLMAX")) : 1);
       if (stalled && LAB.stall == 1 && pr <= 1e-2 && du <= 1e2 * keps * mu) stalled = 0;   /* the barrier problem is about to be solved */
       if (LAB.stall == 2) {   /* progress-based crawl test: theta must have dropped by the factor stall_frac over the last `win` iterations */
         const int win = getenv("LAB_WIN") ? atoi(getenv("LAB_WIN")) : 20; const double fr = getenv("LAB_FRAC") ? atof(getenv("LAB_FRAC")) : 0.5;
@@ -481,7 +481,16 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
       if (!((du > op->reset_du && nreset < op->max_resets) || stalled || (op->reset_delta > 0.0 && delta_last > op->reset_delta && nreset < op->max_resets))) goto no_reset;
       last_reset_it = it;
       cutstreak = 0; nth = 0;
-      nreset++; init_slacks(W, op); mu = LAB.mu_init > 0 ? LAB.mu_init : op->mu_init; nfilt = 0; delta_last = 0.0; streak = 0;
+      nreset++;
+      if ((getenv("LAB_FRESH") && nreset == atoi(getenv("LAB_FRESH"))) || (getenv("LAB_FRESHJAM") && !stalled && nreset <= atoi(getenv("LAB_FRESHJAM")))) {   /* n-th restart: back to the caller's initial guess with another step rule */
+        memcpy(W->x, x0, sizeof(double) * nx);
+        for (i = 0; i < 6; ++i) { W->x[i] = p[o.q_init + i]; W->x[6 + i] = p[o.qd_init + i]; }
+        eval_g(F, W->x, p, W->g);
+        t_clipk_cur = getenv("LAB_FRESHK") ? atoi(getenv("LAB_FRESHK")) : 2;
+        th_max = 0.0;
+      }
+      init_slacks(W, op); mu = LAB.mu_init > 0 ? LAB.mu_init : op->mu_init; nfilt = 0; delta_last = 0.0; streak = 0;
+      if (getenv("LAB_ALTCLIP")) { static const int seq[3] = {4, 2, 1}; t_clipk_cur = seq[nreset % 3]; }   /* another step rule after every restart */
       continue;
     }
     no_reset:;
@@ -628,7 +637,7 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
       continue;
     }
     /* dual steps, step bounds, merit data */
-    t_clip_now = LAB.clipk > 0 && pr > LAB.clipk_until;
+    t_clip_now = (t_clipk_cur >= 0 ? t_clipk_cur : LAB.clipk) > 1 && pr > LAB.clipk_until;
     dual_steps(W, mu, tau, &a_pr, &a_du);
     if (LAB.mehro && (LAB.mehro == 1 || a_pr < 0.5)) {   /* corrector: second-order complementarity term of the predictor step */
       double sg2[24]; double d_io = delta_used; const double sc = (LAB.mehro == 3) ? a_pr * a_du : 1.0;

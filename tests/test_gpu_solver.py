@@ -308,3 +308,29 @@ def test_solver_fp32_factor_reaches_fp64_kkt(oracle_mod):
         if b["status"][m] == 0:
             assert O.kkt(b["x"][m], P[m], b["lam_g"][m]).max() <= 1e-6 * 1.0001
     L.close()
+
+
+@pytest.mark.gpu
+def test_fresh_restart_rescues_the_soak_failures(oracle_mod):
+    """landing_solver_opts::fresh_restart: members found by tools/soak.py (65 536 fresh drop states) that hit max_iter with restarts in
+    place only -- ordinary drop states, each solvable from the same initial guess with another step rule -- converge with the default
+    (restart from the initial guess after a jam / at the second restart, later barrier problems watched), certified by the oracle"""
+    N = 40
+    cases = [(100062, 614), (100062, 438), (100041, 890), (100039, 349), (100031, 450), (100027, 126), (100059, 370), (100044, 440)]
+    O = oracle_mod.Oracle(N)
+    Ps, Xs = [], []
+    for seed, m in cases:
+        P, X0, _, _ = lc("problem").make_batch(1024, N, 0.6, seed=seed)
+        Ps.append(P[m]); Xs.append(X0[m])
+    Ps, Xs = np.array(Ps), np.array(Xs)
+    L = lc("capi").LandingLib(N, device=0)
+    o = L.default_opts(); o.max_iter = 300
+    assert o.fresh_restart == 1
+    r = L.solve_host(Ps, Xs, o)
+    assert (r["status"] == 0).all(), (r["status"], r["iters"])
+    for b in range(len(cases)):
+        assert O.kkt(r["x"][b], Ps[b], r["lam_g"][b]).max() <= 1e-6 * 1.0001
+    o.fresh_restart = 0
+    r0 = L.solve_host(Ps, Xs, o)
+    assert (r0["status"] != 0).sum() >= 4, r0["status"]          # what the rule is for (measured: 8 of 8 fail in place)
+    L.close()
