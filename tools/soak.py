@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 capi = importlib.import_module("landing-controller_amd.capi"); problem = importlib.import_module("landing-controller_amd.problem")
 ap = argparse.ArgumentParser(); ap.add_argument("--batches", type=int, default=64); ap.add_argument("--B", type=int, default=1024); ap.add_argument("--N", type=int, default=40)
-ap.add_argument("--seed0", type=int, default=100000); ap.add_argument("--opts", default=""); a = ap.parse_args()
+ap.add_argument("--seed0", type=int, default=100000); ap.add_argument("--seed-step", type=int, default=1); ap.add_argument("--opts", default=""); a = ap.parse_args()
 L = capi.LandingLib(a.N, 0)
 o = L.default_opts(); o.max_iter = 300
 for kv in a.opts.split(","):
@@ -18,7 +18,7 @@ x, st, it, kkt = mk(a.B, L.nx), mk(a.B, dt=torch.int32), mk(a.B, dt=torch.int32)
 stream = torch.cuda.current_stream().cuda_stream
 its, sts, ms, worst = [], [], [], []
 for b in range(a.batches):
-    seed = a.seed0 + b
+    seed = a.seed0 + b * a.seed_step
     P, X0, _, _ = problem.make_batch(a.B, a.N, 0.6, seed=seed)
     dP, dX0 = torch.tensor(P, device="cuda"), torch.tensor(X0, device="cuda")
     torch.cuda.synchronize(); t = time.perf_counter()
