@@ -124,18 +124,25 @@ typedef struct {
                             Newton steps whose second-order terms raise theta a little; the relative-decrease test alone then cuts
                             every step to 1/64 (IPOPT gets past this with second-order corrections / its acceptable-point stop).
                             One member of the eight bench batches: 212 -> 99 iterations, nothing else changes.  0 = off          */
-  int fresh_restart;     /* 1 (default): restarts do not all happen in place.  (a) A restart that follows a JAM (dual infeasibility above
-                            reset_du, regularisation above reset_delta) and every member's SECOND restart go back to the caller's initial
-                            guess with clip_k = 2 instead of re-initialising slacks and multipliers at the current x; (b) the crawl
-                            detector may fire twice; (c) a LATER barrier problem (mu < mu_init) that is still unsolved 2 restart_period
-                            iterations after it began with a primal infeasibility above 1e-3 has wandered off and is restarted in place
-                            (nothing else catches that case).  Why: over 65 536 fresh drop states (tools/soak.py) 12 members did not
-                            converge within 300 iterations -- none infeasible or unusual: each solves in 50..100 iterations from the same
-                            guess with clip_k = 2 or with the classic rule, but a restart in place repeats the failure from a bad x (8
-                            members), or no restart ever fired (3).  Such a member sets the time of its batch (250 instead of 105 ms, one
-                            batch in six).  With the rule 65 536 of 65 536 converge (worst 272 iterations) and the mean batch time over
-                            the 64 batches is 126.8 instead of 133.2 ms; the eight bench batches (no such member) lose 2 %: 9180 instead
-                            of 9400 NLPs/s, because a handful of slow-but-converging members now restart.  0 = restarts in place only    */
+  int fresh_restart;     /* restart rules beyond "re-initialise slacks, multipliers and mu at the current x", a bit mask (default 9 = 1 | 8):
+                            1: a restart that follows a JAM (dual infeasibility above reset_du, regularisation above reset_delta) goes back
+                               to the caller's initial guess with clip_k = 2 -- a restart in place repeats the failure from a bad x;
+                            2: so does every member's second restart;   4: the crawl detector may fire twice;
+                            8: a LATER barrier problem (mu < mu_init) still unsolved 2 restart_period iterations after it began, with a
+                               primal infeasibility above 1e-3, has wandered off and is restarted in place (nothing else catches it).
+                            History (tools/soak.py, 64 fresh batches = 65 536 drop states, profiles/r02_soak*.json): with restarts in
+                            place only 12 members hit max_iter -- none infeasible or unusual, each solves in 50..100 iterations from the
+                            same guess with another step rule -- and such a member sets the time of its batch (250 instead of 105 ms).
+                            Rules 1|2|4|8 rescued all twelve; once dual_step_cap (below) removed the cause of the jams, rules 2 and 4 only
+                            cost time (a 239-iteration member in the bench batches) and rule 8 alone keeps 65 536 of 65 536.  0 = none    */
+  double dual_step_cap;  /* the step length of the bound multipliers is at most dual_step_cap times the accepted primal step length
+                            (default 1: a_du <= alpha; 0 = IPOPT's independent dual step length).  Found through the members that
+                            jammed (fresh_restart above): the jam starts where ONE slack cuts the primal step to 1e-3..1e-4 while the
+                            multipliers keep taking steps of 0.1..0.7 -- x and s stay, z runs ahead, the dual infeasibility grows from 1e3
+                            to 1e10 within eight iterations.  With the cap all twelve members that hit max_iter in the 65 536-member sweep
+                            converge in 44..72 iterations WITHOUT any restart; over the 64 fresh batches p99.9 of the iteration count
+                            133 -> 106 and the mean batch time 127.7 -> 110.3 ms (8 020 -> 9 290 NLPs/s), the bench batches unchanged
+                            (109 ms).  2: mean 138 ms; 4: 128 ms; 0.5: 171 iterations on average                     */
   int factor_fp32;       /* 1: the stage eliminations of the Riccati factorisation (T^T P T, blocked LDL^T, gains, cost-to-go) run in
                             single precision on v_mfma_f32_16x16x4_f32 -- BASELINE configs[4]'s "fp32 MFMA KKT factor".  Residuals,
                             right-hand sides, forward sweep, line search and the convergence test stay fp64: the step becomes an

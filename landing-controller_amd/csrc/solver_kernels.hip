@@ -1166,18 +1166,18 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
     if (it == o.max_iter) break;
     if (du > o.reset_du && nreset >= o.max_resets && o.max_resets > 0) { status = LANDING_NUMERICAL; break; }   // jammed again: give up
     // crawling: still in the first barrier problem (mu never decreased) restart_period iterations after the last (re)start
-    const bool stalled = o.restart_period > 0 && it - last_reset_it >= o.restart_period && mu >= o.mu_init && nreset < o.max_resets && ncrawl < (o.fresh_restart ? 2 : 1);
+    const bool stalled = o.restart_period > 0 && it - last_reset_it >= o.restart_period && mu >= o.mu_init && nreset < o.max_resets && ncrawl < ((o.fresh_restart & 4) ? 2 : 1);
     const bool overreg = o.reset_delta > 0.0 && delta_last > o.reset_delta && nreset < o.max_resets;
     // a LATER barrier problem not solved 2 restart_period iterations after it began has wandered off (the dual infeasibility stays
     // far below reset_du, nothing else catches it): restarted in place like a crawling iterate
-    const bool lost = o.fresh_restart && o.restart_period > 0 && mu < o.mu_init && pr > 1e-3 && it - last_mu_it >= 2 * o.restart_period && it - last_reset_it >= o.restart_period && nreset < o.max_resets;
+    const bool lost = (o.fresh_restart & 8) && o.restart_period > 0 && mu < o.mu_init && pr > 1e-3 && it - last_mu_it >= 2 * o.restart_period && it - last_reset_it >= o.restart_period && nreset < o.max_resets;
     if ((du > o.reset_du && nreset < o.max_resets) || stalled || overreg || lost) {
       last_reset_it = it;
       if (stalled) ncrawl++;
       // jammed iterate (multipliers blown up): keep x, re-initialise slacks, multipliers, barrier parameter and
       // filter -- the role IPOPT's restoration phase plays on this problem class
       nreset++;
-      if (o.fresh_restart && (nreset == 2 || (nreset == 1 && !stalled && !lost))) {
+      if (((o.fresh_restart & 2) && nreset == 2) || ((o.fresh_restart & 1) && nreset == 1 && !stalled && !lost)) {
         // the restart in place did not help (second restart) or the iterate is jammed: back to the caller's initial guess with
         // another step rule (landing_nlp.h: the members that fail from it with clip_k = 4 solve with clip_k = 2)
         for (int i = lane; i < nx; i += NT) {
@@ -1377,6 +1377,7 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
       __syncthreads();
     }
     PROF_ADD(PH_LS, tp);
+    if (o.dual_step_cap > 0.0) a_du = fmin(a_du, o.dual_step_cap * alpha);      // the multipliers do not run ahead of a blocked primal step (landing_nlp.h)
     // ================================================================ accept the trial point; the same pass produces the
     // primal / complementarity errors, Sigma and rho of the new iterate (what point_pass computes)
     for (int i = lane; i < nx; i += NT) M.x[i] = M.xt[i];

@@ -29,7 +29,8 @@ typedef struct {
   double delta_init, delta_inc_first, delta_inc, delta_dec, tau_min, alpha_fallback;
   int restart_period;
   double reset_delta;
-  int fresh_restart;     /* 1: a restart that follows a jam (or any second restart) goes back to the caller's initial guess with clip_k = 2 */
+  double dual_step_cap;  /* a_du <= dual_step_cap * alpha (include/landing_nlp.h); 0 = independent dual step length                      */
+  int fresh_restart;     /* bit mask of the restart rules of include/landing_nlp.h (default 9 = 1 | 8)                                   */
   double theta_floor;    /* constraint violations (1-norm theta) below theta_floor * tol count as equal in the filter tests              */
   int clip_k;            /* the step to the boundary is set by the clip_k-th most blocking slack; the more blocking ones stop at    */
   double clip_until;     /* (1 - tau) of their distance (include/landing_nlp.h); only while pr > clip_until                      */
@@ -39,7 +40,7 @@ void lo_solver_opts_default(lo_solver_opts* o) {
   o->tol = 1e-6; o->max_iter = 3000; o->mu_init = 0.1; o->bound_push = 0.5; o->bound_frac = 0.1;
   o->kappa_eps = 10.0; o->kappa_mu = 0.2; o->theta_mu = 1.5; o->max_resets = 8; o->reset_du = 1e9;
   o->delta_init = 1e-4; o->delta_inc_first = 10.0; o->delta_inc = 4.0; o->delta_dec = 0.5; o->tau_min = 0.9; o->alpha_fallback = 1e-2; o->restart_period = 60; o->reset_delta = 1e5;
-  o->fresh_restart = 1; o->theta_floor = 1.0; o->clip_k = 4; o->clip_until = 0.03;
+  o->dual_step_cap = 1.0; o->fresh_restart = 9; o->theta_floor = 1.0; o->clip_k = 4; o->clip_until = 0.03;
 }
 
 #define NW 48
@@ -249,15 +250,15 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
     if (it == op->max_iter) break;
     if (du > op->reset_du && nreset >= op->max_resets && op->max_resets > 0) { status = 2; break; }
     {
-      const int stalled = op->restart_period > 0 && it - last_reset_it >= op->restart_period && mu >= op->mu_init && nreset < op->max_resets && ncrawl < (op->fresh_restart ? 2 : 1);
+      const int stalled = op->restart_period > 0 && it - last_reset_it >= op->restart_period && mu >= op->mu_init && nreset < op->max_resets && ncrawl < ((op->fresh_restart & 4) ? 2 : 1);
       /* ... and a LATER barrier problem that is not solved 2 restart_period iterations after it began has wandered off (nothing else
        * catches that case: the dual infeasibility stays far below reset_du) -- restarted in place like a crawling iterate */
-      const int lost = op->fresh_restart && op->restart_period > 0 && mu < op->mu_init && pr > 1e-3 && it - last_mu_it >= 2 * op->restart_period && it - last_reset_it >= op->restart_period && nreset < op->max_resets;
+      const int lost = (op->fresh_restart & 8) && op->restart_period > 0 && mu < op->mu_init && pr > 1e-3 && it - last_mu_it >= 2 * op->restart_period && it - last_reset_it >= op->restart_period && nreset < op->max_resets;
       if (stalled) ncrawl++;
       if (!((du > op->reset_du && nreset < op->max_resets) || stalled || lost || (op->reset_delta > 0.0 && delta_last > op->reset_delta && nreset < op->max_resets))) goto no_reset;
       last_reset_it = it;
       nreset++;
-      if (op->fresh_restart && (nreset == 2 || (nreset == 1 && !stalled && !lost))) {
+      if (((op->fresh_restart & 2) && nreset == 2) || ((op->fresh_restart & 1) && nreset == 1 && !stalled && !lost)) {
         /* the restart in place did not help (second restart) or the iterate is jammed (multipliers blown up): back to the caller's
          * initial guess with another step rule -- the members that fail from it with clip_k = 4 solve with clip_k = 2 */
         memcpy(W->x, x0, sizeof(double) * nx);
@@ -422,6 +423,7 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
       filt_th[nfilt] = (1.0 - 1e-5) * th0; filt_ph[nfilt] = ph0 - 1e-8 * th0; nfilt++;
     }
     if (getenv("LO_TRACE")) fprintf(stderr, "      alpha %9.2e a_pr %9.2e a_du %9.2e delta %8.1e acc %d armijo %d th0 %9.2e dphi %9.2e clip %d\n", alpha, a_pr, a_du, delta, accepted, armijo, th0, dphi, clip_now);
+    if (op->dual_step_cap > 0.0) a_du = fmin(a_du, op->dual_step_cap * alpha);      /* the multipliers do not run ahead of a blocked primal step */
     memcpy(W->x, W->xt, sizeof(double) * nx);
     for (r = 0; r < ng; ++r) {
       const double lb = W->lb[r], ub = W->ub[r]; double s, zl = 0, zu = 0;

@@ -249,10 +249,11 @@ def test_n40_reference_solutions_known_answer(oracle_mod):
         better += r["f"][b] <= f_ref * 1.001
     # measured in round 1: 6 of 17 coincide to <= 1e-4 relative, 8 are better, 3 end in another (worse) local minimum;
     # round 2 (restart_period 60, delta_dec 0.5): 5 coincide, 6 are better, 5 end in a worse local minimum, 1 does not converge
-    # round 2, final (clip_k, theta_floor): 17 of 17 converge, 7 coincide, 12 have the same or a better objective, 5 a worse local minimum
+    # round 2 with clip_k / theta_floor: 17 of 17 converge, 7 coincide, 12 same or better; final (+ dual_step_cap): 17 of 17, 5 coincide,
+    # 13 have the same or a better objective, 4 a worse local minimum
     # (non-convex NLP: which KKT point a run reaches depends on the regularisation path; every returned point is certified above)
     print("N=40 stored reference solutions: converged %d of %d, same local minimum %d, same or better objective %d" % (ok.sum(), len(Ps), same, better))
-    assert same >= 6 and better >= 11, (same, better, ok.sum())
+    assert same >= 4 and better >= 11, (same, better, ok.sum())
 
 
 def test_reference_bound_frac_is_a_supported_configuration(libs, oracle_mod):
@@ -311,10 +312,11 @@ def test_solver_fp32_factor_reaches_fp64_kkt(oracle_mod):
 
 
 @pytest.mark.gpu
-def test_fresh_restart_rescues_the_soak_failures(oracle_mod):
-    """landing_solver_opts::fresh_restart: members found by tools/soak.py (65 536 fresh drop states) that hit max_iter with restarts in
-    place only -- ordinary drop states, each solvable from the same initial guess with another step rule -- converge with the default
-    (restart from the initial guess after a jam / at the second restart, later barrier problems watched), certified by the oracle"""
+def test_soak_failures_are_rescued(oracle_mod):
+    """members found by tools/soak.py (65 536 fresh drop states) that hit max_iter with IPOPT's independent dual step length and
+    restarts in place only -- ordinary drop states, each solvable from the same initial guess with another step rule: they converge
+    with the defaults (landing_solver_opts::dual_step_cap = 1 removes the jam itself; fresh_restart = 9 is the safety net), certified by
+    the oracle; with both off they fail, and each rule alone rescues most of them"""
     N = 40
     cases = [(100062, 614), (100062, 438), (100041, 890), (100039, 349), (100031, 450), (100027, 126), (100059, 370), (100044, 440)]
     O = oracle_mod.Oracle(N)
@@ -325,12 +327,15 @@ def test_fresh_restart_rescues_the_soak_failures(oracle_mod):
     Ps, Xs = np.array(Ps), np.array(Xs)
     L = lc("capi").LandingLib(N, device=0)
     o = L.default_opts(); o.max_iter = 300
-    assert o.fresh_restart == 1
+    assert (o.fresh_restart, o.dual_step_cap) == (9, 1.0)
     r = L.solve_host(Ps, Xs, o)
-    assert (r["status"] == 0).all(), (r["status"], r["iters"])
+    assert (r["status"] == 0).all() and r["iters"].max() <= 120, (r["status"], r["iters"])       # measured: 44..72 iterations
     for b in range(len(cases)):
         assert O.kkt(r["x"][b], Ps[b], r["lam_g"][b]).max() <= 1e-6 * 1.0001
-    o.fresh_restart = 0
+    o.fresh_restart = 0; o.dual_step_cap = 0.0
     r0 = L.solve_host(Ps, Xs, o)
-    assert (r0["status"] != 0).sum() >= 4, r0["status"]          # what the rule is for (measured: 8 of 8 fail in place)
+    assert (r0["status"] != 0).sum() >= 4, r0["status"]          # measured: 8 of 8 fail
+    o.fresh_restart = 15
+    r1 = L.solve_host(Ps, Xs, o)
+    assert (r1["status"] == 0).sum() >= 7, r1["status"]          # the restart rules alone (measured: 8 of 8, 94..207 iterations)
     L.close()
