@@ -118,12 +118,15 @@ typedef struct {
   double clip_until;     /* ... applied only while the primal infeasibility (max norm, slack rows included) is above this value
                             (default 0.03): close to feasibility the classic rule is kept -- without the switch 1 member in 1000
                             parks at pr ~ 2e-2 with diverging multipliers                                                     */
-  double theta_floor;    /* filter line search: constraint violations (theta, 1-norm over the rows) below theta_floor * tol count as
-                            equal -- a trial point that stays below is never rejected for its theta.  Default 1.  At the last barrier
-                            problems theta sits at ~1e-7, far below the tolerance, while the dual infeasibility still needs full
-                            Newton steps whose second-order terms raise theta a little; the relative-decrease test alone then cuts
-                            every step to 1/64 (IPOPT gets past this with second-order corrections / its acceptable-point stop).
-                            One member of the eight bench batches: 212 -> 99 iterations, nothing else changes.  0 = off          */
+  double theta_floor;    /* filter line search: constraint violations (theta, 1-norm over the ~4000 rows) below theta_floor * tol count as
+                            equal -- a trial point that stays below is never rejected for its theta.  Default 30.  At the last barrier
+                            problems theta sits at ~1e-7, far below the tolerance, while the dual infeasibility still needs full Newton
+                            steps whose second-order terms raise theta a little; the relative-decrease test alone then cuts every step to
+                            1/64 .. 1e-7 (IPOPT gets past this with second-order corrections / its acceptable-point stop).  Convergence is
+                            still decided by the max-norm residuals <= tol.  Measured (tools/soak.py, 64 fresh batches): floor 0 -> one
+                            212-iteration member in the bench batches; 1 -> 99, but three members of the 65 536 still need 203..251
+                            iterations with theta pinned AT the floor; 30 -> they need 51..69, mean batch time 110.2 -> 106.2 ms, slowest
+                            batch 223 -> 142 ms; 10: 107.6 ms, 100: 106.1 ms.  0 = off                                              */
   int fresh_restart;     /* restart rules beyond "re-initialise slacks, multipliers and mu at the current x", a bit mask (default 9 = 1 | 8):
                             1: a restart that follows a JAM (dual infeasibility above reset_du, regularisation above reset_delta) goes back
                                to the caller's initial guess with clip_k = 2 -- a restart in place repeats the failure from a bad x;
