@@ -230,6 +230,7 @@ static void init_slacks(work_t* W, const lo_solver_opts* op0) {
 
 typedef struct { int thmin_rel, max_soc, sticky, stall, probe, trace, clip; double clip_tau, mu_init, tau_min, bpush, bfrac, mehro_lo, mehro_hi, piv_jump, piv_keep; int zinit, mehro, zcomp, crawl2; double thcap, thfloor, crawl2_frac; double stall_frac; int restart_period; double kappa_eps; int adapt; double sig_max, mono_fact; int adapt_glob; int clipk; double clipk_until; int full0; double full0_alpha; int clipkd; int fp32; int scaled; int stallany; } lab_t;
 static lab_t LAB;
+#define LAB_THFLOOR (getenv("LAB_THETAFLOOR") ? atof(getenv("LAB_THETAFLOOR")) * 1e-6 : 0.0)
 static int lab_fp32(void) { return LAB.fp32; }
 static void lab_init(void) {
   const char* e;
@@ -684,11 +685,11 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
         trial_point(F, p, W, &o, alpha, mu, &tht, &pht);
         ok_f = (tht <= th_max) && (pht < 1e300) && (pht > -1e300) && (tht < 1e300);
         if (LAB.thcap > 0 && tht > fmax(LAB.thcap * th0, LAB.thfloor)) ok_f = 0;
-        for (e = 0; e < nfilt && ok_f; ++e) if (tht >= filt_th[e] && pht >= filt_ph[e]) ok_f = 0;
+        for (e = 0; e < nfilt && ok_f; ++e) if (tht >= fmax(filt_th[e], LAB_THFLOOR) && pht >= filt_ph[e]) ok_f = 0;
         switching = (dphi < 0.0) && (th0 <= th_min) && (alpha * pow(-dphi, 2.3) > pow(th0, 1.1));
         if (ok_f) {
           if (switching) { if (pht <= ph0 + 1e-8 * alpha * dphi) { accepted = 1; armijo = 1; } }
-          else if (tht <= (1.0 - 1e-5) * th0 || pht <= ph0 - 1e-8 * th0) accepted = 1;
+          else if (tht <= fmax((1.0 - 1e-5) * th0, LAB_THFLOOR) || pht <= ph0 - 1e-8 * th0) accepted = 1;
         }
         if (accepted) break;
         /* second-order correction (Waechter & Biegler, sec. 2.4): only at the first trial point, only when theta went up */
@@ -714,10 +715,10 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
             counters[1]++;
             trial_point(F, p, W, &o, a_soc, mu, &tht2, &pht2);
             okf2 = (tht2 <= th_max) && (pht2 < 1e300) && (pht2 > -1e300) && (tht2 < 1e300);
-            for (e = 0; e < nfilt && okf2; ++e) if (tht2 >= filt_th[e] && pht2 >= filt_ph[e]) okf2 = 0;
+            for (e = 0; e < nfilt && okf2; ++e) if (tht2 >= fmax(filt_th[e], LAB_THFLOOR) && pht2 >= filt_ph[e]) okf2 = 0;
             if (okf2) {
               if (switching) { if (pht2 <= ph0 + 1e-8 * alpha * dphi) { accepted = 1; armijo = 1; } }
-              else if (tht2 <= (1.0 - 1e-5) * th0 || pht2 <= ph0 - 1e-8 * th0) accepted = 1;
+              else if (tht2 <= fmax((1.0 - 1e-5) * th0, LAB_THFLOOR) || pht2 <= ph0 - 1e-8 * th0) accepted = 1;
             }
             if (accepted) { alpha = a_soc; a_du = a_du_soc; soc_acc++; break; }
             if (tht2 > 0.99 * th_prev) break;
@@ -748,6 +749,7 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
     thhist[nth & 31] = th0; nth++;
     if (LAB.trace) fprintf(stderr, "      alpha %9.2e a_pr %9.2e a_du %9.2e delta %8.1e acc %d armijo %d th0 %9.2e dphi %9.2e failstage %d block row %d (stage %d type %d) s-dist %g\n", alpha, a_pr, a_du, delta, accepted, armijo, th0, dphi, RG.fail_stage, (int)g_block_row, g_block_row >= 36 ? (int)((g_block_row - 36) / 104) : -1, g_block_row >= 36 ? (int)((g_block_row - 36) % 104) : (int)g_block_row, g_block_row >= 0 ? fmin(W->s[g_block_row] - W->lb[g_block_row], W->ub[g_block_row] - W->s[g_block_row]) : 0.0);
     RG.fail_stage = 99;
+    if (getenv("LAB_DUALCAP")) a_du = fmin(a_du, atof(getenv("LAB_DUALCAP")) * alpha);
     memcpy(W->x, W->xt, sizeof(double) * nx);
     for (r = 0; r < ng; ++r) {
       const double lb = W->lb[r], ub = W->ub[r]; double s, zl = 0, zu = 0;
