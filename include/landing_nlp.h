@@ -146,6 +146,15 @@ typedef struct {
                             converge in 44..72 iterations WITHOUT any restart; over the 64 fresh batches p99.9 of the iteration count
                             133 -> 106 and the mean batch time 127.7 -> 110.3 ms (8 020 -> 9 290 NLPs/s), the bench batches unchanged
                             (109 ms).  2: mean 138 ms; 4: 128 ms; 0.5: 171 iterations on average                     */
+  double slack_corr;     /* slack correction at a rejected first trial point (default 0.9; 0 = off): when the first trial point of the line
+                            search (alpha = the step to the boundary) is rejected with theta ABOVE its current value, the same point is
+                            tried once more with every inequality slack moved to g(x_trial) -- but never closer to a bound than slack_corr
+                            times its linearised distance -- and, if the filter accepts that, taken.  No new linear solve: it removes the
+                            part of the Maratos effect that comes from the curvature of the inequality rows, which is what IPOPT's
+                            second-order corrections (reference: max_soc 4) would repair with another solve.  The members that set the time
+                            of a typical batch are of this type (20..60 iterations at mu = 0.1 with a full step admissible but cut to
+                            1/8..1/16): CPU port, the stragglers 137 / 203 / 166 / 157 / 145 -> 57 / 58 / 57 / 93 / 68 iterations; numbers at
+                            scale in DESIGN.md 4.2.  Applied at every trial point instead it doubles the mean iteration count       */
   int factor_fp32;       /* 1: the stage eliminations of the Riccati factorisation (T^T P T, blocked LDL^T, gains, cost-to-go) run in
                             single precision on v_mfma_f32_16x16x4_f32 -- BASELINE configs[4]'s "fp32 MFMA KKT factor".  Residuals,
                             right-hand sides, forward sweep, line search and the convergence test stay fp64: the step becomes an

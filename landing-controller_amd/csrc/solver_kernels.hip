@@ -1317,7 +1317,7 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
 
     PROF_ADD(PH_DUAL, tp);
     // ================================================================ filter line search
-    double alpha = a_pr;
+    double alpha = a_pr, s_corr = 0.0;
     bool accepted = false, armijo_step = false;
     while (alpha > 1e-10) {
       if (lane == 0) S.prof[PH_NTRIAL] += 1.0;
@@ -1356,6 +1356,32 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
         }
       }
       if (accepted) break;
+      if (o.slack_corr > 0.0 && alpha == a_pr && tht >= th0) {
+        // slack correction (landing_nlp.h): the rejected first trial point once more with the inequality slacks moved to g(x_trial)
+        double tht2 = 0.0, bt2 = 0.0;
+        for (int rb = lane + 12; rb < ng; rb += NT * RB) {
+          double lbv[RB], ubv[RB], gv[RB], sv[RB], dsv[RB];
+#pragma unroll
+          for (int j = 0; j < RB; ++j) { const int r = rb + j * NT, rr = r < ng ? r : ng - 1; lbv[j] = S.bnd_lb[bidx(rr)]; ubv[j] = S.bnd_ub[bidx(rr)]; gv[j] = r_gt[rr]; sv[j] = r_s[rr]; dsv[j] = r_ds[rr]; }
+#pragma unroll
+          for (int j = 0; j < RB; ++j) {
+            if (rb + j * NT >= ng) continue;
+            const double lb = lbv[j], ub = ubv[j], g = gv[j];
+            if (lb == ub) { tht2 += fabs(g - lb); continue; }
+            double s = sv[j] + alpha * dsv[j];
+            if (omt > 0.0) { if (lb > -INF) s = fmax(s, fma(omt, sv[j] - lb, lb)); if (ub < INF) s = fmin(s, fma(-omt, ub - sv[j], ub)); }
+            const double lo = lb > -INF ? lb + o.slack_corr * (s - lb) : -INF, hi = ub < INF ? ub - o.slack_corr * (ub - s) : INF;
+            s = fmin(fmax(g, lo), hi);
+            tht2 += fabs(g - s);
+            bt2 -= log((lb > -INF ? s - lb : 1.0) * (ub < INF ? ub - s : 1.0));
+          }
+        }
+        { double v[2] = {tht2, bt2}; const int op[2] = {RSUM, RSUM}; block_reduce<2>(v, op, S.red); tht2 = v[0]; bt2 = v[1]; }
+        const double pht2 = ft + mu * bt2;
+        bool ok2 = (tht2 <= th_max) && (pht2 < 1e300) && (pht2 > -1e300);
+        for (int e = 0; e < nfilt && ok2; ++e) if (tht2 >= fmax(S.filt_th[e], th_floor) && pht2 >= S.filt_ph[e]) ok2 = false;
+        if (ok2 && (tht2 <= fmax((1.0 - 1e-5) * th0, th_floor) || pht2 <= ph0 - 1e-8 * th0)) { accepted = true; s_corr = o.slack_corr; break; }
+      }
       alpha *= 0.5;
     }
     if (!accepted) {
@@ -1403,6 +1429,10 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
               const double so = sv[j], ds = dsv[j];
               double s = so + alpha * ds;
               if (omt > 0.0) { if (lb > -INF) s = fmax(s, fma(omt, so - lb, lb)); if (ub < INF) s = fmin(s, fma(-omt, ub - so, ub)); }
+              if (s_corr > 0.0) {
+                const double lo = lb > -INF ? lb + s_corr * (s - lb) : -INF, hi = ub < INF ? ub - s_corr * (ub - s) : INF;
+                s = fmin(fmax(g, lo), hi);
+              }
               double zl = 0.0, zu = 0.0;
               if (lb > -INF) {
                 const double dold = so - lb, ro = fast_rcp(dold), zo = zlv[j], dz = fma(-zo * ro, ds, mu * ro - zo), d = s - lb, rd = fast_rcp(d);

@@ -29,6 +29,7 @@ typedef struct {
   double delta_init, delta_inc_first, delta_inc, delta_dec, tau_min, alpha_fallback;
   int restart_period;
   double reset_delta;
+  double slack_corr;     /* slack correction at a rejected first trial point: slacks moved to g(x_trial), at most to (1 - slack_corr) of the way to a bound */
   double dual_step_cap;  /* a_du <= dual_step_cap * alpha (include/landing_nlp.h); 0 = independent dual step length                      */
   int fresh_restart;     /* bit mask of the restart rules of include/landing_nlp.h (default 9 = 1 | 8)                                   */
   double theta_floor;    /* constraint violations (1-norm theta) below theta_floor * tol count as equal in the filter tests              */
@@ -40,7 +41,7 @@ void lo_solver_opts_default(lo_solver_opts* o) {
   o->tol = 1e-6; o->max_iter = 3000; o->mu_init = 0.1; o->bound_push = 0.5; o->bound_frac = 0.1;
   o->kappa_eps = 10.0; o->kappa_mu = 0.2; o->theta_mu = 1.5; o->max_resets = 8; o->reset_du = 1e9;
   o->delta_init = 1e-4; o->delta_inc_first = 10.0; o->delta_inc = 4.0; o->delta_dec = 0.5; o->tau_min = 0.9; o->alpha_fallback = 1e-2; o->restart_period = 60; o->reset_delta = 1e5;
-  o->dual_step_cap = 1.0; o->fresh_restart = 9; o->theta_floor = 30.0; o->clip_k = 4; o->clip_until = 0.03;
+  o->slack_corr = 0.9; o->dual_step_cap = 1.0; o->fresh_restart = 9; o->theta_floor = 30.0; o->clip_k = 4; o->clip_until = 0.03;
 }
 
 #define NW 48
@@ -172,6 +173,10 @@ static void top4_push(double t[4], double v) {
 }
 /* slack at step length alpha; with `clip` a slack does not pass (1 - tau) of its current distance to either bound (the
  * componentwise fraction-to-the-boundary rule, applied to the few slacks that are more blocking than the one that set alpha) */
+static double slack_reset(double s, double g, double lb, double ub, double k) {
+  const double lo = lb > -INFINITY ? lb + k * (s - lb) : -INFINITY, hi = ub < INFINITY ? ub - k * (ub - s) : INFINITY;
+  return fmin(fmax(g, lo), hi);
+}
 static double slack_step(double s0, double ds, double alpha, double lb, double ub, int clip, double tau) {
   double s = s0 + alpha * ds;
   if (clip) {
@@ -205,7 +210,7 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
   init_slacks(W, op);
   for (it = 0; it <= op->max_iter; ++it) {
     double du = 0, pr = 0, co = 0, tau, delta;
-    int fact_ok = 0, attempt, clip_now;
+    int fact_ok = 0, attempt, clip_now; double use_reset = 0.0;
     double top[4]; const double th_floor = op->theta_floor * op->tol;
     double sig[24], w[NW], a_pr = 1.0, a_du = 1.0, th0 = 0, bar = 0, dphi = 0, f0 = 0, ph0, alpha;
     int accepted = 0, armijo = 0;
@@ -412,6 +417,20 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
         else if (tht <= fmax((1.0 - 1e-5) * th0, th_floor) || pht <= ph0 - 1e-8 * th0) accepted = 1;
       }
       if (accepted) break;
+      if (op->slack_corr > 0.0 && alpha == a_pr && tht >= th0) {   /* slack correction at the rejected first trial point (include/landing_nlp.h): no new solve */
+        const double kk = op->slack_corr; double tht2 = 0, bt2 = 0, pht2; int okf2;
+        for (r = 12; r < ng; ++r) {
+          const double lb = W->lb[r], ub = W->ub[r], g = W->gt[r]; double s2;
+          if (lb == ub) { tht2 += fabs(g - lb); continue; }
+          s2 = slack_reset(slack_step(W->s[r], W->ds[r], alpha, lb, ub, clip_now, tau), g, lb, ub, kk); tht2 += fabs(g - s2);
+          if (lb > -INFINITY) bt2 -= log(s2 - lb);
+          if (ub < INFINITY) bt2 -= log(ub - s2);
+        }
+        pht2 = ft + mu * bt2;
+        okf2 = (tht2 <= th_max) && (pht2 < 1e300) && (pht2 > -1e300);
+        for (e = 0; e < nfilt && okf2; ++e) if (tht2 >= fmax(filt_th[e], th_floor) && pht2 >= filt_ph[e]) okf2 = 0;
+        if (okf2 && (tht2 <= fmax((1.0 - 1e-5) * th0, th_floor) || pht2 <= ph0 - 1e-8 * th0)) { accepted = 1; use_reset = kk; break; }
+      }
       alpha *= 0.5;
     }
     if (!accepted) {
@@ -431,6 +450,7 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
       if (r < 12) continue;
       if (lb == ub) { W->y[r] += alpha * (W->yn[r] - W->y[r]); continue; }
       s = slack_step(W->s[r], W->ds[r], alpha, lb, ub, clip_now, tau);
+      if (use_reset > 0.0) s = slack_reset(s, W->gt[r], lb, ub, use_reset);
       if (lb > -INFINITY) { const double d = s - lb; zl = W->zL[r] + a_du * W->dzL[r]; zl = fmin(fmax(zl, mu / (1e10 * d)), 1e10 * mu / d); }
       if (ub < INFINITY) { const double d = ub - s; zu = W->zU[r] + a_du * W->dzU[r]; zu = fmin(fmax(zu, mu / (1e10 * d)), 1e10 * mu / d); }
       W->s[r] = s; W->zL[r] = zl; W->zU[r] = zu; W->y[r] = zu - zl;
