@@ -155,6 +155,12 @@ typedef struct {
                             of a typical batch are of this type (20..60 iterations at mu = 0.1 with a full step admissible but cut to
                             1/8..1/16): CPU port, the stragglers 137 / 203 / 166 / 157 / 145 -> 57 / 58 / 57 / 93 / 68 iterations; numbers at
                             scale in DESIGN.md 4.2.  Applied at every trial point instead it doubles the mean iteration count       */
+  int watchdog;          /* after this many successive iterations whose accepted step length is at most 1/16 of the step to the boundary, the
+                            next iteration takes the step to the boundary whatever the filter says (only theta <= theta_max is required)
+                            and restarts the filter (default 3; 0 = off; cf. IPOPT's watchdog_shortened_iter_trigger).  The members that
+                            were left as the slowest of the 65 536-member sweep sat for 50..60 iterations with steps of 1e-3 until the
+                            line search failed outright and its fall-back step (alpha_fallback) freed them: CPU port, 161 / 158 / 138 /
+                            136 / 133 / 129 / 115 -> 84 / 69 / 81 / 94 / 83 / 67 / 68 iterations, the bench batch unchanged               */
   int factor_fp32;       /* 1: the stage eliminations of the Riccati factorisation (T^T P T, blocked LDL^T, gains, cost-to-go) run in
                             single precision on v_mfma_f32_16x16x4_f32 -- BASELINE configs[4]'s "fp32 MFMA KKT factor".  Residuals,
                             right-hand sides, forward sweep, line search and the convergence test stay fp64: the step becomes an

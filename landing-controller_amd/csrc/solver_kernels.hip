@@ -1137,7 +1137,8 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
   double mu = o.mu_init, delta_last = 0.0, th_max = 0.0;
   int nfilt = 0, it = 0, status = LANDING_MAX_ITER, need_reg_streak = 0, nreset = 0;
   bool first_failed = false;
-  int last_reset_it = 0, ncrawl = 0, clip_k_cur = o.clip_k, last_mu_it = 0;
+  int last_reset_it = 0, ncrawl = 0, clip_k_cur = o.clip_k, last_mu_it = 0, cutstreak = 0;
+  bool force_step = false;
   double e_pr = 0, e_du = 0, e_co = 0;
 
   for (it = 0; it <= o.max_iter; ++it) {
@@ -1355,6 +1356,7 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
           accepted = true;
         }
       }
+      if (force_step && ok_f) { accepted = true; nfilt = 0; break; }      // watchdog (landing_nlp.h): the step to the boundary is taken whatever the filter says
       if (accepted) break;
       if (o.slack_corr > 0.0 && alpha == a_pr && tht >= th0) {
         // slack correction (landing_nlp.h): the rejected first trial point once more with the inequality slacks moved to g(x_trial)
@@ -1383,6 +1385,11 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
         if (ok2 && (tht2 <= fmax((1.0 - 1e-5) * th0, th_floor) || pht2 <= ph0 - 1e-8 * th0)) { accepted = true; s_corr = o.slack_corr; break; }
       }
       alpha *= 0.5;
+    }
+    force_step = false;
+    if (o.watchdog > 0) {      // successive iterations with step lengths <= 1/16 of the step to the boundary arm the watchdog
+      if (accepted && alpha <= 0.0625 * a_pr) { if (++cutstreak >= o.watchdog) { force_step = true; cutstreak = 0; } }
+      else cutstreak = 0;
     }
     if (!accepted) {
       // no acceptable step: take a short step along the Newton direction and restart the filter

@@ -29,6 +29,7 @@ typedef struct {
   double delta_init, delta_inc_first, delta_inc, delta_dec, tau_min, alpha_fallback;
   int restart_period;
   double reset_delta;
+  int watchdog;          /* forced step to the boundary after this many successive iterations with step lengths <= 1/16 of it; 0 = off */
   double slack_corr;     /* slack correction at a rejected first trial point: slacks moved to g(x_trial), at most to (1 - slack_corr) of the way to a bound */
   double dual_step_cap;  /* a_du <= dual_step_cap * alpha (include/landing_nlp.h); 0 = independent dual step length                      */
   int fresh_restart;     /* bit mask of the restart rules of include/landing_nlp.h (default 9 = 1 | 8)                                   */
@@ -41,7 +42,7 @@ void lo_solver_opts_default(lo_solver_opts* o) {
   o->tol = 1e-6; o->max_iter = 3000; o->mu_init = 0.1; o->bound_push = 0.5; o->bound_frac = 0.1;
   o->kappa_eps = 10.0; o->kappa_mu = 0.2; o->theta_mu = 1.5; o->max_resets = 8; o->reset_du = 1e9;
   o->delta_init = 1e-4; o->delta_inc_first = 10.0; o->delta_inc = 4.0; o->delta_dec = 0.5; o->tau_min = 0.9; o->alpha_fallback = 1e-2; o->restart_period = 60; o->reset_delta = 1e5;
-  o->slack_corr = 0.9; o->dual_step_cap = 1.0; o->fresh_restart = 9; o->theta_floor = 30.0; o->clip_k = 4; o->clip_until = 0.03;
+  o->watchdog = 3; o->slack_corr = 0.9; o->dual_step_cap = 1.0; o->fresh_restart = 9; o->theta_floor = 30.0; o->clip_k = 4; o->clip_until = 0.03;
 }
 
 #define NW 48
@@ -190,7 +191,7 @@ static double slack_step(double s0, double ds, double alpha, double lb, double u
 static int solve_one(const lo_form* F, const double* p, const double* x0, const lo_solver_opts* op, double* x_out,
                      double* lam_out, int* iters_out, double kkt_out[3], long long counters[2]) {
   const int N = F->N; const lo_int nx = lo_nx(N), ng = lo_ng(N);
-  lo_poff o; work_t Wk, *W = &Wk; lo_int i, r; int k, it, status = 1, nfilt = 0, streak = 0, nreset = 0, last_reset_it = 0, ncrawl = 0, last_mu_it = 0;
+  lo_poff o; work_t Wk, *W = &Wk; lo_int i, r; int k, it, status = 1, nfilt = 0, streak = 0, nreset = 0, last_reset_it = 0, ncrawl = 0, last_mu_it = 0, cutstreak = 0, force_step = 0;
   double mu = op->mu_init, delta_last = 0.0, th_max = 0.0, e_du = 0.0; int clip_k_cur = op->clip_k;
   double filt_th[64], filt_ph[64];
   double* gx;
@@ -416,6 +417,7 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
         if (switching) { if (pht <= ph0 + 1e-8 * alpha * dphi) { accepted = 1; armijo = 1; } }
         else if (tht <= fmax((1.0 - 1e-5) * th0, th_floor) || pht <= ph0 - 1e-8 * th0) accepted = 1;
       }
+      if (force_step && ok_f) { accepted = 1; nfilt = 0; break; }      /* watchdog: the step to the boundary is taken whatever the filter says */
       if (accepted) break;
       if (op->slack_corr > 0.0 && alpha == a_pr && tht >= th0) {   /* slack correction at the rejected first trial point (include/landing_nlp.h): no new solve */
         const double kk = op->slack_corr; double tht2 = 0, bt2 = 0, pht2; int okf2;
@@ -432,6 +434,13 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
         if (okf2 && (tht2 <= fmax((1.0 - 1e-5) * th0, th_floor) || pht2 <= ph0 - 1e-8 * th0)) { accepted = 1; use_reset = kk; break; }
       }
       alpha *= 0.5;
+    }
+    /* watchdog (cf. IPOPT's watchdog_shortened_iter_trigger): after `watchdog` successive iterations whose accepted step length is at most
+     * 1/16 of the step to the boundary the next iteration takes that step unconditionally and restarts the filter */
+    force_step = 0;
+    if (op->watchdog > 0) {
+      if (accepted && alpha <= 0.0625 * a_pr) { if (++cutstreak >= op->watchdog) { force_step = 1; cutstreak = 0; } }
+      else cutstreak = 0;
     }
     if (!accepted) {
       nfilt = 0; alpha = fmin(a_pr, op->alpha_fallback);
