@@ -92,8 +92,10 @@ typedef struct {
   int sticky_delta;      /* experimental: restart from delta_last when the previous first trial failed; default 0          */
   int restart_period;    /* re-initialise slacks/multipliers/filter at the current x when the first barrier problem (mu = mu_init)
                             is still not solved this many iterations after the last (re)start (crawling iterate; counts
-                            against max_resets); 0 = never; default 60 (round 2, tests/dev/ipm_lab.py on four seeded
-                            batches: slowest member 149..160 iterations instead of 177..236 with 80, mean +1.3)                                                      */
+                            against max_resets); 0 = never; default 75.  (First half of round 2: 60 instead of 80 -- slowest member of
+                            four seeded batches 149..160 instead of 177..236 iterations.  With the watchdog catching the crawling
+                            iterates early the detector fires needlessly at 60: 75 over 64 fresh batches p99 of the iteration count
+                            90 -> 79, mean batch time 101.9 -> 99.5 ms; 90: the same.)                                              */
   int dispatch_order;    /* 1 (default): members with a large initial body height are dispatched first (they tend to need the most
                             iterations and would otherwise set the batch time from the second wave); 0: batch order.  Results do
                             not depend on it (every member is solved independently)                                          */
