@@ -163,6 +163,14 @@ typedef struct {
                             were left as the slowest of the 65 536-member sweep sat for 50..60 iterations with steps of 1e-3 until the
                             line search failed outright and its fall-back step (alpha_fallback) freed them: CPU port, 161 / 158 / 138 /
                             136 / 133 / 129 / 115 -> 84 / 69 / 81 / 94 / 83 / 67 / 68 iterations, the bench batch unchanged               */
+  double barrier_smax;   /* the test that ends a barrier subproblem, E_mu <= kappa_eps mu, uses IPOPT's SCALED optimality error: the dual
+                            infeasibility divided by s_d = max(s_max, (|y|_1 + |z|_1) / (m + n_z)) / s_max, the complementarity error by
+                            s_c = max(s_max, |z|_1 / n_z) / s_max (Waechter & Biegler 2006, eq. 6; IPOPT's s_max is 100).  Default
+                            s_max = 1: with multipliers of the order of the foot forces the unscaled test over-solves every subproblem by
+                            two or three iterations.  The FINAL test stays the unscaled tol on pr / du / compl.  Tried in the first half
+                            of the round (lab): mean 53.5 -> 48.5 iterations but 1 member in 1000 wandered off at mu = 1e-4; with the
+                            watchdog, the slack correction and the later-barrier-problem restart in place it is safe: CPU port on two
+                            batches mean 53.2 -> 50.3, median 52 -> 49, slowest 107 -> 95 (numbers at scale in DESIGN.md).  0 = unscaled */
   int factor_fp32;       /* 1: the stage eliminations of the Riccati factorisation (T^T P T, blocked LDL^T, gains, cost-to-go) run in
                             single precision on v_mfma_f32_16x16x4_f32 -- BASELINE configs[4]'s "fp32 MFMA KKT factor".  Residuals,
                             right-hand sides, forward sweep, line search and the convergence test stay fp64: the step becomes an

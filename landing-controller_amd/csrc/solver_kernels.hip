@@ -1098,16 +1098,17 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
   // rows; the accept pass below produces the same quantities for the next iterate, so this runs only at the start,
   // after a multiplier reset and when mu changes)
   double c_pr = 0.0, c_co = 0.0, c_cm = 0.0;
+  double c_ys = 0.0, c_zs = 0.0, c_nz = 1.0;     // |y|_1, |z|_1 and the number of bound multipliers (scaled barrier-subproblem test)
   // Row passes: every thread owns the rows lane + NT j.  They are processed RB at a time with ALL loads of a batch issued
   // up-front and unconditionally (every array is fully allocated; out-of-range rows re-read the last row and are masked):
   // one memory round trip per batch instead of two or three dependent ones per row behind the bound-type branches.
   constexpr int RB = 4;
   auto point_pass = [&](double mu_) {
-    double pr = 0.0, co = 0.0, cm = 0.0;
+    double pr = 0.0, co = 0.0, cm = 0.0, ys = 0.0, zs = 0.0, nz = 0.0;
     for (int rb = lane; rb < ng; rb += NT * RB) {
-      double lbv[RB], ubv[RB], gv[RB], sv[RB], zlv[RB], zuv[RB];
+      double lbv[RB], ubv[RB], gv[RB], sv[RB], zlv[RB], zuv[RB], yv[RB];
 #pragma unroll
-      for (int j = 0; j < RB; ++j) { const int r = rb + j * NT, rr = r < ng ? r : ng - 1; lbv[j] = S.bnd_lb[bidx(rr)]; ubv[j] = S.bnd_ub[bidx(rr)]; gv[j] = r_g[rr]; sv[j] = r_s[rr]; zlv[j] = r_zL[rr]; zuv[j] = r_zU[rr]; }
+      for (int j = 0; j < RB; ++j) { const int r = rb + j * NT, rr = r < ng ? r : ng - 1; lbv[j] = S.bnd_lb[bidx(rr)]; ubv[j] = S.bnd_ub[bidx(rr)]; gv[j] = r_g[rr]; sv[j] = r_s[rr]; zlv[j] = r_zL[rr]; zuv[j] = r_zU[rr]; yv[j] = r_y[rr]; }
 #pragma unroll
       for (int j = 0; j < RB; ++j) {
         const int r = rb + j * NT;
@@ -1116,21 +1117,22 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
         double sg = 0.0, rh = 0.0;
         if (r >= 12) {
           const double g = gv[j];
+          ys += fabs(yv[j]);
           if (lb == ub) pr = fmax(pr, fabs(g - lb));
           else {
             const double s = sv[j];
             pr = fmax(pr, fabs(g - s));
-            if (lb > -INF) { const double d = s - lb, rd = fast_rcp(d), zl = zlv[j]; co = fmax(co, d * zl); cm = fmax(cm, fabs(d * zl - mu_)); sg += zl * rd; rh -= mu_ * rd; }
-            if (ub < INF) { const double d = ub - s, rd = fast_rcp(d), zu = zuv[j]; co = fmax(co, d * zu); cm = fmax(cm, fabs(d * zu - mu_)); sg += zu * rd; rh += mu_ * rd; }
+            if (lb > -INF) { const double d = s - lb, rd = fast_rcp(d), zl = zlv[j]; co = fmax(co, d * zl); cm = fmax(cm, fabs(d * zl - mu_)); sg += zl * rd; rh -= mu_ * rd; zs += zl; nz += 1.0; }
+            if (ub < INF) { const double d = ub - s, rd = fast_rcp(d), zu = zuv[j]; co = fmax(co, d * zu); cm = fmax(cm, fabs(d * zu - mu_)); sg += zu * rd; rh += mu_ * rd; zs += zu; nz += 1.0; }
             rh += sg * (g - s);
           }
         }
         r_sig[r] = sg; r_rho[r] = rh;
       }
     }
-    double v[3] = {pr, co, cm}; const int op[3] = {RMAX, RMAX, RMAX};
-    block_reduce<3>(v, op, S.red);
-    c_pr = v[0]; c_co = v[1]; c_cm = v[2];
+    double v[6] = {pr, co, cm, ys, zs, nz}; const int op[6] = {RMAX, RMAX, RMAX, RSUM, RSUM, RSUM};
+    block_reduce<6>(v, op, S.red);
+    c_pr = v[0]; c_co = v[1]; c_cm = v[2]; c_ys = v[3]; c_zs = v[4]; c_nz = fmax(v[5], 1.0);
   };
 
   long long tp = A.prof ? (long long)wall_clock64() : 0;
@@ -1198,7 +1200,12 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
       continue;
     }
     // ---------------------------------------------------------------- barrier parameter (monotone)
-    while (fmax(du, fmax(pr, c_cm)) <= o.kappa_eps * mu && mu > o.tol / 10.0) {
+    double sd = 1.0, sc = 1.0;      // IPOPT's scaling of the optimality error in the barrier-subproblem test (landing_nlp.h)
+    if (o.barrier_smax > 0.0) {
+      sd = fmax(o.barrier_smax, (c_ys + c_zs) / ((double)(ng - 12) + c_nz)) / o.barrier_smax;
+      sc = fmax(o.barrier_smax, c_zs / c_nz) / o.barrier_smax;
+    }
+    while (fmax(du / sd, fmax(pr, c_cm / sc)) <= o.kappa_eps * mu && mu > o.tol / 10.0) {
       mu = fmax(o.tol / 10.0, fmin(o.kappa_mu * mu, pow(mu, o.theta_mu)));
       nfilt = 0; last_mu_it = it;
       point_pass(mu);                     // complementarity error, Sigma, rho for the new mu
@@ -1415,7 +1422,7 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
     // primal / complementarity errors, Sigma and rho of the new iterate (what point_pass computes)
     for (int i = lane; i < nx; i += NT) M.x[i] = M.xt[i];
     {
-      double npr = 0.0, nco = 0.0, ncm = 0.0;
+      double npr = 0.0, nco = 0.0, ncm = 0.0, nys = 0.0, nzs = 0.0, nnz = 0.0;
       for (int rb = lane; rb < ng; rb += NT * RB) {
         double lbv[RB], ubv[RB], gv[RB], sv[RB], dsv[RB], zlv[RB], zuv[RB], yv[RB], ynv[RB];
 #pragma unroll
@@ -1431,7 +1438,7 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
           r_g[r] = g;
           double sg = 0.0, rh = 0.0;
           if (r >= 12) {
-            if (lb == ub) { r_y[r] = yv[j] + alpha * (ynv[j] - yv[j]); npr = fmax(npr, fabs(g - lb)); }
+            if (lb == ub) { const double yn_ = yv[j] + alpha * (ynv[j] - yv[j]); r_y[r] = yn_; nys += fabs(yn_); npr = fmax(npr, fabs(g - lb)); }
             else {
               const double so = sv[j], ds = dsv[j];
               double s = so + alpha * ds;
@@ -1444,24 +1451,24 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
               if (lb > -INF) {
                 const double dold = so - lb, ro = fast_rcp(dold), zo = zlv[j], dz = fma(-zo * ro, ds, mu * ro - zo), d = s - lb, rd = fast_rcp(d);
                 zl = fmin(fmax(zo + a_du * dz, 1e-10 * mu * rd), 1e10 * mu * rd);
-                nco = fmax(nco, d * zl); ncm = fmax(ncm, fabs(d * zl - mu)); sg += zl * rd; rh -= mu * rd;
+                nco = fmax(nco, d * zl); ncm = fmax(ncm, fabs(d * zl - mu)); sg += zl * rd; rh -= mu * rd; nzs += zl; nnz += 1.0;
               }
               if (ub < INF) {
                 const double dold = ub - so, ro = fast_rcp(dold), zo = zuv[j], dz = fma(zo * ro, ds, mu * ro - zo), d = ub - s, rd = fast_rcp(d);
                 zu = fmin(fmax(zo + a_du * dz, 1e-10 * mu * rd), 1e10 * mu * rd);
-                nco = fmax(nco, d * zu); ncm = fmax(ncm, fabs(d * zu - mu)); sg += zu * rd; rh += mu * rd;
+                nco = fmax(nco, d * zu); ncm = fmax(ncm, fabs(d * zu - mu)); sg += zu * rd; rh += mu * rd; nzs += zu; nnz += 1.0;
               }
               npr = fmax(npr, fabs(g - s));
               rh += sg * (g - s);
-              r_s[r] = s; r_zL[r] = zl; r_zU[r] = zu; r_y[r] = zu - zl;
+              r_s[r] = s; r_zL[r] = zl; r_zU[r] = zu; r_y[r] = zu - zl; nys += fabs(zu - zl);
             }
           }
           r_sig[r] = sg; r_rho[r] = rh;
         }
       }
-      double v[3] = {npr, nco, ncm}; const int op[3] = {RMAX, RMAX, RMAX};
-      block_reduce<3>(v, op, S.red);
-      c_pr = v[0]; c_co = v[1]; c_cm = v[2];
+      double v[6] = {npr, nco, ncm, nys, nzs, nnz}; const int op[6] = {RMAX, RMAX, RMAX, RSUM, RSUM, RSUM};
+      block_reduce<6>(v, op, S.red);
+      c_pr = v[0]; c_co = v[1]; c_cm = v[2]; c_ys = v[3]; c_zs = v[4]; c_nz = fmax(v[5], 1.0);
     }
     PROF_ADD(PH_ACCEPT, tp);
   }

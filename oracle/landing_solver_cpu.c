@@ -29,6 +29,7 @@ typedef struct {
   double delta_init, delta_inc_first, delta_inc, delta_dec, tau_min, alpha_fallback;
   int restart_period;
   double reset_delta;
+  double barrier_smax;   /* s_max of the scaled optimality error in the barrier-subproblem test (include/landing_nlp.h); 0 = unscaled */
   int watchdog;          /* forced step to the boundary after this many successive iterations with step lengths <= 1/16 of it; 0 = off */
   double slack_corr;     /* slack correction at a rejected first trial point: slacks moved to g(x_trial), at most to (1 - slack_corr) of the way to a bound */
   double dual_step_cap;  /* a_du <= dual_step_cap * alpha (include/landing_nlp.h); 0 = independent dual step length                      */
@@ -42,7 +43,7 @@ void lo_solver_opts_default(lo_solver_opts* o) {
   o->tol = 1e-6; o->max_iter = 3000; o->mu_init = 0.1; o->bound_push = 0.5; o->bound_frac = 0.1;
   o->kappa_eps = 10.0; o->kappa_mu = 0.2; o->theta_mu = 1.5; o->max_resets = 8; o->reset_du = 1e9;
   o->delta_init = 1e-4; o->delta_inc_first = 10.0; o->delta_inc = 4.0; o->delta_dec = 0.5; o->tau_min = 0.9; o->alpha_fallback = 1e-2; o->restart_period = 75; o->reset_delta = 1e5;
-  o->watchdog = 3; o->slack_corr = 0.9; o->dual_step_cap = 1.0; o->fresh_restart = 9; o->theta_floor = 30.0; o->clip_k = 4; o->clip_until = 0.03;
+  o->barrier_smax = 1.0; o->watchdog = 3; o->slack_corr = 0.9; o->dual_step_cap = 1.0; o->fresh_restart = 9; o->theta_floor = 30.0; o->clip_k = 4; o->clip_until = 0.03;
 }
 
 #define NW 48
@@ -284,7 +285,13 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
         if (lb > -INFINITY) cm = fmax(cm, fabs((W->s[r] - lb) * W->zL[r] - mu));
         if (ub < INFINITY) cm = fmax(cm, fabs((ub - W->s[r]) * W->zU[r] - mu));
       }
-      if (fmax(du, fmax(pr, cm)) <= op->kappa_eps * mu && mu > op->tol / 10.0) { mu = fmax(op->tol / 10.0, fmin(op->kappa_mu * mu, pow(mu, op->theta_mu))); nfilt = 0; last_mu_it = it; }
+      double sd = 1.0, sc = 1.0;
+      if (op->barrier_smax > 0.0) {   /* IPOPT's scaling of the optimality error (s_d, s_c of Waechter & Biegler eq. 6) in the barrier-subproblem test */
+        const double smax = op->barrier_smax; double ys = 0, zs = 0; long long nz = 0;
+        for (r = 12; r < ng; ++r) { ys += fabs(W->y[r]); if (W->lb[r] != W->ub[r]) { if (W->lb[r] > -INFINITY) { zs += W->zL[r]; nz++; } if (W->ub[r] < INFINITY) { zs += W->zU[r]; nz++; } } }
+        sd = fmax(smax, (ys + zs) / (double)(ng - 12 + nz)) / smax; sc = fmax(smax, zs / (double)nz) / smax;
+      }
+      if (fmax(du / sd, fmax(pr, cm / sc)) <= op->kappa_eps * mu && mu > op->tol / 10.0) { mu = fmax(op->tol / 10.0, fmin(op->kappa_mu * mu, pow(mu, op->theta_mu))); nfilt = 0; last_mu_it = it; }
       else break;
     }
     tau = fmax(op->tau_min, 1.0 - mu);

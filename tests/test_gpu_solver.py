@@ -332,7 +332,7 @@ def test_soak_failures_are_rescued(oracle_mod):
     assert (r["status"] == 0).all() and r["iters"].max() <= 120, (r["status"], r["iters"])       # measured: 44..72 iterations
     for b in range(len(cases)):
         assert O.kkt(r["x"][b], Ps[b], r["lam_g"][b]).max() <= 1e-6 * 1.0001
-    o.fresh_restart = 0; o.dual_step_cap = 0.0; o.slack_corr = 0.0; o.watchdog = 0
+    o.fresh_restart = 0; o.dual_step_cap = 0.0; o.slack_corr = 0.0; o.watchdog = 0; o.barrier_smax = 0.0
     r0 = L.solve_host(Ps, Xs, o)
     assert (r0["status"] != 0).sum() >= 4, r0["status"]          # measured: 8 of 8 fail
     o.fresh_restart = 15
