@@ -134,7 +134,8 @@ typedef struct {
                                to the caller's initial guess with clip_k = 2 -- a restart in place repeats the failure from a bad x;
                             2: so does every member's second restart;   4: the crawl detector may fire twice;
                             8: a LATER barrier problem (mu < mu_init) still unsolved 2 restart_period iterations after it began, with a
-                               primal infeasibility above 1e-3, has wandered off and is restarted in place (nothing else catches it).
+                               primal infeasibility above 1e-3 -- or one in which the watchdog has fired three times without effect --
+                               has wandered off and is restarted in place (nothing else catches it).
                             History (tools/soak.py, 64 fresh batches = 65 536 drop states, profiles/r02_soak*.json): with restarts in
                             place only 12 members hit max_iter -- none infeasible or unusual, each solves in 50..100 iterations from the
                             same guess with another step rule -- and such a member sets the time of its batch (250 instead of 105 ms).

@@ -1139,7 +1139,7 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
   double mu = o.mu_init, delta_last = 0.0, th_max = 0.0;
   int nfilt = 0, it = 0, status = LANDING_MAX_ITER, need_reg_streak = 0, nreset = 0;
   bool first_failed = false;
-  int last_reset_it = 0, ncrawl = 0, clip_k_cur = o.clip_k, last_mu_it = 0, cutstreak = 0;
+  int last_reset_it = 0, ncrawl = 0, clip_k_cur = o.clip_k, last_mu_it = 0, cutstreak = 0, wd_count = 0;
   bool force_step = false;
   double e_pr = 0, e_du = 0, e_co = 0;
 
@@ -1173,7 +1173,8 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
     const bool overreg = o.reset_delta > 0.0 && delta_last > o.reset_delta && nreset < o.max_resets;
     // a LATER barrier problem not solved 2 restart_period iterations after it began has wandered off (the dual infeasibility stays
     // far below reset_du, nothing else catches it): restarted in place like a crawling iterate
-    const bool lost = (o.fresh_restart & 8) && o.restart_period > 0 && mu < o.mu_init && pr > 1e-3 && it - last_mu_it >= 2 * o.restart_period && it - last_reset_it >= o.restart_period && nreset < o.max_resets;
+    const bool lost = (o.fresh_restart & 8) && o.restart_period > 0 && mu < o.mu_init && pr > 1e-3 && nreset < o.max_resets &&
+                      ((it - last_mu_it >= 2 * o.restart_period && it - last_reset_it >= o.restart_period) || wd_count >= 3);     // ... or crawls on although the watchdog has fired three times
     if ((du > o.reset_du && nreset < o.max_resets) || stalled || overreg || lost) {
       last_reset_it = it;
       if (stalled) ncrawl++;
@@ -1195,7 +1196,7 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
         th_max = 0.0;
       }
       init_slacks();
-      mu = o.mu_init; nfilt = 0; delta_last = 0.0; need_reg_streak = 0;
+      mu = o.mu_init; nfilt = 0; delta_last = 0.0; need_reg_streak = 0; wd_count = 0;
       point_pass(mu);
       continue;
     }
@@ -1207,7 +1208,7 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
     }
     while (fmax(du / sd, fmax(pr, c_cm / sc)) <= o.kappa_eps * mu && mu > o.tol / 10.0) {
       mu = fmax(o.tol / 10.0, fmin(o.kappa_mu * mu, pow(mu, o.theta_mu)));
-      nfilt = 0; last_mu_it = it;
+      nfilt = 0; last_mu_it = it; wd_count = 0;
       point_pass(mu);                     // complementarity error, Sigma, rho for the new mu
     }
     const double tau = fmax(o.tau_min, 1.0 - mu);
@@ -1395,7 +1396,7 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
     }
     force_step = false;
     if (o.watchdog > 0) {      // successive iterations with step lengths <= 1/16 of the step to the boundary arm the watchdog
-      if (accepted && alpha <= 0.0625 * a_pr) { if (++cutstreak >= o.watchdog) { force_step = true; cutstreak = 0; } }
+      if (accepted && alpha <= 0.0625 * a_pr) { if (++cutstreak >= o.watchdog) { force_step = true; cutstreak = 0; wd_count++; } }
       else cutstreak = 0;
     }
     if (!accepted) {

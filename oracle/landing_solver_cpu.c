@@ -192,7 +192,7 @@ static double slack_step(double s0, double ds, double alpha, double lb, double u
 static int solve_one(const lo_form* F, const double* p, const double* x0, const lo_solver_opts* op, double* x_out,
                      double* lam_out, int* iters_out, double kkt_out[3], long long counters[2]) {
   const int N = F->N; const lo_int nx = lo_nx(N), ng = lo_ng(N);
-  lo_poff o; work_t Wk, *W = &Wk; lo_int i, r; int k, it, status = 1, nfilt = 0, streak = 0, nreset = 0, last_reset_it = 0, ncrawl = 0, last_mu_it = 0, cutstreak = 0, force_step = 0;
+  lo_poff o; work_t Wk, *W = &Wk; lo_int i, r; int k, it, status = 1, nfilt = 0, streak = 0, nreset = 0, last_reset_it = 0, ncrawl = 0, last_mu_it = 0, cutstreak = 0, force_step = 0, wd_count = 0;
   double mu = op->mu_init, delta_last = 0.0, th_max = 0.0, e_du = 0.0; int clip_k_cur = op->clip_k;
   double filt_th[64], filt_ph[64];
   double* gx;
@@ -260,7 +260,8 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
       const int stalled = op->restart_period > 0 && it - last_reset_it >= op->restart_period && mu >= op->mu_init && nreset < op->max_resets && ncrawl < ((op->fresh_restart & 4) ? 2 : 1);
       /* ... and a LATER barrier problem that is not solved 2 restart_period iterations after it began has wandered off (nothing else
        * catches that case: the dual infeasibility stays far below reset_du) -- restarted in place like a crawling iterate */
-      const int lost = (op->fresh_restart & 8) && op->restart_period > 0 && mu < op->mu_init && pr > 1e-3 && it - last_mu_it >= 2 * op->restart_period && it - last_reset_it >= op->restart_period && nreset < op->max_resets;
+      const int lost = (op->fresh_restart & 8) && op->restart_period > 0 && mu < op->mu_init && pr > 1e-3 && nreset < op->max_resets &&
+                       ((it - last_mu_it >= 2 * op->restart_period && it - last_reset_it >= op->restart_period) || wd_count >= 3);     /* ... or crawls on although the watchdog has fired three times */
       if (stalled) ncrawl++;
       if (!((du > op->reset_du && nreset < op->max_resets) || stalled || lost || (op->reset_delta > 0.0 && delta_last > op->reset_delta && nreset < op->max_resets))) goto no_reset;
       last_reset_it = it;
@@ -273,7 +274,7 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
         eval_g(F, W->x, p, W->g);
         clip_k_cur = clip_k_cur > 1 ? 2 : clip_k_cur; th_max = 0.0;
       }
-      init_slacks(W, op); mu = op->mu_init; nfilt = 0; delta_last = 0.0; streak = 0;
+      init_slacks(W, op); mu = op->mu_init; nfilt = 0; delta_last = 0.0; streak = 0; wd_count = 0;
       continue;
     }
     no_reset:;
@@ -291,7 +292,7 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
         for (r = 12; r < ng; ++r) { ys += fabs(W->y[r]); if (W->lb[r] != W->ub[r]) { if (W->lb[r] > -INFINITY) { zs += W->zL[r]; nz++; } if (W->ub[r] < INFINITY) { zs += W->zU[r]; nz++; } } }
         sd = fmax(smax, (ys + zs) / (double)(ng - 12 + nz)) / smax; sc = fmax(smax, zs / (double)nz) / smax;
       }
-      if (fmax(du / sd, fmax(pr, cm / sc)) <= op->kappa_eps * mu && mu > op->tol / 10.0) { mu = fmax(op->tol / 10.0, fmin(op->kappa_mu * mu, pow(mu, op->theta_mu))); nfilt = 0; last_mu_it = it; }
+      if (fmax(du / sd, fmax(pr, cm / sc)) <= op->kappa_eps * mu && mu > op->tol / 10.0) { mu = fmax(op->tol / 10.0, fmin(op->kappa_mu * mu, pow(mu, op->theta_mu))); nfilt = 0; last_mu_it = it; wd_count = 0; }
       else break;
     }
     tau = fmax(op->tau_min, 1.0 - mu);
@@ -446,7 +447,7 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
      * 1/16 of the step to the boundary the next iteration takes that step unconditionally and restarts the filter */
     force_step = 0;
     if (op->watchdog > 0) {
-      if (accepted && alpha <= 0.0625 * a_pr) { if (++cutstreak >= op->watchdog) { force_step = 1; cutstreak = 0; } }
+      if (accepted && alpha <= 0.0625 * a_pr) { if (++cutstreak >= op->watchdog) { force_step = 1; cutstreak = 0; wd_count++; } }
       else cutstreak = 0;
     }
     if (!accepted) {
