@@ -272,6 +272,30 @@ int landing_solve_21(landing_ctx* ctx, int B, const double* Xref, const double* 
                      const double* Ib, const double* Ib_inv, const landing_solver_opts* opts,
                      double* x_star, double* f_star, int* status, int* iters, double* kkt);
 
+/* ---- the same solver function sharded over several devices from the C boundary ---------------------------------
+ * Replaces the serial loop of generate_data/generate_training_data_automated.m:38,130-136: the B drop states are cut into
+ * contiguous shards (landing_shard_range: sizes differ by at most one), one per entry of the device list; every shard is
+ * packed, uploaded, solved and downloaded by its own host thread on its own context (one process, n_dev contexts -- what a mex
+ * file can do).  Members are independent: no collective, every thread writes its slice of the caller's HOST buffers.  A device
+ * index may repeat (two contexts on one GPU).  Results are bit-identical to the single-context calls above whatever the list.
+ * All arguments carry a trailing batch axis as in landing_solve_args21; lam_g [ng x B] (CasADi sign convention) may be NULL. */
+typedef struct landing_multi landing_multi;
+landing_multi* landing_multi_create(int N, const int* devices, int n_dev, const landing_form* form /* NULL = defaults */);
+void landing_multi_destroy(landing_multi* m);
+int landing_multi_count(const landing_multi* m);
+void landing_shard_range(int B, int n_shards, int i, int* lo, int* hi);
+int landing_multi_solve_args21(landing_multi* m, int B, const landing_args21* a, const landing_solver_opts* opts,
+                               double* x_star, double* f_star, double* lam_g, int* status, int* iters, double* kkt);
+/* one-call form for FFI stubs (matlab/landing_solve_mex.c): contexts are cached inside the library per (N, device list) */
+int landing_solve_21_multi(const int* devices, int n_dev, int N, int B, const double* Xref, const double* Uref, const double* dt,
+                           const double* q_min, const double* q_max, const double* qd_min, const double* qd_max,
+                           const double* q_init, const double* qd_init, const double* q_term_min, const double* q_term_max,
+                           const double* qd_term_min, const double* qd_term_max, const double* QN, const double* x0,
+                           const double* mu, const double* l_leg_max, const double* f_max, const double* mass,
+                           const double* Ib, const double* Ib_inv, const landing_solver_opts* opts,
+                           double* x_star, double* f_star, double* lam_g, int* status, int* iters, double* kkt);
+void landing_multi_release_cached(void);
+
 /* ---- tracking-controller synthesis along solved trajectories -------------------------------------
  * SRBM variational linearisation A (24 x 24), B (24 x 12) (utilities_general/srbm-utilities/generateVariationalDynamics.m:29-62)
  * and the Riccati differential equation Pdot = A'P + PA - P B R^-1 B'P + Q integrated backward along the sampled

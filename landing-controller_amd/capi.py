@@ -45,7 +45,9 @@ EXPORTS = ["landing_last_error", "landing_form_default", "landing_solver_opts_de
            "landing_create", "landing_destroy", "landing_device_count", "landing_eval_batch", "landing_eval_batch_host",
            "landing_bounds_batch", "landing_solve_batch", "landing_solve_batch_host", "landing_kernel_name_sweep",
            "landing_sweep_bytes_per_member", "landing_set_profile_buffer", "landing_debug_workspace",
-           "landing_pack_args21", "landing_solve_args21", "landing_solve_21", "landing_riccati_gains_batch", "landing_mpc_shift", "landing_solver_opts_warm", "landing_rbd_set_model", "landing_fb_dynamics_batch",
+           "landing_pack_args21", "landing_solve_args21", "landing_solve_21",
+           "landing_multi_create", "landing_multi_destroy", "landing_multi_count", "landing_shard_range", "landing_multi_solve_args21",
+           "landing_solve_21_multi", "landing_multi_release_cached", "landing_riccati_gains_batch", "landing_mpc_shift", "landing_solver_opts_warm", "landing_rbd_set_model", "landing_fb_dynamics_batch",
            "landing_kinodyn_rows_batch", "landing_leg_ik_batch", "landing_nnz_hess_rc", "landing_pattern_hess_rc",
            "landing_eval_hess_rc_batch", "landing_eval_hess_rc_batch_host"]
 
@@ -129,6 +131,7 @@ class LandingLib:
                 form.QX[i] = run_cost["QX"][i]
             for i in range(3):
                 form.Qc[i] = run_cost["Qc"][i]; form.Qf[i] = run_cost["Qf"][i]; form.f_ref[i] = run_cost.get("f_ref", (0, 0, 0))[i]
+        self.form = form
         self.ctx = self.lib.landing_create(N, device, C.byref(form))
         if not self.ctx:
             raise RuntimeError("landing_create failed: " + self.lib.landing_last_error().decode())
@@ -235,6 +238,30 @@ class LandingLib:
             rc = self.lib.landing_solve_args21(self.ctx, B, C.byref(a), C.byref(opts), *outs)
         self._check(rc, "landing_solve_args21")
         return dict(x=x, f=f, status=status, iters=iters, kkt=kkt)
+
+    def solve_args21_multi(self, args, devices, opts=None, one_call=False, want_lam=True):
+        """the reference's solver-function call sharded over a device list from the C boundary (landing_multi_solve_args21 /
+        landing_solve_21_multi): contiguous shards, one host thread + context per entry of `devices` (an index may repeat)"""
+        a, keep, B = matlab_args21(self.N, args)
+        opts = opts or self.default_opts()
+        x = np.zeros((B, self.nx)); f = np.zeros(B); status = np.zeros(B, np.int32); iters = np.zeros(B, np.int32); kkt = np.zeros((B, 3))
+        lam = np.zeros((B, self.ng)) if want_lam else None
+        outs = (_p(x), _p(f), _p(lam), status.ctypes.data_as(_ip), iters.ctypes.data_as(_ip), _p(kkt))
+        dev = (C.c_int * len(devices))(*devices)
+        if one_call:
+            self.lib.landing_solve_21_multi.restype = C.c_int
+            rc = self.lib.landing_solve_21_multi(dev, len(devices), self.N, B, *[getattr(a, n) for n in ARGS21], C.byref(opts), *outs)
+        else:
+            self.lib.landing_multi_create.restype = C.c_void_p
+            m = self.lib.landing_multi_create(self.N, dev, len(devices), C.byref(self.form))
+            if not m:
+                raise RuntimeError("landing_multi_create: " + self.lib.landing_last_error().decode())
+            try:
+                rc = self.lib.landing_multi_solve_args21(C.c_void_p(m), B, C.byref(a), C.byref(opts), *outs)
+            finally:
+                self.lib.landing_multi_destroy(C.c_void_p(m))
+        self._check(rc, "landing_multi_solve_args21")
+        return dict(x=x, f=f, lam_g=lam, status=status, iters=iters, kkt=kkt)
 
     def riccati_gains_device(self, B, n, d_xref, d_fref, Ib3x3, mass, Q, r_diag, F, dt, rk4=False, d_P=0, d_K=0, d_A=0, d_B=0, stream=0):
         """landing_riccati_gains_batch: VBL linearisation + Riccati tracking gains along B sampled trajectories (device pointers)"""

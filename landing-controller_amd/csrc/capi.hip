@@ -13,6 +13,7 @@
 #include <mutex>
 #include <set>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/landing_nlp.h"
@@ -47,6 +48,7 @@ struct landing_ctx {
   double* d_h4 = nullptr; size_t h4_cap = 0;   // ... and its scratch for the casadi_s4-pattern nonzeros
   // function layer: the Jacobian, Hessian and residual kernels of one landing_eval_batch call are independent; for large
   // batches they run on two auxiliary streams forked from / joined to the caller's stream so that their ramps and tails overlap
+  hipStream_t host_stream = nullptr;  // stream of the *_host entry points (copies + launch), created on first use
   hipStream_t aux[2] = {nullptr, nullptr};
   hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
   bool sweep_concurrent = true;      // Q (576) | F (576) | 1/diag(R) (12) of the last landing_riccati_gains_batch call
@@ -260,6 +262,7 @@ void landing_destroy(landing_ctx* ctx) {
   if (ctx->d_fb_scratch) (void)hipFree(ctx->d_fb_scratch);
   for (int i = 0; i < 2; ++i) { if (ctx->aux[i]) (void)hipStreamDestroy(ctx->aux[i]); if (ctx->ev_join[i]) (void)hipEventDestroy(ctx->ev_join[i]); }
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+  if (ctx->host_stream) (void)hipStreamDestroy(ctx->host_stream);
   delete ctx;
 }
 
@@ -422,3 +425,4 @@ int landing_bounds_batch(landing_ctx* ctx, int B, const double* d_p, double* d_l
 }  // extern "C"
 
 #include "solver_capi.inc"
+#include "multi_capi.inc"

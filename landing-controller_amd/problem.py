@@ -96,10 +96,39 @@ class CallerConstants:
     td_nom: float = 0.35
 
 
-def sample_drop_states(B, seed, dt1, consts=None):
-    """Random drop states, main_scripts/landing_optimization.m:207-218 (the reference never seeds
-    ``rand``; the seed is ours).  Returns q_init[B,6], qd_init[B,6]."""
+# The time grid every production caller of the N=20 solver function uses (main_scripts/landing_optimization.m:28,
+# generate_data/generate_training_data_automated.m:28, generate_data/nn_warmstart.m:49): 20 intervals, 0.75 s, fine steps
+# around touch-down.  `dt_grid="reference"` of the builders below selects it (N must be 20); "uniform" = T/N
+# (analysis/eval_SRBM_CCC.m:22-24, the N=41 script and SURVEY 8(d)'s synthetic bench workload).
+REFERENCE_DT_GRID = np.array([0.05] + [0.02] * 15 + [0.05, 0.05, 0.1, 0.2])
+
+# Drop-state sampling laws of the two batch callers (the third column of numbers is what differs):
+#   "main"    main_scripts/landing_optimization.m:207-208:            v_xy = 1.0 (2U-1),  v_z = -4.5 U - 0.5, f_max 300 (:258)
+#   "datagen" generate_data/generate_training_data_automated.m:47,50: v_xy = 1.75 (2U-1), v_z = -3 U - 3,     f_max 500 (:102)
+DROP_LAWS = {"main": (1.0, -4.5, -0.5), "datagen": (1.75, -3.0, -3.0)}
+
+
+def dt_of(N, T, dt_grid="uniform"):
+    """dt[N] of a caller: "uniform" (T/N) or "reference" (the production grid above, N = 20 only; T is ignored)."""
+    if isinstance(dt_grid, str):
+        if dt_grid == "uniform":
+            return np.full(N, T / N)
+        if dt_grid == "reference":
+            if N != len(REFERENCE_DT_GRID):
+                raise ValueError("the reference's production time grid has %d intervals (N = %d asked)" % (len(REFERENCE_DT_GRID), N))
+            return REFERENCE_DT_GRID.copy()
+        raise ValueError("dt_grid: 'uniform', 'reference' or an array of N step lengths")
+    dt = np.asarray(dt_grid, float).reshape(-1)
+    if dt.size != N or not (dt > 0).all():
+        raise ValueError("dt_grid must hold N positive step lengths")
+    return dt.copy()
+
+
+def sample_drop_states(B, seed, dt1, consts=None, law="main"):
+    """Random drop states of the batch callers (DROP_LAWS; the reference never seeds ``rand``; the seed is ours).
+    Returns q_init[B,6], qd_init[B,6]."""
     c = consts or CallerConstants()
+    vxy, vz_a, vz_b = DROP_LAWS[law]
     rng = np.random.default_rng(seed)
     u = rng.random((B, 9))
     q = np.zeros((B, 6))
@@ -108,8 +137,8 @@ def sample_drop_states(B, seed, dt1, consts=None):
     q[:, 4] = (np.pi / 3) * (2 * u[:, 1] - 1)
     q[:, 5] = 0.25 * (2 * u[:, 2] - 1)
     qd[:, 0:3] = 0.5 * (2 * u[:, 3:6] - 1)
-    qd[:, 3:5] = 1.0 * (2 * u[:, 6:8] - 1)
-    qd[:, 5] = -4.5 * u[:, 8] - 0.5
+    qd[:, 3:5] = vxy * (2 * u[:, 6:8] - 1)
+    qd[:, 5] = vz_a * u[:, 8] + vz_b
     for b in range(B):
         R = rpy_to_rot_xyz(q[b, 3:6])
         hip_z = (R @ HIP_SRBM.T)[2, :]
@@ -148,11 +177,11 @@ def pack_params(N, Xref, dt, q_min, q_max, qd_min, qd_max, q_init, qd_init, q_te
     return p
 
 
-def make_member(N, T, q_init, qd_init, consts=None):
+def make_member(N, T, q_init, qd_init, consts=None, dt_grid="uniform"):
     """(p, x0, Xref, Uref) for one drop state with the callers' fixed arguments; x0=[Xref(:);Uref(:)]."""
     c = consts or CallerConstants()
     mass, Ib, Ib_inv = robot_constants()
-    dt = np.full(N, T / N)
+    dt = dt_of(N, T, dt_grid)
     Xref, Uref = reference_trajectories(N, q_init, qd_init, c)
     p = pack_params(N, Xref, dt, c.q_min, c.q_max, c.qd_min, c.qd_max, q_init, qd_init, c.q_term_min,
                     c.q_term_max, c.qd_term_min, c.qd_term_max, c.QN, c.mu, c.l_leg_max, c.f_max, mass, Ib, Ib_inv)
@@ -160,31 +189,41 @@ def make_member(N, T, q_init, qd_init, consts=None):
     return p, x0, Xref, Uref
 
 
-def make_args21(B, N=40, T=0.6, seed=20211, consts=None):
+def make_args21(B, N=40, T=0.6, seed=20211, consts=None, dt_grid="uniform", law="main"):
     """The 21 arguments of the solver function for B sampled drop states, shaped as the MATLAB callers hold them with a
     trailing batch axis (generate_training_data_automated.m:62-136): dict name -> array."""
     c = consts or CallerConstants()
     mass, Ib, Ib_inv = robot_constants()
-    q, qd = sample_drop_states(B, seed, T / N, c)
+    dtv = dt_of(N, T, dt_grid)
+    q, qd = sample_drop_states(B, seed, dtv[0], c, law)
     Xref = np.zeros((12, N + 1, B)); Uref = np.zeros((24, N, B)); x0 = np.zeros((nx(N), B))
     for b in range(B):
         Xref[:, :, b], Uref[:, :, b] = reference_trajectories(N, q[b], qd[b], c)
         x0[:, b] = np.concatenate([Xref[:, :, b].flatten(order="F"), Uref[:, :, b].flatten(order="F")])
     rep = lambda v: np.repeat(np.asarray(v, float).reshape(-1, 1), B, axis=1)
-    return dict(Xref=Xref, Uref=Uref, dt=np.full((1, N, B), T / N), q_min=rep(c.q_min), q_max=rep(c.q_max), qd_min=rep(c.qd_min),
+    return dict(Xref=Xref, Uref=Uref, dt=np.repeat(dtv.reshape(1, N, 1), B, axis=2), q_min=rep(c.q_min), q_max=rep(c.q_max), qd_min=rep(c.qd_min),
                 qd_max=rep(c.qd_max), q_init=q.T.copy(), qd_init=qd.T.copy(), q_term_min=rep(c.q_term_min), q_term_max=rep(c.q_term_max),
                 qd_term_min=rep(c.qd_term_min), qd_term_max=rep(c.qd_term_max), QN=rep(c.QN), x0=x0, mu=rep([c.mu]),
                 l_leg_max=rep([c.l_leg_max]), f_max=rep([c.f_max]), mass=rep([mass]), Ib=rep(Ib), Ib_inv=rep(Ib_inv))
 
 
-def make_batch(B, N=40, T=0.6, seed=20211, consts=None):
-    """Synthetic drop-state batch of SURVEY 8(d): returns P[B,np], X0[B,nx], q_init, qd_init."""
-    q, qd = sample_drop_states(B, seed, T / N, consts)
+def make_batch(B, N=40, T=0.6, seed=20211, consts=None, dt_grid="uniform", law="main"):
+    """Drop-state batch: returns P[B,np], X0[B,nx], q_init, qd_init.  Defaults = the synthetic workload of SURVEY 8(d)
+    (uniform T/N grid, law "main"); ``dt_grid="reference"`` poses the problem the reference's production callers pose at
+    N = 20 (REFERENCE_DT_GRID; touch-down height from ITS first step, :52-60), ``law`` picks their sampling law (DROP_LAWS)."""
+    dtv = dt_of(N, T, dt_grid)
+    q, qd = sample_drop_states(B, seed, dtv[0], consts, law)
     P = np.zeros((B, n_p(N)))
     X0 = np.zeros((B, nx(N)))
     for b in range(B):
-        P[b], X0[b], _, _ = make_member(N, T, q[b], qd[b], consts)
+        P[b], X0[b], _, _ = make_member(N, T, q[b], qd[b], consts, dtv)
     return P, X0, q, qd
+
+
+def production_constants(law="main"):
+    """CallerConstants of the two production callers: they differ in f_max only (landing_optimization.m:258 -> 300,
+    generate_training_data_automated.m:102 -> 500)."""
+    return CallerConstants(f_max=300.0 if law == "main" else 500.0)
 
 
 def split_solution(N, x):

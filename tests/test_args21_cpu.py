@@ -41,31 +41,91 @@ def test_pack_args21_equals_python_mirror(libs):
 
 
 def test_mex_gateway_compiles_and_matches_packed_path(libs, tmp_path):
+    from conftest import MexGateway
     capi, P = lc("capi"), lc("problem")
     N, B = 8, 1           # small horizon: the emulated kernel runs the gateway's default options to convergence in seconds
-    so = str(tmp_path / "gateway.so")
-    emu_dir = os.path.dirname(libs[1])
-    subprocess.run(["gcc", "-O1", "-std=c99", "-fPIC", "-shared", "-Wall", "-Werror", "-Wno-unused-function", "-I", os.path.join(ROOT, "tests", "stubs"),
-                    "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "matlab", "landing_solve_mex.c"),
-                    os.path.join(ROOT, "tests", "stubs", "mex_driver.c"), "-o", so, "-L", emu_dir, "-llanding_emu",
-                    "-Wl,-rpath," + emu_dir], check=True)
-    gw = C.CDLL(so)
+    gw = MexGateway(tmp_path, os.path.dirname(libs[1]), "landing_emu")
     args = P.make_args21(B, N, 0.6, seed=9)
-    bufs = [np.asfortranarray(np.asarray(args[n], float)) for n in capi.ARGS21]
-    data = (C.POINTER(C.c_double) * 21)(*[b.ctypes.data_as(C.POINTER(C.c_double)) for b in bufs])
-    ndim = (C.c_int * 21)(*[b.ndim for b in bufs])
-    dims = (C.c_int * 84)(*sum([list(b.shape) + [1] * (4 - b.ndim) for b in bufs], []))
-    nx = P.nx(N)
-    X = np.zeros((B, nx)); F = np.zeros(B); st = np.zeros(B, np.int32); it = np.zeros(B, np.int32); kk = np.zeros((B, 3))
-    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double)); ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int))
-    assert gw.call_gateway(data, ndim, dims, dp(X), dp(F), ip(st), ip(it), dp(kk), nx, B) == 0
+    out = gw.call(N, args, capi.ARGS21)
     L = capi.LandingLib(N, lib_path=libs[1])
     Pb, X0, _, _ = P.make_batch(B, N, 0.6, seed=9)
     ref = L.solve_host(Pb, X0)
-    assert st.tolist() == [0] and it.tolist() == ref["iters"].tolist()
-    assert np.array_equal(X, ref["x"]) and np.array_equal(F, ref["f"]) and np.array_equal(kk, ref["kkt"])
+    assert out["status"].tolist() == [0] and out["iters"].tolist() == ref["iters"].tolist()
+    for k in ("x", "f", "kkt", "lam_g"):
+        assert np.array_equal(out[k], ref[k]), k
     # ... and the two C spellings of the entry point agree with it (a few iterations are enough for bit-equality)
     o = L.default_opts(); o.max_iter = 3
     r0 = L.solve_host(Pb, X0, o); r1 = L.solve_args21(args, o); r2 = L.solve_args21(args, o, spelled_out=True)
     for r in (r1, r2):
         assert np.array_equal(r["x"], r0["x"]) and np.array_equal(r["status"], r0["status"]) and np.array_equal(r["kkt"], r0["kkt"])
+
+
+def test_mex_gateway_validates_broadcasts_and_takes_options(libs, tmp_path):
+    """class and element count of every argument are checked; arguments that hold ONE member's worth of values
+    (what the reference's callers pass for q_min, mu, mass, ...) are shared by the batch; outputs are created only when asked for;
+    the options struct reaches landing_solver_opts and the device list shards the batch (two contexts, emulated: sequential)."""
+    from conftest import MexGateway
+    capi, P = lc("capi"), lc("problem")
+    N, B = 6, 3
+    gw = MexGateway(tmp_path, os.path.dirname(libs[1]), "landing_emu")
+    args = P.make_args21(B, N, 0.6, seed=4)
+    few = dict(max_iter=3)
+    full = gw.call(N, args, capi.ARGS21, opts=few)
+    assert (full["iters"] == 3).all() and (full["status"] == 1).all()          # the option arrived (3 iterations, LANDING_MAX_ITER)
+    # shared constants as 6x1 / 1x1 arrays, exactly as generate_training_data_automated.m:130-136 passes them
+    shared = dict(args)
+    for n in ("q_min", "q_max", "qd_min", "qd_max", "q_term_min", "q_term_max", "qd_term_min", "qd_term_max", "QN", "mu", "l_leg_max", "f_max", "mass", "Ib", "Ib_inv", "dt"):
+        shared[n] = np.asarray(args[n])[..., 0]
+    sh = gw.call(N, shared, capi.ARGS21, opts=few)
+    for k in ("x", "f", "status", "iters", "kkt", "lam_g"):
+        assert np.array_equal(sh[k], full[k]), k
+    # sharded over two contexts: bit-identical, ragged shards (3 members over 2) included
+    two = gw.call(N, shared, capi.ARGS21, opts=few, devices=[0, 0])
+    for k in ("x", "f", "status", "iters", "kkt", "lam_g"):
+        assert np.array_equal(two[k], full[k]), k
+    # only the outputs asked for are created (the driver reports rc 2 otherwise)
+    one = gw.call(N, args, capi.ARGS21, opts=few, nlhs=1)
+    assert np.array_equal(one["x"], full["x"]) and not one["f"].any()
+    # refusals
+    bad = dict(args); bad["mu"] = np.ones((1, 2))
+    with pytest.raises(RuntimeError, match=r"argument 16 \(mu\) has 2 elements"):
+        gw.call(N, bad, capi.ARGS21, opts=few)
+    bad = dict(args); bad["x0"] = np.zeros((P.nx(N) - 1, B))
+    with pytest.raises(RuntimeError, match=r"argument 15 \(x0\)"):
+        gw.call(N, bad, capi.ARGS21, opts=few)
+    with pytest.raises(RuntimeError, match="must be a full real double array"):
+        gw.call(N, args, capi.ARGS21, opts=few, single=("Ib",))
+    bad = dict(args); bad["Xref"] = np.zeros((11, N + 1, B))
+    with pytest.raises(RuntimeError, match="Xref must be 12"):
+        gw.call(N, bad, capi.ARGS21, opts=few)
+    with pytest.raises(RuntimeError, match="landing_multi_create"):
+        gw.call(N, args, capi.ARGS21, opts=few, devices=[7])      # the emulation has one device
+
+
+def test_multi_device_entry_points_shard_ranges_and_identity(libs):
+    """landing_shard_range = the contiguous split of sharding.py; landing_multi_solve_args21 over 1, 2 and 3 contexts (emulated)
+    returns exactly the single-context result, ragged shards and B < n_dev included"""
+    capi, P, sh = lc("capi"), lc("problem"), lc("sharding")
+    lib = capi.load(libs[1])
+    lo, hi = C.c_int(), C.c_int()
+    for B in (0, 1, 7, 8, 1024, 8191):
+        for n in (1, 2, 3, 8):
+            got = []
+            for i in range(n):
+                lib.landing_shard_range(B, n, i, C.byref(lo), C.byref(hi)); got.append((lo.value, hi.value))
+            assert got[0][0] == 0 and got[-1][1] == B and all(got[i][1] == got[i + 1][0] for i in range(n - 1))
+            assert max(h - l for l, h in got) - min(h - l for l, h in got) <= 1
+            assert got == [sh.shard_range(B, n, i) for i in range(n)]
+    N, B = 6, 4
+    L = capi.LandingLib(N, lib_path=libs[1])
+    args = P.make_args21(B, N, 0.6, seed=2)
+    o = L.default_opts(); o.max_iter = 4
+    ref = L.solve_args21(args, o)
+    Pb, X0, _, _ = P.make_batch(B, N, 0.6, seed=2)
+    lam_ref = L.solve_host(Pb, X0, o)["lam_g"]
+    for devs, one_call in (([0], False), ([0, 0], False), ([0, 0, 0], True), ([0] * 6, False)):
+        r = L.solve_args21_multi(args, devs, o, one_call=one_call)
+        for k in ("x", "f", "status", "iters", "kkt"):
+            assert np.array_equal(r[k], ref[k]), (devs, k)
+        assert np.array_equal(r["lam_g"], lam_ref)
+    lib.landing_multi_release_cached()

@@ -45,3 +45,35 @@ def test_args21_single_member_matlab_call_shape():
     ref = L.solve_host(Pb, X0)
     assert np.array_equal(r["x"], ref["x"]) and r["status"][0] == 0
     L.close()
+
+
+def test_multi_device_entry_two_contexts_bit_identical(tmp_path):
+    """landing_multi_solve_args21 / landing_solve_21_multi on the 1-GPU box with devices = {0, 0}: two contexts, two host threads,
+    contiguous (ragged) shards -- x*, f*, lam_g, status, iterations, KKT bit-identical to the single-context call; through the mex
+    gateway (matlab/landing_solve_mex.c against the mex.h stub) with shared constants, an options struct and a device list too."""
+    import os
+    from conftest import ROOT, MexGateway
+    capi, P = lc("capi"), lc("problem")
+    N, B = 20, 33
+    L = capi.LandingLib(N, device=0)
+    c = P.production_constants("main")
+    args = P.make_args21(B, N, 0.6, seed=31, consts=c, dt_grid="reference")
+    Pb, X0, _, _ = P.make_batch(B, N, 0.6, seed=31, consts=c, dt_grid="reference")
+    o = L.default_opts(); o.max_iter = 300
+    ref = L.solve_host(Pb, X0, o)
+    assert (ref["status"] == 0).sum() >= B - 1
+    for devs, one_call in (([0, 0], False), ([0, 0, 0], True), ([0], True)):
+        r = L.solve_args21_multi(args, devs, o, one_call=one_call)
+        for k in ("x", "f", "lam_g", "status", "iters", "kkt"):
+            assert np.array_equal(r[k], ref[k]), (devs, k)
+    gw = MexGateway(tmp_path, os.path.join(ROOT, "landing-controller_amd"), "landing_mi355x")
+    shared = dict(args)
+    for n in ("q_min", "q_max", "qd_min", "qd_max", "q_term_min", "q_term_max", "qd_term_min", "qd_term_max", "QN", "mu", "l_leg_max", "f_max", "mass", "Ib", "Ib_inv", "dt"):
+        shared[n] = np.asarray(args[n])[..., 0]
+    out = gw.call(N, shared, capi.ARGS21, opts=dict(max_iter=300), devices=[0, 0])
+    for k in ("x", "f", "lam_g", "status", "iters", "kkt"):
+        assert np.array_equal(out[k], ref[k]), k
+    with pytest.raises(RuntimeError, match="landing_multi_create"):
+        L.solve_args21_multi(args, [0, 99], o)
+    L.lib.landing_multi_release_cached()
+    L.close()

@@ -25,13 +25,12 @@ def libs():
 @pytest.mark.parametrize("N,B", [(20, 24), (40, 32)])
 def test_solver_reaches_kkt_under_oracle_functions(libs, oracle_mod, N, B):
     O = oracle_mod.Oracle(N)
-    P, X0, _, qd = lc("problem").make_batch(B, N, 0.6, seed=1)
+    # N = 40: the uniform 15 ms grid of SURVEY 8(d).  N = 20: the grid the reference's callers pose (problem.REFERENCE_DT_GRID)
+    Pm = lc("problem")
+    P, X0, _, qd = Pm.make_batch(B, N, 0.6, seed=1, consts=Pm.production_constants("main") if N == 20 else None, dt_grid="reference" if N == 20 else "uniform")
     r = libs[N].solve_host(P, X0)
     conv = r["status"] == 0
-    # N = 40: every member converges.  N = 20 (dt = 30 ms): the drops faster than 4.4 m/s are infeasible at that resolution
-    # (tests/dev: the same states converge at N = 40) -- every slower one must converge (measured round 2: 100 %)
-    slow = qd[:, 5] > (-4.4 if N == 20 else -1e9)
-    assert conv[slow].all(), f"{(~conv & slow).sum()} members with |v_z| < 4.4 m/s failed: {np.nonzero(~conv & slow)[0]}"
+    assert conv.all(), f"{(~conv).sum()} members failed: {np.nonzero(~conv)[0]}"
     for b in np.nonzero(conv)[0]:
         k = O.kkt(r["x"][b], P[b], r["lam_g"][b])
         assert k.max() <= KKT_TOL * 1.0001, (b, k)
@@ -98,7 +97,7 @@ def test_solver_other_horizons_and_limits(oracle_mod):
         P, X0, _, _ = lc("problem").make_batch(6, N, 0.6, seed=4)
         r = L.solve_host(P, X0)
         ok = r["status"] == 0
-        assert ok.sum() >= (3 if N == 16 else 6)      # dt = 37.5 ms at N = 16: about a quarter of the drop states (the fast drops) are infeasible at that resolution; N = 30: all solve
+        assert ok.sum() >= (3 if N == 16 else 6)      # measured: N = 16 (uniform dt = 37.5 ms, a grid no caller of the reference uses) about three quarters solve; N = 30: all solve
         for b in np.nonzero(ok)[0]:
             assert O.kkt(r["x"][b], P[b], r["lam_g"][b]).max() <= KKT_TOL * 1.0001
         L.close()
@@ -140,7 +139,7 @@ def test_solver_full_size_batch_properties(libs, oracle_mod):
     torch.cuda.synchronize()
     sth, kh, xh, lh = st.cpu().numpy(), kkt.cpu().numpy(), x.cpu().numpy(), lam.cpu().numpy()
     ok = sth == 0
-    assert ok.sum() >= B - 1, f"{ok.sum()}/{B}"        # measured: 1024/1024 (rounds 1 and 2); one locally infeasible member is tolerated
+    assert ok.sum() >= B - 1, f"{ok.sum()}/{B}"        # measured: 1024/1024 (rounds 1 and 2); one straggler is tolerated
     assert kh[ok].max() <= KKT_TOL * 1.0001
     ith = it.cpu().numpy()
     assert ith.mean() <= 54 and np.percentile(ith, 99) <= 95 and ith.max() <= 150, (ith.mean(), np.percentile(ith, 99), ith.max())     # measured, final settings of round 2: mean 50.3, p99 79, max 95 (first half of the round: 63.9 / 110 / 167)
@@ -270,23 +269,27 @@ def test_reference_bound_frac_is_a_supported_configuration(libs, oracle_mod):
     assert r["kkt"][ok].max() <= KKT_TOL * 1.0001
 
 
-def test_n20_failures_are_the_fast_drops(libs):
-    """N = 20, dt = 30 ms (the reference's generated horizon) over the full synthetic range of drop speeds: the members that do
-    not converge are the fastest drops (|v_z| > 4.4 m/s: the body covers 13 cm per stage -- locally infeasible NLPs, IPOPT would
-    report the same); every slower member converges, and every failing one converges when posed with N = 40."""
-    N, B = 20, 512
+@pytest.mark.parametrize("law,min_conv", [("main", 0.995), ("datagen", 0.95)])
+def test_n20_production_problem_full_batch(libs, oracle_mod, law, min_conv):
+    """BASELINE configs[0] as the reference's production callers pose it: N = 20 on the non-uniform grid
+    dt = [0.05, 0.02 x 15, 0.05, 0.05, 0.1, 0.2] (landing_optimization.m:28, generate_training_data_automated.m:28, nn_warmstart.m:49), both
+    sampling laws (problem.DROP_LAWS), each caller's own f_max, 1024 drop states per law, from the callers' linear references.
+    Converged members are KKT points <= 1e-6 by the kernel's report, re-certified under the oracle's (reference-pinned) functions on a
+    sample.  Measured (CPU port, seed 7): main 1020 / 1024, datagen 984 / 1024 -- the members that do not converge end as
+    LANDING_NUMERICAL / LANDING_MAX_ITER with the primal infeasibility stalled at 0.1 .. 1; no infeasibility certificate is claimed."""
+    N, B = 20, 1024
     Pm = lc("problem")
-    P, X0, q, qd = Pm.make_batch(B, N, 0.6, seed=20211)
-    r = libs[20].solve_host(P, X0)
-    bad = r["status"] != 0
-    assert bad.mean() <= 0.10
-    assert (qd[bad, 5] < -4.4).all(), qd[bad, 5]
-    idx = np.nonzero(bad)[0]
-    P4 = np.zeros((len(idx), Pm.n_p(40))); X4 = np.zeros((len(idx), Pm.nx(40)))
-    for j, b in enumerate(idx):
-        P4[j], X4[j], _, _ = Pm.make_member(40, 0.6, q[b], qd[b])
-    r4 = libs[40].solve_host(P4, X4)
-    assert (r4["status"] == 0).all()
+    O = oracle_mod.Oracle(N)
+    P, X0, _, qd = Pm.make_batch(B, N, 0.6, seed=7, consts=Pm.production_constants(law), dt_grid="reference", law=law)
+    o = libs[N].default_opts(); o.max_iter = 300
+    r = libs[N].solve_host(P, X0, o)
+    ok = r["status"] == 0
+    print("N=20 production grid, law %s: %d / %d converged, iterations mean %.1f p99 %.0f max %d; v_z of the others: %s" %
+          (law, ok.sum(), B, r["iters"][ok].mean(), np.percentile(r["iters"][ok], 99), r["iters"][ok].max(), np.round(np.sort(qd[~ok, 5]), 2)[:12]))
+    assert ok.mean() >= min_conv, f"{ok.sum()}/{B}"
+    assert r["kkt"][ok].max() <= KKT_TOL * 1.0001
+    for b in np.nonzero(ok)[0][::37]:
+        assert O.kkt(r["x"][b], P[b], r["lam_g"][b]).max() <= KKT_TOL * 1.0001
 
 
 @pytest.mark.gpu

