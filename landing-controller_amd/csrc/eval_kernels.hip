@@ -344,8 +344,21 @@ __global__ void __launch_bounds__(256) landing_hess_rc_kernel(Layout L, int B, i
 }
 
 // ---- member-level device functions shared with the solver kernel (lane = stage) -------------------
+// inlining policy of the solver's phase functions (development switches; the defaults are what the product build uses)
+// (measured round 3, A/B on one box: with every phase inlined into landing_ipm_kernel the callee-saved-register traffic disappears
+// -- 209 -> 192 GB of HBM traffic per launch -- but the monolithic kernel is allocated and scheduled far worse: condensation 0.104 ->
+// 0.231 ms, forward sweep 0.082 -> 0.146 ms per iteration under load, 96 -> 141 ms per batch.  Out of line it is.)
+#ifndef LANDING_INL_EVAL_G
+#define LANDING_INL_EVAL_G __noinline__
+#endif
+#ifndef LANDING_INL_TASK
+#define LANDING_INL_TASK __noinline__
+#endif
+#ifndef LANDING_INL_EVAL_JH
+#define LANDING_INL_EVAL_JH __noinline__
+#endif
 // residual g(x) of one member (boundary rows + all stages); the caller synchronises afterwards.
-__device__ __noinline__ void member_eval_g(const Layout& L, const double* x, const double* p, double* g) {
+__device__ LANDING_INL_EVAL_G void member_eval_g(const Layout& L, const double* x, const double* p, double* g) {
   const int N = L.N;
   for (int r = threadIdx.x; r < 36; r += blockDim.x) {
     double v;
@@ -361,7 +374,9 @@ __device__ __noinline__ void member_eval_g(const Layout& L, const double* x, con
     srbm::stage_g(z, P, k == N - 1, out);
   }
 }
-__device__ __noinline__ void eval_task_jac(const Layout& L, const srbm::StageVars& z, const srbm::StageParams& P, int k,
+// out-of-line copy for the rare call sites of the solver (initial point, restart from the initial guess, line-search fall-back)
+__device__ __noinline__ void member_eval_g_rare(const Layout& L, const double* x, const double* p, double* g) { member_eval_g(L, x, p, g); }
+__device__ LANDING_INL_TASK void eval_task_jac(const Layout& L, const srbm::StageVars& z, const srbm::StageParams& P, int k,
                                            const double* fz_prev, double* J) {
   SeqStoreJ ex{J + L.jx(k)}, eu{J + L.ju(k)};
   srbm::stage_jac(z, P, k == 0, k == L.N - 1, fz_prev, ex, eu);
@@ -382,7 +397,7 @@ __device__ __noinline__ void eval_task_jac_tiled(const Layout& L, const double* 
   srbm::stage_jac(z, P, false, false, fz_prev, ex, eu);
   ex.finish(); eu.finish();
 }
-__device__ __noinline__ void eval_task_jty(const Layout& L, const srbm::StageVars& z, const srbm::StageParams& P, int k,
+__device__ LANDING_INL_TASK void eval_task_jty(const Layout& L, const srbm::StageVars& z, const srbm::StageParams& P, int k,
                                            const double* fz_prev, const double* y, double* gx) {
   const bool first = (k == 0);
   const double* lprev = first ? y : y + L.g_stage(k - 1);
@@ -391,7 +406,7 @@ __device__ __noinline__ void eval_task_jty(const Layout& L, const srbm::StageVar
   srbm::stage_jac(z, P, first, k == L.N - 1, fz_prev, ex, eu);
   ex.finish(); eu.finish();
 }
-__device__ __noinline__ void eval_task_hess(const Layout& L, const srbm::StageVars& z, const srbm::StageParams& P, int k,
+__device__ LANDING_INL_TASK void eval_task_hess(const Layout& L, const srbm::StageVars& z, const srbm::StageParams& P, int k,
                                             const double* y, double* H) {
   const bool first = (k == 0);
   double lps[12];
@@ -406,7 +421,7 @@ __device__ __noinline__ void eval_task_hess(const Layout& L, const srbm::StageVa
 }
 
 // Jacobian / Hessian nonzeros (CCS order) and gx = grad f + J^T y of one member.
-__device__ __noinline__ void member_eval_jh(const Layout& L, const double* x, const double* p, const double* y,
+__device__ LANDING_INL_EVAL_JH void member_eval_jh(const Layout& L, const double* x, const double* p, const double* y,
                                             double* J, double* H, double* gx, double* tiles = nullptr, const int* edge_map = nullptr) {
   const int N = L.N;
   for (int i = threadIdx.x; i < 36; i += blockDim.x) J[L.jx(N) + i] = 1.0;

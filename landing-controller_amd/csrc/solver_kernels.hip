@@ -18,6 +18,23 @@
 
 #include "../../include/landing_nlp.h"
 
+// inlining policy of the solver's phase functions (development switches; the defaults are what the product build uses).
+// Measured round 3, A/B on one box: with every phase inlined into landing_ipm_kernel the callee-saved-register traffic disappears
+// (209 -> 192 GB of HBM traffic per launch) but the monolithic kernel is allocated and scheduled far worse -- condensation 0.104 ->
+// 0.231 ms, forward sweep 0.082 -> 0.146 ms per iteration under load, 96 -> 141 ms per batch.  Out of line it is.
+#ifndef LANDING_INL_COND
+#define LANDING_INL_COND __noinline__
+#endif
+#ifndef LANDING_INL_BACK
+#define LANDING_INL_BACK __noinline__
+#endif
+#ifndef LANDING_INL_FWD
+#define LANDING_INL_FWD __noinline__
+#endif
+#ifndef LANDING_INL_ROWP
+#define LANDING_INL_ROWP __noinline__
+#endif
+
 namespace landing {
 
 constexpr int NZ_JX = 0, NZ_JU = 157, NZ_JUN = 385, NZ_HX = 613, NZ_HU = 642, NZ_HUN = 802, NZ_TOT = 962;
@@ -66,7 +83,7 @@ struct SolverWorkspace {
 
 // optional per-member phase timers (wall_clock64 ticks, 100 MHz) -- enabled when SolveArgs.prof != nullptr
 enum { PH_EVAL = 0, PH_ERR, PH_SIGRHO, PH_BACK, PH_FWD, PH_DUAL, PH_LS, PH_ACCEPT, PH_NFACT, PH_NTRIAL, PH_NITER, PH_NSTAGE_OK, PH_B_ASM, PH_NSTAGE, PH_B_ELIM, PH_B_POST, PH_COUNT = 16 };   // 11 / 13: stage eliminations that succeeded / were attempted (stage-0 foot block included)
-#define PROF_ADD(slot, tstart) do { if (SH.prof_on) { const long long n_ = (long long)wall_clock64(); if (threadIdx.x == 0) SH.prof[slot] += (double)(n_ - (tstart)); (tstart) = n_; } } while (0)
+#define PROF_ADD(slot, tstart) do { if (SH.prof_on) { const long long n_ = (long long)wall_clock64(); if (threadIdx.x == 0) { SH.prof[slot] += (double)(n_ - (tstart)); (tstart) = n_; } } } while (0)
 
 struct SolveArgs {
   Layout L; int B; landing_solver_opts o; double* prof;
@@ -145,6 +162,22 @@ __device__ __forceinline__ MemberMem carve(const Layout& L, double* w) {
   return M;
 }
 
+// Scalar state of the interior-point loop, kept in LDS (S.ks) and never in registers across phases.  Every thread reads it in
+// place; ONLY thread 0 writes it, inside KS_BEGIN / KS_END blocks that are fenced by barriers on both sides -- so the scalar
+// control logic of the solver (error test, restarts, barrier update, regularisation schedule, filter, watchdog) runs once per
+// workgroup instead of 256 times, and no value is live across a phase.  Round 2 held these ~45 scalars in VGPRs: the kernel body
+// alone carried 767 static scratch (private-segment) accesses around its calls, executed every iteration by all 256 threads
+// (VERDICT r2 item 8); now 233, none of them on the per-iteration path of the row passes.
+struct IpmState {
+  double mu, delta_last, th_max, c_pr, c_co, c_cm, c_ys, c_zs, c_nz, e_pr, e_du, e_co;
+  double tau, omt, a_pr, a_du, th0, ph0, dphi, alpha, s_corr, delta, ft;
+  long long tp;
+  int nfilt, it, status, need_reg_streak, nreset, last_reset_it, ncrawl, clip_k_cur, last_mu_it, cutstreak, wd_count, first_failed, force_step;
+  int clip_now, accepted, armijo_step, fact_ok, skipped_zero, attempt;
+  int action, flag, fresh, ls_done, need_corr, fallback;
+};
+enum { ACT_GO = 0, ACT_STOP = 1, ACT_RESET = 2 };
+
 // LDS of one member
 constexpr int XCH = 448;   // one exchange buffer of the blocked elimination: pivot rows [64][4] + pivot columns [48][4]
 static_assert(2 * XCH >= 24 * YS, "A1 also holds Y (24 x YS)");
@@ -173,6 +206,7 @@ struct Lds {
   // that every row pass used to stream (6 of ~30 array passes per iteration)
   double bnd_lb[36 + 2 * 104], bnd_ub[36 + 2 * 104];
   MemberMem M; Layout L; const double* p; const int* tab; const int* stage_tab; int prof_on; int fp32;
+  IpmState ks;
 };
 // One instance per workgroup (= per NLP).  Namespace scope keeps the LDS address space visible to every
 // phase function (ds_* instructions instead of flat_*).
@@ -675,7 +709,7 @@ __device__ __forceinline__ bool riccati_step(double* rec, double delta, int k) {
 // balanced (5 terms per thread and stage at N = 40).  A destination whose terms straddle chunk borders is finished by the
 // thread holding its closing term, which adds the carries of its `nprev` predecessors from LDS in thread order --
 // deterministic.  Two stages per batch: their gathers are issued together, one barrier per batch.
-__device__ __noinline__ void condense(const unsigned long long* __restrict__ ctab, int ML, int mid) {
+__device__ LANDING_INL_COND void condense(const unsigned long long* __restrict__ ctab, int ML, int mid) {
   Lds& S = SH;
   const MemberMem& M = S.M;
   const int ng = S.L.ng, N = S.L.N, tid = threadIdx.x;
@@ -764,7 +798,7 @@ __device__ __noinline__ void condense(const unsigned long long* __restrict__ cta
 
 // One backward Riccati sweep with regularisation delta (terminal cost-to-go, stages N-1..0, free feet of
 // stage 0).  false = a pivot was not positive (wrong inertia): the caller raises delta and retries.
-__device__ __noinline__ bool riccati_backward(double delta) {
+__device__ LANDING_INL_BACK bool riccati_backward(double delta) {
   Lds& S = SH;
   const Layout& L = S.L;
   const MemberMem& M = S.M;
@@ -843,7 +877,7 @@ __device__ __noinline__ bool riccati_backward(double delta) {
 // and passed on through a double-buffered LDS slot).  The forces f_k = -(K_f sigma_k + kappa_f) and the multipliers
 // of the dynamics rows y_k = -(P_{k+1} sigma_{k+1} + p_{k+1})_X do not feed the recursion: they are evaluated for
 // all stages at once afterwards.
-__device__ __noinline__ void forward_pass() {
+__device__ LANDING_INL_FWD void forward_pass() {
   Lds& S = SH;
   const Layout& L = S.L;
   const MemberMem& M = S.M;
@@ -928,7 +962,7 @@ __device__ __noinline__ void forward_pass() {
 // with the records of the next batch fetched under the gathers of this one.  (Tried in round 2: the stage-local LDS
 // table scheme of condense() -- one term per thread and stage, carries through LDS, a barrier per 4 stages -- is slower
 // here, alone 0.065 vs 0.039 ms and under load 0.105 vs 0.091: the list is short, 15 k terms, and latency-bound.)
-__device__ __noinline__ void row_products(const unsigned long long* __restrict__ rterm, int rlen) {
+__device__ LANDING_INL_ROWP void row_products(const unsigned long long* __restrict__ rterm, int rlen) {
   Lds& S = SH;
   const MemberMem& M = S.M;
   const int tid = threadIdx.x, NT = blockDim.x;
@@ -959,6 +993,60 @@ __device__ __noinline__ void row_products(const unsigned long long* __restrict__
     }
   }
   __syncthreads();
+}
+
+// Running-cost pieces of the solver (landing_form.run_cost, generate_quadruped_SRBM_CCC.m:81-89): out of line -- cold for the default
+// terminal-cost objective, and their 36-entry gradient arrays stay out of the register allocation of the main loop.
+__device__ __noinline__ void rc_init_hc() {      // constant Hessian entries of the running cost (layout: RUNC)
+  const Layout& L = SH.L; const double* p = SH.p;
+  for (int e = threadIdx.x; e < L.N * RUNC; e += blockDim.x) {
+    const int k = e / RUNC, j = e % RUNC, a = j % 3;
+    const double dt2 = 2.0 * p[L.o_dt + k];
+    double v;
+    if (j < 12) v = dt2 * (L.QX[j] + (j < 3 ? 4.0 * L.Qc[j] : 0.0));
+    else if (j < 24) v = -dt2 * L.Qc[a];
+    else if (j < 36) v = dt2 * L.Qc[a];
+    else v = dt2 * L.Qf[a];
+    SH.M.Hc[e] = v;
+  }
+}
+__device__ __noinline__ void rc_add_grad() {     // objective gradient of the stage variables into gx
+  const Layout& L = SH.L; const MemberMem& M = SH.M;
+  for (int k = threadIdx.x; k < L.N; k += blockDim.x) { double* gU = M.gx + L.x_U(k); (void)run_cost_stage(L, M.x, SH.p, k, M.gx + L.x_X(k), gU, gU + 12); }
+}
+__device__ __noinline__ void rc_add_gamma() {    // ... and into the stage right-hand sides gamma_k (w order X, c, f)
+  const Layout& L = SH.L; const MemberMem& M = SH.M;
+  for (int k = threadIdx.x; k < L.N; k += blockDim.x) {
+    double gr[36];
+#pragma unroll
+    for (int a = 0; a < 36; ++a) gr[a] = 0.0;
+    (void)run_cost_stage(L, M.x, SH.p, k, gr, gr + 12, gr + 24);
+    double* gm = M.cond + (size_t)k * COND_STRIDE + COND_GAM;
+#pragma unroll
+    for (int a = 0; a < 36; ++a) gm[a] += gr[a];
+  }
+}
+__device__ __noinline__ void rc_f_dphi(double& f0, double& dphi) {     // running cost at x and its directional derivative along dx (per-thread partial sums)
+  const Layout& L = SH.L; const MemberMem& M = SH.M;
+  for (int k0 = 0; k0 < L.N; k0 += blockDim.x) {
+    const int k = k0 + threadIdx.x;
+    if (k >= L.N) continue;
+    double gr[36];
+#pragma unroll
+    for (int a = 0; a < 36; ++a) gr[a] = 0.0;
+    f0 += run_cost_stage(L, M.x, SH.p, k, gr, gr + 12, gr + 24);
+    const double* dX = M.dx + L.x_X(k); const double* dU = M.dx + L.x_U(k);
+#pragma unroll
+    for (int a = 0; a < 12; ++a) dphi += gr[a] * dX[a] + gr[12 + a] * dU[a] + gr[24 + a] * dU[12 + a];
+  }
+}
+__device__ __noinline__ double rc_f(const double* x) {                 // running cost at x (per-thread partial sum)
+  const Layout& L = SH.L;
+  double f = 0.0;
+  // (uniform trip count with a lane predicate: a loop whose trip count differs per lane right in front of the block
+  // reduction hung the kernel on gfx950 / ROCm 7.2 even with the branch not taken -- bisected, tools/dev)
+  for (int k0 = 0; k0 < L.N; k0 += blockDim.x) { const int k = k0 + threadIdx.x; if (k < L.N) f += run_cost_stage(L, x, SH.p, k, nullptr, nullptr, nullptr); }
+  return f;
 }
 
 // Workgroups per CU the register budget is sized for.  Measured on MI355X (N = 40, end of round 1, IPRA off): 2 per CU
@@ -1060,20 +1148,9 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
     S.bnd_lb[e] = lb; S.bnd_ub[e] = ub;
   }
   __syncthreads();
-  if (L.run_cost) {   // constant Hessian entries of the running cost (layout: RUNC)
-    for (int e = lane; e < N * RUNC; e += NT) {
-      const int k = e / RUNC, j = e % RUNC, a = j % 3;
-      const double dt2 = 2.0 * p[L.o_dt + k];
-      double v;
-      if (j < 12) v = dt2 * (L.QX[j] + (j < 3 ? 4.0 * L.Qc[j] : 0.0));
-      else if (j < 24) v = -dt2 * L.Qc[a];
-      else if (j < 36) v = dt2 * L.Qc[a];
-      else v = dt2 * L.Qf[a];
-      M.Hc[e] = v;
-    }
-  }
+  if (L.run_cost) rc_init_hc();
   __syncthreads();
-  member_eval_g(L, M.x, p, M.g);
+  member_eval_g_rare(L, M.x, p, M.g);
   __syncthreads();
   auto init_slacks = [&]() {     // slack pushed into the interior (IPOPT bound_push/frac), z = 1, y = z_U - z_L, y_dyn = 0
     for (int r = lane; r < ng; r += NT) {
@@ -1097,12 +1174,18 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
   // primal / complementarity errors, Sigma and rho of the CURRENT point for barrier parameter mu_ (one pass over the
   // rows; the accept pass below produces the same quantities for the next iterate, so this runs only at the start,
   // after a multiplier reset and when mu changes)
-  double c_pr = 0.0, c_co = 0.0, c_cm = 0.0;
-  double c_ys = 0.0, c_zs = 0.0, c_nz = 1.0;     // |y|_1, |z|_1 and the number of bound multipliers (scaled barrier-subproblem test)
+  IpmState& K = S.ks;
+  // K is written by thread 0 only, between barriers (all other threads only read it, after the closing barrier)
+#define KS_BEGIN() __syncthreads(); if (lane == 0) {
+#define KS_BEGIN_SYNCED() if (lane == 0) {      /* directly behind a barrier (block_reduce / block_top4 end with one) */
+#define KS_END() } __syncthreads()
   // Row passes: every thread owns the rows lane + NT j.  They are processed RB at a time with ALL loads of a batch issued
   // up-front and unconditionally (every array is fully allocated; out-of-range rows re-read the last row and are masked):
   // one memory round trip per batch instead of two or three dependent ones per row behind the bound-type branches.
   constexpr int RB = 4;
+  // primal / complementarity errors, Sigma and rho of the CURRENT point for barrier parameter mu_ (one pass over the
+  // rows; the accept pass below produces the same quantities for the next iterate, so this runs only at the start,
+  // after a multiplier reset and when mu changes).  Leaves c_pr, c_co, c_cm, |y|_1, |z|_1 and the number of bound multipliers in K.
   auto point_pass = [&](double mu_) {
     double pr = 0.0, co = 0.0, cm = 0.0, ys = 0.0, zs = 0.0, nz = 0.0;
     for (int rb = lane; rb < ng; rb += NT * RB) {
@@ -1132,207 +1215,227 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
     }
     double v[6] = {pr, co, cm, ys, zs, nz}; const int op[6] = {RMAX, RMAX, RMAX, RSUM, RSUM, RSUM};
     block_reduce<6>(v, op, S.red);
-    c_pr = v[0]; c_co = v[1]; c_cm = v[2]; c_ys = v[3]; c_zs = v[4]; c_nz = fmax(v[5], 1.0);
+    KS_BEGIN_SYNCED() K.c_pr = v[0]; K.c_co = v[1]; K.c_cm = v[2]; K.c_ys = v[3]; K.c_zs = v[4]; K.c_nz = fmax(v[5], 1.0); KS_END();
   };
 
-  long long tp = A.prof ? (long long)wall_clock64() : 0;
-  double mu = o.mu_init, delta_last = 0.0, th_max = 0.0;
-  int nfilt = 0, it = 0, status = LANDING_MAX_ITER, need_reg_streak = 0, nreset = 0;
-  bool first_failed = false;
-  int last_reset_it = 0, ncrawl = 0, clip_k_cur = o.clip_k, last_mu_it = 0, cutstreak = 0, wd_count = 0;
-  bool force_step = false;
-  double e_pr = 0, e_du = 0, e_co = 0;
+  if (lane == 0) {
+    K.tp = A.prof ? (long long)wall_clock64() : 0;
+    K.mu = o.mu_init; K.delta_last = 0.0; K.th_max = 0.0;
+    K.c_pr = 0.0; K.c_co = 0.0; K.c_cm = 0.0; K.c_ys = 0.0; K.c_zs = 0.0; K.c_nz = 1.0;
+    K.nfilt = 0; K.it = 0; K.status = LANDING_MAX_ITER; K.need_reg_streak = 0; K.nreset = 0; K.first_failed = 0;
+    K.last_reset_it = 0; K.ncrawl = 0; K.clip_k_cur = o.clip_k; K.last_mu_it = 0; K.cutstreak = 0; K.wd_count = 0; K.force_step = 0;
+    K.e_pr = 0; K.e_du = 0; K.e_co = 0;
+  }
+  __syncthreads();
+  // the lane = stage phases are called by the lanes that have work only: the callee-saved registers an out-of-line function touches
+  // are saved and restored in scratch memory by every lane that is active at the call
+  const int nst = N > 36 ? N : 36;
 
-  for (it = 0; it <= o.max_iter; ++it) {
+  for (;;) {
     // ---------------------------------------------------------------- derivatives at (x, y)
-    if (A.prof) tp = (long long)wall_clock64();
+    if (A.prof && lane == 0) K.tp = (long long)wall_clock64();
     // (round 2: the coalesced tile write-out of landing_sweep_kernel<0> was tried here for the Jacobian task -- eval_task_jac_tiled,
     // tiles in the dead G array -- and is slower: 0.049 vs 0.039 ms alone, 0.094 vs 0.085 under load; every lane then runs the
     // full middle-stage stream and the wave serialises on 24 tile flushes, while the scattered stores of this version drain
     // asynchronously behind the arithmetic of the other two waves)
-    member_eval_jh(L, M.x, p, M.y, M.J, M.H, M.gx);
+    if (lane < 192 && (lane & 63) < nst) member_eval_jh(L, M.x, p, M.y, M.J, M.H, M.gx);
     __syncthreads();
-    if (L.run_cost) {   // objective gradient of the stage variables (the terminal part is in member_eval_jh)
-      for (int k = lane; k < N; k += NT) { double* gU = M.gx + L.x_U(k); (void)run_cost_stage(L, M.x, p, k, M.gx + L.x_X(k), gU, gU + 12); }
-      __syncthreads();
-    }
-    PROF_ADD(PH_EVAL, tp);
+    if (L.run_cost) { rc_add_grad(); __syncthreads(); }   // objective gradient of the stage variables (the terminal part is in member_eval_jh)
+    PROF_ADD(PH_EVAL, K.tp);
     // ---------------------------------------------------------------- optimality error (unscaled)
-    if (it == 0) point_pass(mu);
-    double du = 0.0;
-    for (int i = lane + 12; i < nx; i += NT) du = fmax(du, fabs(M.gx[i]));
-    du = block_reduce1(du, RMAX, S.red);
-    const double pr = c_pr, co = c_co;
-    e_pr = pr; e_du = du; e_co = co;
-    if (!(du < 1e300) || !(pr < 1e300) || !(co < 1e300)) { status = LANDING_NUMERICAL; break; }
-    if (fmax(du, fmax(pr, co)) <= o.tol) { status = LANDING_CONVERGED; break; }
-    if (it == o.max_iter) break;
-    if (du > o.reset_du && nreset >= o.max_resets && o.max_resets > 0) { status = LANDING_NUMERICAL; break; }   // jammed again: give up
-    // crawling: still in the first barrier problem (mu never decreased) restart_period iterations after the last (re)start
-    const bool stalled = o.restart_period > 0 && it - last_reset_it >= o.restart_period && mu >= o.mu_init && nreset < o.max_resets && ncrawl < ((o.fresh_restart & 4) ? 2 : 1);
-    const bool overreg = o.reset_delta > 0.0 && delta_last > o.reset_delta && nreset < o.max_resets;
-    // a LATER barrier problem not solved 2 restart_period iterations after it began has wandered off (the dual infeasibility stays
-    // far below reset_du, nothing else catches it): restarted in place like a crawling iterate
-    const bool lost = (o.fresh_restart & 8) && o.restart_period > 0 && mu < o.mu_init && pr > 1e-3 && nreset < o.max_resets &&
-                      ((it - last_mu_it >= 2 * o.restart_period && it - last_reset_it >= o.restart_period) || wd_count >= 3);     // ... or crawls on although the watchdog has fired three times
-    if ((du > o.reset_du && nreset < o.max_resets) || stalled || overreg || lost) {
-      last_reset_it = it;
-      if (stalled) ncrawl++;
-      // jammed iterate (multipliers blown up): keep x, re-initialise slacks, multipliers, barrier parameter and
-      // filter -- the role IPOPT's restoration phase plays on this problem class
-      nreset++;
-      if (((o.fresh_restart & 2) && nreset == 2) || ((o.fresh_restart & 1) && nreset == 1 && !stalled && !lost)) {
-        // the restart in place did not help (second restart) or the iterate is jammed: back to the caller's initial guess with
-        // another step rule (landing_nlp.h: the members that fail from it with clip_k = 4 solve with clip_k = 2)
+    if (K.it == 0) point_pass(K.mu);
+    {
+      double du = 0.0;
+      for (int i = lane + 12; i < nx; i += NT) du = fmax(du, fabs(M.gx[i]));
+      du = block_reduce1(du, RMAX, S.red);
+      KS_BEGIN_SYNCED()      // ---- what happens with this iterate: stop, restart, or another iteration
+        const double pr = K.c_pr, co = K.c_co, mu = K.mu;
+        const int it = K.it, nreset = K.nreset;
+        K.e_pr = pr; K.e_du = du; K.e_co = co;
+        int act = ACT_GO;
+        if (!(du < 1e300) || !(pr < 1e300) || !(co < 1e300)) { K.status = LANDING_NUMERICAL; act = ACT_STOP; }
+        else if (fmax(du, fmax(pr, co)) <= o.tol) { K.status = LANDING_CONVERGED; act = ACT_STOP; }
+        else if (it == o.max_iter) act = ACT_STOP;
+        else if (du > o.reset_du && nreset >= o.max_resets && o.max_resets > 0) { K.status = LANDING_NUMERICAL; act = ACT_STOP; }   // jammed again: give up
+        else {
+          // crawling: still in the first barrier problem (mu never decreased) restart_period iterations after the last (re)start
+          const bool stalled = o.restart_period > 0 && it - K.last_reset_it >= o.restart_period && mu >= o.mu_init && nreset < o.max_resets && K.ncrawl < ((o.fresh_restart & 4) ? 2 : 1);
+          const bool overreg = o.reset_delta > 0.0 && K.delta_last > o.reset_delta && nreset < o.max_resets;
+          // a LATER barrier problem not solved 2 restart_period iterations after it began has wandered off (the dual infeasibility stays
+          // far below reset_du, nothing else catches it): restarted in place like a crawling iterate
+          const bool lost = (o.fresh_restart & 8) && o.restart_period > 0 && mu < o.mu_init && pr > 1e-3 && nreset < o.max_resets &&
+                            ((it - K.last_mu_it >= 2 * o.restart_period && it - K.last_reset_it >= o.restart_period) || K.wd_count >= 3);     // ... or crawls on although the watchdog has fired three times
+          if ((du > o.reset_du && nreset < o.max_resets) || stalled || overreg || lost) {
+            act = ACT_RESET;
+            K.last_reset_it = it;
+            if (stalled) K.ncrawl++;
+            // jammed iterate (multipliers blown up): keep x, re-initialise slacks, multipliers, barrier parameter and
+            // filter -- the role IPOPT's restoration phase plays on this problem class
+            K.nreset = nreset + 1;
+            // the restart in place did not help (second restart) or the iterate is jammed: back to the caller's initial guess with
+            // another step rule (landing_nlp.h: the members that fail from it with clip_k = 4 solve with clip_k = 2)
+            K.fresh = (((o.fresh_restart & 2) && nreset + 1 == 2) || ((o.fresh_restart & 1) && nreset + 1 == 1 && !stalled && !lost)) ? 1 : 0;
+            if (K.fresh) { if (K.clip_k_cur > 1) K.clip_k_cur = 2; K.th_max = 0.0; }
+            K.mu = o.mu_init; K.nfilt = 0; K.delta_last = 0.0; K.need_reg_streak = 0; K.wd_count = 0;
+            K.it = it + 1;
+          }
+        }
+        K.action = act;
+      KS_END();
+    }
+    if (K.action == ACT_STOP) break;
+    if (K.action == ACT_RESET) {
+      if (K.fresh) {
         for (int i = lane; i < nx; i += NT) {
           double v = A.x0[(size_t)m * nx + i];
           if (i < 6) v = p[L.o_q_init + i]; else if (i < 12) v = p[L.o_qd_init + i - 6];
           M.x[i] = v;
         }
         __syncthreads();
-        member_eval_g(L, M.x, p, M.g);
+        member_eval_g_rare(L, M.x, p, M.g);
         __syncthreads();
-        if (clip_k_cur > 1) clip_k_cur = 2;
-        th_max = 0.0;
       }
       init_slacks();
-      mu = o.mu_init; nfilt = 0; delta_last = 0.0; need_reg_streak = 0; wd_count = 0;
-      point_pass(mu);
+      point_pass(K.mu);
       continue;
     }
     // ---------------------------------------------------------------- barrier parameter (monotone)
-    double sd = 1.0, sc = 1.0;      // IPOPT's scaling of the optimality error in the barrier-subproblem test (landing_nlp.h)
-    if (o.barrier_smax > 0.0) {
-      sd = fmax(o.barrier_smax, (c_ys + c_zs) / ((double)(ng - 12) + c_nz)) / o.barrier_smax;
-      sc = fmax(o.barrier_smax, c_zs / c_nz) / o.barrier_smax;
+    for (;;) {
+      KS_BEGIN()
+        double sd = 1.0, sc = 1.0;      // IPOPT's scaling of the optimality error in the barrier-subproblem test (landing_nlp.h)
+        if (o.barrier_smax > 0.0) {
+          sd = fmax(o.barrier_smax, (K.c_ys + K.c_zs) / ((double)(ng - 12) + K.c_nz)) / o.barrier_smax;
+          sc = fmax(o.barrier_smax, K.c_zs / K.c_nz) / o.barrier_smax;
+        }
+        const double mu = K.mu;
+        if (fmax(K.e_du / sd, fmax(K.c_pr, K.c_cm / sc)) <= o.kappa_eps * mu && mu > o.tol / 10.0) {
+          K.mu = fmax(o.tol / 10.0, fmin(o.kappa_mu * mu, pow(mu, o.theta_mu)));
+          K.nfilt = 0; K.last_mu_it = K.it; K.wd_count = 0;
+          K.flag = 1;
+        } else {
+          K.flag = 0;
+          K.tau = fmax(o.tau_min, 1.0 - mu);
+        }
+      KS_END();
+      if (!K.flag) break;
+      point_pass(K.mu);                     // complementarity error, Sigma, rho for the new mu
     }
-    while (fmax(du / sd, fmax(pr, c_cm / sc)) <= o.kappa_eps * mu && mu > o.tol / 10.0) {
-      mu = fmax(o.tol / 10.0, fmin(o.kappa_mu * mu, pow(mu, o.theta_mu)));
-      nfilt = 0; last_mu_it = it; wd_count = 0;
-      point_pass(mu);                     // complementarity error, Sigma, rho for the new mu
-    }
-    const double tau = fmax(o.tau_min, 1.0 - mu);
-    PROF_ADD(PH_ERR, tp);
+    PROF_ADD(PH_ERR, K.tp);
 
     condense(A.ctab, A.c_ml, A.c_mid);
-    if (L.run_cost) {   // ... and in the stage right-hand sides gamma_k (w order X, c, f)
-      for (int k = lane; k < N; k += NT) {
-        double gr[36];
-#pragma unroll
-        for (int a = 0; a < 36; ++a) gr[a] = 0.0;
-        (void)run_cost_stage(L, M.x, p, k, gr, gr + 12, gr + 24);
-        double* gm = M.cond + (size_t)k * COND_STRIDE + COND_GAM;
-#pragma unroll
-        for (int a = 0; a < 36; ++a) gm[a] += gr[a];
-      }
-      __syncthreads();
-    }
-    PROF_ADD(PH_SIGRHO, tp);
+    if (L.run_cost) { rc_add_gamma(); __syncthreads(); }   // ... and in the stage right-hand sides gamma_k (w order X, c, f)
+    PROF_ADD(PH_SIGRHO, K.tp);
     // ================================================================ Riccati factorisation with inertia correction
     // IPOPT's inertia-correction schedule (delta_w = 0 first, then max(1e-20, delta_last/3), then x8 / x100),
     // except that an iteration following a regularised one starts from delta_last/3 directly when the
     // unregularised attempt failed twice in a row (saves one full factorisation in nonconvex phases)
     // (o.sticky_delta = 1: when the first trial of the previous iteration failed, start from delta_last itself)
-    double delta = (need_reg_streak >= 2 && delta_last > 0.0) ? fmax(1e-20, delta_last * ((o.sticky_delta && first_failed) ? 1.0 : o.delta_dec)) : 0.0;
-    const bool skipped_zero = delta > 0.0;
-    bool fact_ok = false;
-    for (int attempt = 0; attempt < 60 && !fact_ok; ++attempt) {
-      if (attempt > 0) {
-        if (delta == 0.0) delta = (delta_last == 0.0) ? o.delta_init : fmax(1e-20, delta_last * o.delta_dec);
-        else delta *= (delta_last == 0.0 ? o.delta_inc_first : o.delta_inc);
-        if (delta > 1e40) break;
-      }
-      if (lane == 0) S.prof[PH_NFACT] += 1.0;
-      __syncthreads();
-      const bool ok = riccati_backward(delta);
-      fact_ok = ok;
-      if (attempt == 0) first_failed = skipped_zero && !ok;
+    KS_BEGIN()
+      const double dl = K.delta_last;
+      K.delta = (K.need_reg_streak >= 2 && dl > 0.0) ? fmax(1e-20, dl * ((o.sticky_delta && K.first_failed) ? 1.0 : o.delta_dec)) : 0.0;
+      K.skipped_zero = K.delta > 0.0;
+      K.fact_ok = 0; K.attempt = 0; K.flag = 1;
+      S.prof[PH_NFACT] += 1.0;
+    KS_END();
+    for (;;) {
+      const bool ok = riccati_backward(K.delta);
+      KS_BEGIN()
+        K.fact_ok = ok ? 1 : 0;
+        if (K.attempt == 0) K.first_failed = (K.skipped_zero && !ok) ? 1 : 0;
+        K.attempt++;
+        K.flag = 0;
+        if (!ok && K.attempt < 60) {      // next attempt with a larger regularisation
+          double d = K.delta; const double dl = K.delta_last;
+          if (d == 0.0) d = (dl == 0.0) ? o.delta_init : fmax(1e-20, dl * o.delta_dec);
+          else d *= (dl == 0.0 ? o.delta_inc_first : o.delta_inc);
+          if (!(d > 1e40)) { K.delta = d; K.flag = 1; S.prof[PH_NFACT] += 1.0; }
+        }
+      KS_END();
+      if (!K.flag) break;
     }
-    if (!fact_ok) { status = LANDING_NUMERICAL; break; }
-    if (delta > 0.0) { delta_last = delta; need_reg_streak++; } else need_reg_streak = 0;
-    if (need_reg_streak > 8) need_reg_streak = 0;      // probe delta = 0 again from time to time
-    PROF_ADD(PH_BACK, tp);
+    if (!K.fact_ok) { KS_BEGIN() K.status = LANDING_NUMERICAL; KS_END(); break; }
+    KS_BEGIN()
+      if (K.delta > 0.0) { K.delta_last = K.delta; K.need_reg_streak++; } else K.need_reg_streak = 0;
+      if (K.need_reg_streak > 8) K.need_reg_streak = 0;      // probe delta = 0 again from time to time
+    KS_END();
+    PROF_ADD(PH_BACK, K.tp);
 
     forward_pass();
     row_products(A.rterm, A.rlen);
 
-    PROF_ADD(PH_FWD, tp);
+    PROF_ADD(PH_FWD, K.tp);
     // ================================================================ dual steps, step bounds, merit data
     // fraction-to-the-boundary as tau / max(-ds/d), tau / max(-dz/z): reciprocals instead of divisions in the row
     // loop, one logarithm per row (log of the product of the two distances)
     // clip_k rule (landing_nlp.h): while the point is far from feasible the step length comes from the clip_k-th largest
     // ratio |ds| / distance; the slacks with a larger one stop at (1 - tau) of their distance (omt > 0 in the passes below)
-    const bool clip_now = clip_k_cur > 1 && pr > o.clip_until;
-    const double omt = clip_now ? 1.0 - tau : -1.0;
-    double top[4] = {0.0, 0.0, 0.0, 0.0};
-    double m_pr = 0.0, m_du = 0.0, th0 = 0.0, bar = 0.0, dphi = 0.0;
-    for (int rb = lane + 12; rb < ng; rb += NT * RB) {
-      double lbv[RB], ubv[RB], gv[RB], sv[RB], dsv[RB], zlv[RB], zuv[RB];
+    {
+      const double mu = K.mu;
+      const bool clip_now = K.clip_k_cur > 1 && K.c_pr > o.clip_until;
+      double top[4] = {0.0, 0.0, 0.0, 0.0};
+      double m_pr = 0.0, m_du = 0.0, th0 = 0.0, bar = 0.0, dphi = 0.0;
+      for (int rb = lane + 12; rb < ng; rb += NT * RB) {
+        double lbv[RB], ubv[RB], gv[RB], sv[RB], dsv[RB], zlv[RB], zuv[RB];
 #pragma unroll
-      for (int j = 0; j < RB; ++j) { const int r = rb + j * NT, rr = r < ng ? r : ng - 1; lbv[j] = S.bnd_lb[bidx(rr)]; ubv[j] = S.bnd_ub[bidx(rr)]; gv[j] = r_g[rr]; sv[j] = r_s[rr]; dsv[j] = r_ds[rr]; zlv[j] = r_zL[rr]; zuv[j] = r_zU[rr]; }
+        for (int j = 0; j < RB; ++j) { const int r = rb + j * NT, rr = r < ng ? r : ng - 1; lbv[j] = S.bnd_lb[bidx(rr)]; ubv[j] = S.bnd_ub[bidx(rr)]; gv[j] = r_g[rr]; sv[j] = r_s[rr]; dsv[j] = r_ds[rr]; zlv[j] = r_zL[rr]; zuv[j] = r_zU[rr]; }
 #pragma unroll
-      for (int j = 0; j < RB; ++j) {
-        if (rb + j * NT >= ng) continue;
-        const double lb = lbv[j], ub = ubv[j], g = gv[j];
-        if (lb == ub) { th0 += fabs(g - lb); continue; }
-        const double s = sv[j], ds = dsv[j];
-        th0 += fabs(g - s);
-        double dprod = 1.0;
-        if (lb > -INF) {
-          const double d = s - lb, rd = fast_rcp(d), zl = zlv[j];
-          const double dz = fma(-zl * rd, ds, mu * rd - zl);
-          m_pr = fmax(m_pr, -ds * rd); top4_push(top, -ds * rd);
-          m_du = fmax(m_du, -dz * fast_rcp(zl));
-          dprod = d; dphi -= mu * ds * rd;
+        for (int j = 0; j < RB; ++j) {
+          if (rb + j * NT >= ng) continue;
+          const double lb = lbv[j], ub = ubv[j], g = gv[j];
+          if (lb == ub) { th0 += fabs(g - lb); continue; }
+          const double s = sv[j], ds = dsv[j];
+          th0 += fabs(g - s);
+          double dprod = 1.0;
+          if (lb > -INF) {
+            const double d = s - lb, rd = fast_rcp(d), zl = zlv[j];
+            const double dz = fma(-zl * rd, ds, mu * rd - zl);
+            m_pr = fmax(m_pr, -ds * rd); top4_push(top, -ds * rd);
+            m_du = fmax(m_du, -dz * fast_rcp(zl));
+            dprod = d; dphi -= mu * ds * rd;
+          }
+          if (ub < INF) {
+            const double d = ub - s, rd = fast_rcp(d), zu = zuv[j];
+            const double dz = fma(zu * rd, ds, mu * rd - zu);
+            m_pr = fmax(m_pr, ds * rd); top4_push(top, ds * rd);
+            m_du = fmax(m_du, -dz * fast_rcp(zu));
+            dprod *= d; dphi += mu * ds * rd;
+          }
+          bar -= log(dprod);
         }
-        if (ub < INF) {
-          const double d = ub - s, rd = fast_rcp(d), zu = zuv[j];
-          const double dz = fma(zu * rd, ds, mu * rd - zu);
-          m_pr = fmax(m_pr, ds * rd); top4_push(top, ds * rd);
-          m_du = fmax(m_du, -dz * fast_rcp(zu));
-          dprod *= d; dphi += mu * ds * rd;
-        }
-        bar -= log(dprod);
       }
+      double f0 = 0.0;
+      if (lane < 12) {
+        const double d = M.x[12 * N + lane] - p[12 * N + lane], qn = p[L.o_QN + lane];
+        f0 = qn * d * d; dphi += 2.0 * qn * d * M.dx[12 * N + lane];
+      }
+      if (L.run_cost) rc_f_dphi(f0, dphi);
+      double v[6] = {m_pr, m_du, th0, bar, dphi, f0}; const int op[6] = {RMAX, RMAX, RSUM, RSUM, RSUM, RSUM};
+      block_reduce<6>(v, op, S.red);
+      if (clip_now) block_top4(top, S.red);         // (uniform: clip_now comes from K)
+      KS_BEGIN_SYNCED()
+        const double tau = K.tau;
+        double a_pr = (v[0] > tau) ? tau / v[0] : 1.0;
+        K.a_du = (v[1] > tau) ? tau / v[1] : 1.0;
+        if (clip_now) {
+          const double rk = top[(K.clip_k_cur > 4 ? 4 : K.clip_k_cur) - 1];
+          a_pr = (rk > tau) ? tau / rk : 1.0;
+        }
+        K.a_pr = a_pr;
+        K.clip_now = clip_now ? 1 : 0; K.omt = clip_now ? 1.0 - tau : -1.0;
+        K.th0 = v[2]; K.dphi = v[4]; K.ph0 = v[5] + mu * v[3];
+        if (K.th_max == 0.0) K.th_max = 1e4 * fmax(1.0, v[2]);
+        // line search state
+        K.alpha = a_pr; K.s_corr = 0.0; K.accepted = 0; K.armijo_step = 0; K.ls_done = a_pr > 1e-10 ? 0 : 1;
+      KS_END();
     }
-    double f0 = 0.0;
-    if (lane < 12) {
-      const double d = M.x[12 * N + lane] - p[12 * N + lane], qn = p[L.o_QN + lane];
-      f0 = qn * d * d; dphi += 2.0 * qn * d * M.dx[12 * N + lane];
-    }
-    if (L.run_cost) for (int k0 = 0; k0 < N; k0 += NT) {
-      const int k = k0 + lane;
-      if (k >= N) continue;
-      double gr[36];
-#pragma unroll
-      for (int a = 0; a < 36; ++a) gr[a] = 0.0;
-      f0 += run_cost_stage(L, M.x, p, k, gr, gr + 12, gr + 24);
-      const double* dX = M.dx + L.x_X(k); const double* dU = M.dx + L.x_U(k);
-#pragma unroll
-      for (int a = 0; a < 12; ++a) dphi += gr[a] * dX[a] + gr[12 + a] * dU[a] + gr[24 + a] * dU[12 + a];
-    }
-    double a_pr, a_du;
-    { double v[6] = {m_pr, m_du, th0, bar, dphi, f0}; const int op[6] = {RMAX, RMAX, RSUM, RSUM, RSUM, RSUM};
-      block_reduce<6>(v, op, S.red); th0 = v[2]; bar = v[3]; dphi = v[4]; f0 = v[5];
-      a_pr = (v[0] > tau) ? tau / v[0] : 1.0; a_du = (v[1] > tau) ? tau / v[1] : 1.0; }
-    if (clip_now) {
-      block_top4(top, S.red);
-      const double rk = top[(clip_k_cur > 4 ? 4 : clip_k_cur) - 1];
-      a_pr = (rk > tau) ? tau / rk : 1.0;
-    }
-    const double ph0 = f0 + mu * bar;
-    if (th_max == 0.0) th_max = 1e4 * fmax(1.0, th0);
-    const double th_min = 1e-4, th_floor = o.theta_floor * o.tol;     // violations below the tolerance count as equal (landing_nlp.h)
-
-    PROF_ADD(PH_DUAL, tp);
+    PROF_ADD(PH_DUAL, K.tp);
     // ================================================================ filter line search
-    double alpha = a_pr, s_corr = 0.0;
-    bool accepted = false, armijo_step = false;
-    while (alpha > 1e-10) {
+    while (!K.ls_done) {
+      const double alpha = K.alpha, omt = K.omt, mu = K.mu;
       if (lane == 0) S.prof[PH_NTRIAL] += 1.0;
       for (int i = lane; i < nx; i += NT) M.xt[i] = M.x[i] + alpha * M.dx[i];
       __syncthreads();
-      member_eval_g(L, M.xt, p, M.gt);
+      if (lane < nst) member_eval_g(L, M.xt, p, M.gt);
       __syncthreads();
       double tht = 0.0, bt = 0.0, ft = 0.0;
       for (int rb = lane + 12; rb < ng; rb += NT * RB) {
@@ -1351,22 +1454,35 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
         }
       }
       if (lane < 12) { const double d = M.xt[12 * N + lane] - p[12 * N + lane]; ft = p[L.o_QN + lane] * d * d; }
-      if (L.run_cost) for (int k0 = 0; k0 < N; k0 += NT) { const int k = k0 + lane; if (k < N) ft += run_cost_stage(L, M.xt, p, k, nullptr, nullptr, nullptr); }
+      if (L.run_cost) ft += rc_f(M.xt);
       { double v[3] = {tht, bt, ft}; const int op[3] = {RSUM, RSUM, RSUM}; block_reduce<3>(v, op, S.red); tht = v[0]; bt = v[1]; ft = v[2]; }
-      const double pht = ft + mu * bt;
-      bool ok_f = (tht <= th_max) && (pht < 1e300) && (pht > -1e300) && (tht < 1e300);
-      for (int e = 0; e < nfilt && ok_f; ++e) if (tht >= fmax(S.filt_th[e], th_floor) && pht >= S.filt_ph[e]) ok_f = false;
-      const bool switching = (dphi < 0.0) && (th0 <= th_min) && (alpha * pow(-dphi, 2.3) > 1.0 * pow(th0, 1.1));
-      if (ok_f) {
-        if (switching) {
-          if (pht <= ph0 + 1e-8 * alpha * dphi) { accepted = true; armijo_step = true; }
-        } else if (tht <= fmax((1.0 - 1e-5) * th0, th_floor) || pht <= ph0 - 1e-8 * th0) {
-          accepted = true;
+      KS_BEGIN_SYNCED()
+        const double th_min = 1e-4, th_floor = o.theta_floor * o.tol;     // violations below the tolerance count as equal (landing_nlp.h)
+        const double th0 = K.th0, ph0 = K.ph0, dphi = K.dphi;
+        const int nfilt = K.nfilt;
+        const double pht = ft + mu * bt;
+        bool ok_f = (tht <= K.th_max) && (pht < 1e300) && (pht > -1e300) && (tht < 1e300);
+        for (int e = 0; e < nfilt && ok_f; ++e) if (tht >= fmax(S.filt_th[e], th_floor) && pht >= S.filt_ph[e]) ok_f = false;
+        const bool switching = (dphi < 0.0) && (th0 <= th_min) && (alpha * pow(-dphi, 2.3) > 1.0 * pow(th0, 1.1));
+        bool accepted = false, done = false;
+        if (ok_f) {
+          if (switching) {
+            if (pht <= ph0 + 1e-8 * alpha * dphi) { accepted = true; K.armijo_step = 1; }
+          } else if (tht <= fmax((1.0 - 1e-5) * th0, th_floor) || pht <= ph0 - 1e-8 * th0) {
+            accepted = true;
+          }
         }
-      }
-      if (force_step && ok_f) { accepted = true; nfilt = 0; break; }      // watchdog (landing_nlp.h): the step to the boundary is taken whatever the filter says
-      if (accepted) break;
-      if (o.slack_corr > 0.0 && alpha == a_pr && tht >= th0) {
+        if (K.force_step && ok_f) { accepted = true; K.nfilt = 0; done = true; }      // watchdog (landing_nlp.h): the step to the boundary is taken whatever the filter says
+        if (accepted) done = true;
+        K.need_corr = 0;
+        if (!done) {
+          if (o.slack_corr > 0.0 && alpha == K.a_pr && tht >= th0) { K.need_corr = 1; K.ft = ft; }
+          else { K.alpha = alpha * 0.5; if (!(K.alpha > 1e-10)) done = true; }
+        }
+        K.accepted = accepted ? 1 : 0;
+        K.ls_done = done ? 1 : 0;
+      KS_END();
+      if (K.need_corr) {
         // slack correction (landing_nlp.h): the rejected first trial point once more with the inequality slacks moved to g(x_trial)
         double tht2 = 0.0, bt2 = 0.0;
         for (int rb = lane + 12; rb < ng; rb += NT * RB) {
@@ -1387,42 +1503,54 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
           }
         }
         { double v[2] = {tht2, bt2}; const int op[2] = {RSUM, RSUM}; block_reduce<2>(v, op, S.red); tht2 = v[0]; bt2 = v[1]; }
-        const double pht2 = ft + mu * bt2;
-        bool ok2 = (tht2 <= th_max) && (pht2 < 1e300) && (pht2 > -1e300);
-        for (int e = 0; e < nfilt && ok2; ++e) if (tht2 >= fmax(S.filt_th[e], th_floor) && pht2 >= S.filt_ph[e]) ok2 = false;
-        if (ok2 && (tht2 <= fmax((1.0 - 1e-5) * th0, th_floor) || pht2 <= ph0 - 1e-8 * th0)) { accepted = true; s_corr = o.slack_corr; break; }
+        KS_BEGIN_SYNCED()
+          const double th_floor = o.theta_floor * o.tol, th0 = K.th0, ph0 = K.ph0;
+          const int nfilt = K.nfilt;
+          const double pht2 = K.ft + mu * bt2;
+          bool ok2 = (tht2 <= K.th_max) && (pht2 < 1e300) && (pht2 > -1e300);
+          for (int e = 0; e < nfilt && ok2; ++e) if (tht2 >= fmax(S.filt_th[e], th_floor) && pht2 >= S.filt_ph[e]) ok2 = false;
+          if (ok2 && (tht2 <= fmax((1.0 - 1e-5) * th0, th_floor) || pht2 <= ph0 - 1e-8 * th0)) { K.accepted = 1; K.s_corr = o.slack_corr; K.ls_done = 1; }
+          else { K.alpha = alpha * 0.5; if (!(K.alpha > 1e-10)) K.ls_done = 1; }
+        KS_END();
       }
-      alpha *= 0.5;
     }
-    force_step = false;
-    if (o.watchdog > 0) {      // successive iterations with step lengths <= 1/16 of the step to the boundary arm the watchdog
-      if (accepted && alpha <= 0.0625 * a_pr) { if (++cutstreak >= o.watchdog) { force_step = true; cutstreak = 0; wd_count++; } }
-      else cutstreak = 0;
-    }
-    if (!accepted) {
-      // no acceptable step: take a short step along the Newton direction and restart the filter
-      nfilt = 0;
-      alpha = fmin(a_pr, o.alpha_fallback);
+    KS_BEGIN()
+      const double a_pr = K.a_pr;
+      K.force_step = 0;
+      if (o.watchdog > 0) {      // successive iterations with step lengths <= 1/16 of the step to the boundary arm the watchdog
+        if (K.accepted && K.alpha <= 0.0625 * a_pr) { if (++K.cutstreak >= o.watchdog) { K.force_step = 1; K.cutstreak = 0; K.wd_count++; } }
+        else K.cutstreak = 0;
+      }
+      K.fallback = 0;
+      if (!K.accepted) {
+        // no acceptable step: take a short step along the Newton direction and restart the filter
+        K.nfilt = 0;
+        K.alpha = fmin(a_pr, o.alpha_fallback);
+        K.fallback = 1;
+      } else if (!K.armijo_step) {
+        int nfilt = K.nfilt;
+        if (nfilt == FILT_CAP) {     // drop the oldest entry (serial, rare)
+          for (int e = 0; e + 1 < FILT_CAP; ++e) { S.filt_th[e] = S.filt_th[e + 1]; S.filt_ph[e] = S.filt_ph[e + 1]; }
+          nfilt = FILT_CAP - 1;
+        }
+        S.filt_th[nfilt] = (1.0 - 1e-5) * K.th0; S.filt_ph[nfilt] = K.ph0 - 1e-8 * K.th0;
+        K.nfilt = nfilt + 1;
+      }
+      if (o.dual_step_cap > 0.0) K.a_du = fmin(K.a_du, o.dual_step_cap * K.alpha);      // the multipliers do not run ahead of a blocked primal step (landing_nlp.h)
+    KS_END();
+    if (K.fallback) {
+      const double alpha = K.alpha;
       for (int i = lane; i < nx; i += NT) M.xt[i] = M.x[i] + alpha * M.dx[i];
       __syncthreads();
-      member_eval_g(L, M.xt, p, M.gt);
-      __syncthreads();
-    } else if (!armijo_step) {
-      __syncthreads();
-      if (nfilt == FILT_CAP) {     // drop the oldest entry (serial, rare)
-        if (lane == 0) for (int e = 0; e + 1 < FILT_CAP; ++e) { S.filt_th[e] = S.filt_th[e + 1]; S.filt_ph[e] = S.filt_ph[e + 1]; }
-        nfilt = FILT_CAP - 1;
-      }
-      if (lane == 0) { S.filt_th[nfilt] = (1.0 - 1e-5) * th0; S.filt_ph[nfilt] = ph0 - 1e-8 * th0; }
-      nfilt++;
+      member_eval_g_rare(L, M.xt, p, M.gt);
       __syncthreads();
     }
-    PROF_ADD(PH_LS, tp);
-    if (o.dual_step_cap > 0.0) a_du = fmin(a_du, o.dual_step_cap * alpha);      // the multipliers do not run ahead of a blocked primal step (landing_nlp.h)
+    PROF_ADD(PH_LS, K.tp);
     // ================================================================ accept the trial point; the same pass produces the
     // primal / complementarity errors, Sigma and rho of the new iterate (what point_pass computes)
     for (int i = lane; i < nx; i += NT) M.x[i] = M.xt[i];
     {
+      const double alpha = K.alpha, a_du = K.a_du, omt = K.omt, mu = K.mu, s_corr = K.s_corr;
       double npr = 0.0, nco = 0.0, ncm = 0.0, nys = 0.0, nzs = 0.0, nnz = 0.0;
       for (int rb = lane; rb < ng; rb += NT * RB) {
         double lbv[RB], ubv[RB], gv[RB], sv[RB], dsv[RB], zlv[RB], zuv[RB], yv[RB], ynv[RB];
@@ -1469,20 +1597,21 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
       }
       double v[6] = {npr, nco, ncm, nys, nzs, nnz}; const int op[6] = {RMAX, RMAX, RMAX, RSUM, RSUM, RSUM};
       block_reduce<6>(v, op, S.red);
-      c_pr = v[0]; c_co = v[1]; c_cm = v[2]; c_ys = v[3]; c_zs = v[4]; c_nz = fmax(v[5], 1.0);
+      KS_BEGIN_SYNCED()
+        K.c_pr = v[0]; K.c_co = v[1]; K.c_cm = v[2]; K.c_ys = v[3]; K.c_zs = v[4]; K.c_nz = fmax(v[5], 1.0);
+        K.it++;
+      KS_END();
     }
-    PROF_ADD(PH_ACCEPT, tp);
+    PROF_ADD(PH_ACCEPT, K.tp);
   }
   __syncthreads();
-  if (A.prof && lane == 0) { S.prof[PH_NITER] = (double)it; for (int i = 0; i < PH_COUNT; ++i) A.prof[(size_t)m * PH_COUNT + i] = S.prof[i]; }
+  if (A.prof && lane == 0) { S.prof[PH_NITER] = (double)K.it; for (int i = 0; i < PH_COUNT; ++i) A.prof[(size_t)m * PH_COUNT + i] = S.prof[i]; }
 
   // -------------------------------------------------------------------- outputs
   // multipliers of the initial-state rows from stationarity of X(:,1): lam = -(grad f + J^T y)
   double fo = 0.0;
   if (lane < 12) { M.y[lane] = -M.gx[lane]; const double d = M.x[12 * N + lane] - p[12 * N + lane]; fo = p[L.o_QN + lane] * d * d; }
-  // (uniform trip count with a lane predicate: a loop whose trip count differs per lane right in front of the block
-  // reduction hung the kernel on gfx950 / ROCm 7.2 even with the branch not taken -- bisected, tools/dev)
-  if (L.run_cost) for (int k0 = 0; k0 < N; k0 += NT) { const int k = k0 + lane; if (k < N) fo += run_cost_stage(L, M.x, p, k, nullptr, nullptr, nullptr); }
+  if (L.run_cost) fo += rc_f(M.x);
   fo = block_reduce1(fo, RSUM, S.red);
   // reference-consistent KKT residual: max_viol(g), ||grad f + J^T lam||_inf, |lam * dist|
   double kp = 0.0, kc = 0.0;
@@ -1499,11 +1628,13 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
   if (A.lam_out) for (int r = lane; r < ng; r += NT) A.lam_out[(size_t)m * ng + r] = M.y[r];
   if (lane == 0) {
     if (A.f_out) A.f_out[m] = fo;
-    if (A.status) A.status[m] = status;
-    if (A.iters) A.iters[m] = it;
-    if (A.kkt) { A.kkt[3 * m] = kp; A.kkt[3 * m + 1] = e_du; A.kkt[3 * m + 2] = kc; }
+    if (A.status) A.status[m] = K.status;
+    if (A.iters) A.iters[m] = K.it;
+    if (A.kkt) { A.kkt[3 * m] = kp; A.kkt[3 * m + 1] = K.e_du; A.kkt[3 * m + 2] = kc; }
   }
-  (void)e_pr; (void)e_co;
+#undef KS_BEGIN
+#undef KS_BEGIN_SYNCED
+#undef KS_END
 }
 
 }  // namespace landing
