@@ -179,7 +179,10 @@ struct IpmState {
 enum { ACT_GO = 0, ACT_STOP = 1, ACT_RESET = 2 };
 
 // LDS of one member
-constexpr int XCH = 448;   // one exchange buffer of the blocked elimination: pivot rows [64][4] + pivot columns [48][4]
+#ifndef LANDING_PIVOT_BLOCK
+#define LANDING_PIVOT_BLOCK 4      // pivot-block size of the fp64 stage elimination (8: built, measured, slower -- pivot_block_step)
+#endif
+constexpr int XCH = 112 * LANDING_PIVOT_BLOCK;   // one exchange buffer of the blocked elimination: pivot rows [64][PB] + pivot columns [48][PB]
 static_assert(2 * XCH >= 24 * YS, "A1 also holds Y (24 x YS)");
 struct Lds {
   double G[48 * GS];
@@ -354,7 +357,104 @@ __device__ __forceinline__ void stage_copy_store(const StageCopy& R) {
 #define ELIM_T0() do { } while (0)
 #define ELIM_T(n) do { } while (0)
 #endif
-template <int NU>
+// One step of the blocked Gauss-Jordan elimination with a PS x PS pivot block (PS = 4 or 8) at rows / columns [OFF, OFF + PS) of the
+// tile array T (wave ct owns column tile ct, accumulator layout: T[rt][r] = element (row 16 rt + lk + 4 r, column 16 ct + lj)).
+// Exchange through LDS (buffer STEP & 1 of S.A1): every lane publishes the PS pivot-row entries of its column, W[c][PS]; the PS
+// lane-columns that hold the pivot columns publish them, C[row][PS]; one barrier; then every lane factors the pivot block
+// D = L diag(d) L^T redundantly from the broadcast copy (no further communication), solves D r = w for its own column and the
+// wave applies the rank-PS update T -= C R with PS / 4 matrix-core instructions per tile; the pivot rows become R itself
+// (forming them as W - (D - I) R would cancel at the scale of W).  The scalar pivots d are those of the unblocked elimination
+// (inertia test unchanged).  PS = 4 is the product setting.  8 x 8 blocks (3 exchange + barrier rounds per stage
+// instead of 6) were built and measured in round 3 and are SLOWER: the redundant per-lane factorisation grows with PS^3 -- about 210
+// fp64 operations per lane and block at 4 issue cycles each against 2 x 40 -- which costs more than the three barrier rounds it
+// saves: backward sweep 0.353 instead of 0.293 ms per iteration with the CU to itself (tools/dev/ab.sh, -DLANDING_PIVOT_BLOCK=8).
+template <int NU, int PS, int OFF, int STEP>
+__device__ __forceinline__ bool pivot_block_step(f64x4 (&T)[3], int ct, int lj, int lk, int c) {
+  static_assert(PS == 4 || PS == 8, "pivot blocks of 4 or 8");
+  static_assert((OFF & 3) == 0 && (OFF >> 4) == ((OFF + PS - 1) >> 4), "a pivot block lies inside one row tile");
+  Lds& S = SH;
+  constexpr int RTB = OFF >> 4, R0 = (OFF & 15) >> 2, NQ = PS / 4;
+  constexpr int WSZ = 64 * PS;
+  static_assert(WSZ + 48 * PS <= XCH, "exchange buffer");
+  double* W = S.A1 + (STEP & 1) * XCH;
+  double* C = W + WSZ;
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) W[c * PS + 4 * q + lk] = T[RTB][R0 + q];
+  if (ct == RTB && lj >= (OFF & 15) && lj < (OFF & 15) + PS) {
+#pragma unroll
+    for (int rt = 0; rt < 3; ++rt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) C[(16 * rt + lk + 4 * r) * PS + (lj - (OFF & 15))] = T[rt][r];
+  }
+  __syncthreads();
+  // pivot block (uniform reads), pivot rows of the own column, pivot-column operands
+  double a[PS][PS];
+#pragma unroll
+  for (int i = 0; i < PS; ++i)
+#pragma unroll
+    for (int j = 0; j <= i; ++j) a[i][j] = C[(OFF + i) * PS + j];
+  double w[PS];
+#pragma unroll
+  for (int i = 0; i < PS; ++i) w[i] = W[c * PS + i];
+  double am[NQ][3];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q)
+#pragma unroll
+    for (int rt = 0; rt < 3; ++rt) { const int row = 16 * rt + lj; const double cv = C[row * PS + 4 * q + lk]; am[q][rt] = (row >= OFF && row < OFF + PS) ? 0.0 : cv; }   // pivot rows: no update
+  auto recip = [](double d) { double i = __builtin_amdgcn_rcp(d); i = fma(i, fma(-d, i, 1.0), i); return fma(i, fma(-d, i, 1.0), i); };
+  // D = L diag(d) L^T: t[i][j] = l[i][j] d[j] = a[i][j] - sum_{k<j} l[i][k] t[j][k]
+  double l[PS][PS], t[PS][PS], inv[PS];
+  unsigned hm = 0u;
+#pragma unroll
+  for (int j = 0; j < PS; ++j) {
+#pragma unroll
+    for (int i = j; i < PS; ++i) {
+      double acc = a[i][j];
+#pragma unroll
+      for (int kk = 0; kk < j; ++kk) acc = fma(-l[i][kk], t[j][kk], acc);
+      t[i][j] = acc;
+    }
+    inv[j] = recip(t[j][j]);
+#pragma unroll
+    for (int i = j + 1; i < PS; ++i) l[i][j] = t[i][j] * inv[j];
+    // all pivots in (2^-1022, ~1e300): one unsigned range test on the high words (negative, zero, subnormal, huge, inf and NaN
+    // pivots all fall outside)
+    const unsigned h = (unsigned)__double2hiint(t[j][j]) - 0x00100000u;
+    hm = h > hm ? h : hm;
+  }
+  const bool ok = hm < (0x7e37e43cu - 0x00100000u);
+  // normalised pivot rows of the own column: D r = w by the two triangular solves (no explicit inverse: a badly conditioned
+  // pivot block costs no more accuracy than the scalar elimination would); lane group lk keeps r[4 q + lk]
+  double y[PS], r[PS];
+#pragma unroll
+  for (int i = 0; i < PS; ++i) {
+    double acc = w[i];
+#pragma unroll
+    for (int kk = 0; kk < i; ++kk) acc = fma(-l[i][kk], y[kk], acc);
+    y[i] = acc;
+  }
+#pragma unroll
+  for (int i = PS - 1; i >= 0; --i) {
+    double acc = y[i] * inv[i];
+#pragma unroll
+    for (int kk = i + 1; kk < PS; ++kk) acc = fma(-l[kk][i], r[kk], acc);
+    r[i] = acc;
+  }
+  double R[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) R[q] = lk == 0 ? r[4 * q] : (lk == 1 ? r[4 * q + 1] : (lk == 2 ? r[4 * q + 2] : r[4 * q + 3]));
+  if (16 * ct + 16 > OFF) {                              // tiles whose columns are all eliminated already stay as they are
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+      for (int rt = 0; rt < 3; ++rt) T[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(am[q][rt], -R[q], T[rt], 0, 0, 0);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) T[RTB][R0 + q] = R[q];  // the pivot rows become the normalised rows, exactly
+  }
+  return ok;                                             // identical in every lane of the workgroup (tested after the update so
+}                                                        // that the operand fetches are not held behind it)
+
+template <int NU, int PB>
 __device__ __noinline__ bool block_eliminate(double* __restrict__ rec, double delta, int k) {
   Lds& S = SH;
   constexpr int NR = NU + 24;                         // rows; column NR is gamma
@@ -426,62 +526,15 @@ __device__ __noinline__ bool block_eliminate(double* __restrict__ rec, double de
   }
   ELIM_T(2);
   StageCopy nxt;
-#pragma unroll
-  for (int b = 0; b < NU / 4; ++b) {
-    const int rtb = (4 * b) >> 4, rb = b & 3;
-    double* W = S.A1 + (b & 1) * XCH;
-    double* C = W + 256;
-    W[c * 4 + lk] = T[rtb][rb];
-    if (ct == rtb && (lj >> 2) == rb) {
-#pragma unroll
-      for (int rt = 0; rt < 3; ++rt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) C[(16 * rt + lk + 4 * r) * 4 + (lj & 3)] = T[rt][r];
-    }
-    __syncthreads();
-    if (b == 0) stage_copy_load(k - 1, nxt);             // every wave is past the prologue: the staging area is free, and
+  bool ok = pivot_block_step<NU, (PB > NU ? NU : PB), 0, 0>(T, ct, lj, lk, c);
+  stage_copy_load(k - 1, nxt);                           // every wave is past the prologue: the staging area is free, and
                                                          // the loads have the remaining block steps to arrive
-    // 4 x 4 pivot block (uniform reads), LDL^T, inverse
-    const double* Dp = C + 16 * b;
-    const double a00 = Dp[0], a10 = Dp[4], a11 = Dp[5], a20 = Dp[8], a21 = Dp[9], a22 = Dp[10], a30 = Dp[12], a31 = Dp[13], a32 = Dp[14], a33 = Dp[15];
-    const double w0 = W[c * 4 + 0], w1 = W[c * 4 + 1], w2 = W[c * 4 + 2], w3 = W[c * 4 + 3];
-    double am[3];
-#pragma unroll
-    for (int rt = 0; rt < 3; ++rt) { const double cv = C[(16 * rt + lj) * 4 + lk]; am[rt] = ((16 * rt + lj) >> 2 == b) ? 0.0 : cv; }   // pivot rows: no update
-    auto recip = [](double d) { double i = __builtin_amdgcn_rcp(d); i = fma(i, fma(-d, i, 1.0), i); return fma(i, fma(-d, i, 1.0), i); };
-    const double d0 = a00, i0 = recip(d0);
-    const double l10 = a10 * i0, l20 = a20 * i0, l30 = a30 * i0;
-    const double d1 = fma(-l10, a10, a11), i1 = recip(d1);
-    const double t21 = fma(-l20, a10, a21), t31 = fma(-l30, a10, a31);
-    const double l21 = t21 * i1, l31 = t31 * i1;
-    const double d2 = fma(-l21, t21, fma(-l20, a20, a22)), i2 = recip(d2);
-    const double t32 = fma(-l31, t21, fma(-l30, a20, a32));
-    const double l32 = t32 * i2;
-    const double d3 = fma(-l32, t32, fma(-l31, t31, fma(-l30, a30, a33))), i3 = recip(d3);
-    // all four pivots in (2^-1022, ~1e300): one unsigned range test on the high words (negative, zero, subnormal,
-    // huge, inf and NaN pivots all fall outside)
-    const unsigned h0 = (unsigned)__double2hiint(d0) - 0x00100000u, h1 = (unsigned)__double2hiint(d1) - 0x00100000u;
-    const unsigned h2 = (unsigned)__double2hiint(d2) - 0x00100000u, h3 = (unsigned)__double2hiint(d3) - 0x00100000u;
-    const unsigned h01 = h0 > h1 ? h0 : h1, h23 = h2 > h3 ? h2 : h3, hm = h01 > h23 ? h01 : h23;
-    const bool ok = hm < (0x7e37e43cu - 0x00100000u);
-    // normalised pivot rows of the own column: D r = w by the two triangular solves (no explicit inverse: a badly
-    // conditioned pivot block costs no more accuracy than the scalar elimination would); lane group lk keeps r[lk]
-    const double y1 = fma(-l10, w0, w1);
-    const double y2 = fma(-l21, y1, fma(-l20, w0, w2));
-    const double y3 = fma(-l32, y2, fma(-l31, y1, fma(-l30, w0, w3)));
-    const double r3 = y3 * i3;
-    const double r2 = fma(-l32, r3, y2 * i2);
-    const double r1 = fma(-l31, r3, fma(-l21, r2, y1 * i1));
-    const double r0 = fma(-l30, r3, fma(-l20, r2, fma(-l10, r1, w0 * i0)));
-    const double R = lk == 0 ? r0 : (lk == 1 ? r1 : (lk == 2 ? r2 : r3));
-    if (16 * ct + 16 > 4 * b) {                          // tiles whose columns are all eliminated already stay as they are
-#pragma unroll
-      for (int rt = 0; rt < 3; ++rt) T[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(am[rt], -R, T[rt], 0, 0, 0);
-      T[rtb][rb] = R;                                    // the pivot rows become the normalised rows, exactly
-    }
-    if (!ok) return false;                               // identical in every lane of the workgroup (tested after the
-                                                         // update so that the operand fetches are not held behind it)
-  }
+  if (!ok) return false;
+  if constexpr (NU > PB) { if (!pivot_block_step<NU, (NU - PB >= PB ? PB : NU - PB), PB, 1>(T, ct, lj, lk, c)) return false; }
+  if constexpr (NU > 2 * PB) { if (!pivot_block_step<NU, (NU - 2 * PB >= PB ? PB : NU - 2 * PB), 2 * PB, 2>(T, ct, lj, lk, c)) return false; }
+  if constexpr (NU > 3 * PB) { if (!pivot_block_step<NU, (NU - 3 * PB >= PB ? PB : NU - 3 * PB), 3 * PB, 3>(T, ct, lj, lk, c)) return false; }
+  if constexpr (NU > 4 * PB) { if (!pivot_block_step<NU, (NU - 4 * PB >= PB ? PB : NU - 4 * PB), 4 * PB, 4>(T, ct, lj, lk, c)) return false; }
+  if constexpr (NU > 5 * PB) { if (!pivot_block_step<NU, (NU - 5 * PB >= PB ? PB : NU - 5 * PB), 5 * PB, 5>(T, ct, lj, lk, c)) return false; }
   ELIM_T(3);
   stage_copy_store(nxt);                                 // before the record stores below (in-order memory counter)
   {   // closed-loop state map for the forward sweep: X+ = A^_sigma sigma + A^_f f + b with f = -(K_f sigma + kappa_f), i.e.
@@ -695,7 +748,7 @@ __device__ __noinline__ bool block_eliminate_f32(double* __restrict__ rec, doubl
 template <int NU>
 __device__ __forceinline__ bool riccati_step(double* rec, double delta, int k) {
   Lds& S = SH;
-  const bool ok = S.fp32 ? block_eliminate_f32<NU>(rec, delta, k) : block_eliminate<NU>(rec, delta, k);
+  const bool ok = S.fp32 ? block_eliminate_f32<NU>(rec, delta, k) : block_eliminate<NU, LANDING_PIVOT_BLOCK>(rec, delta, k);
   if (!ok) { __syncthreads(); return false; }
   __syncthreads();
   return true;
