@@ -179,6 +179,9 @@ struct IpmState {
 enum { ACT_GO = 0, ACT_STOP = 1, ACT_RESET = 2 };
 
 // LDS of one member
+#ifndef LANDING_REC_LDS
+#define LANDING_REC_LDS 0          // 1: stage records leave the CU through an LDS buffer, stored (coalesced) during the NEXT stage's elimination
+#endif
 #ifndef LANDING_PIVOT_BLOCK
 #define LANDING_PIVOT_BLOCK 4      // pivot-block size of the fp64 stage elimination (8: built, measured, slower -- pivot_block_step)
 #endif
@@ -200,6 +203,9 @@ struct Lds {
   // condensed data of the next stage, copied in by the elimination of the current one (global latency hidden behind
   // the block steps) + the scatter codes of the most common stage table, cached once per launch
   double stg[COND_STRIDE + 12];
+#if LANDING_REC_LDS
+  double recbuf[RIC_STRIDE];      // stage record of the elimination that just finished, on its way to HBM (flush_record)
+#endif
   int cab[COND_GAM]; int cat[COND_STRIDE - COND_AH]; int c_tab, c_nT, c_nA;
   // condensation: packed term table of the most frequent stage type (the others are read from L2) and, per stage, the
   // bases of the seven [J | H | Hc] segments + the type id (slot 7)
@@ -336,6 +342,35 @@ __device__ __forceinline__ void stage_copy_store(const StageCopy& R) {
   S.stg[tid] = R.v[0]; S.stg[tid + 256] = R.v[1];
   if (tid < COND_STRIDE - 512) S.stg[tid + 512] = R.v[2];
   if (tid < 12) S.stg[COND_STRIDE + tid] = R.g;
+}
+
+// Where the elimination of a stage leaves its record, and how the record reaches HBM.  Round 2 stored it from the accumulator
+// tiles straight to the member's workspace at the end of block_eliminate (24 flat_store instructions of scattered 8-byte words per
+// thread): a function return waits for every outstanding memory operation of the wave, so the HBM write latency of those stores sat
+// on the serial chain of EVERY stage (the "epilogue" of DESIGN.md 4.2's stage budget, 0.77 us alone, more under load).  Now the
+// record is assembled in LDS and the next stage's elimination copies it out right after its first block step -- coalesced 8-byte
+// stores in the global address space that drain behind the remaining block steps; only the last record of a sweep is exposed.
+// MEASURED (round 3, tools/dev/ab.sh, same box): no gain -- backward sweep 0.2974 vs 0.2933 ms per iteration alone, 0.3616 vs 0.3611
+// under load, same HBM traffic: the stores are acknowledged by L2 long before the return.  Left in as a switch, off.
+#if LANDING_REC_LDS
+#define REC_DST(rec) (SH.recbuf)
+#else
+#define REC_DST(rec) (rec)
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef double __attribute__((address_space(1)))* landing_gptr_w;
+#else
+typedef double* landing_gptr_w;
+#endif
+__device__ __forceinline__ void flush_record(int k) {      // LDS record buffer -> record k of the member (all threads)
+#if LANDING_REC_LDS
+  landing_gptr_w dst = (landing_gptr_w)(SH.M.ric + (size_t)k * RIC_STRIDE);
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int j = 0; j < (RIC_STRIDE + SOLVER_THREADS - 1) / SOLVER_THREADS; ++j) { const int e = tid + j * SOLVER_THREADS; if (e < RIC_STRIDE) dst[e] = SH.recbuf[e]; }
+#else
+  (void)k;
+#endif
 }
 
 // Elimination of the controls of one stage by the whole workgroup on the matrix cores: blocked Gauss-Jordan with
@@ -529,6 +564,8 @@ __device__ __noinline__ bool block_eliminate(double* __restrict__ rec, double de
   bool ok = pivot_block_step<NU, (PB > NU ? NU : PB), 0, 0>(T, ct, lj, lk, c);
   stage_copy_load(k - 1, nxt);                           // every wave is past the prologue: the staging area is free, and
                                                          // the loads have the remaining block steps to arrive
+  if (NU == 24) flush_record(k + 1);                     // the record the previous elimination left in LDS (none before the last stage's)
+  ELIM_T(5);
   if (!ok) return false;
   if constexpr (NU > PB) { if (!pivot_block_step<NU, (NU - PB >= PB ? PB : NU - PB), PB, 1>(T, ct, lj, lk, c)) return false; }
   if constexpr (NU > 2 * PB) { if (!pivot_block_step<NU, (NU - 2 * PB >= PB ? PB : NU - 2 * PB), 2 * PB, 2>(T, ct, lj, lk, c)) return false; }
@@ -537,6 +574,7 @@ __device__ __noinline__ bool block_eliminate(double* __restrict__ rec, double de
   if constexpr (NU > 5 * PB) { if (!pivot_block_step<NU, (NU - 5 * PB >= PB ? PB : NU - 5 * PB), 5 * PB, 5>(T, ct, lj, lk, c)) return false; }
   ELIM_T(3);
   stage_copy_store(nxt);                                 // before the record stores below (in-order memory counter)
+  ELIM_T(6);
   {   // closed-loop state map for the forward sweep: X+ = A^_sigma sigma + A^_f f + b with f = -(K_f sigma + kappa_f), i.e.
       // Mt = A^_sigma - A^_f K_f, mv = b - A^_f kappa_f.  K_f / kappa_f are rows 0..11 of the first row tile, already in
       // B-operand layout (k-step kt = accumulator kt).
@@ -550,8 +588,8 @@ __device__ __noinline__ bool block_eliminate(double* __restrict__ rec, double de
 #pragma unroll
       for (int r = 0; r < 3; ++r) {
         const int i = lk + 4 * r;
-        if (c < NR) rec[RIC_MT + i * 24 + (c - NU)] = S.Ah[i * YS + (c - NU)] - Mq[r];
-        else rec[RIC_MV + i] = S.bv[i] - Mq[r];
+        if (c < NR) REC_DST(rec)[RIC_MT + i * 24 + (c - NU)] = S.Ah[i * YS + (c - NU)] - Mq[r];
+        else REC_DST(rec)[RIC_MV + i] = S.bv[i] - Mq[r];
       }
     }
   }
@@ -565,11 +603,11 @@ __device__ __noinline__ bool block_eliminate(double* __restrict__ rec, double de
         const int rho = 16 * rt + lk + 4 * r;
         const double v = T[rt][r];
         if (rho < NU) {
-          if (c < NR) rec[RIC_K + rho * 24 + sj] = v; else rec[RIC_KAP + rho] = v;
+          if (c < NR) REC_DST(rec)[RIC_K + rho * 24 + sj] = v; else REC_DST(rec)[RIC_KAP + rho] = v;
         } else if (rho < NR) {
           const int i = rho - NU;
-          if (c < NR) { S.P[i * PS + sj] = v; if (i < 12) rec[RIC_PX + i * 24 + sj] = v; }
-          else { S.pv[i] = v; if (i < 12) rec[RIC_PV + i] = v; }
+          if (c < NR) { S.P[i * PS + sj] = v; if (i < 12) REC_DST(rec)[RIC_PX + i * 24 + sj] = v; }
+          else { S.pv[i] = v; if (i < 12) REC_DST(rec)[RIC_PV + i] = v; }
         }
       }
   }
@@ -673,7 +711,7 @@ __device__ __noinline__ bool block_eliminate_f32(double* __restrict__ rec, doubl
         for (int r = 0; r < 4; ++r) C[(16 * rt + 4 * lk + r) * 4 + (lj & 3)] = T[rt][r];
     }
     __syncthreads();
-    if (b == 0) stage_copy_load(k - 1, nxt);
+    if (b == 0) { stage_copy_load(k - 1, nxt); if (NU == 24) flush_record(k + 1); }
     const float* Dp = C + 16 * b;
     const float a00 = Dp[0], a10 = Dp[4], a11 = Dp[5], a20 = Dp[8], a21 = Dp[9], a22 = Dp[10], a30 = Dp[12], a31 = Dp[13], a32 = Dp[14], a33 = Dp[15];
     const float w0 = W[c * 4 + 0], w1 = W[c * 4 + 1], w2 = W[c * 4 + 2], w3 = W[c * 4 + 3];
@@ -718,8 +756,8 @@ __device__ __noinline__ bool block_eliminate_f32(double* __restrict__ rec, doubl
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int i = 4 * lk + r;
-        if (c < NR) rec[RIC_MT + i * 24 + (c - NU)] = S.Ah[i * YS + (c - NU)] - (double)Mq[r];
-        else rec[RIC_MV + i] = S.bv[i] - (double)Mq[r];
+        if (c < NR) REC_DST(rec)[RIC_MT + i * 24 + (c - NU)] = S.Ah[i * YS + (c - NU)] - (double)Mq[r];
+        else REC_DST(rec)[RIC_MV + i] = S.bv[i] - (double)Mq[r];
       }
     }
   }
@@ -732,11 +770,11 @@ __device__ __noinline__ bool block_eliminate_f32(double* __restrict__ rec, doubl
         const int rho = 16 * rt + 4 * lk + r;
         const double v = (double)T[rt][r];
         if (rho < NU) {
-          if (c < NR) rec[RIC_K + rho * 24 + sj] = v; else rec[RIC_KAP + rho] = v;
+          if (c < NR) REC_DST(rec)[RIC_K + rho * 24 + sj] = v; else REC_DST(rec)[RIC_KAP + rho] = v;
         } else if (rho < NR) {
           const int i = rho - NU;
-          if (c < NR) { S.P[i * PS + sj] = v; if (i < 12) rec[RIC_PX + i * 24 + sj] = v; }
-          else { S.pv[i] = v; if (i < 12) rec[RIC_PV + i] = v; }
+          if (c < NR) { S.P[i * PS + sj] = v; if (i < 12) REC_DST(rec)[RIC_PX + i * 24 + sj] = v; }
+          else { S.pv[i] = v; if (i < 12) REC_DST(rec)[RIC_PV + i] = v; }
         }
       }
   }
@@ -897,6 +935,7 @@ __device__ LANDING_INL_BACK bool riccati_backward(double delta) {
     PROF_ADD(PH_B_ELIM, tb_);
   }
   if (ok) {
+    flush_record(0);      // (the riccati_step of stage 0 ended with a barrier: the record is complete in LDS)
     // ---- stage 0: X_0 fixed, feet c_0 free: P_cc dc0 = -(p_c + P_cx dX0), same elimination on a 12x12 block
     if (lane < 12) {
       const int i = lane;
@@ -1235,7 +1274,10 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
   // Row passes: every thread owns the rows lane + NT j.  They are processed RB at a time with ALL loads of a batch issued
   // up-front and unconditionally (every array is fully allocated; out-of-range rows re-read the last row and are masked):
   // one memory round trip per batch instead of two or three dependent ones per row behind the bound-type branches.
-  constexpr int RB = 4;
+#ifndef LANDING_RB
+#define LANDING_RB 4
+#endif
+  constexpr int RB = LANDING_RB;
   // primal / complementarity errors, Sigma and rho of the CURRENT point for barrier parameter mu_ (one pass over the
   // rows; the accept pass below produces the same quantities for the next iterate, so this runs only at the start,
   // after a multiplier reset and when mu changes).  Leaves c_pr, c_co, c_cm, |y|_1, |z|_1 and the number of bound multipliers in K.
