@@ -46,7 +46,18 @@ FP64_PEAK_TFLOPS = 78.6      # MI355X fp64 vector = matrix peak (AMD datasheet; 
 HBM_PEAK_GBPS = 8000.0       # MI355X_MICROARCH.md
 SURVEY_8D_KKT_FLOPS = 4.4e6  # block-tridiagonal factor+solve per interior-point iteration at N=40
 SURVEY_8D_CALLBACK_FLOPS = 0.14e6
-PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_ipm.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_ipm.json")      # default of --pmc-file
+
+
+def kernel_source_sha():
+    """sha256 over the sources that make up landing_ipm_kernel: stamped into profiles/*_pmc_ipm.json by tools/pmc_summary.py and
+    compared here, so that a PMC traffic figure measured on another build of the kernel is never attached to this run"""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "landing-controller_amd", "csrc")
+    for f in ("solver_kernels.hip", "eval_kernels.hip", "srbm_stage.hpp", "layout.hpp", "Makefile"):
+        h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()
 
 
 def flop_model(N):
@@ -96,6 +107,7 @@ def main():
     ap.add_argument("--max-iter", type=int, default=300)
     ap.add_argument("--distinct-batches", type=int, default=8, help="timed steps cycle through this many different synthetic batches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pmc-file", default=PMC_FILE, help="rocprofv3 --pmc summary (tools/profile_round.sh) the HBM traffic of the roofline object is read from; ignored unless it was measured on this very kernel source")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo only with --dry (CPU launcher test)")
     ap.add_argument("--no-extras", action="store_true", help="skip the PCIe-inclusive and two-batches-in-flight legs (profiling runs: only the headline launches)")
     ap.add_argument("--dry", action="store_true", help="no GPU work: exercise the multi-rank path with a stub solve")
@@ -280,15 +292,21 @@ def main():
             dPq, dXq = dev_batches[i % n_batches]
             Lq.solve_device(B, dPq.data_ptr(), dXq.data_ptr(), opts, xq.data_ptr(), 0, 0, stq.data_ptr(), itq.data_ptr(), 0, sq.cuda_stream)
         pstep(0); pstep(1); sync()
-        conv_p = torch.zeros(1, device=dev, dtype=torch.float64)
+        # converged-member counts are accumulated ON the lane's stream (one accumulator per lane), stream-ordered between the solve that
+        # wrote the status buffer and the next solve of that lane that overwrites it (the read used to sit on another stream)
+        conv_lane = [torch.zeros(1, device=dev, dtype=torch.float64) for _ in range(2)]
+        def pcount(i):
+            with torch.cuda.stream(lanes[i % 2][1]):
+                conv_lane[i % 2] += (lanes[i % 2][3] == 0).sum()
         tq = time.perf_counter()
         for i in range(a.steps):
-            if i >= 2:       # the lane's previous step must be read before its buffers are reused
-                lanes[i % 2][1].synchronize(); conv_p += (lanes[i % 2][3] == 0).sum()
+            if i >= 2:
+                pcount(i)
             pstep(i)
         for i in range(min(2, a.steps)):
-            lanes[i][1].synchronize(); conv_p += (lanes[i][3] == 0).sum()
+            pcount(i)
         sync()
+        conv_p = conv_lane[0] + conv_lane[1]
         tq = time.perf_counter() - tq
         tqe = torch.tensor([tq], device=dev, dtype=torch.float64)
         if multi:
@@ -346,12 +364,16 @@ def measure_details(a, lib, np, torch, dev, mk, B, N, P, X0, dP, dX0, st, it, kk
     ach8d = flops_8d / (k_ms * 1e-3) / 1e12
     achim = flops_impl / (k_ms * 1e-3) / 1e12
     traffic = None
-    pmc_note = "no PMC file"
-    if os.path.exists(PMC_FILE):
+    pmc_note = "no PMC file (%s)" % os.path.relpath(a.pmc_file, ROOT)
+    if os.path.exists(a.pmc_file):
         try:
-            pm = json.load(open(PMC_FILE))
-            traffic = pm.get("traffic_bytes_per_launch")
-            pmc_note = pm.get("note", "")
+            pm = json.load(open(a.pmc_file))
+            if pm.get("kernel_source_sha256") == kernel_source_sha():
+                traffic = pm.get("traffic_bytes_per_launch")
+                pmc_note = "%s (kernel sources %s..., command: %s); %s" % (os.path.relpath(a.pmc_file, ROOT), pm["kernel_source_sha256"][:12], pm.get("what", "?"), pm.get("note", ""))
+            else:
+                pmc_note = "%s was measured on other kernel sources (sha %s..., this build %s...): traffic not reported" % (
+                    os.path.relpath(a.pmc_file, ROOT), str(pm.get("kernel_source_sha256"))[:12], kernel_source_sha()[:12])
         except Exception as e:   # noqa: BLE001
             pmc_note = "unreadable PMC file: %s" % e
     roofline = {"kernel": "landing_ipm_kernel", "bound": "mfma", "achieved": ach8d, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",

@@ -98,7 +98,8 @@ typedef struct {
                             90 -> 79, mean batch time 101.9 -> 99.5 ms; 90: the same.)                                              */
   int dispatch_order;    /* 1 (default): members with a large initial body height are dispatched first (they tend to need the most
                             iterations and would otherwise set the batch time from the second wave); 0: batch order.  Results do
-                            not depend on it (every member is solved independently)                                          */
+                            not depend on it (every member is solved independently).  Applied only to batches that do not fit the GPU at
+                            once (more than 512 members) and up to 16 384 members (the ranking kernel compares all pairs)               */
   double delta_init;     /* first trial regularisation when none was needed before (IPOPT first_hessian_perturbation, 1e-4) */
   double delta_inc_first;/* growth factor while no regularised iteration happened yet (IPOPT 100; default 10)            */
   double delta_inc;      /* growth factor afterwards (IPOPT 8; default 4: finer steps over-regularise less, tools/strag.py) */
@@ -159,8 +160,9 @@ typedef struct {
                             1/8..1/16): CPU port, the stragglers 137 / 203 / 166 / 157 / 145 -> 57 / 58 / 57 / 93 / 68 iterations; numbers at
                             scale in DESIGN.md 4.2.  Applied at every trial point instead it doubles the mean iteration count       */
   int watchdog;          /* after this many successive iterations whose accepted step length is at most 1/16 of the step to the boundary, the
-                            next iteration takes the step to the boundary whatever the filter says (only theta <= theta_max is required)
-                            and restarts the filter (default 3; 0 = off; cf. IPOPT's watchdog_shortened_iter_trigger).  The members that
+                            next iteration takes the first trial point (the step to the boundary) without the sufficient-decrease / switching
+                            tests -- it must still pass theta <= theta_max and must not be dominated by a filter entry -- and restarts the
+                            filter (default 3; 0 = off; cf. IPOPT's watchdog_shortened_iter_trigger).  The members that
                             were left as the slowest of the 65 536-member sweep sat for 50..60 iterations with steps of 1e-3 until the
                             line search failed outright and its fall-back step (alpha_fallback) freed them: CPU port, 161 / 158 / 138 /
                             136 / 133 / 129 / 115 -> 84 / 69 / 81 / 94 / 83 / 67 / 68 iterations, the bench batch unchanged               */

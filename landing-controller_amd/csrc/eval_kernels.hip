@@ -149,8 +149,11 @@ struct TileStore {
 // placeholders of the two edge stages.  Reported by landing_kernel_name_sweep() for profilers.
 // (register budget: the Jacobian stream fits 256 VGPRs -> 2 waves/SIMD; the Hessian stream needs the AGPR overflow
 // of the default bound, capping it costs 750 B of scratch per lane and doubles its time)
+#ifndef LANDING_SWEEP_H_WAVES
+#define LANDING_SWEEP_H_WAVES(FAM) ((FAM) == 1 ? 1 : 2)
+#endif
 template <int FAM>
-__global__ void __launch_bounds__(64, FAM == 1 ? 1 : 2) landing_sweep_kernel(Layout L, int B, EvalArgs A) {
+__global__ void __launch_bounds__(64, LANDING_SWEEP_H_WAVES(FAM)) landing_sweep_kernel(Layout L, int B, EvalArgs A) {
   const int m = blockIdx.x;
   if (m >= B) return;
   const int N = L.N, ln = threadIdx.x;

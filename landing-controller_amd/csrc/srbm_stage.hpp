@@ -69,10 +69,12 @@ __host__ __device__ __forceinline__ M3 rz1_mul(double c, double s, const M3& q) 
 }
 
 // Rotation set: R = rz(psi)' ry(theta)' rx(phi)' and derivatives w.r.t. e=(phi,theta,psi).
-// d1[a]; d2 stored as [0]=pp [1]=pt [2]=ps [3]=tt [4]=ts [5]=ss  (p=phi,t=theta,s=psi)
+// d1[a] are stored; the six second derivatives D2(a, b) (p=phi, t=theta, s=psi: pp pt ps tt ts ss) are formed where they are
+// consumed (each is used once, in the (e_b, e_a) block of the Hessian): holding them cost 108 VGPRs over the whole Hessian stream,
+// which then needed the AGPR overflow of a 1-wave-per-SIMD launch bound (round 2: 444 VGPRs + 188 AGPRs).
 template <bool SECOND>
 struct RotSet {
-  M3 R, d1[3], d2[6];
+  M3 R, d1[3];
   double sp, cp, st, ct, ss, cs;
   __host__ __device__ __forceinline__ void eval(double phi, double th, double psi) {
     sincos(phi, &sp, &cp);
@@ -86,23 +88,19 @@ struct RotSet {
     d1[0] = rz_mul(cs, ss, Qp);
     d1[1] = rz_mul(cs, ss, Qt);
     d1[2] = rz1_mul(cs, ss, Q);
-    if (SECOND) {
-      M3 Qpp = {{{0.0, -st * sp, -st * cp}, {0.0, -cp, sp}, {0.0, -ct * sp, -ct * cp}}};
-      M3 Qpt = {{{0.0, ct * cp, -ct * sp}, {0.0, 0.0, 0.0}, {0.0, -st * cp, st * sp}}};
-      M3 Qtt = {{{-ct, -st * sp, -st * cp}, {0.0, 0.0, 0.0}, {st, -ct * sp, -ct * cp}}};
-      d2[0] = rz_mul(cs, ss, Qpp);
-      d2[1] = rz_mul(cs, ss, Qpt);
-      d2[2] = rz1_mul(cs, ss, Qp);
-      d2[3] = rz_mul(cs, ss, Qtt);
-      d2[4] = rz1_mul(cs, ss, Qt);
-      // Rz'' Q = -(rows 0,1 of R), row 2 = 0
-#pragma unroll
-      for (int j = 0; j < 3; ++j) { d2[5].a[0][j] = -R.a[0][j]; d2[5].a[1][j] = -R.a[1][j]; d2[5].a[2][j] = 0.0; }
-    }
   }
-  __host__ __device__ __forceinline__ const M3& D2(int a, int b) const {  // symmetric index
+  __host__ __device__ __forceinline__ M3 D2(int a, int b) const {  // symmetric index
     const int lo = a < b ? a : b, hi = a < b ? b : a;
-    return d2[lo == 0 ? hi : (lo == 1 ? 2 + hi : 5)];
+    if (lo == 0 && hi == 0) { const M3 Qpp = {{{0.0, -st * sp, -st * cp}, {0.0, -cp, sp}, {0.0, -ct * sp, -ct * cp}}}; return rz_mul(cs, ss, Qpp); }
+    if (lo == 0 && hi == 1) { const M3 Qpt = {{{0.0, ct * cp, -ct * sp}, {0.0, 0.0, 0.0}, {0.0, -st * cp, st * sp}}}; return rz_mul(cs, ss, Qpt); }
+    if (lo == 0 && hi == 2) { const M3 Qp = {{{0.0, st * cp, -st * sp}, {0.0, -sp, -cp}, {0.0, ct * cp, -ct * sp}}}; return rz1_mul(cs, ss, Qp); }
+    if (lo == 1 && hi == 1) { const M3 Qtt = {{{-ct, -st * sp, -st * cp}, {0.0, 0.0, 0.0}, {st, -ct * sp, -ct * cp}}}; return rz_mul(cs, ss, Qtt); }
+    if (lo == 1 && hi == 2) { const M3 Qt = {{{-st, ct * sp, ct * cp}, {0.0, 0.0, 0.0}, {-ct, -st * sp, -st * cp}}}; return rz1_mul(cs, ss, Qt); }
+    // Rz'' Q = -(rows 0,1 of R), row 2 = 0
+    M3 r;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { r.a[0][j] = -R.a[0][j]; r.a[1][j] = -R.a[1][j]; r.a[2][j] = 0.0; }
+    return r;
   }
 };
 
@@ -383,7 +381,7 @@ __host__ __device__ __forceinline__ void stage_hess(const StageVars& z, const St
     hx.put(hp.x); hx.put(hp.y); hx.put(hp.z);
 #pragma unroll
     for (int b = 0; b <= a; ++b) {
-      const M3& Rab = RS.D2(a, b);
+      const M3 Rab = RS.D2(a, b);
       double s = -dt * dot(mul(Rab, mub), tau);
       if (a == 0 && b == 0) s += -dt * dot(le, dde_pp);
       if (a == 1 && b == 0) s += -dt * dot(le, dde_pt);

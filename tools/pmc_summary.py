@@ -30,6 +30,9 @@ def stats(d, sub):
 if __name__ == "__main__":
     tag, d_stats, d_f, d_w, d_sq = sys.argv[1:6]
     out = {"what": "rocprofv3 --kernel-trace --stats and separate --pmc passes of `python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-extras` (per-launch averages of landing_ipm_kernel)"}
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    out["kernel_source_sha256"] = bench.kernel_source_sha()      # bench.py refuses the traffic figure on any other build of the kernel
     out["kernel_stats"] = stats(d_stats, "landing_ipm_kernel")
     per = {}
     for name, d in (("FETCH_SIZE", d_f), ("WRITE_SIZE", d_w)):
