@@ -62,7 +62,12 @@ typedef struct {
    * Supported by landing_solve_batch and by every output of landing_eval_batch except d_hess: the running cost adds
    * diagonal entries that casadi_s4 does not hold, so its Hessian is returned by landing_eval_hess_rc_batch in the
    * extended pattern of landing_pattern_hess_rc. */
-  int run_cost;
+  int run_cost;       /* 0 off; 1 on, weights / force reference = the constants below, p as in the IPOPT variant (np = 13N+94);
+                         2 on, with the N=41 script's OWN parameter vector (generate_quadruped_SRBM_CCC.m:49-71, Opti's order of the active
+                         parameters): p = [Xref 12(N+1) | Uref 24N | dt N | q_min .. qd_term_max 60 | QX 12 | QN 12 | Qc 3 | Qf 3 | mu l_leg_max
+                         f_max mass | Ib 3 | Ib_inv 3], np = 37N+112 (landing_np_ccc); QX, Qc, Qf and the force part of Uref are read from p,
+                         grad_gamma_p has entries for them, the fields QX / Qc / Qf / f_ref below are ignored.  The solver function of that
+                         script has 25 arguments: landing_pack_args25 / landing_solve_args25                                              */
   double QX[12], Qc[3], Qf[3];
   double f_ref[3];    /* Uref(13:24,k) = f_ref per leg in the callers (test_loadCasadi_ws.m:68-72) */
   double p_hip[12];   /* CCC :76-79 */
@@ -273,6 +278,22 @@ int landing_solve_21(landing_ctx* ctx, int B, const double* Xref, const double* 
                      const double* mu, const double* l_leg_max, const double* f_max, const double* mass,
                      const double* Ib, const double* Ib_inv, const landing_solver_opts* opts,
                      double* x_star, double* f_star, int* status, int* iters, double* kkt);
+
+/* ---- the 25-argument solver function of the reference's N=41 script ----------------------------------------------------------
+ *   [x*, f*] = f_quad_SRBM(Xref, Uref, dt, q_min, q_max, qd_min, qd_max, q_init, qd_init, c_init, q_term_min, q_term_max, qd_term_min,
+ *                          qd_term_max, QX, QN, Qc, Qf, x0, mu, l_leg_max, f_max, mass, Ib, Ib_inv)
+ * (generate_solver/generate_quadruped_SRBM_CCC.m; call site analysis/eval_SRBM_CCC.m:72-78).  c_init is an inactive parameter of that
+ * script (its constraint is commented out, :98) and may be NULL.  Contexts created with landing_form.run_cost = 2 and that script's
+ * kin-box (.05, .05, .27).  Arrays as in landing_args21: column-major with a trailing batch axis; lam_g may be NULL. */
+typedef struct {
+  const double *Xref, *Uref, *dt, *q_min, *q_max, *qd_min, *qd_max, *q_init, *qd_init, *c_init, *q_term_min, *q_term_max,
+      *qd_term_min, *qd_term_max, *QX, *QN, *Qc, *Qf, *x0, *mu, *l_leg_max, *f_max, *mass, *Ib, *Ib_inv;
+} landing_args25;
+long long landing_np_ccc(int N);                       /* 37N + 112 */
+long long landing_ctx_np(const landing_ctx* ctx);      /* length of p for this context's formulation */
+int landing_pack_args25(int N, int B, const landing_args25* a, double* p);
+int landing_solve_args25(landing_ctx* ctx, int B, const landing_args25* a, const landing_solver_opts* opts,
+                         double* x_star, double* f_star, double* lam_g, int* status, int* iters, double* kkt);
 
 /* ---- the same solver function sharded over several devices from the C boundary ---------------------------------
  * Replaces the serial loop of generate_data/generate_training_data_automated.m:38,130-136: the B drop states are cut into

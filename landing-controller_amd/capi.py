@@ -35,6 +35,15 @@ ARGS21 = ["Xref", "Uref", "dt", "q_min", "q_max", "qd_min", "qd_max", "q_init", 
           "qd_term_min", "qd_term_max", "QN", "x0", "mu", "l_leg_max", "f_max", "mass", "Ib", "Ib_inv"]
 
 
+ARGS25 = ["Xref", "Uref", "dt", "q_min", "q_max", "qd_min", "qd_max", "q_init", "qd_init", "c_init", "q_term_min", "q_term_max",
+          "qd_term_min", "qd_term_max", "QX", "QN", "Qc", "Qf", "x0", "mu", "l_leg_max", "f_max", "mass", "Ib", "Ib_inv"]
+
+
+class Args25(C.Structure):
+    """landing_args25: the 25 solver-function arguments of the reference's N=41 script (analysis/eval_SRBM_CCC.m:72-78), host pointers"""
+    _fields_ = [(n, _dp) for n in ARGS25]
+
+
 class Args21(C.Structure):
     """landing_args21: the reference's 21 solver-function arguments (generate_landingCtrller_IPOPT.m:323-327), host pointers"""
     _fields_ = [(n, _dp) for n in ARGS21]
@@ -47,7 +56,8 @@ EXPORTS = ["landing_last_error", "landing_form_default", "landing_solver_opts_de
            "landing_sweep_bytes_per_member", "landing_set_profile_buffer", "landing_debug_workspace",
            "landing_pack_args21", "landing_solve_args21", "landing_solve_21",
            "landing_multi_create", "landing_multi_destroy", "landing_multi_count", "landing_shard_range", "landing_multi_solve_args21",
-           "landing_solve_21_multi", "landing_multi_release_cached", "landing_riccati_gains_batch", "landing_mpc_shift", "landing_solver_opts_warm", "landing_rbd_set_model", "landing_fb_dynamics_batch",
+           "landing_solve_21_multi", "landing_multi_release_cached",
+           "landing_np_ccc", "landing_ctx_np", "landing_pack_args25", "landing_solve_args25", "landing_riccati_gains_batch", "landing_mpc_shift", "landing_solver_opts_warm", "landing_rbd_set_model", "landing_fb_dynamics_batch",
            "landing_kinodyn_rows_batch", "landing_leg_ik_batch", "landing_nnz_hess_rc", "landing_pattern_hess_rc",
            "landing_eval_hess_rc_batch", "landing_eval_hess_rc_batch_host"]
 
@@ -63,9 +73,11 @@ def load(path=None):
     lib = C.CDLL(path)
     lib.landing_last_error.restype = C.c_char_p
     lib.landing_kernel_name_sweep.restype = C.c_char_p
-    for n in ("landing_nx", "landing_ng", "landing_np", "landing_nnz_jac", "landing_nnz_hess", "landing_sweep_bytes_per_member"):
+    for n in ("landing_nx", "landing_ng", "landing_np", "landing_np_ccc", "landing_nnz_jac", "landing_nnz_hess", "landing_sweep_bytes_per_member"):
         getattr(lib, n).restype = C.c_longlong
         getattr(lib, n).argtypes = [C.c_int]
+    lib.landing_ctx_np.restype = C.c_longlong
+    lib.landing_ctx_np.argtypes = [C.c_void_p]
     lib.landing_pattern_jac.argtypes = [C.c_int, _llp, _llp]
     lib.landing_pattern_hess.argtypes = [C.c_int, _llp, _llp]
     lib.landing_create.restype = C.c_void_p
@@ -89,8 +101,32 @@ def load(path=None):
         lib.landing_riccati_gains_batch.argtypes = [vp, C.c_int, C.c_int, vp, vp, _dp, C.c_double, _dp, _dp, _dp, C.c_double, C.c_int, vp, vp, vp, vp, vp]
     if hasattr(lib, "landing_mpc_shift"):
         lib.landing_mpc_shift.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp]
+    if hasattr(lib, "landing_solve_args25"):
+        lib.landing_pack_args25.argtypes = [C.c_int, C.c_int, C.POINTER(Args25), _dp]
+        lib.landing_solve_args25.argtypes = [vp, C.c_int, C.POINTER(Args25), C.POINTER(SolverOpts), _dp, _dp, _dp, _ip, _ip, _dp]
+    if hasattr(lib, "landing_multi_create"):
+        lib.landing_multi_create.restype = C.c_void_p
+        lib.landing_multi_create.argtypes = [C.c_int, C.POINTER(C.c_int), C.c_int, C.POINTER(LandingForm)]
+        lib.landing_multi_destroy.argtypes = [vp]
+        lib.landing_multi_solve_args21.argtypes = [vp, C.c_int, C.POINTER(Args21), C.POINTER(SolverOpts), _dp, _dp, _dp, _ip, _ip, _dp]
+        lib.landing_solve_21_multi.argtypes = [C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int] + [_dp] * 21 + [C.POINTER(SolverOpts), _dp, _dp, _dp, _ip, _ip, _dp]
     lib.landing_solve_21.argtypes = [vp, C.c_int] + [_dp] * 21 + [C.POINTER(SolverOpts), _dp, _dp, _ip, _ip, _dp]
     return lib
+
+
+def matlab_args25(N, args):
+    """the same for the 25 arguments of the N=41 script (c_init may be missing: inactive)"""
+    keep, a = [], Args25()
+    B = np.asarray(args["x0"]).shape[-1] if np.asarray(args["x0"]).ndim > 1 else 1
+    for n in ARGS25:
+        v = args.get(n)
+        if v is None:
+            setattr(a, n, None)
+            continue
+        buf = np.ascontiguousarray(np.asarray(v, float).reshape((-1, B), order="F").T)
+        keep.append(buf)
+        setattr(a, n, buf.ctypes.data_as(_dp))
+    return a, keep, B
 
 
 def matlab_args21(N, args):
@@ -117,7 +153,7 @@ def _p(a):
 class LandingLib:
     """Thin object wrapper: one context per (N, device)."""
 
-    def __init__(self, N, device=0, kin_box=None, lib_path=None, run_cost=None):
+    def __init__(self, N, device=0, kin_box=None, lib_path=None, run_cost=None, ccc_params=False):
         self.lib = load(lib_path)
         self.N = N
         form = LandingForm()
@@ -131,11 +167,13 @@ class LandingLib:
                 form.QX[i] = run_cost["QX"][i]
             for i in range(3):
                 form.Qc[i] = run_cost["Qc"][i]; form.Qf[i] = run_cost["Qf"][i]; form.f_ref[i] = run_cost.get("f_ref", (0, 0, 0))[i]
+        if ccc_params:                # the N=41 script's own parameter vector: weights and force reference are entries of p (run_cost = 2)
+            form.run_cost = 2
         self.form = form
         self.ctx = self.lib.landing_create(N, device, C.byref(form))
         if not self.ctx:
             raise RuntimeError("landing_create failed: " + self.lib.landing_last_error().decode())
-        self.nx, self.ng, self.np_ = self.lib.landing_nx(N), self.lib.landing_ng(N), self.lib.landing_np(N)
+        self.nx, self.ng, self.np_ = self.lib.landing_nx(N), self.lib.landing_ng(N), self.lib.landing_ctx_np(self.ctx)
         self.nnz_jac, self.nnz_hess = self.lib.landing_nnz_jac(N), self.lib.landing_nnz_hess(N)
 
     def close(self):
@@ -238,6 +276,15 @@ class LandingLib:
             rc = self.lib.landing_solve_args21(self.ctx, B, C.byref(a), C.byref(opts), *outs)
         self._check(rc, "landing_solve_args21")
         return dict(x=x, f=f, status=status, iters=iters, kkt=kkt)
+
+    def solve_args25(self, args, opts=None):
+        """the N=41 script's solver-function call, batched: args = dict of its 25 MATLAB-shaped arrays (batch = last axis)"""
+        a, keep, B = matlab_args25(self.N, args)
+        opts = opts or self.default_opts()
+        x = np.zeros((B, self.nx)); f = np.zeros(B); lam = np.zeros((B, self.ng)); status = np.zeros(B, np.int32); iters = np.zeros(B, np.int32); kkt = np.zeros((B, 3))
+        rc = self.lib.landing_solve_args25(self.ctx, B, C.byref(a), C.byref(opts), _p(x), _p(f), _p(lam), status.ctypes.data_as(_ip), iters.ctypes.data_as(_ip), _p(kkt))
+        self._check(rc, "landing_solve_args25")
+        return dict(x=x, f=f, lam_g=lam, status=status, iters=iters, kkt=kkt)
 
     def solve_args21_multi(self, args, devices, opts=None, one_call=False, want_lam=True):
         """the reference's solver-function call sharded over a device list from the C boundary (landing_multi_solve_args21 /

@@ -90,6 +90,8 @@ void landing_solver_opts_warm(landing_solver_opts* o) {
 long long landing_nx(int N) { return 36LL * N + 12; }
 long long landing_ng(int N) { return 104LL * N + 12; }
 long long landing_np(int N) { return 13LL * N + 94; }
+long long landing_np_ccc(int N) { return 37LL * N + 112; }      /* parameter vector of the N=41 script (landing_form.run_cost = 2) */
+long long landing_ctx_np(const landing_ctx* ctx) { return ctx ? ctx->L.np : 0; }
 long long landing_nnz_jac(int N) { return 36 + 385LL * (N - 1) + 313; }
 long long landing_nnz_hess(int N) { return 177LL * N + 12LL * (N - 1) + 12; }
 long long landing_sweep_bytes_per_member(int N) {
@@ -243,7 +245,8 @@ landing_ctx* landing_create(int N, int device, const landing_form* form) {
   if (form) {
     for (int i = 0; i < 3; ++i) c->L.kin_box[i] = form->kin_box[i];
     c->L.kin_z_off = form->kin_z_off; c->L.comp_eps = form->comp_eps; c->L.slip_eps = form->slip_eps;
-    c->L.run_cost = form->run_cost ? 1 : 0;
+    c->L.run_cost = form->run_cost == 2 ? 2 : (form->run_cost ? 1 : 0);
+    if (c->L.run_cost == 2) landing::layout_ccc_params(c->L);      // the N=41 script's own parameter vector: Uref, QX, Qc, Qf are entries of p
     for (int i = 0; i < 12; ++i) { c->L.QX[i] = form->QX[i]; c->L.p_hip[i] = form->p_hip[i]; }
     for (int i = 0; i < 3; ++i) { c->L.Qc[i] = form->Qc[i]; c->L.Qf[i] = form->Qf[i]; c->L.f_ref[i] = form->f_ref[i]; }
   }

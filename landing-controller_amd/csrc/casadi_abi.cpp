@@ -11,6 +11,12 @@
 #ifndef LANDING_N
 #define LANDING_N 20
 #endif
+// LANDING_CCC = 1: the NLP of the reference's N=41 script (generate_quadruped_SRBM_CCC.m; its generated library would be
+// codegen_casadi/nlp_quad_SRBM.so, :340-341 -- absent from the reference tree): kin-box .05/.05/.27 (:169-171), running cost (:81-89), the
+// script's own parameter vector (np = 37N+112: Uref, QX, Qc, Qf are parameters), Hessian in the extended pattern landing_pattern_hess_rc
+#ifndef LANDING_CCC
+#define LANDING_CCC 0
+#endif
 
 namespace {
 const int N = LANDING_N;
@@ -26,14 +32,14 @@ void dense(std::vector<long long>& s, long long n) {
 }
 void build_sparsity() {
   if (!s_x.empty()) return;
-  const long long nx = landing_nx(N), ng = landing_ng(N), np = landing_np(N);
+  const long long nx = landing_nx(N), ng = landing_ng(N), np = LANDING_CCC ? landing_np_ccc(N) : landing_np(N);
   dense(s_x, nx); dense(s_p, np); dense(s_one, 1); dense(s_g, ng);
   std::vector<long long> ci(nx + 1), r(landing_nnz_jac(N));
   landing_pattern_jac(N, ci.data(), r.data());
   s_jac.clear(); s_jac.push_back(ng); s_jac.push_back(nx);
   s_jac.insert(s_jac.end(), ci.begin(), ci.end()); s_jac.insert(s_jac.end(), r.begin(), r.end());
-  r.resize(landing_nnz_hess(N));
-  landing_pattern_hess(N, ci.data(), r.data());
+  r.resize(LANDING_CCC ? landing_nnz_hess_rc(N) : landing_nnz_hess(N));
+  if (LANDING_CCC) landing_pattern_hess_rc(N, ci.data(), r.data()); else landing_pattern_hess(N, ci.data(), r.data());
   s_hess.clear(); s_hess.push_back(nx); s_hess.push_back(nx);
   s_hess.insert(s_hess.end(), ci.begin(), ci.end()); s_hess.insert(s_hess.end(), r.begin(), r.end());
   zeros.assign((size_t)std::max(std::max(nx, ng), np), 0.0);
@@ -43,7 +49,10 @@ landing_ctx* ctx() {
   build_sparsity();
   if (!g_ctx) {
     const char* d = std::getenv("LANDING_DEVICE");
-    g_ctx = landing_create(N, d ? std::atoi(d) : 0, nullptr);
+    landing_form form;
+    landing_form_default(&form);
+    if (LANDING_CCC) { form.kin_box[0] = 0.05; form.kin_box[1] = 0.05; form.kin_box[2] = 0.27; form.run_cost = 2; }
+    g_ctx = landing_create(N, d ? std::atoi(d) : 0, &form);
   }
   return g_ctx;
 }
@@ -61,6 +70,11 @@ int eval(const double* x, const double* p, const double* lam_f, const double* la
   landing_ctx* c = ctx();
   if (!c) return 1;
   if (!f && !g && !grad_f && !jac && !hess && !ggx && !ggp) return 0;
+  if (LANDING_CCC && hess) {      // the running cost adds diagonals casadi_s4 does not hold: extended pattern, own entry point
+    if (landing_eval_hess_rc_batch_host(c, 1, x, p, lam_f, lam_g, hess) != 0) return 1;
+    hess = nullptr;
+    if (!f && !g && !grad_f && !jac && !ggx && !ggp) return 0;
+  }
   return landing_eval_batch_host(c, 1, x, p, lam_f, lam_g, f, g, grad_f, jac, hess, ggx, ggp) == 0 ? 0 : 1;
 }
 void addref() { std::lock_guard<std::mutex> lk(g_mu); ++g_refs; }

@@ -24,6 +24,13 @@ __host__ __device__ __forceinline__ int dyn_row_of_state(int i) {  // state inde
   return i < 6 ? i : (i < 9 ? i + 3 : i - 3);
 }
 
+// Weights and force reference of the running cost: constants of the context (run_cost 1) or entries of p (run_cost 2: the N=41
+// script's own parameter vector, layout_ccc_params).  Value accessors (no pointers into the by-value Layout kernel argument).
+__device__ __forceinline__ double rc_QX(const Layout& L, const double* p, int i) { return L.run_cost == 2 ? p[L.o_QX + i] : L.QX[i]; }
+__device__ __forceinline__ double rc_Qc(const Layout& L, const double* p, int a) { return L.run_cost == 2 ? p[L.o_Qc + a] : L.Qc[a]; }
+__device__ __forceinline__ double rc_Qf(const Layout& L, const double* p, int a) { return L.run_cost == 2 ? p[L.o_Qf + a] : L.Qf[a]; }
+__device__ __forceinline__ double rc_fref(const Layout& L, const double* p, int k, int l, int a) { return L.run_cost == 2 ? p[L.o_Uref + 24 * k + 12 + 3 * l + a] : L.f_ref[a]; }
+
 // Running cost of stage k (generate_quadruped_SRBM_CCC.m:81-89) and, optionally, its gradient added to gX / gc / gf.
 __device__ __forceinline__ double run_cost_stage(const Layout& L, const double* x, const double* p, int k, double* gX, double* gc, double* gf) {
   const double* X = x + L.x_X(k); const double* U = x + L.x_U(k);
@@ -31,19 +38,20 @@ __device__ __forceinline__ double run_cost_stage(const Layout& L, const double* 
   double s = 0.0;
 #pragma unroll
   for (int i = 0; i < 12; ++i) {
-    const double e = X[i] - p[12 * k + i];
-    s += L.QX[i] * e * e;
-    if (gX) gX[i] += 2.0 * dt * L.QX[i] * e;
+    const double e = X[i] - p[12 * k + i], q = rc_QX(L, p, i);
+    s += q * e * e;
+    if (gX) gX[i] += 2.0 * dt * q * e;
   }
 #pragma unroll
   for (int l = 0; l < 4; ++l)
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-      const double r = X[a] + L.p_hip[3 * l + a] - U[3 * l + a], u = U[12 + 3 * l + a] - L.f_ref[a];
-      s += L.Qc[a] * r * r + L.Qf[a] * u * u;
-      if (gX) gX[a] += 2.0 * dt * L.Qc[a] * r;
-      if (gc) gc[3 * l + a] -= 2.0 * dt * L.Qc[a] * r;
-      if (gf) gf[3 * l + a] += 2.0 * dt * L.Qf[a] * u;
+      const double r = X[a] + L.p_hip[3 * l + a] - U[3 * l + a], u = U[12 + 3 * l + a] - rc_fref(L, p, k, l, a);
+      const double qc = rc_Qc(L, p, a), qf = rc_Qf(L, p, a);
+      s += qc * r * r + qf * u * u;
+      if (gX) gX[a] += 2.0 * dt * qc * r;
+      if (gc) gc[3 * l + a] -= 2.0 * dt * qc * r;
+      if (gf) gf[3 * l + a] += 2.0 * dt * qf * u;
     }
   return dt * s;
 }
@@ -209,7 +217,8 @@ __global__ void __launch_bounds__(64) landing_sweep_misc_kernel(Layout L, int B,
   const double* p = A.p + (size_t)m * L.np;
   const double* lam_g = A.lam_g ? A.lam_g + (size_t)m * L.ng : nullptr;
   const double lam_f = A.lam_f ? A.lam_f[m] : 1.0;
-  __shared__ double red[64][9];
+  constexpr int NGP = 9 + 18;      // shared-parameter sums over the stages: dt-free part (9, stage_gradp) + QX (12), Qc (3), Qf (3) of the running cost
+  __shared__ double red[64][NGP];
 
   // ---- objective: terminal cost only (gen:83-87) ----
   if (threadIdx.x == 0 && (A.f || A.grad_f || A.ggx || A.ggp)) {
@@ -260,8 +269,8 @@ __global__ void __launch_bounds__(64) landing_sweep_misc_kernel(Layout L, int B,
       gx[12 * N + i] = v;
     }
   }
-  double gp_acc[9];
-  for (int i = 0; i < 9; ++i) gp_acc[i] = 0.0;
+  double gp_acc[NGP];
+  for (int i = 0; i < NGP; ++i) gp_acc[i] = 0.0;
 
   // ---- stages (only when a per-stage output is left for this kernel) ----
   const bool stage_work = (A.g && !A.g_staged) || (A.ggx && lam_g) || (A.ggp && lam_g);
@@ -304,11 +313,21 @@ __global__ void __launch_bounds__(64) landing_sweep_misc_kernel(Layout L, int B,
     }
   }
   if (L.run_cost && A.ggp && lam_g) {   // d/d dt_k of the running cost (the stage loop above wrote the constraint part)
-    for (int k = threadIdx.x; k < N; k += blockDim.x)
-      A.ggp[(size_t)m * L.np + L.o_dt + k] += lam_f * run_cost_stage(L, x, p, k, nullptr, nullptr, nullptr) / p[L.o_dt + k];
+    for (int k = threadIdx.x; k < N; k += blockDim.x) {
+      const double dt = p[L.o_dt + k];
+      A.ggp[(size_t)m * L.np + L.o_dt + k] += lam_f * run_cost_stage(L, x, p, k, nullptr, nullptr, nullptr) / dt;
+      if (L.run_cost == 2) {      // the weights are parameters: d/dQX_i = lam_f sum_k dt_k e_i^2, d/dQc_a, d/dQf_a likewise (per-lane partial sums)
+        const double* X = x + L.x_X(k); const double* U = x + L.x_U(k);
+        for (int i = 0; i < 12; ++i) { const double e = X[i] - p[12 * k + i]; gp_acc[9 + i] += lam_f * dt * e * e; }
+        for (int l = 0; l < 4; ++l) for (int a = 0; a < 3; ++a) {
+          const double r = X[a] + L.p_hip[3 * l + a] - U[3 * l + a], u = U[12 + 3 * l + a] - rc_fref(L, p, k, l, a);
+          gp_acc[21 + a] += lam_f * dt * r * r; gp_acc[24 + a] += lam_f * dt * u * u;
+        }
+      }
+    }
   }
   if (A.ggp && lam_g) {   // uniform branch: reduce the shared-parameter sums over stages
-    for (int i = 0; i < 9; ++i) red[threadIdx.x][i] = gp_acc[i];
+    for (int i = 0; i < NGP; ++i) red[threadIdx.x][i] = gp_acc[i];
     __syncthreads();
     double* gp = A.ggp + (size_t)m * L.np;
     for (int i = threadIdx.x; i < L.np; i += blockDim.x) {
@@ -318,10 +337,17 @@ __global__ void __launch_bounds__(64) landing_sweep_misc_kernel(Layout L, int B,
       if (i == L.o_mu) slot = 1; else if (i == L.o_mass) slot = 2;
       else if (i >= L.o_Ib && i < L.o_Ib + 3) slot = 3 + (i - L.o_Ib);
       else if (i >= L.o_Ib_inv && i < L.o_Ib_inv + 3) slot = 6 + (i - L.o_Ib_inv);
+      else if (L.run_cost == 2 && i >= L.o_QX && i < L.o_QX + 12) slot = 9 + (i - L.o_QX);
+      else if (L.run_cost == 2 && i >= L.o_Qc && i < L.o_Qc + 3) slot = 21 + (i - L.o_Qc);
+      else if (L.run_cost == 2 && i >= L.o_Qf && i < L.o_Qf + 3) slot = 24 + (i - L.o_Qf);
       if (slot >= 0) { for (int t = 0; t < (int)blockDim.x; ++t) v += red[t][slot]; }
       else if (i >= 12 * N && i < 12 * N + 12) { const int t = i - 12 * N; v = -2.0 * lam_f * p[L.o_QN + t] * (x[12 * N + t] - p[12 * N + t]); }
       else if (i >= L.o_QN && i < L.o_QN + 12) { const int t = i - L.o_QN; const double d = x[12 * N + t] - p[12 * N + t]; v = lam_f * d * d; }
-      else if (L.run_cost && i < 12 * N) { const int k = i / 12; v = -2.0 * lam_f * p[L.o_dt + k] * L.QX[i - 12 * k] * (x[i] - p[i]); }   // Xref_k
+      else if (L.run_cost && i < 12 * N) { const int k = i / 12; v = -2.0 * lam_f * p[L.o_dt + k] * rc_QX(L, p, i - 12 * k) * (x[i] - p[i]); }   // Xref_k
+      else if (L.run_cost == 2 && i >= L.o_Uref && i < L.o_Uref + 24 * N) {      // Uref: the foot part is inactive in the cost (0), the force part is f_ref
+        const int k = (i - L.o_Uref) / 24, j = (i - L.o_Uref) % 24;
+        if (j >= 12) v = -2.0 * lam_f * p[L.o_dt + k] * rc_Qf(L, p, (j - 12) % 3) * (x[L.x_U(k) + j] - p[i]);
+      }
       gp[i] = v;
     }
   }
@@ -340,8 +366,9 @@ __global__ void __launch_bounds__(256) landing_hess_rc_kernel(Layout L, int B, i
   const int kind = e.y & 15;
   if (kind && L.run_cost) {
     const int a = (e.y >> 4) & 15, k = e.y >> 8;
-    const double w = kind == 1 ? L.QX[a] + (a < 3 ? 4.0 * L.Qc[a] : 0.0) : kind == 2 ? -L.Qc[a] : kind == 3 ? L.Qc[a] : L.Qf[a];
-    v += 2.0 * (lam_f ? lam_f[m] : 1.0) * p[(size_t)m * L.np + L.o_dt + k] * w;
+    const double* pm = p + (size_t)m * L.np;
+    const double w = kind == 1 ? rc_QX(L, pm, a) + (a < 3 ? 4.0 * rc_Qc(L, pm, a) : 0.0) : kind == 2 ? -rc_Qc(L, pm, a) : kind == 3 ? rc_Qc(L, pm, a) : rc_Qf(L, pm, a);
+    v += 2.0 * (lam_f ? lam_f[m] : 1.0) * pm[L.o_dt + k] * w;
   }
   out[(size_t)m * nnz_rc + j] = v;
 }

@@ -1095,10 +1095,10 @@ __device__ __noinline__ void rc_init_hc() {      // constant Hessian entries of 
     const int k = e / RUNC, j = e % RUNC, a = j % 3;
     const double dt2 = 2.0 * p[L.o_dt + k];
     double v;
-    if (j < 12) v = dt2 * (L.QX[j] + (j < 3 ? 4.0 * L.Qc[j] : 0.0));
-    else if (j < 24) v = -dt2 * L.Qc[a];
-    else if (j < 36) v = dt2 * L.Qc[a];
-    else v = dt2 * L.Qf[a];
+    if (j < 12) v = dt2 * (rc_QX(L, p, j) + (j < 3 ? 4.0 * rc_Qc(L, p, j) : 0.0));
+    else if (j < 24) v = -dt2 * rc_Qc(L, p, a);
+    else if (j < 36) v = dt2 * rc_Qc(L, p, a);
+    else v = dt2 * rc_Qf(L, p, a);
     SH.M.Hc[e] = v;
   }
 }

@@ -177,6 +177,34 @@ def pack_params(N, Xref, dt, q_min, q_max, qd_min, qd_max, q_init, qd_init, q_te
     return p
 
 
+def n_p_ccc(N):
+    """length of the N=41 script's own parameter vector (generate_quadruped_SRBM_CCC.m:49-71): 37N + 112"""
+    return 37 * N + 112
+
+
+def pack_params_ccc(N, Xref, Uref, dt, q_min, q_max, qd_min, qd_max, q_init, qd_init, q_term_min, q_term_max,
+                    qd_term_min, qd_term_max, QX, QN, Qc, Qf, mu, l_leg_max, f_max, mass, Ib, Ib_inv):
+    """p of the N=41 script in Opti's order of its active parameters (c_init is declared but unused: dropped)"""
+    parts = [np.asarray(Xref, float).reshape(12, N + 1).flatten(order="F"), np.asarray(Uref, float).reshape(24, N).flatten(order="F"),
+             np.asarray(dt, float).reshape(N)]
+    for v in (q_min, q_max, qd_min, qd_max, q_init, qd_init, q_term_min, q_term_max, qd_term_min, qd_term_max):
+        parts.append(np.asarray(v, float).reshape(6))
+    parts += [np.asarray(QX, float).reshape(12), np.asarray(QN, float).reshape(12), np.asarray(Qc, float).reshape(3), np.asarray(Qf, float).reshape(3)]
+    parts.append(np.array([mu, l_leg_max, f_max, mass], float))
+    parts += [np.asarray(Ib, float).reshape(3), np.asarray(Ib_inv, float).reshape(3)]
+    p = np.concatenate(parts)
+    assert p.size == n_p_ccc(N)
+    return p
+
+
+def ccc_from_ipopt_params(N, p, Uref, QX, Qc, Qf):
+    """the N=41 script's parameter vector holding the same problem as an IPOPT-variant p (np = 13N+94) plus Uref and the running-cost weights"""
+    o = param_offsets(N)
+    six = [p[o[n]:o[n] + 6] for n in ("q_min", "q_max", "qd_min", "qd_max", "q_init", "qd_init", "q_term_min", "q_term_max", "qd_term_min", "qd_term_max")]
+    return pack_params_ccc(N, p[:12 * (N + 1)].reshape(12, N + 1, order="F"), Uref, p[o["dt"]:o["dt"] + N], *six, QX, p[o["QN"]:o["QN"] + 12], Qc, Qf,
+                           p[o["mu"]], p[o["l_leg_max"]], p[o["f_max"]], p[o["mass"]], p[o["Ib"]:o["Ib"] + 3], p[o["Ib_inv"]:o["Ib_inv"] + 3])
+
+
 def make_member(N, T, q_init, qd_init, consts=None, dt_grid="uniform"):
     """(p, x0, Xref, Uref) for one drop state with the callers' fixed arguments; x0=[Xref(:);Uref(:)]."""
     c = consts or CallerConstants()

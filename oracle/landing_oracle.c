@@ -30,26 +30,54 @@ void lo_form_default(lo_form* F, int N) {
     for (i = 0; i < 3; i++) { F->Qc[i] = 0.0; F->Qf[i] = 0.0; F->f_ref[i] = 0.0; } }
 }
 
+static double rcQX(const lo_form* F, const lo_poff* o, const double* p, int i);
+static double rcQc(const lo_form* F, const lo_poff* o, const double* p, int a);
+static double rcQf(const lo_form* F, const lo_poff* o, const double* p, int a);
+static double rcfref(const lo_form* F, const lo_poff* o, const double* p, int k, int l, int a);
 double lo_run_cost_stage(const lo_form* F, const double* x, const double* p, int k, double* gX, double* gc, double* gf) {
   /* CCC :81-89 */
   const int N = F->N; lo_poff o; int i, l, a; double s = 0.0, dt;
   const double* X = x + 12 * k; const double* U = x + 12 * (N + 1) + 24 * k;
-  lo_param_offsets(N, &o);
+  lo_param_offsets_form(F, &o);
   dt = p[o.dt + k];
   for (i = 0; i < 12; i++) {
-    const double e = X[i] - p[o.Xref + 12 * k + i];
-    s += F->QX[i] * e * e;
-    if (gX) gX[i] += 2.0 * dt * F->QX[i] * e;
+    const double e = X[i] - p[o.Xref + 12 * k + i], q = rcQX(F, &o, p, i);
+    s += q * e * e;
+    if (gX) gX[i] += 2.0 * dt * q * e;
   }
   for (l = 0; l < 4; l++) for (a = 0; a < 3; a++) {
-    const double r = X[a] + F->p_hip[3 * l + a] - U[3 * l + a], u = U[12 + 3 * l + a] - F->f_ref[a];
-    s += F->Qc[a] * r * r + F->Qf[a] * u * u;
-    if (gX) gX[a] += 2.0 * dt * F->Qc[a] * r;
-    if (gc) gc[3 * l + a] -= 2.0 * dt * F->Qc[a] * r;
-    if (gf) gf[3 * l + a] += 2.0 * dt * F->Qf[a] * u;
+    const double r = X[a] + F->p_hip[3 * l + a] - U[3 * l + a], u = U[12 + 3 * l + a] - rcfref(F, &o, p, k, l, a);
+    const double qc = rcQc(F, &o, p, a), qf = rcQf(F, &o, p, a);
+    s += qc * r * r + qf * u * u;
+    if (gX) gX[a] += 2.0 * dt * qc * r;
+    if (gc) gc[3 * l + a] -= 2.0 * dt * qc * r;
+    if (gf) gf[3 * l + a] += 2.0 * dt * qf * u;
   }
   return dt * s;
 }
+
+/* form-aware offsets: run_cost == 2 is the N=41 script's own parameter vector (generate_quadruped_SRBM_CCC.m:49-71, Opti's order of
+ * the active parameters; c_init is declared but unused and dropped): Xref | Uref | dt | bounds 60 | QX | QN | Qc | Qf | mu .. | Ib | Ib_inv */
+void lo_param_offsets_form(const lo_form* F, lo_poff* o) {
+  const int N = F->N; int b;
+  lo_param_offsets(N, o);
+  o->Uref = o->QX = o->Qc = o->Qf = -1;
+  if (F->run_cost != 2) return;
+  o->Uref = 12 * (N + 1);
+  o->dt = o->Uref + 24 * N;
+  b = o->dt + N;
+  o->q_min = b; o->q_max = b + 6; o->qd_min = b + 12; o->qd_max = b + 18;
+  o->q_init = b + 24; o->qd_init = b + 30;
+  o->q_term_min = b + 36; o->q_term_max = b + 42; o->qd_term_min = b + 48; o->qd_term_max = b + 54;
+  o->QX = b + 60; o->QN = b + 72; o->Qc = b + 84; o->Qf = b + 87;
+  o->mu = b + 90; o->l_leg_max = b + 91; o->f_max = b + 92; o->mass = b + 93; o->Ib = b + 94; o->Ib_inv = b + 97; o->np = b + 100;
+}
+lo_int lo_np_form(const lo_form* F) { lo_poff o; lo_param_offsets_form(F, &o); return o.np; }
+/* weights / force reference of the running cost: constants of the form (run_cost 1) or entries of p (run_cost 2) */
+static double rcQX(const lo_form* F, const lo_poff* o, const double* p, int i) { return F->run_cost == 2 ? p[o->QX + i] : F->QX[i]; }
+static double rcQc(const lo_form* F, const lo_poff* o, const double* p, int a) { return F->run_cost == 2 ? p[o->Qc + a] : F->Qc[a]; }
+static double rcQf(const lo_form* F, const lo_poff* o, const double* p, int a) { return F->run_cost == 2 ? p[o->Qf + a] : F->Qf[a]; }
+static double rcfref(const lo_form* F, const lo_poff* o, const double* p, int k, int l, int a) { return F->run_cost == 2 ? p[o->Uref + 24 * k + 12 + 3 * l + a] : F->f_ref[a]; }
 
 void lo_param_offsets(int N, lo_poff* o) { /* gen:51-75, order of opti.parameter() calls */
   int b;
@@ -61,6 +89,7 @@ void lo_param_offsets(int N, lo_poff* o) { /* gen:51-75, order of opti.parameter
   o->q_term_min = b + 36; o->q_term_max = b + 42; o->qd_term_min = b + 48; o->qd_term_max = b + 54;
   o->QN = b + 60; o->mu = b + 72; o->l_leg_max = b + 73; o->f_max = b + 74; o->mass = b + 75;
   o->Ib = b + 76; o->Ib_inv = b + 79; o->np = b + 82;
+  o->Uref = o->QX = o->Qc = o->Qf = -1;
 }
 
 /* hipSrbmLocation, ref: utilities_general/dynamics-utilities/get_robot_params.m:90-91 */
@@ -207,7 +236,7 @@ void lo_stage_eval(const lo_form* F, int k, const double* x, const double* p,
   const double *pp, *e, *w, *v;
   const int need2 = (H != NULL && lam != NULL);
 
-  lo_param_offsets(N, &o);
+  lo_param_offsets_form(F, &o);
   dt = p[o.dt + k]; mu = p[o.mu]; mass = p[o.mass];
   for (i = 0; i < 3; i++) { Ib[i] = p[o.Ib + i]; Ibi[i] = p[o.Ib_inv + i]; }
   for (i = 0; i < LO_NLOC; i++) {
@@ -554,7 +583,7 @@ static lo_int ccs_find(const lo_int* colind, const lo_int* row, lo_int r, lo_int
 void lo_nlp_grad_f(const lo_form* F, const double* x, const double* p, double* f, double* grad) {
   /* gen:83-87: cost = X_err'*diag(QN)*X_err, X_err = X(:,end)-Xref(:,end) */
   const int N = F->N; lo_poff o; int i; double s = 0;
-  lo_param_offsets(N, &o);
+  lo_param_offsets_form(F, &o);
   if (grad) memset(grad, 0, sizeof(double) * (size_t)lo_nx(N));
   for (i = 0; i < 12; i++) {
     double d = x[12 * N + i] - p[o.Xref + 12 * N + i];
@@ -617,7 +646,7 @@ void lo_nlp_hess_l(const lo_form* F, const double* x, const double* p, double la
   double H[LO_NLOC * LO_NLOC]; unsigned char S[LO_NLOC * LO_NLOC];
   double lam[LO_NROW]; lo_poff o;
   int k, i, j;
-  lo_param_offsets(N, &o);
+  lo_param_offsets_form(F, &o);
   lo_pattern_hess(N, colind, row);
   memset(hess, 0, sizeof(double) * (size_t)nnz);
   for (k = 0; k < N; k++) {
@@ -667,7 +696,7 @@ void lo_nlp_hess_l_rc(const lo_form* F, const double* x, const double* p, double
   double* h4 = (double*)malloc(sizeof(double) * (size_t)nnz);
   lo_poff o; lo_int c, i; int k, l, a;
   (void)x;
-  lo_param_offsets(N, &o);
+  lo_param_offsets_form(F, &o);
   lo_pattern_hess_rc(N, ci, ro); lo_pattern_hess(N, c4, r4);
   lo_nlp_hess_l(F, x, p, lam_f, lam_g, h4);
   memset(hess, 0, sizeof(double) * (size_t)nrc);
@@ -675,11 +704,11 @@ void lo_nlp_hess_l_rc(const lo_form* F, const double* x, const double* p, double
   if (F->run_cost) for (k = 0; k < N; k++) {      /* second derivatives of dt_k (|X - Xref|^2_QX + sum_legs |pos + p_hip - c|^2_Qc + |f - f_ref|^2_Qf) */
     const double d2 = 2.0 * lam_f * p[o.dt + k];
     const lo_int X = 12 * (lo_int)k, U = 12 * (lo_int)(N + 1) + 24 * (lo_int)k;
-    for (a = 0; a < 12; a++) hess[ccs_find(ci, ro, X + a, X + a)] += d2 * (F->QX[a] + (a < 3 ? 4.0 * F->Qc[a] : 0.0));
+    for (a = 0; a < 12; a++) hess[ccs_find(ci, ro, X + a, X + a)] += d2 * (rcQX(F, &o, p, a) + (a < 3 ? 4.0 * rcQc(F, &o, p, a) : 0.0));
     for (l = 0; l < 4; l++) for (a = 0; a < 3; a++) {
-      hess[ccs_find(ci, ro, X + a, U + 3 * l + a)] += -d2 * F->Qc[a];
-      hess[ccs_find(ci, ro, U + 3 * l + a, U + 3 * l + a)] += d2 * F->Qc[a];
-      hess[ccs_find(ci, ro, U + 12 + 3 * l + a, U + 12 + 3 * l + a)] += d2 * F->Qf[a];
+      hess[ccs_find(ci, ro, X + a, U + 3 * l + a)] += -d2 * rcQc(F, &o, p, a);
+      hess[ccs_find(ci, ro, U + 3 * l + a, U + 3 * l + a)] += d2 * rcQc(F, &o, p, a);
+      hess[ccs_find(ci, ro, U + 12 + 3 * l + a, U + 12 + 3 * l + a)] += d2 * rcQf(F, &o, p, a);
     }
   }
   free(ci); free(ro); free(c4); free(r4); free(h4);
@@ -691,7 +720,7 @@ void lo_nlp_grad(const lo_form* F, const double* x, const double* p, double lam_
   lo_poff o; int k, i, j, l; lo_int r;
   double J[LO_NROW * LO_NLOC];
   double* gg = (double*)malloc(sizeof(double) * (size_t)ng);
-  lo_param_offsets(N, &o);
+  lo_param_offsets_form(F, &o);
   boundary_g(F, x, gg);
   if (grad_x) {
     double ff;
@@ -744,10 +773,20 @@ void lo_nlp_grad(const lo_form* F, const double* x, const double* p, double lam_
     grad_p[o.Xref + 12 * N + i] += -2 * lam_f * p[o.QN + i] * d;
     grad_p[o.QN + i] += lam_f * d * d;
   }
-  if (grad_p && F->run_cost) for (k = 0; k < N; k++) {   /* running cost: d/dXref_k and d/ddt_k (the weights are constants of the form) */
+  if (grad_p && F->run_cost) for (k = 0; k < N; k++) {   /* running cost: d/dXref_k and d/ddt_k; with run_cost 2 also d/dUref_k (force part), d/dQX, d/dQc, d/dQf */
     const double dt = p[o.dt + k];
-    for (i = 0; i < 12; i++) grad_p[o.Xref + 12 * k + i] += -2.0 * lam_f * dt * F->QX[i] * (x[12 * k + i] - p[o.Xref + 12 * k + i]);
+    const double* X = x + 12 * k; const double* U = x + 12 * (N + 1) + 24 * k;
+    for (i = 0; i < 12; i++) grad_p[o.Xref + 12 * k + i] += -2.0 * lam_f * dt * rcQX(F, &o, p, i) * (X[i] - p[o.Xref + 12 * k + i]);
     grad_p[o.dt + k] += lam_f * lo_run_cost_stage(F, x, p, k, NULL, NULL, NULL) / dt;
+    if (F->run_cost == 2) {
+      int l2, a2;
+      for (i = 0; i < 12; i++) { const double e = X[i] - p[o.Xref + 12 * k + i]; grad_p[o.QX + i] += lam_f * dt * e * e; }
+      for (l2 = 0; l2 < 4; l2++) for (a2 = 0; a2 < 3; a2++) {
+        const double r = X[a2] + F->p_hip[3 * l2 + a2] - U[3 * l2 + a2], u = U[12 + 3 * l2 + a2] - p[o.Uref + 24 * k + 12 + 3 * l2 + a2];
+        grad_p[o.Qc + a2] += lam_f * dt * r * r; grad_p[o.Qf + a2] += lam_f * dt * u * u;
+        grad_p[o.Uref + 24 * k + 12 + 3 * l2 + a2] += -2.0 * lam_f * dt * p[o.Qf + a2] * u;
+      }
+    }
   }
   if (f) lo_nlp_f(F, x, p, f);
   if (g) memcpy(g, gg, sizeof(double) * (size_t)ng);
@@ -760,7 +799,7 @@ void lo_nlp_grad(const lo_form* F, const double* x, const double* p, double lam_
 void lo_bounds(const lo_form* F, const double* p, double* lbg, double* ubg) {
   const int N = F->N; lo_poff o; int k, i, l;
   const double inf = INFINITY;
-  lo_param_offsets(N, &o);
+  lo_param_offsets_form(F, &o);
   for (i = 0; i < 6; i++) {
     lbg[i] = ubg[i] = p[o.q_init + i]; lbg[6 + i] = ubg[6 + i] = p[o.qd_init + i];
     lbg[12 + i] = p[o.q_term_min + i]; ubg[12 + i] = inf;

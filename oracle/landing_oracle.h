@@ -35,7 +35,8 @@ typedef struct {
   double slip_eps;    /* 1e-2, :143-144 */
   /* running cost of the N=41 script (generate_quadruped_SRBM_CCC.m:81-89), off by default:
    *   sum_k dt_k ( |X_k - Xref_k|^2_QX + |pos_k + p_hip - c_k|^2_Qc (per leg) + |f_k - f_ref|^2_Qf (per leg) )
-   * QX, Qc, Qf are parameters of that script; the callers pass constants, so they live here. */
+   * run_cost 1: QX, Qc, Qf, f_ref are the constants below and p is the IPOPT variant's; run_cost 2: the script's OWN parameter vector
+   * (lo_param_offsets_form: Uref, QX, Qc, Qf are entries of p, grad_gamma_p has entries for them; the fields below are ignored). */
   int run_cost;
   double QX[12], Qc[3], Qf[3];
   double f_ref[3];    /* Uref(13:24,k) = f_ref per leg in the callers (test_loadCasadi_ws.m:68-72) */
@@ -58,8 +59,11 @@ lo_int lo_nnz_hess(int N);
 typedef struct {
   int Xref, dt, q_min, q_max, qd_min, qd_max, q_init, qd_init, q_term_min, q_term_max,
       qd_term_min, qd_term_max, QN, mu, l_leg_max, f_max, mass, Ib, Ib_inv, np;
+  int Uref, QX, Qc, Qf;      /* only with lo_form.run_cost == 2 (the N=41 script's own parameter vector); -1 otherwise */
 } lo_poff;
 void lo_param_offsets(int N, lo_poff* o);
+void lo_param_offsets_form(const lo_form* F, lo_poff* o);
+lo_int lo_np_form(const lo_form* F);      /* 13N+94, or 37N+112 with run_cost == 2 */
 
 /* CCS patterns: colind[nx+1], row[nnz] (casadi mem.h:73-91 without the 2-int header) */
 void lo_pattern_jac(int N, lo_int* colind, lo_int* row);

@@ -196,7 +196,7 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
   double mu = op->mu_init, delta_last = 0.0, th_max = 0.0, e_du = 0.0; int clip_k_cur = op->clip_k;
   double filt_th[64], filt_ph[64];
   double* gx;
-  lo_param_offsets(N, &o);
+  lo_param_offsets_form(F, &o);
   W->N = N; W->nx = nx; W->ng = ng;
   W->x = dalloc(nx); W->xt = dalloc(nx); W->dx = dalloc(nx); gx = dalloc(nx);
   W->g = dalloc(ng); W->gt = dalloc(ng); W->s = dalloc(ng); W->ds = dalloc(ng); W->zL = dalloc(ng); W->zU = dalloc(ng);
@@ -487,7 +487,7 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
 /* batch driver: B members, `threads` OpenMP threads (<=0: all).  counters[0..1] = total factorisations, trial points. */
 int lo_solve_batch(const lo_form* F, int B, const double* p, const double* x0, const lo_solver_opts* opts, int threads,
                    double* x, double* lam_g, int* status, int* iters, double* kkt, long long* counters) {
-  const lo_int nx = lo_nx(F->N), ng = lo_ng(F->N), np = lo_np(F->N);
+  const lo_int nx = lo_nx(F->N), ng = lo_ng(F->N), np = lo_np_form(F);
   lo_solver_opts o; long long c0 = 0, c1 = 0; int b;
   if (opts) o = *opts; else lo_solver_opts_default(&o);
 #ifdef _OPENMP
@@ -509,7 +509,7 @@ int lo_solve_batch(const lo_form* F, int B, const double* p, const double* x0, c
 /* Full derivative sweeps of a batch (g, grad f, Jacobian and Hessian nonzeros of every member; SURVEY 8d unit of work for
  * the function layer), `reps` times, OpenMP over members: CPU timing leg of bench.py.  Outputs go to per-thread scratch. */
 int lo_sweep_batch(const lo_form* F, int B, const double* x, const double* p, const double* lam_g, int reps, int threads) {
-  const lo_int nx = lo_nx(F->N), ng = lo_ng(F->N), np = lo_np(F->N), nj = lo_nnz_jac(F->N), nh = lo_nnz_hess(F->N);
+  const lo_int nx = lo_nx(F->N), ng = lo_ng(F->N), np = lo_np_form(F), nj = lo_nnz_jac(F->N), nh = lo_nnz_hess(F->N);
   int bad = 0;
 #ifdef _OPENMP
   if (threads > 0) omp_set_num_threads(threads);

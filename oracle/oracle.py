@@ -38,7 +38,7 @@ def _p(a):
 
 
 class Oracle:
-    def __init__(self, N, kin_box=None, run_cost=None):
+    def __init__(self, N, kin_box=None, run_cost=None, ccc_params=False):
         path = os.path.join(HERE, "liblanding_oracle.so")
         if not os.path.exists(path):
             build()
@@ -58,7 +58,10 @@ class Oracle:
                 self.form.QX[i] = run_cost["QX"][i]
             for i in range(3):
                 self.form.Qc[i] = run_cost["Qc"][i]; self.form.Qf[i] = run_cost["Qf"][i]; self.form.f_ref[i] = run_cost.get("f_ref", (0, 0, 0))[i]
-        self.nx, self.ng, self.np_ = lib.lo_nx(N), lib.lo_ng(N), lib.lo_np(N)
+        if ccc_params:                # the N=41 script's own parameter vector (lo_param_offsets_form): weights / force reference from p
+            self.form.run_cost = 2
+        lib.lo_np_form.restype = _ll
+        self.nx, self.ng, self.np_ = lib.lo_nx(N), lib.lo_ng(N), lib.lo_np_form(C.byref(self.form))
         self.nnz_jac, self.nnz_hess = lib.lo_nnz_jac(N), lib.lo_nnz_hess(N)
         self._F = C.byref(self.form)
 
@@ -76,9 +79,9 @@ class Oracle:
     def param_offsets(self):
         names = ["Xref", "dt", "q_min", "q_max", "qd_min", "qd_max", "q_init", "qd_init", "q_term_min",
                  "q_term_max", "qd_term_min", "qd_term_max", "QN", "mu", "l_leg_max", "f_max", "mass",
-                 "Ib", "Ib_inv", "np"]
+                 "Ib", "Ib_inv", "np", "Uref", "QX", "Qc", "Qf"]
         arr = (C.c_int * len(names))()
-        self.lib.lo_param_offsets(self.N, arr)
+        self.lib.lo_param_offsets_form(C.byref(self.form), arr)
         return dict(zip(names, list(arr)))
 
     # -- callbacks --------------------------------------------------------------------

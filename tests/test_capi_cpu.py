@@ -36,7 +36,7 @@ def test_library_exports_every_declared_symbol(built):
         assert hasattr(lib, n), n
 
 
-@pytest.mark.parametrize("so", ["landingCtrller_IPOPT_mi355x.so", "landingCtrller_IPOPT_N40_mi355x.so"])
+@pytest.mark.parametrize("so", ["landingCtrller_IPOPT_mi355x.so", "landingCtrller_IPOPT_N40_mi355x.so", "nlp_quad_SRBM_mi355x.so"])
 def test_casadi_dropin_exports_reference_symbol_set(built, so):
     lib = C.CDLL(os.path.join(PKG, so))
     suffixes = ["", "_alloc_mem", "_init_mem", "_free_mem", "_checkout", "_release", "_incref", "_decref", "_n_in",
@@ -69,6 +69,26 @@ def test_dropin_sparsity_equals_reference_pattern(built):
     f = lib.nlp_f_sparsity_in; f.restype = C.POINTER(C.c_longlong); f.argtypes = [C.c_longlong]
     ptr = f(1)
     assert [ptr[i] for i in range(4)] == [354, 1, 0, 354]   # casadi_s1, landingCtrller_IPOPT.c:60
+
+
+def test_ccc_dropin_metadata(built):
+    """nlp_quad_SRBM_mi355x.so = the NLP of the reference's N=41 script (generate_quadruped_SRBM_CCC.m:340-341): x 1452, its own parameter
+    vector p 37N+112 = 1592, g 4172, the Hessian in the extended (running-cost) pattern -- upper triangular, rows sorted"""
+    lib = C.CDLL(os.path.join(PKG, "nlp_quad_SRBM_mi355x.so"))
+    main = C.CDLL(os.path.join(PKG, "liblanding_mi355x.so"))
+    main.landing_nnz_hess_rc.restype = C.c_longlong
+    f = lib.nlp_f_sparsity_in; f.restype = C.POINTER(C.c_longlong); f.argtypes = [C.c_longlong]
+    assert [f(0)[i] for i in range(2)] == [1452, 1] and [f(1)[i] for i in range(4)] == [1592, 1, 0, 1592]
+    h = lib.nlp_hess_l_sparsity_out; h.restype = C.POINTER(C.c_longlong); h.argtypes = [C.c_longlong]
+    ptr = h(0)
+    nnz = main.landing_nnz_hess_rc(40)
+    assert (ptr[0], ptr[1]) == (1452, 1452) and ptr[2 + 1452] == nnz == 7560 + 18 * 40
+    ci = np.array([ptr[2 + i] for i in range(1453)]); r = np.array([ptr[3 + 1452 + i] for i in range(nnz)])
+    for c in range(1452):
+        rows = r[ci[c]:ci[c + 1]]
+        assert (np.diff(rows) > 0).all() and (rows <= c).all()
+    gp = lib.nlp_grad_sparsity_out; gp.restype = C.POINTER(C.c_longlong); gp.argtypes = [C.c_longlong]
+    assert gp(3)[0] == 1592                                      # grad_gamma_p has an entry for every parameter, QX / Qc / Qf / Uref included
 
 
 def test_no_device_means_loud_failure(built):

@@ -99,6 +99,43 @@ def test_casadi_dropin_on_gpu_matches_reference_golden():
     lib.nlp_decref()
 
 
+def test_ccc_dropin_on_gpu_matches_oracle(oracle_mod):
+    """nlp_quad_SRBM_mi355x.so (the N=41 script's NLP: kin-box .05/.05/.27, running cost, QX / Qc / Qf / Uref in p) through the CasADi ABI
+    against the oracle; no generated C of that script exists in the reference, so the oracle's restatement (finite-difference checked,
+    tests/test_ccc_params.py, tests/test_hess_rc.py) is the pin"""
+    N = 40
+    rc = dict(QX=[0.3, 0.2, 10, 1, 1, 0.4, .1, .2, .1, .3, .1, .2], Qc=[1.0, 0.8, 0.5], Qf=[1e-4, 2e-4, 1e-3], f_ref=[0, 0, 0])
+    O = oracle_mod.Oracle(N, kin_box=(0.05, 0.05, 0.27), run_cost=rc, ccc_params=True)
+    Pm = lc("problem")
+    P, X0, _, _ = Pm.make_batch(1, N, 0.6, seed=9)
+    rng = np.random.default_rng(4)
+    Uref = X0[0][12 * (N + 1):].reshape(24, N, order="F").copy(); Uref[12:] = 5.0 + rng.normal(size=(12, N))
+    p = Pm.ccc_from_ipopt_params(N, P[0], Uref, rc["QX"], rc["Qc"], rc["Qf"])
+    x = X0[0] + 0.02 * rng.normal(size=X0[0].shape); lam = rng.normal(size=O.ng); lf = np.array([0.7])
+    lib = C.CDLL(os.path.join(PKG, "nlp_quad_SRBM_mi355x.so"))
+    dp = C.POINTER(C.c_double)
+    ptr = lambda a: a.ctypes.data_as(dp)
+
+    def call(name, ins, outs):
+        arg = (dp * len(ins))(*[ptr(a) if a is not None else None for a in ins])
+        res = (dp * len(outs))(*[ptr(a) if a is not None else None for a in outs])
+        f = getattr(lib, name); f.restype = C.c_int
+        assert f(arg, res, None, None, 0) == 0
+    lib.nlp_incref()
+    f = np.zeros(1); g = np.zeros(O.ng); gx = np.zeros(O.nx); gp = np.zeros(O.np_)
+    call("nlp_grad", [x, p, lf, lam], [f, g, gx, gp])
+    fo, go, gxo, gpo = O.grad(x, p, 0.7, lam)
+    assert abs(f[0] - fo) <= 1e-12 * abs(fo) and np.allclose(g, go, rtol=0, atol=1e-12)
+    assert np.allclose(gx, gxo, rtol=1e-10, atol=1e-11) and np.allclose(gp, gpo, rtol=1e-10, atol=1e-11)
+    h = np.zeros(7560 + 18 * N)
+    call("nlp_hess_l", [x, p, lf, lam], [h])
+    assert np.allclose(h, O.hess_l_rc(x, p, 0.7, lam), rtol=1e-11, atol=1e-12)
+    jac = np.zeros(O.nnz_jac); g2 = np.zeros(O.ng)
+    call("nlp_jac_g", [x, p], [g2, jac])
+    assert np.allclose(jac, O.jac_g(x, p)[1], rtol=0, atol=1e-12)
+    lib.nlp_decref()
+
+
 def test_bounds_kernel_matches_oracle(libs, oracle_mod):
     import torch
     N = 40
