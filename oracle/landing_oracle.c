@@ -72,6 +72,12 @@ void lo_param_offsets_form(const lo_form* F, lo_poff* o) {
   o->QX = b + 60; o->QN = b + 72; o->Qc = b + 84; o->Qf = b + 87;
   o->mu = b + 90; o->l_leg_max = b + 91; o->f_max = b + 92; o->mass = b + 93; o->Ib = b + 94; o->Ib_inv = b + 97; o->np = b + 100;
 }
+double lo_rc_weight(const lo_form* F, const double* p, int which, int i) {      /* which: 0 QX[i], 1 Qc[i], 2 Qf[i] -- from the form or from p (run_cost 2) */
+  lo_poff o;
+  if (F->run_cost != 2) return which == 0 ? F->QX[i] : (which == 1 ? F->Qc[i] : F->Qf[i]);
+  lo_param_offsets_form(F, &o);
+  return p[(which == 0 ? o.QX : (which == 1 ? o.Qc : o.Qf)) + i];
+}
 lo_int lo_np_form(const lo_form* F) { lo_poff o; lo_param_offsets_form(F, &o); return o.np; }
 /* weights / force reference of the running cost: constants of the form (run_cost 1) or entries of p (run_cost 2) */
 static double rcQX(const lo_form* F, const lo_poff* o, const double* p, int i) { return F->run_cost == 2 ? p[o->QX + i] : F->QX[i]; }

@@ -63,7 +63,8 @@ typedef struct {
 } lo_poff;
 void lo_param_offsets(int N, lo_poff* o);
 void lo_param_offsets_form(const lo_form* F, lo_poff* o);
-lo_int lo_np_form(const lo_form* F);      /* 13N+94, or 37N+112 with run_cost == 2 */
+lo_int lo_np_form(const lo_form* F);
+double lo_rc_weight(const lo_form* F, const double* p, int which, int i);   /* QX / Qc / Qf of the running cost: form constants or entries of p */      /* 13N+94, or 37N+112 with run_cost == 2 */
 
 /* CCS patterns: colind[nx+1], row[nnz] (casadi mem.h:73-91 without the 2-int header) */
 void lo_pattern_jac(int N, lo_int* colind, lo_int* row);

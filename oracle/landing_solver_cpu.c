@@ -37,6 +37,12 @@ typedef struct {
   double theta_floor;    /* constraint violations (1-norm theta) below theta_floor * tol count as equal in the filter tests              */
   int clip_k;            /* the step to the boundary is set by the clip_k-th most blocking slack; the more blocking ones stop at    */
   double clip_until;     /* (1 - tau) of their distance (include/landing_nlp.h); only while pr > clip_until                      */
+  int feas_phase;        /* feasibility (restoration) phase, include/landing_nlp.h: a solve that would end as NUMERICAL / MAX_ITER continues on
+                            the ELASTIC problem -- every inequality row may be violated by n, p >= 0 at the price feas_rho (n + p), no objective --
+                            with the same primal-dual machinery; a feasible point restarts the solve from there, a KKT point of the elastic
+                            problem with positive violation ends it as LANDING_INFEASIBLE (3): a certificate of local infeasibility           */
+  double feas_rho;       /* price of a unit of violation (IPOPT's restoration phase: 1000)                                                   */
+  double feas_cert;      /* l1 violation above which the elastic KKT point counts as a certificate                                           */
 } lo_solver_opts;
 
 void lo_solver_opts_default(lo_solver_opts* o) {
@@ -44,6 +50,7 @@ void lo_solver_opts_default(lo_solver_opts* o) {
   o->kappa_eps = 10.0; o->kappa_mu = 0.2; o->theta_mu = 1.5; o->max_resets = 8; o->reset_du = 1e9;
   o->delta_init = 1e-4; o->delta_inc_first = 10.0; o->delta_inc = 4.0; o->delta_dec = 0.5; o->tau_min = 0.9; o->alpha_fallback = 1e-2; o->restart_period = 75; o->reset_delta = 1e5;
   o->barrier_smax = 1.0; o->watchdog = 3; o->slack_corr = 0.9; o->dual_step_cap = 1.0; o->fresh_restart = 9; o->theta_floor = 30.0; o->clip_k = 4; o->clip_until = 0.03;
+  o->feas_phase = 0; o->feas_rho = 1000.0; o->feas_cert = 1e-4;
 }
 
 #define NW 48
@@ -52,7 +59,8 @@ static const int ROW2STATE[12] = {0, 1, 2, 3, 4, 5, 9, 10, 11, 6, 7, 8};
 static int loc2w(int loc) { if (loc < 36) return loc; if (loc < 48) return -1; return 36 + (loc - 48); }
 
 typedef struct {
-  int N; lo_int nx, ng;
+  int N; lo_int nx, ng; int feas;
+  double *en, *ep, *wn, *wp, *den, *dep, *dwn, *dwp;      /* elastic variables of the feasibility phase and their steps */
   double *x, *xt, *dx, *g, *gt, *s, *ds, *zL, *zU, *dzL, *dzU, *y, *yn, *lb, *ub, *sig, *rho;
   double *Jst;   /* N x 104 x 60 */
   double *Hst;   /* N x 60 x 60  */
@@ -97,7 +105,7 @@ static int riccati_backward(const lo_form* F, const double* p, work_t* W, double
   memset(P, 0, sizeof(P)); memset(pv, 0, sizeof(pv));
   for (i = 0; i < 12; ++i) {
     const int ra = i < 6 ? 12 + i : 24 + (i - 6), rb = i < 6 ? 18 + i : 30 + (i - 6);
-    const double qn2 = 2.0 * p[o->QN + i];
+    const double qn2 = W->feas ? 0.0 : 2.0 * p[o->QN + i];      /* the feasibility phase has no objective */
     P[i * 24 + i] = qn2 + W->sig[ra] + W->sig[rb] + delta;
     pv[i] = qn2 * (W->x[12 * N + i] - p[12 * N + i]) + W->rho[ra] + W->rho[rb];
   }
@@ -196,8 +204,10 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
   double mu = op->mu_init, delta_last = 0.0, th_max = 0.0, e_du = 0.0; int clip_k_cur = op->clip_k;
   double filt_th[64], filt_ph[64];
   double* gx;
+  int feas = 0, feas_used = 0, lim = op->max_iter; const double frho = op->feas_rho;
   lo_param_offsets_form(F, &o);
-  W->N = N; W->nx = nx; W->ng = ng;
+  W->N = N; W->nx = nx; W->ng = ng; W->feas = 0;
+  W->en = dalloc(ng); W->ep = dalloc(ng); W->wn = dalloc(ng); W->wp = dalloc(ng); W->den = dalloc(ng); W->dep = dalloc(ng); W->dwn = dalloc(ng); W->dwp = dalloc(ng);
   W->x = dalloc(nx); W->xt = dalloc(nx); W->dx = dalloc(nx); gx = dalloc(nx);
   W->g = dalloc(ng); W->gt = dalloc(ng); W->s = dalloc(ng); W->ds = dalloc(ng); W->zL = dalloc(ng); W->zU = dalloc(ng);
   W->dzL = dalloc(ng); W->dzU = dalloc(ng); W->y = dalloc(ng); W->yn = dalloc(ng); W->lb = dalloc(ng); W->ub = dalloc(ng);
@@ -210,7 +220,7 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
   lo_bounds(F, p, W->lb, W->ub);
   eval_g(F, W->x, p, W->g);
   init_slacks(W, op);
-  for (it = 0; it <= op->max_iter; ++it) {
+  for (it = 0; it <= lim; ++it) {
     double du = 0, pr = 0, co = 0, tau, delta;
     int fact_ok = 0, attempt, clip_now; double use_reset = 0.0;
     double top[4]; const double th_floor = op->theta_floor * op->tol;
@@ -219,7 +229,7 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
     /* derivatives per stage + gx = grad f + J^T y */
     memset(gx, 0, sizeof(double) * nx);
     for (i = 0; i < 12; ++i) {
-      gx[12 * N + i] = 2.0 * p[o.QN + i] * (W->x[12 * N + i] - p[12 * N + i]) + (i < 6 ? W->y[12 + i] + W->y[18 + i] : W->y[24 + i - 6] + W->y[30 + i - 6]);
+      gx[12 * N + i] = (feas ? 0.0 : 2.0 * p[o.QN + i] * (W->x[12 * N + i] - p[12 * N + i])) + (i < 6 ? W->y[12 + i] + W->y[18 + i] : W->y[24 + i - 6] + W->y[30 + i - 6]);
     }
     for (k = 0; k < N; ++k) {
       const int nr = lo_stage_rows(F, k); int q, c;
@@ -230,11 +240,11 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
         double* Hs = W->Hst + (size_t)k * 3600; const double dtk = p[o.dt + k]; int a, l2;
         double* gU = gx + 12 * (N + 1) + 24 * k;
         (void)lo_run_cost_stage(F, W->x, p, k, gx + 12 * k, gU, gU + 12);
-        for (c = 0; c < 12; ++c) Hs[c * 60 + c] += 2.0 * dtk * F->QX[c];
+        for (c = 0; c < 12; ++c) Hs[c * 60 + c] += 2.0 * dtk * lo_rc_weight(F, p, 0, c);
         for (l2 = 0; l2 < 4; ++l2) for (a = 0; a < 3; ++a) {
-          const int ic = 12 + 3 * l2 + a, jf = 24 + 3 * l2 + a; const double hc = 2.0 * dtk * F->Qc[a];
+          const int ic = 12 + 3 * l2 + a, jf = 24 + 3 * l2 + a; const double hc = 2.0 * dtk * lo_rc_weight(F, p, 1, a);
           Hs[a * 60 + a] += hc; Hs[ic * 60 + ic] += hc; Hs[a * 60 + ic] -= hc; Hs[ic * 60 + a] -= hc;
-          Hs[jf * 60 + jf] += 2.0 * dtk * F->Qf[a];
+          Hs[jf * 60 + jf] += 2.0 * dtk * lo_rc_weight(F, p, 2, a);
         }
       }
       for (q = 0; q < nr; ++q) for (c = 0; c < 60; ++c) if (J[q * 60 + c] != 0.0) {
@@ -247,15 +257,62 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
       const double lb = W->lb[r], ub = W->ub[r], g = W->g[r];
       if (lb == ub) { pr = fmax(pr, fabs(g - lb)); continue; }
       pr = fmax(pr, fabs(g - W->s[r]));
+      if (feas) {
+        if (lb > -INFINITY) { co = fmax(co, (W->s[r] - lb + W->en[r]) * W->zL[r]); co = fmax(co, W->en[r] * W->wn[r]); du = fmax(du, fabs(W->zL[r] + W->wn[r] - frho)); }
+        if (ub < INFINITY) { co = fmax(co, (ub + W->ep[r] - W->s[r]) * W->zU[r]); co = fmax(co, W->ep[r] * W->wp[r]); du = fmax(du, fabs(W->zU[r] + W->wp[r] - frho)); }
+        continue;
+      }
       if (lb > -INFINITY) co = fmax(co, (W->s[r] - lb) * W->zL[r]);
       if (ub < INFINITY) co = fmax(co, (ub - W->s[r]) * W->zU[r]);
     }
     e_du = du;
     if (getenv("LO_TRACE")) fprintf(stderr, "it %4d pr %9.2e du %9.2e co %9.2e mu %8.1e dlast %8.1e nreset %d nfilt %d\n", it, pr, du, co, mu, delta_last, nreset, nfilt);
-    if (!(du < 1e300) || !(pr < 1e300) || !(co < 1e300)) { status = 2; break; }
-    if (fmax(du, fmax(pr, co)) <= op->tol) { status = 0; break; }
-    if (it == op->max_iter) break;
-    if (du > op->reset_du && nreset >= op->max_resets && op->max_resets > 0) { status = 2; break; }
+    if (feas) {
+      double vmax = 0.0, v1 = 0.0; int back = 0;
+      for (r = 12; r < ng; ++r) {
+        const double lb = W->lb[r], ub = W->ub[r], g = W->g[r], v = fmax(fmax(lb - g, g - ub), 0.0);
+        if (lb == ub) continue;
+        vmax = fmax(vmax, v); v1 += v;
+      }
+      if (getenv("LO_TRACE")) fprintf(stderr, "   feas: viol_inf %9.2e viol_1 %9.2e\n", vmax, v1);
+      if (!(du < 1e300) || !(pr < 1e300) || !(co < 1e300)) { status = 2; break; }
+      if (vmax <= 1e-9 && pr <= op->tol) back = 1;                       /* a feasible point: back to the interior-point solve from here */
+      else if (fmax(du, fmax(pr, co)) <= op->tol) { if (v1 > op->feas_cert) { status = 3; break; } back = 1; }
+      if (back) {
+        feas = 0; W->feas = 0; lim = it + op->max_iter;
+        init_slacks(W, op); mu = op->mu_init; nfilt = 0; delta_last = 0.0; streak = 0; wd_count = 0; th_max = 0.0; nreset = 0; last_reset_it = it; ncrawl = 0; cutstreak = 0; force_step = 0;
+        for (r = 12; r < ng; ++r) if (W->lb[r] == W->ub[r]) W->y[r] = 0.0;
+        continue;
+      }
+      if (it == lim) break;
+      goto no_reset;
+    }
+    {
+      int give_up = 0;
+      if (!(du < 1e300) || !(pr < 1e300) || !(co < 1e300)) { status = 2; give_up = 1; }
+      else if (fmax(du, fmax(pr, co)) <= op->tol) { status = 0; break; }
+      else if (it == lim) give_up = 1;
+      else if (du > op->reset_du && nreset >= op->max_resets && op->max_resets > 0) { status = 2; give_up = 1; }
+      if (give_up) {
+        if (!op->feas_phase || feas_used) break;
+        /* feasibility phase: from the current point (from the caller's initial guess when the iterate is not finite) */
+        feas = 1; W->feas = 1; feas_used = 1; status = 1; nfilt = 0; th_max = 0.0; delta_last = 0.0; streak = 0; lim = it + op->max_iter; cutstreak = 0; force_step = 0; wd_count = 0;
+        { int bad = 0; for (i = 0; i < nx; ++i) if (!(fabs(W->x[i]) < 1e6)) bad = 1;
+          if (bad) { memcpy(W->x, x0, sizeof(double) * nx); for (i = 0; i < 6; ++i) { W->x[i] = p[o.q_init + i]; W->x[6 + i] = p[o.qd_init + i]; } }
+          eval_g(F, W->x, p, W->g); }
+        mu = op->mu_init;
+        for (r = 12; r < ng; ++r) {
+          const double lb = W->lb[r], ub = W->ub[r], g = W->g[r];
+          if (lb == ub) { W->y[r] = 0.0; continue; }
+          /* slack on the row value; violation variables sized so that both distances start at a comfortable value */
+          W->s[r] = g; W->zL[r] = W->zU[r] = W->wn[r] = W->wp[r] = W->en[r] = W->ep[r] = 0.0;
+          if (lb > -INFINITY) { const double v = lb - g, n0 = fmax(v, 0.0) + fmax(1e-2, 0.1 * fabs(v)); W->en[r] = n0; W->zL[r] = fmin(mu / (g - lb + n0), 0.5 * frho); W->wn[r] = frho - W->zL[r]; }
+          if (ub < INFINITY) { const double v = g - ub, p0 = fmax(v, 0.0) + fmax(1e-2, 0.1 * fabs(v)); W->ep[r] = p0; W->zU[r] = fmin(mu / (ub + p0 - g), 0.5 * frho); W->wp[r] = frho - W->zU[r]; }
+          W->y[r] = W->zU[r] - W->zL[r];
+        }
+        continue;
+      }
+    }
     {
       const int stalled = op->restart_period > 0 && it - last_reset_it >= op->restart_period && mu >= op->mu_init && nreset < op->max_resets && ncrawl < ((op->fresh_restart & 4) ? 2 : 1);
       /* ... and a LATER barrier problem that is not solved 2 restart_period iterations after it began has wandered off (nothing else
@@ -283,6 +340,11 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
       for (r = 12; r < ng; ++r) {
         const double lb = W->lb[r], ub = W->ub[r];
         if (lb == ub) continue;
+        if (feas) {
+          if (lb > -INFINITY) { cm = fmax(cm, fabs((W->s[r] - lb + W->en[r]) * W->zL[r] - mu)); cm = fmax(cm, fabs(W->en[r] * W->wn[r] - mu)); }
+          if (ub < INFINITY) { cm = fmax(cm, fabs((ub + W->ep[r] - W->s[r]) * W->zU[r] - mu)); cm = fmax(cm, fabs(W->ep[r] * W->wp[r] - mu)); }
+          continue;
+        }
         if (lb > -INFINITY) cm = fmax(cm, fabs((W->s[r] - lb) * W->zL[r] - mu));
         if (ub < INFINITY) cm = fmax(cm, fabs((ub - W->s[r]) * W->zU[r] - mu));
       }
@@ -298,6 +360,22 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
     tau = fmax(op->tau_min, 1.0 - mu);
     for (r = 0; r < ng; ++r) {
       const double lb = W->lb[r], ub = W->ub[r]; double sg = 0, rh = 0;
+      if (feas) {      /* elastic row: z + dz = (z + c) -/+ sigma ds after eliminating the violation variable and its multiplier */
+        if (r >= 12 && lb != ub) {
+          const double s = W->s[r];
+          if (lb > -INFINITY) {
+            const double n = W->en[r], a = s - lb + n, zl = W->zL[r], w = W->wn[r], D = a + zl * n / w;
+            const double c = (mu - a * zl - zl * (mu - n * w + n * (zl + w - frho)) / w) / D;
+            sg += zl / D; rh -= zl + c;
+          }
+          if (ub < INFINITY) {
+            const double q = W->ep[r], b = ub + q - s, zu = W->zU[r], w = W->wp[r], D = b + zu * q / w;
+            const double c = (mu - b * zu - zu * (mu - q * w + q * (zu + w - frho)) / w) / D;
+            sg += zu / D; rh += zu + c;
+          }
+          rh += sg * (W->g[r] - s);
+        }
+      } else
       if (r >= 12 && lb != ub) {
         const double s = W->s[r];
         if (lb > -INFINITY) { const double d = s - lb; sg += W->zL[r] / d; rh -= mu / d; }
@@ -367,12 +445,36 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
     }
     /* dual steps, step bounds, merit data.  clip_now: the primal step length comes from the clip_k-th largest ratio
      * |ds| / distance (top[] holds the four largest); the slacks with a larger ratio are clipped in slack_step(). */
-    clip_now = clip_k_cur > 1 && pr > op->clip_until;
+    clip_now = !feas && clip_k_cur > 1 && pr > op->clip_until;
     top[0] = top[1] = top[2] = top[3] = 0.0;
     for (r = 12; r < ng; ++r) {
       const double lb = W->lb[r], ub = W->ub[r], g = W->g[r]; double s, ds, yn;
       if (lb == ub) { th0 += fabs(g - lb); continue; }
       s = W->s[r]; ds = W->ds[r]; th0 += fabs(g - s); yn = W->sig[r] * ds;
+      if (feas) {      /* steps of the eliminated variables, step bounds (a, n, b, p and their multipliers stay positive), merit data */
+        W->dzL[r] = W->dzU[r] = W->den[r] = W->dep[r] = W->dwn[r] = W->dwp[r] = 0.0;
+        if (lb > -INFINITY) {
+          const double n = W->en[r], a = s - lb + n, zl = W->zL[r], w = W->wn[r], D = a + zl * n / w, rn = zl + w - frho;
+          const double dz = (mu - a * zl - zl * (mu - n * w + n * rn) / w - zl * ds) / D, dw = -dz - rn, dn = (mu - n * w - n * dw) / w, da = ds + dn;
+          W->dzL[r] = dz; W->dwn[r] = dw; W->den[r] = dn;
+          if (da < 0.0) a_pr = fmin(a_pr, -tau * a / da);
+          if (dn < 0.0) a_pr = fmin(a_pr, -tau * n / dn);
+          if (dz < 0.0) a_du = fmin(a_du, -tau * zl / dz);
+          if (dw < 0.0) a_du = fmin(a_du, -tau * w / dw);
+          bar -= log(a) + log(n); dphi += frho * dn - mu * (da / a + dn / n); f0 += frho * n;
+        }
+        if (ub < INFINITY) {
+          const double q = W->ep[r], b = ub + q - s, zu = W->zU[r], w = W->wp[r], D = b + zu * q / w, rp = zu + w - frho;
+          const double dz = (mu - b * zu - zu * (mu - q * w + q * rp) / w + zu * ds) / D, dw = -dz - rp, dq = (mu - q * w - q * dw) / w, db = dq - ds;
+          W->dzU[r] = dz; W->dwp[r] = dw; W->dep[r] = dq;
+          if (db < 0.0) a_pr = fmin(a_pr, -tau * b / db);
+          if (dq < 0.0) a_pr = fmin(a_pr, -tau * q / dq);
+          if (dz < 0.0) a_du = fmin(a_du, -tau * zu / dz);
+          if (dw < 0.0) a_du = fmin(a_du, -tau * w / dw);
+          bar -= log(b) + log(q); dphi += frho * dq - mu * (db / b + dq / q); f0 += frho * q;
+        }
+        continue;
+      }
       if (lb > -INFINITY) {
         const double d = s - lb, zl = W->zL[r], dz = mu / d - zl - zl / d * ds;
         W->dzL[r] = dz; yn -= mu / d;
@@ -389,8 +491,8 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
       } else W->dzU[r] = 0.0;
       W->yn[r] = yn;
     }
-    for (i = 0; i < 12; ++i) { const double d = W->x[12 * N + i] - p[12 * N + i], qn = p[o.QN + i]; f0 += qn * d * d; dphi += 2.0 * qn * d * W->dx[12 * N + i]; }
-    if (F->run_cost) for (k = 0; k < N; ++k) {
+    if (!feas) for (i = 0; i < 12; ++i) { const double d = W->x[12 * N + i] - p[12 * N + i], qn = p[o.QN + i]; f0 += qn * d * d; dphi += 2.0 * qn * d * W->dx[12 * N + i]; }
+    if (F->run_cost && !feas) for (k = 0; k < N; ++k) {
       double gX[12] = {0}, gc[12] = {0}, gf[12] = {0}; const double* dX = W->dx + 12 * k; const double* dU = W->dx + 12 * (N + 1) + 24 * k;
       f0 += lo_run_cost_stage(F, W->x, p, k, gX, gc, gf);
       for (i = 0; i < 12; ++i) dphi += gX[i] * dX[i] + gc[i] * dU[i] + gf[i] * dU[12 + i];
@@ -407,12 +509,18 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
       for (r = 12; r < ng; ++r) {
         const double lb = W->lb[r], ub = W->ub[r], g = W->gt[r]; double s;
         if (lb == ub) { tht += fabs(g - lb); continue; }
+        if (feas) {
+          s = W->s[r] + alpha * W->ds[r]; tht += fabs(g - s);
+          if (lb > -INFINITY) { const double n = W->en[r] + alpha * W->den[r]; bt -= log(s - lb + n) + log(n); ft += frho * n; }
+          if (ub < INFINITY) { const double q = W->ep[r] + alpha * W->dep[r]; bt -= log(ub + q - s) + log(q); ft += frho * q; }
+          continue;
+        }
         s = slack_step(W->s[r], W->ds[r], alpha, lb, ub, clip_now, tau); tht += fabs(g - s);
         if (lb > -INFINITY) bt -= log(s - lb);
         if (ub < INFINITY) bt -= log(ub - s);
       }
-      for (i = 0; i < 12; ++i) { const double d = W->xt[12 * N + i] - p[12 * N + i]; ft += p[o.QN + i] * d * d; }
-      if (F->run_cost) for (k = 0; k < N; ++k) ft += lo_run_cost_stage(F, W->xt, p, k, NULL, NULL, NULL);
+      if (!feas) for (i = 0; i < 12; ++i) { const double d = W->xt[12 * N + i] - p[12 * N + i]; ft += p[o.QN + i] * d * d; }
+      if (F->run_cost && !feas) for (k = 0; k < N; ++k) ft += lo_run_cost_stage(F, W->xt, p, k, NULL, NULL, NULL);
       pht = ft + mu * bt;
       ok_f = (tht <= th_max) && (pht < 1e300) && (pht > -1e300) && (tht < 1e300);
       for (e = 0; e < nfilt && ok_f; ++e) if (tht >= fmax(filt_th[e], th_floor) && pht >= filt_ph[e]) ok_f = 0;
@@ -427,7 +535,7 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
       }
       if (force_step && ok_f) { accepted = 1; nfilt = 0; break; }      /* watchdog: the step to the boundary is taken whatever the filter says */
       if (accepted) break;
-      if (op->slack_corr > 0.0 && alpha == a_pr && tht >= th0) {   /* slack correction at the rejected first trial point (include/landing_nlp.h): no new solve */
+      if (!feas && op->slack_corr > 0.0 && alpha == a_pr && tht >= th0) {   /* slack correction at the rejected first trial point (include/landing_nlp.h): no new solve */
         const double kk = op->slack_corr; double tht2 = 0, bt2 = 0, pht2; int okf2;
         for (r = 12; r < ng; ++r) {
           const double lb = W->lb[r], ub = W->ub[r], g = W->gt[r]; double s2;
@@ -446,7 +554,7 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
     /* watchdog (cf. IPOPT's watchdog_shortened_iter_trigger): after `watchdog` successive iterations whose accepted step length is at most
      * 1/16 of the step to the boundary the next iteration takes that step unconditionally and restarts the filter */
     force_step = 0;
-    if (op->watchdog > 0) {
+    if (op->watchdog > 0 && !feas) {
       if (accepted && alpha <= 0.0625 * a_pr) { if (++cutstreak >= op->watchdog) { force_step = 1; cutstreak = 0; wd_count++; } }
       else cutstreak = 0;
     }
@@ -466,6 +574,21 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
       W->g[r] = W->gt[r];
       if (r < 12) continue;
       if (lb == ub) { W->y[r] += alpha * (W->yn[r] - W->y[r]); continue; }
+      if (feas) {
+        s = W->s[r] + alpha * W->ds[r];
+        if (lb > -INFINITY) {
+          const double n = W->en[r] + alpha * W->den[r], a = s - lb + n;
+          zl = W->zL[r] + a_du * W->dzL[r]; zl = fmin(fmax(zl, mu / (1e10 * a)), 1e10 * mu / a);
+          W->wn[r] = fmin(fmax(W->wn[r] + a_du * W->dwn[r], mu / (1e10 * n)), 1e10 * mu / n); W->en[r] = n;
+        }
+        if (ub < INFINITY) {
+          const double q = W->ep[r] + alpha * W->dep[r], b = ub + q - s;
+          zu = W->zU[r] + a_du * W->dzU[r]; zu = fmin(fmax(zu, mu / (1e10 * b)), 1e10 * mu / b);
+          W->wp[r] = fmin(fmax(W->wp[r] + a_du * W->dwp[r], mu / (1e10 * q)), 1e10 * mu / q); W->ep[r] = q;
+        }
+        W->s[r] = s; W->zL[r] = zl; W->zU[r] = zu; W->y[r] = zu - zl;
+        continue;
+      }
       s = slack_step(W->s[r], W->ds[r], alpha, lb, ub, clip_now, tau);
       if (use_reset > 0.0) s = slack_reset(s, W->gt[r], lb, ub, use_reset);
       if (lb > -INFINITY) { const double d = s - lb; zl = W->zL[r] + a_du * W->dzL[r]; zl = fmin(fmax(zl, mu / (1e10 * d)), 1e10 * mu / d); }
@@ -480,6 +603,7 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
   if (kkt_out) { lo_kkt(F, W->x, p, W->y, kkt_out); (void)e_du; }
   free(W->x); free(W->xt); free(W->dx); free(gx); free(W->g); free(W->gt); free(W->s); free(W->ds); free(W->zL); free(W->zU);
   free(W->dzL); free(W->dzU); free(W->y); free(W->yn); free(W->lb); free(W->ub); free(W->sig); free(W->rho); free(W->Jst); free(W->Hst);
+  free(W->en); free(W->ep); free(W->wn); free(W->wp); free(W->den); free(W->dep); free(W->dwn); free(W->dwp);
   free(W->M); free(W->mvec); free(W->Ah); free(W->bv); free(W->K); free(W->kap); free(W->Px); free(W->pvx);
   return status;
 }
