@@ -189,12 +189,27 @@ typedef struct {
                             (0.325 vs 0.292 ms of backward sweep per iteration with a CU to itself): the operands are still staged in
                             the fp64 LDS arrays and converted at fetch, and the sweep is latency-bound, not matrix-core-bound
                                                                                                                     */
+  int feas_phase;        /* feasibility (restoration) phase, default 1 (0 in landing_solver_opts_warm).  The reference configures IPOPT, whose
+                            answer to a jammed iterate is its restoration phase; here a solve that would end as LANDING_NUMERICAL or
+                            LANDING_MAX_ITER continues, once, on the ELASTIC problem: every inequality row may be violated by n, q >= 0 at the
+                            price feas_rho (n + q), no objective, same condensation / Riccati sweep / filter line search (the elastic row
+                            enters the condensed system exactly like a slack row, solver_kernels.hip el_step).  Outcomes: a feasible point ->
+                            the interior-point solve restarts from it with max_iter fresh iterations; a KKT point of the elastic problem
+                            with positive violation -> LANDING_INFEASIBLE.  Measured on the reference's production problem (N = 20,
+                            non-uniform grid, 1024 drop states per sampling law, CPU port): law "datagen" 984 -> 996 converged + 27
+                            certified locally infeasible + 1 undecided; law "main" 1020 converged + 4 certified.  Members that converge
+                            without it are untouched (bit-identical)                                                                   */
+  double feas_rho;       /* price of a unit of violation in the elastic problem (IPOPT's restoration phase: 1000)                     */
+  double feas_cert;      /* 1-norm violation above which the elastic KKT point counts as a certificate (1e-4)                        */
 } landing_solver_opts;
 
 /* status codes written per batch member by landing_solve_batch */
 #define LANDING_CONVERGED 0
 #define LANDING_MAX_ITER 1
 #define LANDING_NUMERICAL 2     /* NaN/Inf or regularisation blow-up; other members unaffected */
+#define LANDING_INFEASIBLE 3    /* the feasibility phase (landing_solver_opts::feas_phase) ended at a KKT point of the elastic problem with positive
+                                   violation: a certificate of LOCAL infeasibility (what IPOPT reports as "converged to a point of local
+                                   infeasibility"); x is that point, kkt[0] its largest violation                                            */
 
 void landing_form_default(landing_form* f);
 void landing_solver_opts_default(landing_solver_opts* o);

@@ -452,13 +452,13 @@ __device__ LANDING_INL_TASK void eval_task_hess(const Layout& L, const srbm::Sta
 
 // Jacobian / Hessian nonzeros (CCS order) and gx = grad f + J^T y of one member.
 __device__ LANDING_INL_EVAL_JH void member_eval_jh(const Layout& L, const double* x, const double* p, const double* y,
-                                            double* J, double* H, double* gx, double* tiles = nullptr, const int* edge_map = nullptr) {
-  const int N = L.N;
+                                            double* J, double* H, double* gx, double* tiles = nullptr, const int* edge_map = nullptr, double obj = 1.0) {
+  const int N = L.N;      // obj: 1, or 0 in the solver's feasibility phase (no objective)
   for (int i = threadIdx.x; i < 36; i += blockDim.x) J[L.jx(N) + i] = 1.0;
   for (int i = threadIdx.x; i < 12; i += blockDim.x) {
-    H[L.hx(N) + i] = 2.0 * p[L.o_QN + i];
+    H[L.hx(N) + i] = obj * 2.0 * p[L.o_QN + i];
     const double* lp = y + L.g_stage(N - 1);
-    double v = 2.0 * p[L.o_QN + i] * (x[12 * N + i] - p[12 * N + i]) + lp[dyn_row_of_state(i)];
+    double v = obj * 2.0 * p[L.o_QN + i] * (x[12 * N + i] - p[12 * N + i]) + lp[dyn_row_of_state(i)];
     v += (i < 6) ? y[12 + i] + y[18 + i] : y[24 + i - 6] + y[30 + i - 6];
     gx[12 * N + i] = v;
   }

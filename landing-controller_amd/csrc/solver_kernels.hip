@@ -75,7 +75,7 @@ struct SolverWorkspace {
   int* d_rterm = nullptr; int rlen = 0;
   int *d_ctab = nullptr, *d_ctype = nullptr; int c_ml = 0, c_mid = 0;     // packed per-stage-type condensation tables
   static size_t member_stride(const Layout& L) {
-    return (size_t)4 * L.nx + (size_t)10 * L.ng + L.nnz_jac + L.nnz_hess + (size_t)L.N * RUNC + (size_t)(L.N + 1) * RIC_STRIDE + (size_t)L.N * COND_STRIDE;
+    return (size_t)4 * L.nx + (size_t)14 * L.ng + L.nnz_jac + L.nnz_hess + (size_t)L.N * RUNC + (size_t)(L.N + 1) * RIC_STRIDE + (size_t)L.N * COND_STRIDE;
   }
   int ensure(const Layout& L, int B, hipStream_t stream);
   void release();
@@ -149,6 +149,7 @@ struct MemberMem {
   double *x, *xt, *dx, *gx;
   double *g, *gt, *s, *ds, *zL, *zU, *y, *yn, *sig, *rho;
   double *J, *H, *Hc, *ric, *cond;
+  double *en, *ep, *wn, *wp;      // feasibility phase: violation variables of the lower / upper side of every inequality row and their multipliers
 };
 
 __device__ __forceinline__ MemberMem carve(const Layout& L, double* w) {
@@ -158,7 +159,8 @@ __device__ __forceinline__ MemberMem carve(const Layout& L, double* w) {
   M.zL = w; w += L.ng; M.zU = w; w += L.ng;
   M.y = w; w += L.ng; M.yn = w; w += L.ng;
   M.sig = w; w += L.ng; M.rho = w; w += L.ng;
-  M.J = w; w += L.nnz_jac; M.H = w; w += L.nnz_hess; M.Hc = w; w += (size_t)L.N * RUNC; M.ric = w; w += (size_t)(L.N + 1) * RIC_STRIDE; M.cond = w;
+  M.J = w; w += L.nnz_jac; M.H = w; w += L.nnz_hess; M.Hc = w; w += (size_t)L.N * RUNC; M.ric = w; w += (size_t)(L.N + 1) * RIC_STRIDE; M.cond = w; w += (size_t)L.N * COND_STRIDE;
+  M.en = w; w += L.ng; M.ep = w; w += L.ng; M.wn = w; w += L.ng; M.wp = w;
   return M;
 }
 
@@ -175,8 +177,11 @@ struct IpmState {
   int nfilt, it, status, need_reg_streak, nreset, last_reset_it, ncrawl, clip_k_cur, last_mu_it, cutstreak, wd_count, first_failed, force_step;
   int clip_now, accepted, armijo_step, fact_ok, skipped_zero, attempt;
   int action, flag, fresh, ls_done, need_corr, fallback;
+  // feasibility (restoration) phase, landing_nlp.h: 1 while the elastic problem is being solved; lim = iteration limit in force
+  int feas, feas_used, lim, fact_failed;
+  double c_rn, f_vmax, f_v1;      // |z + w - rho|_inf of the elastic rows; max-norm and 1-norm violation of the inequality rows at x
 };
-enum { ACT_GO = 0, ACT_STOP = 1, ACT_RESET = 2 };
+enum { ACT_GO = 0, ACT_STOP = 1, ACT_RESET = 2, ACT_FEAS = 3, ACT_BACK = 4 };
 
 // LDS of one member
 #ifndef LANDING_REC_LDS
@@ -903,7 +908,7 @@ __device__ LANDING_INL_BACK bool riccati_backward(double delta) {
   if (lane < 12) {
     const int i = lane;
     const int ra = i < 6 ? 12 + i : 24 + (i - 6), rb = i < 6 ? 18 + i : 30 + (i - 6);
-    const double qn2 = 2.0 * p[L.o_QN + i];
+    const double qn2 = S.ks.feas ? 0.0 : 2.0 * p[L.o_QN + i];      // (the feasibility phase has no objective)
     S.P[i * PS + i] = qn2 + M.sig[ra] + M.sig[rb] + delta;
     S.pv[i] = qn2 * (M.x[12 * N + i] - p[12 * N + i]) + M.rho[ra] + M.rho[rb];
     double* rec = M.ric + (size_t)N * RIC_STRIDE;      // record N: P_N (diag), p_N
@@ -1141,6 +1146,23 @@ __device__ __noinline__ double rc_f(const double* x) {                 // runnin
   return f;
 }
 
+// ---- feasibility (restoration) phase: one side of an elastic inequality row ------------------------------------------------------
+// The row  lb <= s  becomes  a = s - lb + n >= 0,  n >= 0  with the price rho_pen * n  (upper side: b = ub + q - s, q >= 0); multipliers
+// z (of a >= 0) and w (of n >= 0), stationarity  rho_pen - z - w = 0.  Eliminating (dn, dw) from the primal-dual Newton system leaves
+//   dz = c - sd * (z / D) ds,   D = a + z n / w,   c = (mu - a z - z (mu - n w + n (z + w - rho_pen)) / w) / D
+// (sd = +1 lower side, -1 upper side: d(dist) = sd ds + dn), i.e. the row enters the condensed system with sigma = z / D exactly like
+// a plain slack row with sigma = z / d -- condensation, Riccati sweep and forward sweep are those of the normal iteration.
+struct ElStep { double dz, dw, dn, da; };
+__device__ __forceinline__ ElStep el_step(double sd, double a, double n, double z, double w, double mu, double rho_pen, double ds) {
+  ElStep e;
+  const double D = a + z * n / w, rn = z + w - rho_pen;
+  e.dz = (mu - a * z - z * (mu - n * w + n * rn) / w - sd * z * ds) / D;
+  e.dw = -e.dz - rn;
+  e.dn = (mu - n * w - n * e.dw) / w;
+  e.da = sd * ds + e.dn;
+  return e;
+}
+
 // Workgroups per CU the register budget is sized for.  Measured on MI355X (N = 40, end of round 1, IPRA off): 2 per CU
 // (256 VGPRs) beats 3 (168) at batch 1024 -- 5220 vs 4760 NLPs/s -- and ties beyond (2048: 5410 vs 5330, 8192: 7080 vs
 // 7050); 4 per CU (128 VGPRs, and the 46 KB of LDS would only fit three) is far behind.  Every phase is latency-bound:
@@ -1281,7 +1303,46 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
   // primal / complementarity errors, Sigma and rho of the CURRENT point for barrier parameter mu_ (one pass over the
   // rows; the accept pass below produces the same quantities for the next iterate, so this runs only at the start,
   // after a multiplier reset and when mu changes).  Leaves c_pr, c_co, c_cm, |y|_1, |z|_1 and the number of bound multipliers in K.
+  // the same for the elastic problem of the feasibility phase (plain row loops: the phase is rare); also leaves the violation of the
+  // inequality rows at x (max norm, 1-norm) and |z + w - rho_pen|_inf in K
+  auto feas_point_pass = [&](double mu_) {
+    const double frho = o.feas_rho;
+    double pr = 0.0, co = 0.0, cm = 0.0, rn = 0.0, ys = 0.0, zs = 0.0, nz = 0.0, vmax = 0.0, v1 = 0.0;
+    for (int r = lane; r < ng; r += NT) {
+      const double lb = S.bnd_lb[bidx(r)], ub = S.bnd_ub[bidx(r)];
+      double sg = 0.0, rh = 0.0;
+      if (r >= 12) {
+        const double g = r_g[r];
+        ys += fabs(r_y[r]);
+        if (lb == ub) pr = fmax(pr, fabs(g - lb));
+        else {
+          const double s = r_s[r], v = fmax(fmax(lb - g, g - ub), 0.0);
+          pr = fmax(pr, fabs(g - s)); vmax = fmax(vmax, v); v1 += v;
+          if (lb > -INF) {
+            const double n = M.en[r], a = s - lb + n, z = r_zL[r], w = M.wn[r], D = a + z * n / w;
+            const double c = (mu_ - a * z - z * (mu_ - n * w + n * (z + w - frho)) / w) / D;
+            co = fmax(co, fmax(a * z, n * w)); cm = fmax(cm, fmax(fabs(a * z - mu_), fabs(n * w - mu_))); rn = fmax(rn, fabs(z + w - frho));
+            sg += z / D; rh -= z + c; zs += z; nz += 1.0;
+          }
+          if (ub < INF) {
+            const double q = M.ep[r], b = ub + q - s, z = r_zU[r], w = M.wp[r], D = b + z * q / w;
+            const double c = (mu_ - b * z - z * (mu_ - q * w + q * (z + w - frho)) / w) / D;
+            co = fmax(co, fmax(b * z, q * w)); cm = fmax(cm, fmax(fabs(b * z - mu_), fabs(q * w - mu_))); rn = fmax(rn, fabs(z + w - frho));
+            sg += z / D; rh += z + c; zs += z; nz += 1.0;
+          }
+          rh += sg * (g - s);
+        }
+      }
+      r_sig[r] = sg; r_rho[r] = rh;
+    }
+    double v[6] = {pr, co, cm, ys, zs, nz}; const int op[6] = {RMAX, RMAX, RMAX, RSUM, RSUM, RSUM};
+    block_reduce<6>(v, op, S.red);
+    double u[3] = {rn, vmax, v1}; const int op3[3] = {RMAX, RMAX, RSUM};
+    block_reduce<3>(u, op3, S.red);
+    KS_BEGIN_SYNCED() K.c_pr = v[0]; K.c_co = v[1]; K.c_cm = v[2]; K.c_ys = v[3]; K.c_zs = v[4]; K.c_nz = fmax(v[5], 1.0); K.c_rn = u[0]; K.f_vmax = u[1]; K.f_v1 = u[2]; KS_END();
+  };
   auto point_pass = [&](double mu_) {
+    if (K.feas) { feas_point_pass(mu_); return; }
     double pr = 0.0, co = 0.0, cm = 0.0, ys = 0.0, zs = 0.0, nz = 0.0;
     for (int rb = lane; rb < ng; rb += NT * RB) {
       double lbv[RB], ubv[RB], gv[RB], sv[RB], zlv[RB], zuv[RB], yv[RB];
@@ -1320,6 +1381,7 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
     K.nfilt = 0; K.it = 0; K.status = LANDING_MAX_ITER; K.need_reg_streak = 0; K.nreset = 0; K.first_failed = 0;
     K.last_reset_it = 0; K.ncrawl = 0; K.clip_k_cur = o.clip_k; K.last_mu_it = 0; K.cutstreak = 0; K.wd_count = 0; K.force_step = 0;
     K.e_pr = 0; K.e_du = 0; K.e_co = 0;
+    K.feas = 0; K.feas_used = 0; K.fact_failed = 0; K.lim = o.max_iter; K.c_rn = 0.0; K.f_vmax = 0.0; K.f_v1 = 0.0;
   }
   __syncthreads();
   // the lane = stage phases are called by the lanes that have work only: the callee-saved registers an out-of-line function touches
@@ -1333,9 +1395,9 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
     // tiles in the dead G array -- and is slower: 0.049 vs 0.039 ms alone, 0.094 vs 0.085 under load; every lane then runs the
     // full middle-stage stream and the wave serialises on 24 tile flushes, while the scattered stores of this version drain
     // asynchronously behind the arithmetic of the other two waves)
-    if (lane < 192 && (lane & 63) < nst) member_eval_jh(L, M.x, p, M.y, M.J, M.H, M.gx);
+    if (lane < 192 && (lane & 63) < nst) member_eval_jh(L, M.x, p, M.y, M.J, M.H, M.gx, nullptr, nullptr, K.feas ? 0.0 : 1.0);
     __syncthreads();
-    if (L.run_cost) { rc_add_grad(); __syncthreads(); }   // objective gradient of the stage variables (the terminal part is in member_eval_jh)
+    if (L.run_cost && !K.feas) { rc_add_grad(); __syncthreads(); }   // objective gradient of the stage variables (the terminal part is in member_eval_jh)
     PROF_ADD(PH_EVAL, K.tp);
     // ---------------------------------------------------------------- optimality error (unscaled)
     if (K.it == 0) point_pass(K.mu);
@@ -1346,12 +1408,31 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
       KS_BEGIN_SYNCED()      // ---- what happens with this iterate: stop, restart, or another iteration
         const double pr = K.c_pr, co = K.c_co, mu = K.mu;
         const int it = K.it, nreset = K.nreset;
+        if (K.feas) du = fmax(du, K.c_rn);      // the elastic problem has the extra stationarity rows rho_pen - z - w = 0
         K.e_pr = pr; K.e_du = du; K.e_co = co;
         int act = ACT_GO;
-        if (!(du < 1e300) || !(pr < 1e300) || !(co < 1e300)) { K.status = LANDING_NUMERICAL; act = ACT_STOP; }
+        bool give_up = false;
+        if (K.feas) {
+          // feasibility phase: a feasible point (or an elastic KKT point with negligible violation) restarts the solve from here, an elastic
+          // KKT point with positive violation is the certificate of local infeasibility
+          const bool conv = fmax(du, fmax(pr, co)) <= o.tol;
+          if (!(du < 1e300) || !(pr < 1e300) || !(co < 1e300)) { K.status = LANDING_NUMERICAL; act = ACT_STOP; }
+          else if (K.f_vmax <= 1e-9 && pr <= o.tol) act = ACT_BACK;
+          else if (conv && K.f_v1 > o.feas_cert) { K.status = LANDING_INFEASIBLE; act = ACT_STOP; }
+          else if (conv) act = ACT_BACK;
+          else if (it == K.lim) act = ACT_STOP;
+          if (act == ACT_BACK) {
+            K.feas = 0; K.lim = it + o.max_iter; K.status = LANDING_MAX_ITER;
+            K.mu = o.mu_init; K.nfilt = 0; K.delta_last = 0.0; K.need_reg_streak = 0; K.wd_count = 0; K.th_max = 0.0; K.nreset = 0; K.last_reset_it = it; K.ncrawl = 0;
+            K.cutstreak = 0; K.force_step = 0;
+            K.it = it + 1;
+          }
+        }
+        else if (K.fact_failed) { K.status = LANDING_NUMERICAL; K.fact_failed = 0; give_up = true; }      // no regularisation made the last step computable
+        else if (!(du < 1e300) || !(pr < 1e300) || !(co < 1e300)) { K.status = LANDING_NUMERICAL; give_up = true; }
         else if (fmax(du, fmax(pr, co)) <= o.tol) { K.status = LANDING_CONVERGED; act = ACT_STOP; }
-        else if (it == o.max_iter) act = ACT_STOP;
-        else if (du > o.reset_du && nreset >= o.max_resets && o.max_resets > 0) { K.status = LANDING_NUMERICAL; act = ACT_STOP; }   // jammed again: give up
+        else if (it == K.lim) give_up = true;
+        else if (du > o.reset_du && nreset >= o.max_resets && o.max_resets > 0) { K.status = LANDING_NUMERICAL; give_up = true; }   // jammed again: give up
         else {
           // crawling: still in the first barrier problem (mu never decreased) restart_period iterations after the last (re)start
           const bool stalled = o.restart_period > 0 && it - K.last_reset_it >= o.restart_period && mu >= o.mu_init && nreset < o.max_resets && K.ncrawl < ((o.fresh_restart & 4) ? 2 : 1);
@@ -1375,10 +1456,60 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
             K.it = it + 1;
           }
         }
+        if (give_up) {
+          // the solve would end here as NUMERICAL / MAX_ITER: enter the feasibility phase once (landing_solver_opts::feas_phase)
+          if (o.feas_phase && !K.feas_used) {
+            act = ACT_FEAS;
+            K.feas = 1; K.feas_used = 1; K.status = LANDING_MAX_ITER; K.lim = it + o.max_iter;
+            K.mu = o.mu_init; K.nfilt = 0; K.th_max = 0.0; K.delta_last = 0.0; K.need_reg_streak = 0; K.cutstreak = 0; K.force_step = 0; K.wd_count = 0;
+            K.it = it + 1;
+          } else act = ACT_STOP;
+        }
         K.action = act;
       KS_END();
     }
     if (K.action == ACT_STOP) break;
+    if (K.action == ACT_FEAS) {
+      // ---- enter the feasibility phase from the current point (from the caller's initial guess when the iterate is not finite)
+      double big = 0.0;
+      for (int i = lane; i < nx; i += NT) { const double v = fabs(M.x[i]); big = fmax(big, v < 1e6 ? v : 1e300); }
+      big = block_reduce1(big, RMAX, S.red);
+      if (!(big < 1e6)) {
+        for (int i = lane; i < nx; i += NT) {
+          double v = A.x0[(size_t)m * nx + i];
+          if (i < 6) v = p[L.o_q_init + i]; else if (i < 12) v = p[L.o_qd_init + i - 6];
+          M.x[i] = v;
+        }
+      }
+      __syncthreads();
+      member_eval_g_rare(L, M.x, p, M.g);
+      if (L.run_cost) for (int e = lane; e < N * RUNC; e += NT) M.Hc[e] = 0.0;      // no objective: its constant Hessian entries leave the condensation
+      __syncthreads();
+      {
+        const double frho = o.feas_rho, mu0 = o.mu_init;
+        for (int r = lane + 12; r < ng; r += NT) {
+          const double lb = S.bnd_lb[bidx(r)], ub = S.bnd_ub[bidx(r)], g = M.g[r];
+          if (lb == ub) { M.y[r] = 0.0; continue; }
+          // slack on the row value; violation variables sized so that both distances start at a comfortable value
+          double zl = 0.0, zu = 0.0, n0 = 0.0, q0 = 0.0, wl = 0.0, wu = 0.0;
+          if (lb > -INF) { const double v = lb - g; n0 = fmax(v, 0.0) + fmax(1e-2, 0.1 * fabs(v)); zl = fmin(mu0 / (g - lb + n0), 0.5 * frho); wl = frho - zl; }
+          if (ub < INF) { const double v = g - ub; q0 = fmax(v, 0.0) + fmax(1e-2, 0.1 * fabs(v)); zu = fmin(mu0 / (ub + q0 - g), 0.5 * frho); wu = frho - zu; }
+          M.s[r] = g; M.en[r] = n0; M.ep[r] = q0; M.zL[r] = zl; M.zU[r] = zu; M.wn[r] = wl; M.wp[r] = wu; M.y[r] = zu - zl;
+        }
+      }
+      __syncthreads();
+      point_pass(K.mu);
+      continue;
+    }
+    if (K.action == ACT_BACK) {
+      // ---- a feasible point (or negligible violation): the interior-point solve restarts from it
+      if (L.run_cost) rc_init_hc();
+      for (int r = lane + 12; r < ng; r += NT) if (S.bnd_lb[bidx(r)] == S.bnd_ub[bidx(r)]) M.y[r] = 0.0;
+      __syncthreads();
+      init_slacks();
+      point_pass(K.mu);
+      continue;
+    }
     if (K.action == ACT_RESET) {
       if (K.fresh) {
         for (int i = lane; i < nx; i += NT) {
@@ -1418,7 +1549,7 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
     PROF_ADD(PH_ERR, K.tp);
 
     condense(A.ctab, A.c_ml, A.c_mid);
-    if (L.run_cost) { rc_add_gamma(); __syncthreads(); }   // ... and in the stage right-hand sides gamma_k (w order X, c, f)
+    if (L.run_cost && !K.feas) { rc_add_gamma(); __syncthreads(); }   // ... and in the stage right-hand sides gamma_k (w order X, c, f)
     PROF_ADD(PH_SIGRHO, K.tp);
     // ================================================================ Riccati factorisation with inertia correction
     // IPOPT's inertia-correction schedule (delta_w = 0 first, then max(1e-20, delta_last/3), then x8 / x100),
@@ -1448,7 +1579,11 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
       KS_END();
       if (!K.flag) break;
     }
-    if (!K.fact_ok) { KS_BEGIN() K.status = LANDING_NUMERICAL; KS_END(); break; }
+    if (!K.fact_ok) {      // the step cannot be computed: give up (status NUMERICAL), or -- once -- continue in the feasibility phase
+      KS_BEGIN() K.status = LANDING_NUMERICAL; K.fact_failed = (o.feas_phase && !K.feas_used && !K.feas) ? 1 : 0; KS_END();
+      if (K.fact_failed) continue;
+      break;
+    }
     KS_BEGIN()
       if (K.delta > 0.0) { K.delta_last = K.delta; K.need_reg_streak++; } else K.need_reg_streak = 0;
       if (K.need_reg_streak > 8) K.need_reg_streak = 0;      // probe delta = 0 again from time to time
@@ -1466,9 +1601,32 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
     // ratio |ds| / distance; the slacks with a larger one stop at (1 - tau) of their distance (omt > 0 in the passes below)
     {
       const double mu = K.mu;
-      const bool clip_now = K.clip_k_cur > 1 && K.c_pr > o.clip_until;
+      const bool feas = K.feas != 0;
+      const bool clip_now = !feas && K.clip_k_cur > 1 && K.c_pr > o.clip_until;
       double top[4] = {0.0, 0.0, 0.0, 0.0};
       double m_pr = 0.0, m_du = 0.0, th0 = 0.0, bar = 0.0, dphi = 0.0;
+      double f0 = 0.0;
+      if (feas) {      // elastic rows: steps of the eliminated variables, step bounds (a, n, b, q and their multipliers stay positive), merit data
+        const double frho = o.feas_rho;
+        for (int r = lane + 12; r < ng; r += NT) {
+          const double lb = S.bnd_lb[bidx(r)], ub = S.bnd_ub[bidx(r)], g = r_g[r];
+          if (lb == ub) { th0 += fabs(g - lb); continue; }
+          const double s = r_s[r], ds = r_ds[r];
+          th0 += fabs(g - s);
+          if (lb > -INF) {
+            const double n = M.en[r], a = s - lb + n, z = r_zL[r], w = M.wn[r];
+            const ElStep e = el_step(1.0, a, n, z, w, mu, frho, ds);
+            m_pr = fmax(m_pr, fmax(-e.da / a, -e.dn / n)); m_du = fmax(m_du, fmax(-e.dz / z, -e.dw / w));
+            bar -= log(a * n); dphi += frho * e.dn - mu * (e.da / a + e.dn / n); f0 += frho * n;
+          }
+          if (ub < INF) {
+            const double q = M.ep[r], b = ub + q - s, z = r_zU[r], w = M.wp[r];
+            const ElStep e = el_step(-1.0, b, q, z, w, mu, frho, ds);
+            m_pr = fmax(m_pr, fmax(-e.da / b, -e.dn / q)); m_du = fmax(m_du, fmax(-e.dz / z, -e.dw / w));
+            bar -= log(b * q); dphi += frho * e.dn - mu * (e.da / b + e.dn / q); f0 += frho * q;
+          }
+        }
+      } else
       for (int rb = lane + 12; rb < ng; rb += NT * RB) {
         double lbv[RB], ubv[RB], gv[RB], sv[RB], dsv[RB], zlv[RB], zuv[RB];
 #pragma unroll
@@ -1498,12 +1656,11 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
           bar -= log(dprod);
         }
       }
-      double f0 = 0.0;
-      if (lane < 12) {
+      if (lane < 12 && !feas) {
         const double d = M.x[12 * N + lane] - p[12 * N + lane], qn = p[L.o_QN + lane];
         f0 = qn * d * d; dphi += 2.0 * qn * d * M.dx[12 * N + lane];
       }
-      if (L.run_cost) rc_f_dphi(f0, dphi);
+      if (L.run_cost && !feas) rc_f_dphi(f0, dphi);
       double v[6] = {m_pr, m_du, th0, bar, dphi, f0}; const int op[6] = {RMAX, RMAX, RSUM, RSUM, RSUM, RSUM};
       block_reduce<6>(v, op, S.red);
       if (clip_now) block_top4(top, S.red);         // (uniform: clip_now comes from K)
@@ -1533,6 +1690,18 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
       if (lane < nst) member_eval_g(L, M.xt, p, M.gt);
       __syncthreads();
       double tht = 0.0, bt = 0.0, ft = 0.0;
+      const bool feas = K.feas != 0;
+      if (feas) {      // elastic rows at the trial step length: theta over all rows, merit = rho_pen (n + q) - mu sum of logs (mu applied below)
+        const double frho = o.feas_rho;
+        for (int r = lane + 12; r < ng; r += NT) {
+          const double lb = S.bnd_lb[bidx(r)], ub = S.bnd_ub[bidx(r)], g = r_gt[r];
+          if (lb == ub) { tht += fabs(g - lb); continue; }
+          const double s0 = r_s[r], ds = r_ds[r], s = s0 + alpha * ds;
+          tht += fabs(g - s);
+          if (lb > -INF) { const double n0 = M.en[r]; const ElStep e = el_step(1.0, s0 - lb + n0, n0, r_zL[r], M.wn[r], mu, frho, ds); const double n = n0 + alpha * e.dn; bt -= log((s - lb + n) * n); ft += frho * n; }
+          if (ub < INF) { const double q0 = M.ep[r]; const ElStep e = el_step(-1.0, ub + q0 - s0, q0, r_zU[r], M.wp[r], mu, frho, ds); const double q = q0 + alpha * e.dn; bt -= log((ub + q - s) * q); ft += frho * q; }
+        }
+      } else
       for (int rb = lane + 12; rb < ng; rb += NT * RB) {
         double lbv[RB], ubv[RB], gv[RB], sv[RB], dsv[RB];
 #pragma unroll
@@ -1548,8 +1717,8 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
           bt -= log((lb > -INF ? s - lb : 1.0) * (ub < INF ? ub - s : 1.0));
         }
       }
-      if (lane < 12) { const double d = M.xt[12 * N + lane] - p[12 * N + lane]; ft = p[L.o_QN + lane] * d * d; }
-      if (L.run_cost) ft += rc_f(M.xt);
+      if (lane < 12 && !feas) { const double d = M.xt[12 * N + lane] - p[12 * N + lane]; ft = p[L.o_QN + lane] * d * d; }
+      if (L.run_cost && !feas) ft += rc_f(M.xt);
       { double v[3] = {tht, bt, ft}; const int op[3] = {RSUM, RSUM, RSUM}; block_reduce<3>(v, op, S.red); tht = v[0]; bt = v[1]; ft = v[2]; }
       KS_BEGIN_SYNCED()
         const double th_min = 1e-4, th_floor = o.theta_floor * o.tol;     // violations below the tolerance count as equal (landing_nlp.h)
@@ -1571,7 +1740,7 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
         if (accepted) done = true;
         K.need_corr = 0;
         if (!done) {
-          if (o.slack_corr > 0.0 && alpha == K.a_pr && tht >= th0) { K.need_corr = 1; K.ft = ft; }
+          if (o.slack_corr > 0.0 && !K.feas && alpha == K.a_pr && tht >= th0) { K.need_corr = 1; K.ft = ft; }
           else { K.alpha = alpha * 0.5; if (!(K.alpha > 1e-10)) done = true; }
         }
         K.accepted = accepted ? 1 : 0;
@@ -1612,7 +1781,7 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
     KS_BEGIN()
       const double a_pr = K.a_pr;
       K.force_step = 0;
-      if (o.watchdog > 0) {      // successive iterations with step lengths <= 1/16 of the step to the boundary arm the watchdog
+      if (o.watchdog > 0 && !K.feas) {      // successive iterations with step lengths <= 1/16 of the step to the boundary arm the watchdog
         if (K.accepted && K.alpha <= 0.0625 * a_pr) { if (++K.cutstreak >= o.watchdog) { K.force_step = 1; K.cutstreak = 0; K.wd_count++; } }
         else K.cutstreak = 0;
       }
@@ -1644,7 +1813,35 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
     // ================================================================ accept the trial point; the same pass produces the
     // primal / complementarity errors, Sigma and rho of the new iterate (what point_pass computes)
     for (int i = lane; i < nx; i += NT) M.x[i] = M.xt[i];
-    {
+    if (K.feas) {      // elastic rows: primal variables with alpha, multipliers with a_du (kept inside the kappa_Sigma band), then the quantities of the new point
+      const double alpha = K.alpha, a_du = K.a_du, mu = K.mu, frho = o.feas_rho;
+      for (int r = lane; r < ng; r += NT) {
+        const double lb = S.bnd_lb[bidx(r)], ub = S.bnd_ub[bidx(r)];
+        r_g[r] = r_gt[r];
+        if (r < 12) continue;
+        if (lb == ub) { r_y[r] = r_y[r] + alpha * (r_yn[r] - r_y[r]); continue; }
+        const double s0 = r_s[r], ds = r_ds[r], s = s0 + alpha * ds;
+        double zl = 0.0, zu = 0.0;
+        if (lb > -INF) {
+          const double n0 = M.en[r], z0 = r_zL[r], w0 = M.wn[r];
+          const ElStep e = el_step(1.0, s0 - lb + n0, n0, z0, w0, mu, frho, ds);
+          const double n = n0 + alpha * e.dn, a = s - lb + n;
+          zl = fmin(fmax(z0 + a_du * e.dz, 1e-10 * mu / a), 1e10 * mu / a);
+          M.wn[r] = fmin(fmax(w0 + a_du * e.dw, 1e-10 * mu / n), 1e10 * mu / n); M.en[r] = n;
+        }
+        if (ub < INF) {
+          const double q0 = M.ep[r], z0 = r_zU[r], w0 = M.wp[r];
+          const ElStep e = el_step(-1.0, ub + q0 - s0, q0, z0, w0, mu, frho, ds);
+          const double q = q0 + alpha * e.dn, b = ub + q - s;
+          zu = fmin(fmax(z0 + a_du * e.dz, 1e-10 * mu / b), 1e10 * mu / b);
+          M.wp[r] = fmin(fmax(w0 + a_du * e.dw, 1e-10 * mu / q), 1e10 * mu / q); M.ep[r] = q;
+        }
+        r_s[r] = s; r_zL[r] = zl; r_zU[r] = zu; r_y[r] = zu - zl;
+      }
+      __syncthreads();
+      feas_point_pass(mu);
+      KS_BEGIN() K.it++; KS_END();
+    } else {
       const double alpha = K.alpha, a_du = K.a_du, omt = K.omt, mu = K.mu, s_corr = K.s_corr;
       double npr = 0.0, nco = 0.0, ncm = 0.0, nys = 0.0, nzs = 0.0, nnz = 0.0;
       for (int rb = lane; rb < ng; rb += NT * RB) {

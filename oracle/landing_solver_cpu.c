@@ -50,7 +50,7 @@ void lo_solver_opts_default(lo_solver_opts* o) {
   o->kappa_eps = 10.0; o->kappa_mu = 0.2; o->theta_mu = 1.5; o->max_resets = 8; o->reset_du = 1e9;
   o->delta_init = 1e-4; o->delta_inc_first = 10.0; o->delta_inc = 4.0; o->delta_dec = 0.5; o->tau_min = 0.9; o->alpha_fallback = 1e-2; o->restart_period = 75; o->reset_delta = 1e5;
   o->barrier_smax = 1.0; o->watchdog = 3; o->slack_corr = 0.9; o->dual_step_cap = 1.0; o->fresh_restart = 9; o->theta_floor = 30.0; o->clip_k = 4; o->clip_until = 0.03;
-  o->feas_phase = 0; o->feas_rho = 1000.0; o->feas_cert = 1e-4;
+  o->feas_phase = 1; o->feas_rho = 1000.0; o->feas_cert = 1e-4;
 }
 
 #define NW 48
@@ -204,7 +204,7 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
   double mu = op->mu_init, delta_last = 0.0, th_max = 0.0, e_du = 0.0; int clip_k_cur = op->clip_k;
   double filt_th[64], filt_ph[64];
   double* gx;
-  int feas = 0, feas_used = 0, lim = op->max_iter; const double frho = op->feas_rho;
+  int feas = 0, feas_used = 0, fact_failed = 0, lim = op->max_iter; const double frho = op->feas_rho;
   lo_param_offsets_form(F, &o);
   W->N = N; W->nx = nx; W->ng = ng; W->feas = 0;
   W->en = dalloc(ng); W->ep = dalloc(ng); W->wn = dalloc(ng); W->wp = dalloc(ng); W->den = dalloc(ng); W->dep = dalloc(ng); W->dwn = dalloc(ng); W->dwp = dalloc(ng);
@@ -289,7 +289,8 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
     }
     {
       int give_up = 0;
-      if (!(du < 1e300) || !(pr < 1e300) || !(co < 1e300)) { status = 2; give_up = 1; }
+      if (fact_failed) { status = 2; fact_failed = 0; give_up = 1; }      /* no regularisation made the last step computable */
+      else if (!(du < 1e300) || !(pr < 1e300) || !(co < 1e300)) { status = 2; give_up = 1; }
       else if (fmax(du, fmax(pr, co)) <= op->tol) { status = 0; break; }
       else if (it == lim) give_up = 1;
       else if (du > op->reset_du && nreset >= op->max_resets && op->max_resets > 0) { status = 2; give_up = 1; }
@@ -414,7 +415,7 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
       counters[0]++;
       fact_ok = riccati_backward(F, p, W, delta, &o, sig);
     }
-    if (!fact_ok) { status = 2; break; }
+    if (!fact_ok) { status = 2; if (op->feas_phase && !feas_used && !feas) { fact_failed = 1; continue; } break; }
     if (delta > 0.0) { delta_last = delta; streak++; } else streak = 0;
     if (streak > 8) streak = 0;
     /* forward sweep */

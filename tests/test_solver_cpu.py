@@ -58,13 +58,13 @@ def test_emulated_kernel_follows_cpu_port(emu_lib, oracle_mod, clip_k, theta_flo
     O = oracle_mod.Oracle(N)
     P, X0, _, _ = lc("problem").make_batch(1, N, 0.6, seed=1)
     L = lc("capi").LandingLib(N, lib_path=emu_lib)
-    o = L.default_opts(); o.max_iter = K; o.clip_k = clip_k; o.theta_floor = theta_floor
+    o = L.default_opts(); o.max_iter = K; o.clip_k = clip_k; o.theta_floor = theta_floor; o.feas_phase = 0      # (K iterations, then stop: no feasibility phase)
     classic = dict(dual_step_cap=0.0, fresh_restart=0, slack_corr=0.0, watchdog=0, barrier_smax=0.0) if clip_k == 1 else {}
     for k_, v_ in classic.items():
         setattr(o, k_, v_)
     assert (L.default_opts().clip_k, L.default_opts().theta_floor) == (4, 30.0)
     g = L.solve_host(P, X0, o)
-    c = oracle_mod.cpu_solve_batch(O, P, X0, threads=1, max_iter=K, clip_k=clip_k, theta_floor=theta_floor, **classic)
+    c = oracle_mod.cpu_solve_batch(O, P, X0, threads=1, max_iter=K, clip_k=clip_k, theta_floor=theta_floor, feas_phase=0, **classic)
     assert g["status"][0] == 1 and c["status"][0] == 1 and g["iters"][0] == c["iters"][0] == K
     assert np.max(np.abs(g["x"][0] - c["x"][0])) < 1e-7 * max(1.0, np.max(np.abs(c["x"][0])))
     assert np.max(np.abs(g["lam_g"][0] - c["lam_g"][0])) < 1e-6 * max(1.0, np.max(np.abs(c["lam_g"][0])))
@@ -98,9 +98,9 @@ def test_emulated_kernel_follows_cpu_port_with_running_cost(emu_lib, oracle_mod)
     O = oracle_mod.Oracle(N, run_cost=RUN_COST)
     P, X0, _, _ = lc("problem").make_batch(1, N, 0.6, seed=1)
     L = lc("capi").LandingLib(N, lib_path=emu_lib, run_cost=RUN_COST)
-    o = L.default_opts(); o.max_iter = K
+    o = L.default_opts(); o.max_iter = K; o.feas_phase = 0
     g = L.solve_host(P, X0, o)
-    c = oracle_mod.cpu_solve_batch(O, P, X0, threads=1, max_iter=K)
+    c = oracle_mod.cpu_solve_batch(O, P, X0, threads=1, max_iter=K, feas_phase=0)
     assert g["iters"][0] == c["iters"][0] == K
     assert np.max(np.abs(g["x"][0] - c["x"][0])) < 1e-7 * max(1.0, np.max(np.abs(c["x"][0])))
     assert np.allclose(g["kkt"][0], O.kkt(g["x"][0], P[0], g["lam_g"][0]), rtol=1e-6, atol=1e-12)
@@ -115,7 +115,7 @@ def test_emulated_fp32_factor_follows_and_converges(emu_lib, oracle_mod):
     O = oracle_mod.Oracle(N)
     P, X0, _, _ = lc("problem").make_batch(1, N, 0.6, seed=1)
     L = lc("capi").LandingLib(N, lib_path=emu_lib)
-    o = L.default_opts(); o.max_iter = 5
+    o = L.default_opts(); o.max_iter = 5; o.feas_phase = 0
     a = L.solve_host(P, X0, o)
     o.factor_fp32 = 1
     b = L.solve_host(P, X0, o)
@@ -141,3 +141,36 @@ def test_clip_rule_changes_the_path_and_shortens_it(oracle_mod):
     for r in (a, b):
         for m in range(8):
             assert O.kkt(r["x"][m], P[m], r["lam_g"][m]).max() <= 1e-6 * 1.0001
+
+
+def test_feasibility_phase_rescues_or_certifies(oracle_mod):
+    """landing_solver_opts::feas_phase (the restoration phase of the reference's IPOPT, as a solve of the elastic problem with the same
+    machinery): on a hard small-horizon batch the emulated kernel follows the CPU port -- members that ended NUMERICAL / MAX_ITER are either
+    rescued (KKT <= 1e-6 under the oracle's functions) or certified locally infeasible (status 3: equality rows met, positive violation that
+    equals the kernel's report); members that converge without the phase are the same bits with it."""
+    subprocess.run(["make", "-C", os.path.join(PKG, "csrc"), "emu"], check=True, capture_output=True)
+    N, B = 10, 6
+    O = oracle_mod.Oracle(N)
+    L = lc("capi").LandingLib(N, lib_path=os.path.join(ROOT, "tests", "emu", "liblanding_emu.so"))
+    P, X0, _, _ = lc("problem").make_batch(B, N, 0.6, seed=3)
+    keep = [1, 2, 5]; P, X0, B = P[keep], X0[keep], 3      # (one member of each kind: certified, rescued, converged anyway -- the emulation is slow)
+    o = L.default_opts(); o.max_iter = 150
+    assert o.feas_phase == 1 and o.feas_rho == 1000.0
+    r1 = L.solve_host(P, X0, o)
+    o.feas_phase = 0
+    r0 = L.solve_host(P, X0, o)
+    c1 = oracle_mod.cpu_solve_batch(O, P, X0, threads=4, max_iter=150, feas_phase=1)
+    assert (r0["status"] != 0).sum() == 2                                    # two of the three fail without the phase
+    assert np.array_equal(r1["status"], c1["status"]), (r1["status"], c1["status"])
+    assert (r1["status"] == 0).sum() > (r0["status"] == 0).sum() and (r1["status"] == 3).sum() >= 1
+    same = r0["status"] == 0
+    assert np.array_equal(r0["x"][same], r1["x"][same]) and np.array_equal(r0["iters"][same], r1["iters"][same])
+    for b in range(B):
+        if r1["status"][b] == 0:
+            assert O.kkt(r1["x"][b], P[b], r1["lam_g"][b]).max() <= 1e-6 * 1.0001
+        if r1["status"][b] == 3:
+            g = O.g(r1["x"][b], P[b]); lb, ub = O.bounds(P[b]); eq = lb == ub
+            viol = np.maximum(np.maximum(lb - g, g - ub), 0.0)
+            assert np.abs(g[eq] - lb[eq]).max() <= 1e-6 and abs(viol.max() - r1["kkt"][b, 0]) <= 1e-12 and viol.sum() > 1e-4
+            assert np.abs(r1["x"][b] - c1["x"][b]).max() <= 1e-6             # the CPU port ends at the same elastic KKT point
+    L.close()
