@@ -69,7 +69,7 @@ def test_mex_gateway_validates_broadcasts_and_takes_options(libs, tmp_path):
     N, B = 6, 3
     gw = MexGateway(tmp_path, os.path.dirname(libs[1]), "landing_emu")
     args = P.make_args21(B, N, 0.6, seed=4)
-    few = dict(max_iter=3)
+    few = dict(max_iter=3, feas_phase=0)
     full = gw.call(N, args, capi.ARGS21, opts=few)
     assert (full["iters"] == 3).all() and (full["status"] == 1).all()          # the option arrived (3 iterations, LANDING_MAX_ITER)
     # shared constants as 6x1 / 1x1 arrays, exactly as generate_training_data_automated.m:130-136 passes them

@@ -19,7 +19,7 @@ P, X0, _, _ = problem.make_batch(2, N, 0.6, seed=3)
 L = capi.LandingLib(N, lib_path=%r)
 o = L.default_opts(); o.max_iter = K
 g = L.solve_host(P, X0, o)
-assert g["iters"].tolist() == [K, K], g["iters"]
+assert g["iters"].tolist() == [2 * K, 2 * K], g["iters"]      # K interior-point iterations, then K of the feasibility phase (its elastic row passes run under the sanitizers too)
 assert np.isfinite(g["x"]).all() and np.isfinite(g["kkt"]).all()
 e = L.eval_host(X0, P, np.ones(2), np.ones((2, L.ng)))
 assert all(np.isfinite(v).all() for v in e.values())
