@@ -49,8 +49,9 @@ struct landing_ctx {
   // function layer: the Jacobian, Hessian and residual kernels of one landing_eval_batch call are independent; for large
   // batches they run on two auxiliary streams forked from / joined to the caller's stream so that their ramps and tails overlap
   hipStream_t host_stream = nullptr;  // stream of the *_host entry points (copies + launch), created on first use
-  hipStream_t aux[2] = {nullptr, nullptr};
-  hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
+  hipStream_t aux[3] = {nullptr, nullptr, nullptr};
+  hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
+  bool hess_split = false;           // LANDING_SWEEP_HSPLIT=1: the Hessian stream as two launches (landing_sweep_kernel<3>, <4>) -- measured slower, see below
   bool sweep_concurrent = true;      // Q (576) | F (576) | 1/diag(R) (12) of the last landing_riccati_gains_batch call
   std::mutex mu;      // serialises landing_solve_batch calls on one context (the workspace belongs to the context)
 };
@@ -222,6 +223,10 @@ landing_ctx* landing_create(int N, int device, const landing_form* form) {
   c->L = landing::make_layout(N);
   c->device = device;
   { const char* e = getenv("LANDING_SWEEP_SERIAL"); c->sweep_concurrent = !(e && e[0] == '1'); }
+  // (round 3: the forces half needs 154 VGPRs instead of 256 + 198 and finishes in 190 us, but the other half still takes as long as the
+  // whole stream did and the Jacobian stream slows down -- the sweep is bound by the aggregate of resident waves, not by one stream's latency:
+  // 36-38 % of 8 TB/s against 39.5-41.7 % with the single stream on the same box, profiles/r03_sweep_timeline.txt)
+  { const char* e = getenv("LANDING_SWEEP_HSPLIT"); c->hess_split = (e && e[0] == '1'); }
   {  // positions of the U_k Jacobian entries of stages 0 / N-1 inside the uniform (middle-stage) emission sequence
     struct RecCodes { std::vector<int>* v; void col() {} void put(int r, double) { v->push_back(r); } };
     std::vector<int> cx, cu;
@@ -265,7 +270,7 @@ void landing_destroy(landing_ctx* ctx) {
   if (ctx->d_rc_map) (void)hipFree(ctx->d_rc_map);
   if (ctx->d_h4) (void)hipFree(ctx->d_h4);
   if (ctx->d_fb_scratch) (void)hipFree(ctx->d_fb_scratch);
-  for (int i = 0; i < 2; ++i) { if (ctx->aux[i]) (void)hipStreamDestroy(ctx->aux[i]); if (ctx->ev_join[i]) (void)hipEventDestroy(ctx->ev_join[i]); }
+  for (int i = 0; i < 3; ++i) { if (ctx->aux[i]) (void)hipStreamDestroy(ctx->aux[i]); if (ctx->ev_join[i]) (void)hipEventDestroy(ctx->ev_join[i]); }
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
   if (ctx->host_stream) (void)hipStreamDestroy(ctx->host_stream);
   delete ctx;
@@ -282,27 +287,32 @@ int landing_eval_batch(landing_ctx* ctx, int B, const double* d_x, const double*
   HIP_TRY(hipSetDevice(ctx->device));
   landing::EvalArgs A{d_x, d_p, d_lam_f, d_lam_g, d_f, d_g, d_grad_f, d_jac, d_hess, d_ggx, d_ggp, ctx->d_edge_map, d_g ? 1 : 0};
   if (ctx->L.N < 3) return fail(LANDING_E_ARG, "landing_eval_batch: N >= 3 required");
-  hipStream_t s0 = (hipStream_t)stream, sj = s0, sh = s0;
+  hipStream_t s0 = (hipStream_t)stream, sj = s0, sh = s0, sh2 = s0;
   const bool fork = ctx->sweep_concurrent && B >= 512 && d_jac && d_hess;
   if (fork) {
     std::lock_guard<std::mutex> lock(ctx->mu);
     if (!ctx->aux[0]) {
-      HIP_TRY(hipStreamCreateWithFlags(&ctx->aux[0], hipStreamNonBlocking)); HIP_TRY(hipStreamCreateWithFlags(&ctx->aux[1], hipStreamNonBlocking));
+      for (int i = 0; i < 3; ++i) { HIP_TRY(hipStreamCreateWithFlags(&ctx->aux[i], hipStreamNonBlocking)); HIP_TRY(hipEventCreateWithFlags(&ctx->ev_join[i], hipEventDisableTiming)); }
       HIP_TRY(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
-      HIP_TRY(hipEventCreateWithFlags(&ctx->ev_join[0], hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&ctx->ev_join[1], hipEventDisableTiming));
     }
-    sj = ctx->aux[0]; sh = ctx->aux[1];
+    sj = ctx->aux[0]; sh = ctx->aux[1]; sh2 = ctx->aux[2];
     HIP_TRY(hipEventRecord(ctx->ev_fork, s0));
-    HIP_TRY(hipStreamWaitEvent(sj, ctx->ev_fork, 0)); HIP_TRY(hipStreamWaitEvent(sh, ctx->ev_fork, 0));
+    HIP_TRY(hipStreamWaitEvent(sj, ctx->ev_fork, 0)); HIP_TRY(hipStreamWaitEvent(sh, ctx->ev_fork, 0)); HIP_TRY(hipStreamWaitEvent(sh2, ctx->ev_fork, 0));
   }
-  if (d_hess) hipLaunchKernelGGL(landing::landing_sweep_kernel<1>, dim3(B), dim3(64), 0, sh, ctx->L, B, A);
+  if (d_hess && ctx->hess_split) {
+    hipLaunchKernelGGL(landing::landing_sweep_kernel<3>, dim3(B), dim3(64), 0, sh, ctx->L, B, A);
+    hipLaunchKernelGGL(landing::landing_sweep_kernel<4>, dim3(B), dim3(64), 0, sh2, ctx->L, B, A);
+  } else if (d_hess) hipLaunchKernelGGL(landing::landing_sweep_kernel<1>, dim3(B), dim3(64), 0, sh, ctx->L, B, A);
   if (d_jac) hipLaunchKernelGGL(landing::landing_sweep_kernel<0>, dim3(B), dim3(64), 0, sj, ctx->L, B, A);
   if (d_g) hipLaunchKernelGGL(landing::landing_sweep_kernel<2>, dim3(B), dim3(64), 0, s0, ctx->L, B, A);
-  hipLaunchKernelGGL(landing::landing_sweep_misc_kernel, dim3(B), dim3(64), 0, s0, ctx->L, B, A);
+  // the part of the sweep that needs no stage evaluation has its own light instantiation (eval_kernels.hip)
+  const bool heavy = (ctx->L.run_cost && (d_f || d_grad_f)) || (d_g && !A.g_staged) || d_ggx || d_ggp;
+  if (heavy) hipLaunchKernelGGL(landing::landing_sweep_misc_kernel<false>, dim3(B), dim3(64), 0, s0, ctx->L, B, A);
+  else hipLaunchKernelGGL(landing::landing_sweep_misc_kernel<true>, dim3(B), dim3(64), 0, s0, ctx->L, B, A);
   HIP_TRY(hipGetLastError());
   if (fork) {
-    HIP_TRY(hipEventRecord(ctx->ev_join[0], sj)); HIP_TRY(hipEventRecord(ctx->ev_join[1], sh));
-    HIP_TRY(hipStreamWaitEvent(s0, ctx->ev_join[0], 0)); HIP_TRY(hipStreamWaitEvent(s0, ctx->ev_join[1], 0));
+    HIP_TRY(hipEventRecord(ctx->ev_join[0], sj)); HIP_TRY(hipEventRecord(ctx->ev_join[1], sh)); HIP_TRY(hipEventRecord(ctx->ev_join[2], sh2));
+    for (int i = 0; i < 3; ++i) HIP_TRY(hipStreamWaitEvent(s0, ctx->ev_join[i], 0));
   }
   return 0;
 }
@@ -352,7 +362,7 @@ int landing_eval_hess_rc_batch(landing_ctx* ctx, int B, const double* d_x, const
   hipStream_t s0 = (hipStream_t)stream;
   landing::EvalArgs A{d_x, d_p, d_lam_f, d_lam_g, nullptr, nullptr, nullptr, nullptr, ctx->d_h4, nullptr, nullptr, ctx->d_edge_map, 0};
   hipLaunchKernelGGL(landing::landing_sweep_kernel<1>, dim3(B), dim3(64), 0, s0, L, B, A);
-  hipLaunchKernelGGL(landing::landing_sweep_misc_kernel, dim3(B), dim3(64), 0, s0, L, B, A);     // terminal-cost block of the Hessian
+  hipLaunchKernelGGL(landing::landing_sweep_misc_kernel<true>, dim3(B), dim3(64), 0, s0, L, B, A);     // terminal-cost block of the Hessian
   hipLaunchKernelGGL(landing::landing_hess_rc_kernel, dim3((nrc + 255) / 256, B), dim3(256), 0, s0, L, B, nrc, ctx->d_rc_map, ctx->d_h4, d_p, d_lam_f, d_hess_rc);
   HIP_TRY(hipGetLastError());
   return 0;

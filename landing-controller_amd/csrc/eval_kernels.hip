@@ -107,35 +107,62 @@ constexpr int TILE_LD = 17;
 // write-out of one tile.  Inlined (an out-of-line call makes every write-out wait for its stores at the return), but
 // the position counter is laundered through an empty asm so that the 25 call sites of a stage are not specialised
 // and hoisted into one giant live range (that version spilled 1.9 KB per lane).
+// tile rows whose LDS reads are issued together in the write-out (1 = round 2's loop: one LDS round trip per row).  The Jacobian stream
+// sits at its 256-VGPR bound (2 waves per SIMD): 2; the Hessian stream runs at 1 wave per SIMD with room in the AGPRs and nothing to hide
+// an LDS round trip behind: more; the residual stream has registers to spare.
+#ifndef LANDING_FLUSH_GROUP_J
+#define LANDING_FLUSH_GROUP_J 2
+#endif
+#ifndef LANDING_FLUSH_GROUP_H
+#define LANDING_FLUSH_GROUP_H 5
+#endif
+#ifndef LANDING_FLUSH_GROUP_G
+#define LANDING_FLUSH_GROUP_G 4
+#endif
 template <int KIND>
 __device__ __forceinline__ void tile_flush(const double* tile, double* gbase, const Layout* L, const int* map, int k0, int nrow, int cnt_, int n_) {
   int cnt = cnt_, n = n_;
   LANDING_OPAQUE_UNIFORM(cnt); LANDING_OPAQUE_UNIFORM(n);
   __builtin_amdgcn_wave_barrier();
   const int lane = threadIdx.x & 63, c = lane & 15, N = L->N;
+  constexpr int FG = KIND <= 1 ? LANDING_FLUSH_GROUP_J : (KIND <= 3 ? LANDING_FLUSH_GROUP_H : LANDING_FLUSH_GROUP_G);
   if (c < n) {
+    // a lane writes column c of the tile rows lane>>4, +4, +8, ...; the rows are taken FG at a time with their LDS reads issued
+    // together (round 2 read, waited and stored one row per trip: the write-out was a chain of exposed LDS round trips, as long as the
+    // arithmetic of the stage itself)
 #pragma unroll 1
-    for (int row = lane >> 4; row < nrow; row += 4) {
-      const int k = k0 + row;
-      int pos = cnt - n + c;
-      int seg;
-      if (KIND == 0) seg = L->jx(k);
-      else if (KIND == 1) { seg = L->ju(k); if (k == 0) pos = map[pos]; else if (k == N - 1) pos = map[228 + pos]; }
-      else if (KIND == 2) seg = L->hx(k);
-      else if (KIND == 3) { seg = L->hu(k); if (k == 0) pos = (pos < 72) ? ((pos % 6 == 4) ? -1 : pos - (pos / 6) - (pos % 6 > 4 ? 1 : 0)) : pos - 12; }
-      else {   // KIND 4: residual rows; the last stage has no no-slip rows (80 instead of 104 rows)
-        seg = L->g_stage(k);
-        if (k == N - 1) {
-          if (pos >= 64) pos -= 24;
-          else if (pos >= 16) { const int l = (pos - 16) / 12, t = (pos - 16) % 12; pos = t < 2 ? 16 + 6 * l + t : (t < 8 ? -1 : 16 + 6 * l + t - 6); }
+    for (int row0 = lane >> 4; row0 < nrow; row0 += 4 * FG) {
+      double v[FG];
+#pragma unroll
+      for (int j = 0; j < FG; ++j) { const int row = row0 + 4 * j; v[j] = tile[(row < nrow ? row : row0) * TILE_LD + c]; }
+#pragma unroll
+      for (int j = 0; j < FG; ++j) {
+        const int row = row0 + 4 * j;
+        if (row >= nrow) continue;
+        const int k = k0 + row;
+        int pos = cnt - n + c;
+        int seg;
+        if (KIND == 0) seg = L->jx(k);
+        else if (KIND == 1) { seg = L->ju(k); if (k == 0) pos = map[pos]; else if (k == N - 1) pos = map[228 + pos]; }
+        else if (KIND == 2) seg = L->hx(k);
+        else if (KIND == 3) { seg = L->hu(k); if (k == 0) pos = (pos < 72) ? ((pos % 6 == 4) ? -1 : pos - (pos / 6) - (pos % 6 > 4 ? 1 : 0)) : pos - 12; }
+        else {   // KIND 4: residual rows; the last stage has no no-slip rows (80 instead of 104 rows)
+          seg = L->g_stage(k);
+          if (k == N - 1) {
+            if (pos >= 64) pos -= 24;
+            else if (pos >= 16) { const int l = (pos - 16) / 12, t = (pos - 16) % 12; pos = t < 2 ? 16 + 6 * l + t : (t < 8 ? -1 : 16 + 6 * l + t - 6); }
+          }
         }
+        if (pos >= 0) gbase[seg + pos] = v[j];
       }
-      if (pos >= 0) gbase[seg + pos] = tile[row * TILE_LD + c];
     }
   }
   __builtin_amdgcn_wave_barrier();
 }
-template <int KIND>   // 0: Jacobian X_k columns, 1: Jacobian U_k columns, 2: Hessian X_k columns, 3: Hessian U_k columns, 4: g rows
+// LO, HI: window of the emitted sequence this instance really writes (positions [LO, HI), multiples of 16 or the ends).  The position
+// counter is a compile-time constant at every put() of the unrolled stage code, so outside the window the store AND the arithmetic that
+// produced the value are dead code: the two halves of the split Hessian stream (landing_sweep_kernel<3>, <4>) each compute only their own part.
+template <int KIND, int LO = 0, int HI = (1 << 30)>   // 0: Jacobian X_k columns, 1: Jacobian U_k columns, 2: Hessian X_k columns, 3: Hessian U_k columns, 4: g rows
 struct TileStore {
   double* tile;          // LDS, 64 x TILE_LD
   double* gbase;         // member's J or H array
@@ -145,11 +172,11 @@ struct TileStore {
   __device__ __forceinline__ void col() {}
   __device__ __forceinline__ void put(int, double v) { put(v); }
   __device__ __forceinline__ void put(double v) {
-    tile[(threadIdx.x & 63) * TILE_LD + (cnt & 15)] = v;
+    if (cnt >= LO && cnt < HI) tile[(threadIdx.x & 63) * TILE_LD + (cnt & 15)] = v;
     ++cnt;
-    if ((cnt & 15) == 0) tile_flush<KIND>(tile, gbase, L, map, k0, nrow, cnt, 16);
+    if ((cnt & 15) == 0 && cnt > LO && cnt <= HI) tile_flush<KIND>(tile, gbase, L, map, k0, nrow, cnt, 16);
   }
-  __device__ __forceinline__ void finish() { if (cnt & 15) tile_flush<KIND>(tile, gbase, L, map, k0, nrow, cnt, cnt & 15); }
+  __device__ __forceinline__ void finish() { if ((cnt & 15) && cnt > LO && cnt <= HI) tile_flush<KIND>(tile, gbase, L, map, k0, nrow, cnt, cnt & 15); }
 };
 
 // Jacobian (FAM 0), Hessian (FAM 1) nonzeros or residual rows (FAM 2) of every stage of one member: one wavefront per member, lane = stage,
@@ -158,7 +185,7 @@ struct TileStore {
 // (register budget: the Jacobian stream fits 256 VGPRs -> 2 waves/SIMD; the Hessian stream needs the AGPR overflow
 // of the default bound, capping it costs 750 B of scratch per lane and doubles its time)
 #ifndef LANDING_SWEEP_H_WAVES
-#define LANDING_SWEEP_H_WAVES(FAM) ((FAM) == 1 ? 1 : 2)
+#define LANDING_SWEEP_H_WAVES(FAM) (((FAM) == 1 || (FAM) == 3) ? 1 : 2)
 #endif
 template <int FAM>
 __global__ void __launch_bounds__(64, LANDING_SWEEP_H_WAVES(FAM)) landing_sweep_kernel(Layout L, int B, EvalArgs A) {
@@ -169,6 +196,8 @@ __global__ void __launch_bounds__(64, LANDING_SWEEP_H_WAVES(FAM)) landing_sweep_
   const double* p = A.p + (size_t)m * L.np;
   const double* lam_g = A.lam_g ? A.lam_g + (size_t)m * L.ng : nullptr;
   __shared__ double tileX[64 * TILE_LD], tileU[64 * TILE_LD];
+  __shared__ int emap[456];      // compaction maps of the edge stages (FAM 0): read at every U-column write-out -- from LDS, not through a dependent global load
+  if (FAM == 0) { for (int i = ln; i < 456; i += 64) emap[i] = A.edge_map[i]; __builtin_amdgcn_wave_barrier(); }
   for (int k0 = 0; k0 < N; k0 += 64) {
     const int rows_here = N - k0 < 64 ? N - k0 : 64;
     int k = k0 + ln;
@@ -180,7 +209,7 @@ __global__ void __launch_bounds__(64, LANDING_SWEEP_H_WAVES(FAM)) landing_sweep_
       if (k > 0) { const double* Up = x + L.x_U(k - 1); for (int l = 0; l < 4; ++l) fz_prev[l] = Up[12 + 3 * l + 2]; }
       double* J = A.jac + (size_t)m * L.nnz_jac;
       TileStore<0> ex{tileX, J, &L, nullptr, k0, rows_here, 0};
-      TileStore<1> eu{tileU, J, &L, A.edge_map, k0, rows_here, 0};
+      TileStore<1> eu{tileU, J, &L, emap, k0, rows_here, 0};
       srbm::stage_jac(z, P, false, false, fz_prev, ex, eu);
       ex.finish(); eu.finish();
     } else if (FAM == 2) {
@@ -188,6 +217,10 @@ __global__ void __launch_bounds__(64, LANDING_SWEEP_H_WAVES(FAM)) landing_sweep_
       srbm::stage_g(z, P, false, og);
       og.finish();
     } else {
+      // FAM 1: the whole Hessian segment of the stage; FAM 3 / 4: its two halves as separate launches (X_k columns + the first 80 positions
+      // of the U_k columns | the last 80) -- the Hessian stream runs at one wave per SIMD and was the critical path of every sweep call
+      // (347 of 382 us at 4096 members, profiles/r03_sweep_timeline.txt); two shorter streams halve the per-member latency
+      constexpr int XHI = FAM == 4 ? 0 : (1 << 30), ULO = FAM == 4 ? 80 : 0, UHI = FAM == 3 ? 80 : (1 << 30);
       double* H = A.hess + (size_t)m * L.nnz_hess;
       double lps[12];
       for (int i = 0; i < 12; ++i) lps[i] = 0.0;
@@ -196,8 +229,8 @@ __global__ void __launch_bounds__(64, LANDING_SWEEP_H_WAVES(FAM)) landing_sweep_
         for (int l = 0; l < 4; ++l) for (int i = 0; i < 3; ++i) lps[3 * l + i] = lp[16 + 12 * l + 2 + i] + lp[16 + 12 * l + 5 + i];
       }
       LamStage lam{lam_g + L.g_stage(k)};
-      TileStore<2> hx{tileX, H, &L, nullptr, k0, rows_here, 0};
-      TileStore<3> hu{tileU, H, &L, nullptr, k0, rows_here, 0};
+      TileStore<2, 0, XHI> hx{tileX, H, &L, nullptr, k0, rows_here, 0};
+      TileStore<3, ULO, UHI> hu{tileU, H, &L, nullptr, k0, rows_here, 0};
       // the last stage reads its multipliers through its own row numbering (80 rows); the emitted sequence is the same
       // for every lane (runtime `last` only selects row offsets), so the tile write-outs stay convergent
       srbm::stage_hess(z, P, false, k == N - 1, lam, lps, hx, hu);
@@ -209,6 +242,12 @@ __global__ void __launch_bounds__(64, LANDING_SWEEP_H_WAVES(FAM)) landing_sweep_
 // name is reported by landing_kernel_name_sweep() for profilers
 // Everything else of the function layer (direct stores): f, grad_f, boundary rows, g of every stage, the X_N blocks
 // of J and H, grad_gamma_x / grad_gamma_p.  `A.jac` / `A.hess` stage segments are written by the kernels above.
+// LIGHT = true: only what needs no stage evaluation -- terminal-cost f and grad_f, boundary rows, the X_N blocks -- for the common call
+// (g, grad_f, Jacobian, Hessian of the terminal-cost NLP; landing_eval_batch picks it).  The full kernel carries the stage code of
+// grad_gamma_x / grad_gamma_p / the running cost and is allocated 256 VGPRs + 100 AGPRs for it: one wave per SIMD and no co-residency
+// with the Jacobian / Hessian streams, so that in round 2 this trivial part of the sweep took 246 us on the critical path of every call
+// (rocprofv3 kernel trace at 4096 members, profiles/r03_sweep_timeline.txt).
+template <bool LIGHT>
 __global__ void __launch_bounds__(64) landing_sweep_misc_kernel(Layout L, int B, EvalArgs A) {
   const int m = blockIdx.x;
   if (m >= B) return;
@@ -227,7 +266,7 @@ __global__ void __launch_bounds__(64) landing_sweep_misc_kernel(Layout L, int B,
       const double d = x[12 * N + i] - p[12 * N + i];
       s += d * p[L.o_QN + i] * d;
     }
-    if (L.run_cost) for (int k = 0; k < N; ++k) s += run_cost_stage(L, x, p, k, nullptr, nullptr, nullptr);
+    if (!LIGHT && L.run_cost) for (int k = 0; k < N; ++k) s += run_cost_stage(L, x, p, k, nullptr, nullptr, nullptr);
     if (A.f) A.f[m] = s;
   }
   if (A.grad_f) {
@@ -236,7 +275,7 @@ __global__ void __launch_bounds__(64) landing_sweep_misc_kernel(Layout L, int B,
       const int t = i - 12 * N;
       gf[i] = (t >= 0 && t < 12) ? 2.0 * p[L.o_QN + t] * (x[i] - p[12 * N + t]) : 0.0;
     }
-    if (L.run_cost) {
+    if (!LIGHT && L.run_cost) {
       __builtin_amdgcn_wave_barrier();
       for (int k = threadIdx.x; k < N; k += blockDim.x) { double* gU = gf + L.x_U(k); (void)run_cost_stage(L, x, p, k, gf + L.x_X(k), gU, gU + 12); }
     }
@@ -260,6 +299,7 @@ __global__ void __launch_bounds__(64) landing_sweep_misc_kernel(Layout L, int B,
     double* H = A.hess + (size_t)m * L.nnz_hess + L.hx(N);
     for (int i = threadIdx.x; i < 12; i += blockDim.x) H[i] = 2.0 * lam_f * p[L.o_QN + i];
   }
+  if (LIGHT) return;      // (uniform: everything below needs stage evaluations)
   if (A.ggx && lam_g) {
     double* gx = A.ggx + (size_t)m * L.nx;
     for (int i = threadIdx.x; i < 12; i += blockDim.x) {
