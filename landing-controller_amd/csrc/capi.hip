@@ -53,8 +53,17 @@ struct landing_ctx {
   hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
   bool hess_split = false;           // LANDING_SWEEP_HSPLIT=1: the Hessian stream as two launches (landing_sweep_kernel<3>, <4>) -- measured slower, see below
   bool sweep_concurrent = true;      // Q (576) | F (576) | 1/diag(R) (12) of the last landing_riccati_gains_batch call
+  // every scratch block above is re-used by the next call of its entry point, possibly on another stream: the launches that use it are
+  // fenced by this event (recorded behind them, waited for before the next writer / reader touches the block) -- ADVICE r2
+  hipEvent_t scratch_done = nullptr;
   std::mutex mu;      // serialises landing_solve_batch calls on one context (the workspace belongs to the context)
 };
+// call with ctx->mu held: the stream waits for the previous user of the context's scratch blocks
+static hipError_t scratch_acquire(landing_ctx* ctx, hipStream_t s) {
+  if (!ctx->scratch_done) { hipError_t e = hipEventCreateWithFlags(&ctx->scratch_done, hipEventDisableTiming); if (e != hipSuccess) return e; return hipSuccess; }
+  return hipStreamWaitEvent(s, ctx->scratch_done, 0);
+}
+static hipError_t scratch_release(landing_ctx* ctx, hipStream_t s) { return hipEventRecord(ctx->scratch_done, s); }
 
 extern "C" {
 
@@ -272,6 +281,7 @@ void landing_destroy(landing_ctx* ctx) {
   if (ctx->d_fb_scratch) (void)hipFree(ctx->d_fb_scratch);
   for (int i = 0; i < 3; ++i) { if (ctx->aux[i]) (void)hipStreamDestroy(ctx->aux[i]); if (ctx->ev_join[i]) (void)hipEventDestroy(ctx->ev_join[i]); }
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+  if (ctx->scratch_done) { (void)hipEventSynchronize(ctx->scratch_done); (void)hipEventDestroy(ctx->scratch_done); }
   if (ctx->host_stream) (void)hipStreamDestroy(ctx->host_stream);
   delete ctx;
 }
@@ -360,11 +370,13 @@ int landing_eval_hess_rc_batch(landing_ctx* ctx, int B, const double* d_x, const
     ctx->h4_cap = need;
   }
   hipStream_t s0 = (hipStream_t)stream;
+  HIP_TRY(scratch_acquire(ctx, s0));
   landing::EvalArgs A{d_x, d_p, d_lam_f, d_lam_g, nullptr, nullptr, nullptr, nullptr, ctx->d_h4, nullptr, nullptr, ctx->d_edge_map, 0};
   hipLaunchKernelGGL(landing::landing_sweep_kernel<1>, dim3(B), dim3(64), 0, s0, L, B, A);
   hipLaunchKernelGGL(landing::landing_sweep_misc_kernel<true>, dim3(B), dim3(64), 0, s0, L, B, A);     // terminal-cost block of the Hessian
   hipLaunchKernelGGL(landing::landing_hess_rc_kernel, dim3((nrc + 255) / 256, B), dim3(256), 0, s0, L, B, nrc, ctx->d_rc_map, ctx->d_h4, d_p, d_lam_f, d_hess_rc);
   HIP_TRY(hipGetLastError());
+  HIP_TRY(scratch_release(ctx, s0));
   return 0;
 }
 
