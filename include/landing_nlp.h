@@ -201,6 +201,19 @@ typedef struct {
                             without it are untouched (bit-identical)                                                                   */
   double feas_rho;       /* price of a unit of violation in the elastic problem (IPOPT's restoration phase: 1000)                     */
   double feas_cert;      /* 1-norm violation above which the elastic KKT point counts as a certificate (1e-4)                        */
+  double delta_floor;    /* proximal term of the terminal-cost form: the first regularisation tried in an iteration is delta_floor instead
+                            of 0 (forms with a running cost and the feasibility phase: always 0).  With the terminal cost only, the feet in
+                            flight, the lateral translation ... have NO curvature in the Lagrangian: the Newton step along them is set by
+                            whatever delta_w the inertia correction last left behind, and the later barrier problems crawl under a saw-tooth
+                            delta_w (1e-6 .. 3e-5, wild steps each time it touches the inertia threshold).  A constant (1/2) delta |x - x_k|^2
+                            damps exactly those directions; the KKT conditions at the solution do not see it.  Measured (CPU port, 4 x 1024
+                            drop states of the bench distribution, N = 40): iterations mean 50.4 -> 48.0, p99 79 -> 61, max 96..116 -> 64..72;
+                            N = 20 production grid: law "main" 52.6 -> 49.5, law "datagen" 69.8 -> 62.1; N = 64: 57.2 -> 52.9.  A batch of
+                            1024 on 512 slots ends with its slowest late starter, so the tail is what the launch time follows: MI355X, 64 fresh
+                            batches of 1024: 95.7 -> 84.9 ms per batch; hold-out 128 batches 131 072 / 131 072 converged, worst member 110
+                            iterations (profiles/r03_delta_floor.txt).  3e-3 and above slows every member (linear rate delta / (sigma +
+                            delta)); 4e-4 .. 1e-3 are equivalent within the box-to-box spread.  Default 5e-4; 0 = the plain IPOPT schedule
+                            (first trial delta_w = 0)                                                                                    */
 } landing_solver_opts;
 
 /* status codes written per batch member by landing_solve_batch */

@@ -1559,6 +1559,7 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
     KS_BEGIN()
       const double dl = K.delta_last;
       K.delta = (K.need_reg_streak >= 2 && dl > 0.0) ? fmax(1e-20, dl * ((o.sticky_delta && K.first_failed) ? 1.0 : o.delta_dec)) : 0.0;
+      if (!L.run_cost && !K.feas) K.delta = fmax(K.delta, o.delta_floor);      // proximal term of the terminal-cost form (landing_nlp.h)
       K.skipped_zero = K.delta > 0.0;
       K.fact_ok = 0; K.attempt = 0; K.flag = 1;
       S.prof[PH_NFACT] += 1.0;

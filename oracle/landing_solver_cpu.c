@@ -43,6 +43,7 @@ typedef struct {
                             problem with positive violation ends it as LANDING_INFEASIBLE (3): a certificate of local infeasibility           */
   double feas_rho;       /* price of a unit of violation (IPOPT's restoration phase: 1000)                                                   */
   double feas_cert;      /* l1 violation above which the elastic KKT point counts as a certificate                                           */
+  double delta_floor;    /* first regularisation tried in an iteration of the terminal-cost form (include/landing_nlp.h)                     */
 } lo_solver_opts;
 
 void lo_solver_opts_default(lo_solver_opts* o) {
@@ -51,6 +52,7 @@ void lo_solver_opts_default(lo_solver_opts* o) {
   o->delta_init = 1e-4; o->delta_inc_first = 10.0; o->delta_inc = 4.0; o->delta_dec = 0.5; o->tau_min = 0.9; o->alpha_fallback = 1e-2; o->restart_period = 75; o->reset_delta = 1e5;
   o->barrier_smax = 1.0; o->watchdog = 3; o->slack_corr = 0.9; o->dual_step_cap = 1.0; o->fresh_restart = 9; o->theta_floor = 30.0; o->clip_k = 4; o->clip_until = 0.03;
   o->feas_phase = 1; o->feas_rho = 1000.0; o->feas_cert = 1e-4;
+  o->delta_floor = 5e-4;
 }
 
 #define NW 48
@@ -406,6 +408,7 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
     }
     /* factorisation with inertia correction (same schedule as the HIP kernel) */
     delta = (streak >= 2 && delta_last > 0.0) ? fmax(1e-20, delta_last * op->delta_dec) : 0.0;
+    if (!F->run_cost && !feas) delta = fmax(delta, op->delta_floor);
     for (attempt = 0; attempt < 60 && !fact_ok; ++attempt) {
       if (attempt > 0) {
         if (delta == 0.0) delta = (delta_last == 0.0) ? op->delta_init : fmax(1e-20, delta_last * op->delta_dec);
