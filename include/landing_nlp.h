@@ -126,10 +126,8 @@ typedef struct {
   double clip_until;     /* ... applied only while the primal infeasibility (max norm, slack rows included) is above this value
                             (default 0.03): close to feasibility the classic rule is kept -- without the switch 1 member in 1000
                             parks at pr ~ 2e-2 with diverging multipliers                                                     */
-  double theta_floor;    /* RETIRED in round 3 (default 0 = off; was 30): with delta_floor the rule changes nothing any more (64 fresh + 8 bench
-                            batches: same convergence, iterations 47.78 vs 47.79).  Filter line search: constraint violations (theta, 1-norm
-                            over the ~4000 rows) below theta_floor * tol count as
-                            equal -- a trial point that stays below is never rejected for its theta.  At the last barrier
+  double theta_floor;    /* filter line search: constraint violations (theta, 1-norm over the ~4000 rows) below theta_floor * tol count as
+                            equal -- a trial point that stays below is never rejected for its theta.  Default 30.  At the last barrier
                             problems theta sits at ~1e-7, far below the tolerance, while the dual infeasibility still needs full Newton
                             steps whose second-order terms raise theta a little; the relative-decrease test alone then cuts every step to
                             1/64 .. 1e-7 (IPOPT gets past this with second-order corrections / its acceptable-point stop).  Convergence is
@@ -137,9 +135,7 @@ typedef struct {
                             212-iteration member in the bench batches; 1 -> 99, but three members of the 65 536 still need 203..251
                             iterations with theta pinned AT the floor; 30 -> they need 51..69, mean batch time 110.2 -> 106.2 ms, slowest
                             batch 223 -> 142 ms; 10: 107.6 ms, 100: 106.1 ms.  0 = off                                              */
-  int fresh_restart;     /* RETIRED in round 3 (default 0 = none; was 9 = 1 | 8): with delta_floor no member of the 64 fresh + 8 bench + 128 hold-out
-                            batches (196 608 drop states) and of the N = 20 production sweeps needs them (identical iteration statistics).
-                            Restart rules beyond "re-initialise slacks, multipliers and mu at the current x", a bit mask:
+  int fresh_restart;     /* restart rules beyond "re-initialise slacks, multipliers and mu at the current x", a bit mask (default 9 = 1 | 8):
                             1: a restart that follows a JAM (dual infeasibility above reset_du, regularisation above reset_delta) goes back
                                to the caller's initial guess with clip_k = 2 -- a restart in place repeats the failure from a bad x;
                             2: so does every member's second restart;   4: the crawl detector may fire twice;
@@ -168,11 +164,10 @@ typedef struct {
                             of a typical batch are of this type (20..60 iterations at mu = 0.1 with a full step admissible but cut to
                             1/8..1/16): CPU port, the stragglers 137 / 203 / 166 / 157 / 145 -> 57 / 58 / 57 / 93 / 68 iterations; numbers at
                             scale in DESIGN.md 4.2.  Applied at every trial point instead it doubles the mean iteration count       */
-  int watchdog;          /* RETIRED in round 3 (default 0 = off; was 3): identical iteration statistics with and without it once delta_floor is on.
-                            After this many successive iterations whose accepted step length is at most 1/16 of the step to the boundary, the
+  int watchdog;          /* after this many successive iterations whose accepted step length is at most 1/16 of the step to the boundary, the
                             next iteration takes the first trial point (the step to the boundary) without the sufficient-decrease / switching
                             tests -- it must still pass theta <= theta_max and must not be dominated by a filter entry -- and restarts the
-                            filter (cf. IPOPT's watchdog_shortened_iter_trigger).  The members that
+                            filter (default 3; 0 = off; cf. IPOPT's watchdog_shortened_iter_trigger).  The members that
                             were left as the slowest of the 65 536-member sweep sat for 50..60 iterations with steps of 1e-3 until the
                             line search failed outright and its fall-back step (alpha_fallback) freed them: CPU port, 161 / 158 / 138 /
                             136 / 133 / 129 / 115 -> 84 / 69 / 81 / 94 / 83 / 67 / 68 iterations, the bench batch unchanged               */

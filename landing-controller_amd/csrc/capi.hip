@@ -84,8 +84,7 @@ void landing_solver_opts_default(landing_solver_opts* o) {
   o->kappa_eps = 10.0; o->kappa_mu = 0.2; o->theta_mu = 1.5; o->max_soc = 0; o->max_resets = 8; o->reset_du = 1e9;
   o->delta_init = 1e-4; o->delta_inc_first = 10.0; o->delta_inc = 4.0; o->delta_dec = 0.5; o->tau_min = 0.9; o->alpha_fallback = 1e-2;
   o->stage_local_reg = 0; o->sticky_delta = 0; o->restart_period = 75; o->reset_delta = 1e5; o->dispatch_order = 1;
-  o->clip_k = 4; o->clip_until = 0.03; o->dual_step_cap = 1.0; o->slack_corr = 0.9; o->barrier_smax = 1.0; o->factor_fp32 = 0;
-  o->theta_floor = 0.0; o->fresh_restart = 0; o->watchdog = 0;      // round-2 rules, retired in round 3: with delta_floor they no longer change any member of the 196 608-member sweeps
+  o->clip_k = 4; o->clip_until = 0.03; o->theta_floor = 30.0; o->fresh_restart = 9; o->dual_step_cap = 1.0; o->slack_corr = 0.9; o->watchdog = 3; o->barrier_smax = 1.0; o->factor_fp32 = 0;
   o->feas_phase = 1; o->feas_rho = 1000.0; o->feas_cert = 1e-4;
   o->delta_floor = 5e-4;
 }

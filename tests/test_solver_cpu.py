@@ -52,17 +52,17 @@ def test_cpu_port_reference_default_problem(oracle_mod):
     assert O.kkt(r["x"][0], p, r["lam_g"][0]).max() <= 1e-6 * 1.0001
 
 
-@pytest.mark.parametrize("clip_k,theta_floor", [(4, 0.0), (4, 30.0), (1, 0.0)])      # the defaults; the retired theta rule; IPOPT's classic step rule and filter tests
+@pytest.mark.parametrize("clip_k,theta_floor", [(4, 30.0), (1, 0.0)])      # the defaults; IPOPT's classic step rule and filter tests
 def test_emulated_kernel_follows_cpu_port(emu_lib, oracle_mod, clip_k, theta_floor):
     N, K = 20, 6
     O = oracle_mod.Oracle(N)
     P, X0, _, _ = lc("problem").make_batch(1, N, 0.6, seed=1)
     L = lc("capi").LandingLib(N, lib_path=emu_lib)
     o = L.default_opts(); o.max_iter = K; o.clip_k = clip_k; o.theta_floor = theta_floor; o.feas_phase = 0      # (K iterations, then stop: no feasibility phase)
-    classic = dict(dual_step_cap=0.0, fresh_restart=0, slack_corr=0.0, watchdog=0, barrier_smax=0.0, delta_floor=0.0) if clip_k == 1 else {}
+    classic = dict(dual_step_cap=0.0, fresh_restart=0, slack_corr=0.0, watchdog=0, barrier_smax=0.0) if clip_k == 1 else {}
     for k_, v_ in classic.items():
         setattr(o, k_, v_)
-    assert (L.default_opts().clip_k, L.default_opts().theta_floor) == (4, 0.0)
+    assert (L.default_opts().clip_k, L.default_opts().theta_floor) == (4, 30.0)
     g = L.solve_host(P, X0, o)
     c = oracle_mod.cpu_solve_batch(O, P, X0, threads=1, max_iter=K, clip_k=clip_k, theta_floor=theta_floor, feas_phase=0, **classic)
     assert g["status"][0] == 1 and c["status"][0] == 1 and g["iters"][0] == c["iters"][0] == K
@@ -135,7 +135,7 @@ def test_clip_rule_changes_the_path_and_shortens_it(oracle_mod):
     O = oracle_mod.Oracle(N)
     P, X0, _, _ = lc("problem").make_batch(8, N, 0.6, seed=20211)
     a = oracle_mod.cpu_solve_batch(O, P, X0, threads=8, max_iter=300)
-    b = oracle_mod.cpu_solve_batch(O, P, X0, threads=8, max_iter=300, clip_k=1, theta_floor=0.0, dual_step_cap=0.0, fresh_restart=0, slack_corr=0.0, watchdog=0, barrier_smax=0.0, delta_floor=0.0)
+    b = oracle_mod.cpu_solve_batch(O, P, X0, threads=8, max_iter=300, clip_k=1, theta_floor=0.0, dual_step_cap=0.0, fresh_restart=0, slack_corr=0.0, watchdog=0, barrier_smax=0.0)
     assert (a["status"] == 0).all() and (b["status"] == 0).all()
     assert a["iters"].sum() < b["iters"].sum(), (a["iters"], b["iters"])
     for r in (a, b):
