@@ -79,11 +79,11 @@ typedef struct {
   double tol;            /* unscaled KKT tolerance on pr/du/compl (default 1e-6)   */
   int max_iter;          /* default 3000 (:232)                                    */
   double mu_init;        /* 0.1 (:247)                                             */
-  double bound_push;     /* default 1.0 (the reference sets 0.5 for IPOPT, :242): the one-sided rows (foot heights, force bounds ...) start a
-                            little deeper inside.  MI355X, 64 fresh batches of 1024 (N = 40), with kappa_eps 80: 0.5 -> 40.1 iterations /
-                            72.0 ms per batch, 1.0 -> 36.7 / 68.1 ms; 0.3 (kappa_eps 10): 52.2 against 47.8.  Every family of the CPU-port
-                            sweep gains (profiles/r03_delta_floor.txt): N = 20 production grid law main 42.6 -> 38.6, law datagen 58.5 ->
-                            50.2, running cost N = 40 60.0 -> 56.1, N = 64 45.4 -> 41.2 iterations, same members converged (+-1)          */
+  double bound_push;     /* 0.5 (:242), the reference's value.  1.0 is faster on every family tried (MI355X, 64 fresh batches of 1024, N = 40,
+                            kappa_eps 80: 40.1 -> 36.7 iterations, 72.0 -> 68.1 ms per batch; CPU port: N = 20 production grid 42.6 -> 38.6 /
+                            58.5 -> 50.2, running cost 60.0 -> 56.1) but ends at a WORSE local minimum than the reference's stored N = 40
+                            solutions more often (same-or-better objective on 9 of 17 instead of 11..13, tests/test_gpu_solver.py) -- the
+                            reference's value stays the default (profiles/r03_delta_floor.txt)                                          */
   double bound_frac;     /* default 0.1.  The reference sets 0.5 for IPOPT (:241); with 0.5 the slack of every two-sided row starts at
                             the mid-point of its interval whatever the initial guess says.  Measured on three seeded batches of
                             1024..2048 drop states (N=40, tools/dev/fracsweep.py): 0.5 -> 97.6 % solved, mean 80 iterations;
@@ -96,7 +96,7 @@ typedef struct {
                             80 / 160 / 400 -> 49.1 / 47.8 / 46.0 / 42.5 / 40.1 / 38.6 / 36.1 iterations on average, 86.7 / 84.9 / 80.7 /
                             76.4 / 72.0 / 74.0 / 79.4 ms per batch (beyond 80 the tail grows: p99.9 61 -> 70 -> 106).  With 80 and
                             bound_push 1: two hold-out sets of 128 batches each, 262 144 / 262 144 converged, worst member 122 iterations,
-                            67.7 ms per batch.  One member in ~50 000 then leans on watchdog / theta_floor / fresh_restart (a 350 .. 690
+                            67.7 ms per batch; with the default bound_push see profiles/r03_delta_floor.txt.  One member in ~50 000 then leans on watchdog / theta_floor / fresh_restart (a 350 .. 690
                             iteration crawl without them), which at kappa_eps 10 had become no-ops (profiles/r03_delta_floor.txt)          */
   double kappa_mu;       /* 0.2                                                    */
   double theta_mu;       /* 1.5                                                    */

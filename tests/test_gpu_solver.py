@@ -335,7 +335,7 @@ def test_soak_failures_are_rescued(oracle_mod):
     """members found by tools/soak.py (65 536 fresh drop states) that hit max_iter with IPOPT's independent dual step length and
     restarts in place only -- ordinary drop states, each solvable from the same initial guess with another step rule: they converge
     with the defaults (landing_solver_opts::dual_step_cap = 1 removes the jam itself; fresh_restart = 9 is the safety net), certified by
-    the oracle; with both off they fail, and each rule alone rescues most of them"""
+    the oracle; with every rule off they fail, and the proximal term (delta_floor) or the restart rules alone rescue them"""
     N = 40
     cases = [(100062, 614), (100062, 438), (100041, 890), (100039, 349), (100031, 450), (100027, 126), (100059, 370), (100044, 440)]
     O = oracle_mod.Oracle(N)
@@ -352,6 +352,9 @@ def test_soak_failures_are_rescued(oracle_mod):
     for b in range(len(cases)):
         assert O.kkt(r["x"][b], Ps[b], r["lam_g"][b]).max() <= 1e-6 * 1.0001
     o.fresh_restart = 0; o.dual_step_cap = 0.0; o.slack_corr = 0.0; o.watchdog = 0; o.barrier_smax = 0.0; o.feas_phase = 0
+    r2 = L.solve_host(Ps, Xs, o)
+    assert (r2["status"] == 0).sum() >= 7, r2["status"]          # the proximal term alone (delta_floor, round 3) un-jams them: measured 8 of 8
+    o.delta_floor = 0.0; o.kappa_eps = 10.0                      # ... the round-2 schedule they were found with
     r0 = L.solve_host(Ps, Xs, o)
     assert (r0["status"] != 0).sum() >= 4, r0["status"]          # measured: 8 of 8 fail
     o.fresh_restart = 15
