@@ -1,0 +1,84 @@
+"""SURVEY 8(f) row N1 -- the rows of the reference's kinodynamic refinement NLP (landing_optimization.m:100-189), pinned by
+reference-held data: the two kinodynamic solutions stored beside the reference's test scripts (tests/golden/n1_kinodyn_solutions.npz,
+written by tests/make_golden_n1.py; both on the uniform grid dt = 0.03, N = 20) satisfy every row group of oracle/kinodyn_oracle.py to
+the tolerance of the solver that produced them -- Euler defects under rpyToRotMat_xyz / Binv, contact / LCP / no-slip rows, friction
+pyramid, the forward-kinematics band |c - FK([q; jpos])| (ACTIVE in both: 1e-3 in the older file, 1e-2 in the newer one, the value of
+landing_optimization.m:186-187), leg torques J_f'(-R' f) within tauMax, joint limits, kinematic box.  A wrong rotation convention, leg
+geometry, side sign or inertia shows up here as a violation orders of magnitude above these tolerances (e.g. the production grid
+instead of dt = 0.03: defects of 1.1).  CPU: oracle + the kernel through tests/emu; GPU: landing_kinodyn_rows_batch on the same data."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT, lc
+
+PKG = os.path.join(ROOT, "landing-controller_amd")
+DT = np.full(20, 0.03)
+
+
+def _sol(tag):
+    d = np.load(os.path.join(GOLDEN, "n1_kinodyn_solutions.npz"))
+    return d["X_" + tag], d["U_" + tag], d["J_" + tag]
+
+
+@pytest.mark.parametrize("tag,mu,band", [("a", 0.5, 1e-3), ("b", 1.0, 1e-2)])
+def test_stored_kinodynamic_solutions_satisfy_the_oracle_rows(tag, mu, band):
+    from oracle import kinodyn_oracle as ko
+    mass, Ib, Ibi = lc("constants").robot_constants()
+    X, U, J = _sol(tag)
+    assert X.shape == (12, 21) and U.shape == (24, 20) and J.shape == (12, 20)
+    dd = ko.dynamics_defects(X, U, DT, mass, np.asarray(Ib), np.asarray(Ibi))
+    assert np.abs(dd).max() <= 5e-5, np.abs(dd).reshape(4, 3, -1).max(axis=(1, 2))          # measured: 2.3e-5 (omega rows) / 3e-7
+    fz, cz, lcp, slip = ko.contact_rows(U)
+    assert fz.min() >= -1e-6 and cz.min() >= -1e-5 and lcp.max() <= 1e-3 * 1.001 and np.abs(slip).max() <= 1e-3 * 1.001
+    assert lcp.max() >= 0.8e-3                                                               # (the complementarity row is active)
+    assert ko.friction_rows(U, mu).min() >= -1e-5                                            # friction pyramid at the file's mu (a: active)
+    fk_err, tau = ko.kinematic_rows(X, U, J)
+    assert 0.98 * band <= np.abs(fk_err).max() <= band * 1.002                               # the FK band is ACTIVE at its bound
+    assert (np.abs(tau).reshape(-1, 4, 3).max(axis=(0, 1)) <= ko.TAU_MAX).all()
+    assert (J.T >= ko.JPOS_MIN - 1e-6).all() and (J.T <= ko.JPOS_MAX + 1e-6).all()
+    pr = ko.hip_relative(X, U)
+    assert pr[..., 2].max() <= -0.075 + 1e-3 and pr[..., 2].min() >= -0.4 - 1e-3 and np.linalg.norm(pr, axis=-1).max() <= 0.4 + 1e-3
+    assert X[2].min() >= 0.075
+
+
+def _rows_through(L, dev):
+    import torch
+    R = lc("rbd").Rbd(L)
+    out = {}
+    for tag in "ab":
+        X, U, J = _sol(tag)
+        t = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float64, device=dev)
+        q6, c, f, jp = t(X[:6, :20].T), t(U[:12].T), t(U[12:].T), t(J.T)
+        fk, err, tau = (torch.zeros(20, 12, dtype=torch.float64, device=dev) for _ in range(3))
+        st = torch.cuda.current_stream().cuda_stream if dev == "cuda" else 0
+        R.kinodyn_rows(20, q6.data_ptr(), c.data_ptr(), f.data_ptr(), jp.data_ptr(), fk.data_ptr(), err.data_ptr(), tau.data_ptr(), st)
+        if dev == "cuda":
+            torch.cuda.synchronize()
+        out[tag] = (err.cpu().numpy(), tau.cpu().numpy())
+    return out
+
+
+def _check_rows(out):
+    from oracle import kinodyn_oracle as ko
+    for tag, band in (("a", 1e-3), ("b", 1e-2)):
+        X, U, J = _sol(tag)
+        fe, to = ko.kinematic_rows(X, U, J)
+        err, tau = out[tag]
+        assert np.abs(err - fe).max() <= 1e-12 and np.abs(tau - to).max() <= 1e-11 * max(1.0, np.abs(to).max())
+        assert 0.98 * band <= np.abs(err).max() <= band * 1.002 and (np.abs(tau).reshape(-1, 4, 3).max(axis=(0, 1)) <= ko.TAU_MAX).all()
+
+
+def test_kinodyn_rows_kernel_on_stored_solutions_emulated():
+    subprocess.run(["make", "-C", os.path.join(PKG, "csrc"), "emu"], check=True, capture_output=True)
+    L = lc("capi").LandingLib(20, lib_path=os.path.join(ROOT, "tests", "emu", "liblanding_emu.so"))
+    _check_rows(_rows_through(L, "cpu"))
+
+
+@pytest.mark.gpu
+def test_kinodyn_rows_kernel_on_stored_solutions_gpu():
+    L = lc("capi").LandingLib(20, device=0)
+    _check_rows(_rows_through(L, "cuda"))
+    L.close()
