@@ -225,8 +225,11 @@ typedef struct {
                             1024 on 512 slots ends with its slowest late starter, so the tail is what the launch time follows: MI355X, 64 fresh
                             batches of 1024: 95.7 -> 84.9 ms per batch; hold-out 128 batches 131 072 / 131 072 converged, worst member 110
                             iterations (profiles/r03_delta_floor.txt).  3e-3 and above slows every member (linear rate delta / (sigma +
-                            delta)); 4e-4 .. 1e-3 are equivalent within the box-to-box spread.  Default 5e-4; 0 = the plain IPOPT schedule
-                            (first trial delta_w = 0)                                                                                    */
+                            delta)); with kappa_eps 10, 4e-4 .. 1e-3 are equivalent within the box-to-box spread; with the final kappa_eps 80 the slow-down
+                            already starts at 1e-3 (44.9 instead of 40.1 iterations, one member of 65 536 lost) while 3e-4 and 5e-4 are
+                            equivalent (72.7 / 71.3 ms per batch): the default is 3e-4, a factor 3 below that cliff (two hold-out sets of
+                            131 072 drop states: all converged, worst member 167 iterations).  0 = the plain IPOPT schedule (first trial
+                            delta_w = 0)                                                                                                 */
 } landing_solver_opts;
 
 /* status codes written per batch member by landing_solve_batch */

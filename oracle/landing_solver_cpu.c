@@ -52,7 +52,7 @@ void lo_solver_opts_default(lo_solver_opts* o) {
   o->delta_init = 1e-4; o->delta_inc_first = 10.0; o->delta_inc = 4.0; o->delta_dec = 0.5; o->tau_min = 0.9; o->alpha_fallback = 1e-2; o->restart_period = 75; o->reset_delta = 1e5;
   o->barrier_smax = 1.0; o->watchdog = 3; o->slack_corr = 0.9; o->dual_step_cap = 1.0; o->fresh_restart = 9; o->theta_floor = 30.0; o->clip_k = 4; o->clip_until = 0.03;
   o->feas_phase = 1; o->feas_rho = 1000.0; o->feas_cert = 1e-4;
-  o->delta_floor = 5e-4;
+  o->delta_floor = 3e-4;
 }
 
 #define NW 48
