@@ -96,10 +96,15 @@ def test_solver_other_horizons_and_limits(oracle_mod):
         L = capi.LandingLib(N, device=0)
         P, X0, _, _ = lc("problem").make_batch(6, N, 0.6, seed=4)
         r = L.solve_host(P, X0)
-        ok = r["status"] == 0
-        assert ok.sum() >= (3 if N == 16 else 6)      # measured: N = 16 (uniform dt = 37.5 ms, a grid no caller of the reference uses) about three quarters solve; N = 30: all solve
+        ok = r["status"] == 0; cert = r["status"] == 3
+        # every member is DECIDED: a KKT point, or a certificate of local infeasibility from the feasibility phase (round 3).  Measured: N = 16
+        # (uniform dt = 37.5 ms, a grid no caller of the reference uses) 5 converge + 1 certified (round 2: "about three quarters solve"); N = 30: all solve
+        assert (ok | cert).all() and ok.sum() >= (5 if N == 16 else 6), r["status"]
         for b in np.nonzero(ok)[0]:
             assert O.kkt(r["x"][b], P[b], r["lam_g"][b]).max() <= KKT_TOL * 1.0001
+        for b in np.nonzero(cert)[0]:      # the certificate: equality rows met, a positive violation of the inequality rows (1-norm above feas_cert)
+            g = O.g(r["x"][b], P[b]); lb, ub = O.bounds(P[b]); eq = lb == ub
+            assert np.abs(g[eq] - lb[eq]).max() <= 1e-6 and np.maximum(np.maximum(lb - g, g - ub), 0.0)[~eq].sum() > 1e-4
         L.close()
     L = capi.LandingLib(80, device=0)
     P, X0, _, _ = lc("problem").make_batch(1, 80, 0.6, seed=4)
@@ -194,7 +199,8 @@ def test_solver_with_running_cost(oracle_mod, N, B):
     P, X0, _, _ = lc("problem").make_batch(B, N, 0.6, seed=2)
     r = L.solve_host(P, X0)
     conv = r["status"] == 0
-    assert conv.mean() >= (0.85 if N == 20 else 0.96), f"only {conv.sum()}/{B} members converged"
+    # round 3: every member is decided (converged, or certified locally infeasible by the feasibility phase); measured N = 20: 15 + 1, N = 40: 32 + 0
+    assert (conv | (r["status"] == 3)).all() and conv.mean() >= (0.9 if N == 20 else 0.96), f"only {conv.sum()}/{B} members converged: {r['status']}"
     for b in np.nonzero(conv)[0][:12]:
         assert O.kkt(r["x"][b], P[b], r["lam_g"][b]).max() <= KKT_TOL * 1.0001
         assert abs(O.f(r["x"][b], P[b]) - r["f"][b]) < 1e-9 * max(1.0, abs(r["f"][b]))
