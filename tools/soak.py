@@ -8,8 +8,11 @@ sys.path.insert(0, ROOT)
 capi = importlib.import_module("landing-controller_amd.capi"); problem = importlib.import_module("landing-controller_amd.problem")
 ap = argparse.ArgumentParser(); ap.add_argument("--batches", type=int, default=64); ap.add_argument("--B", type=int, default=1024); ap.add_argument("--N", type=int, default=40)
 ap.add_argument("--grid", default="uniform", help="uniform | reference (the production callers' N=20 grid, problem.REFERENCE_DT_GRID)"); ap.add_argument("--law", default="main", help="main | datagen (problem.DROP_LAWS)")
+ap.add_argument("--form", default="terminal", help="terminal | running (the running cost of generate_quadruped_SRBM_CCC.m:81-89 with the weights of tests/test_gpu_solver.py::RUN_COST) | ccc (kin-box .05/.05/.27, GRF cost only: the formulation of the stored N=40 solutions)")
 ap.add_argument("--seed0", type=int, default=100000); ap.add_argument("--seed-step", type=int, default=1); ap.add_argument("--opts", default=""); a = ap.parse_args()
-L = capi.LandingLib(a.N, 0)
+FORMS = {"terminal": {}, "running": dict(run_cost=dict(QX=[0, 0, 10, 1, 1, 0, .1, .1, .1, .1, .1, .1], Qc=[1.0, 1.0, 0.5], Qf=[1e-4, 1e-4, 1e-3], f_ref=[0, 0, 20.0])),
+         "ccc": dict(kin_box=(0.05, 0.05, 0.27), run_cost=dict(QX=[0] * 12, Qc=[0, 0, 0], Qf=[1e-4, 1e-4, 1e-3], f_ref=[0, 0, 0]))}
+L = capi.LandingLib(a.N, 0, **FORMS[a.form])
 o = L.default_opts(); o.max_iter = 300
 for kv in a.opts.split(","):
     if "=" in kv:
@@ -35,7 +38,7 @@ for b in range(a.batches):
         worst.append((int(ih[m]), seed, int(m), int(sh[m])))
 its, sts, ms = np.concatenate(its), np.concatenate(sts), np.array(ms[1:] if len(ms) > 1 else ms)
 worst = sorted(set(worst), reverse=True)[:16]
-print(json.dumps({"workload": "%d batches x %d drop states, N=%d, dt grid %s, sampling law %s, max_iter 300, KKT tol 1e-6" % (a.batches, a.B, a.N, a.grid, a.law), "options": a.opts,
+print(json.dumps({"workload": "%d batches x %d drop states, N=%d, dt grid %s, sampling law %s, objective form %s, max_iter 300, KKT tol 1e-6" % (a.batches, a.B, a.N, a.grid, a.law, a.form), "options": a.opts,
                   "vz_of_unconverged_min_max": [min(vz_fail), max(vz_fail)] if vz_fail else None,
                   "members": int(its.size), "converged": int((sts == 0).sum()), "max_iter_hit": int((sts == 1).sum()), "numerical": int((sts == 2).sum()), "certified_locally_infeasible": int((sts == 3).sum()),
                   "iters_mean": float(its.mean()), "iters_p50": float(np.median(its)), "iters_p99": float(np.percentile(its, 99)), "iters_p999": float(np.percentile(its, 99.9)), "iters_max": int(its.max()),
