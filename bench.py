@@ -403,7 +403,17 @@ def measure_details(a, lib, np, torch, dev, mk, B, N, P, X0, dP, dX0, st, it, kk
     s_ms = ev0.elapsed_time(ev1) / 20
     by = lib.lib.landing_sweep_bytes_per_member(N) * Bs
     sweep = {"kernel": "one landing_eval_batch call (g, grad f, Jacobian and Hessian nonzeros)", "bound": "hbm", "achieved": by / s_ms / 1e6, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-             "frac": by / s_ms / 1e6 / HBM_PEAK_GBPS, "traffic": None, "launch_ms": s_ms, "members": Bs}
+             "frac": by / s_ms / 1e6 / HBM_PEAK_GBPS, "traffic": None, "launch_ms": s_ms, "members": Bs, "algorithmic_bytes": by}
+    sw_file = os.path.join(os.path.dirname(a.pmc_file), os.path.basename(a.pmc_file).replace("pmc_ipm", "pmc_sweep").replace("summary.json", "summary_sweep.json"))
+    if os.path.exists(sw_file) and sw_file != a.pmc_file:      # HBM bytes of one call from the PMC passes of tools/profile_round.sh -- same source-stamp rule as above
+        try:
+            sw = json.load(open(sw_file))
+            if sw.get("kernel_source_sha256") == kernel_source_sha() and sw.get("members") == Bs:
+                sweep["traffic"] = sw.get("traffic_bytes_per_call"); sweep["traffic_source"] = os.path.relpath(sw_file, ROOT)
+            else:
+                sweep["traffic_source"] = "%s was measured on other kernel sources or another batch: not reported" % os.path.relpath(sw_file, ROOT)
+        except Exception as e:   # noqa: BLE001
+            sweep["traffic_source"] = "unreadable: %s" % e
     # ---- CPU baseline (oracle port) on a bounded sample of the same workload
     cpu = None
     if not a.no_cpu_baseline and world == 1:      # CPU legs on rank 0 of the single-GPU run only
