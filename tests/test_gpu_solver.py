@@ -147,7 +147,8 @@ def test_solver_full_size_batch_properties(libs, oracle_mod):
     assert ok.sum() >= B - 1, f"{ok.sum()}/{B}"        # measured: 1024/1024 (rounds 1 and 2); one straggler is tolerated
     assert kh[ok].max() <= KKT_TOL * 1.0001
     ith = it.cpu().numpy()
-    assert ith.mean() <= 54 and np.percentile(ith, 99) <= 95 and ith.max() <= 150, (ith.mean(), np.percentile(ith, 99), ith.max())     # measured, final settings of round 2: mean 50.3, p99 79, max 95 (first half of the round: 63.9 / 110 / 167)
+    # measured: round 2 mean 50.3, p99 79, max 95; round 3 (delta_floor, kappa_eps 80): mean 40.1, p99 52, max 75
+    assert ith.mean() <= 44 and np.percentile(ith, 99) <= 65 and ith.max() <= 120, (ith.mean(), np.percentile(ith, 99), ith.max())
     po = O.param_offsets()
     assert np.array_equal(xh[:, :6], P[:, po["q_init"]:po["q_init"] + 6]) and np.array_equal(xh[:, 6:12], P[:, po["qd_init"]:po["qd_init"] + 6])
     for b in np.nonzero(ok)[0][::97]:
