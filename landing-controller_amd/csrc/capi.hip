@@ -56,6 +56,7 @@ struct landing_ctx {
   // every scratch block above is re-used by the next call of its entry point, possibly on another stream: the launches that use it are
   // fenced by this event (recorded behind them, waited for before the next writer / reader touches the block) -- ADVICE r2
   hipEvent_t scratch_done = nullptr;
+  bool rbd_arrow = false;      // the model set by landing_rbd_set_model is "six base joints + four 3-joint legs on the base": H is block-arrow (wb_kernels.hip)
   std::mutex mu;      // serialises landing_solve_batch calls on one context (the workspace belongs to the context)
 };
 // call with ctx->mu held: the stream waits for the previous user of the context's scratch blocks

@@ -161,7 +161,7 @@ __global__ void __launch_bounds__(64) landing_wb_backward_kernel(WbBackArgs a) {
 }
 
 struct WbRollArgs {
-  const RbdModel* model; int B, N, nalpha; double dt;
+  const RbdModel* model; int B, N, nalpha; double dt; int arrow;      // arrow: the model's H is block-arrow (base 6 + four 3-joint legs on the base): structured solve
   const double* alphas;                                          // [nalpha]
   const double* x; const double* u; const double* xref; const double* f_foot;   // current trajectory, reference, foot forces [B][N][12] or null
   const double* K; const double* kff;                            // null: open-loop rollout of u (initialisation)
@@ -201,6 +201,282 @@ __global__ void __launch_bounds__(64) landing_wb_rollout_kernel(WbRollArgs a) {
     for (int i = 0; i < WB_NX; ++i) xo[(k + 1) * WB_NX + i] = xs[i];
   }
   for (int i = 0; i < WB_NX; ++i) { const double d = xs[i] - rb[N * WB_NX + i]; cost += 0.5 * a.QN[i] * d * d; }
+  a.cost[(size_t)ia * a.B + b] = (ok && cost == cost) ? cost : INFINITY;
+}
+
+// ---- the same rollout with every per-thread array in LDS -------------------------------------------------------------------------
+// The kernel above keeps E[18][9], r[18][3], v, a, f (18 spatial vectors each), the composite inertias, H (18 x 18) and the state in private
+// memory (8.5 KB per thread): the 18-body recursion indexes them through the model's parent array, so they live in scratch and one forward-dynamics
+// evaluation costs ~325 us of dependent scratch round trips (13 ms per rollout of 40 knots).  Here the arrays of WB_TPB
+// threads sit in LDS, element-major ([element][thread]: the WB_TPB lanes of a wave touch consecutive banks), one workgroup = one wave with WB_TPB
+// active lanes.  Same arithmetic in the same order as hand_c / chol_solve18 / landing_wb_rollout_kernel: results are identical bit for bit.
+constexpr int WB_TPB = 16;
+constexpr int WS_E = 0, WS_R = 162, WS_V = 216, WS_F = 324, WS_U = 432, WS_H = 612, WS_C = 936, WS_RHS = 954, WS_X = 972, WS_UN = 1008, WS_PER = 1020;
+static_assert(WB_TPB * WS_PER * 8 + 4096 <= 160 * 1024, "LDS of one workgroup");
+struct WsView {
+  double* base;
+  __device__ __forceinline__ double& operator()(int i) const { return base[i * WB_TPB]; }
+};
+__device__ __forceinline__ SV ws_ld_sv(const WsView& W, int off, int i) { SV s; s.a = mk3(W(off + 6 * i), W(off + 6 * i + 1), W(off + 6 * i + 2)); s.l = mk3(W(off + 6 * i + 3), W(off + 6 * i + 4), W(off + 6 * i + 5)); return s; }
+__device__ __forceinline__ void ws_st_sv(const WsView& W, int off, int i, SV s) { W(off + 6 * i) = s.a.x; W(off + 6 * i + 1) = s.a.y; W(off + 6 * i + 2) = s.a.z; W(off + 6 * i + 3) = s.l.x; W(off + 6 * i + 4) = s.l.y; W(off + 6 * i + 5) = s.l.z; }
+__device__ __forceinline__ void ws_ld_xf(const WsView& W, int i, double* E, double* r) {
+#pragma unroll
+  for (int j = 0; j < 9; ++j) E[j] = W(WS_E + 9 * i + j);
+#pragma unroll
+  for (int j = 0; j < 3; ++j) r[j] = W(WS_R + 3 * i + j);
+}
+// H -> W(WS_H + 18 i + j), C -> W(WS_C + i); q = W(WS_X + i), qd = W(WS_X + 18 + i)   (hand_c above, line for line)
+__device__ void hand_c_lds(const RbdModel& M, const double* f_foot, const WsView& W) {
+  double Ei[9], ri[3];
+  for (int i = 0; i < RB_NB; ++i) {
+    joint_xform(M.jtype[i], W(WS_X + i), M.E[i], M.r[i], Ei, ri);
+#pragma unroll
+    for (int j = 0; j < 9; ++j) W(WS_E + 9 * i + j) = Ei[j];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) W(WS_R + 3 * i + j) = ri[j];
+    const SV vJ = sunit(M.jtype[i], W(WS_X + 18 + i));
+    const int pa = M.parent[i];
+    SV vi, ai;
+    if (pa == 0) {
+      SV g; g.a = mk3(0, 0, 0); g.l = mk3(0, 0, 9.81);
+      vi = vJ; ai = xmotion(Ei, ri, g);
+    } else {
+      const SV vp = xmotion(Ei, ri, ws_ld_sv(W, WS_V, pa - 1));
+      vi.a = add3(vp.a, vJ.a); vi.l = add3(vp.l, vJ.l);
+      const SV ap = xmotion(Ei, ri, ws_ld_sv(W, WS_U, pa - 1)), cv = crm_mul(vi, vJ);
+      ai.a = add3(ap.a, cv.a); ai.l = add3(ap.l, cv.l);
+    }
+    ws_st_sv(W, WS_V, i, vi); ws_st_sv(W, WS_U, i, ai);
+    const SV Ia = inertia_mul(M.m[i], M.h[i], M.I[i], ai), Iv = inertia_mul(M.m[i], M.h[i], M.I[i], vi), cf = crf_mul(vi, Iv);
+    SV fi; fi.a = add3(Ia.a, cf.a); fi.l = add3(Ia.l, cf.l);
+    ws_st_sv(W, WS_F, i, fi);
+  }
+  if (f_foot) {
+    double E0[9], r0[3];
+    for (int j = 0; j < 9; ++j) E0[j] = (j % 4 == 0) ? 1.0 : 0.0;
+    r0[0] = r0[1] = r0[2] = 0.0;
+    auto compose = [](const double* Eu, const double* ru, double* Ea, double* ra) {
+      const V3d t = mulT3(Ea, mk3(ru[0], ru[1], ru[2]));
+      double En[9];
+      for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) En[3 * a + b] = Eu[3 * a] * Ea[b] + Eu[3 * a + 1] * Ea[3 + b] + Eu[3 * a + 2] * Ea[6 + b];
+      for (int j = 0; j < 9; ++j) Ea[j] = En[j];
+      ra[0] += t.x; ra[1] += t.y; ra[2] += t.z;
+    };
+    for (int i = 0; i < 6; ++i) { ws_ld_xf(W, i, Ei, ri); compose(Ei, ri, E0, r0); }
+    for (int leg = 0; leg < 4; ++leg) {
+      double El[9], rl[3];
+      for (int j = 0; j < 9; ++j) El[j] = E0[j];
+      for (int j = 0; j < 3; ++j) rl[j] = r0[j];
+      const int jb = M.b_foot[leg] - 1;
+      for (int i = jb - 2; i <= jb; ++i) { ws_ld_xf(W, i, Ei, ri); compose(Ei, ri, El, rl); }
+      const V3d pf = add3(mk3(rl[0], rl[1], rl[2]), mulT3(El, mk3(M.foot_r[leg][0], M.foot_r[leg][1], M.foot_r[leg][2])));
+      const V3d fw = mk3(f_foot[3 * leg], f_foot[3 * leg + 1], f_foot[3 * leg + 2]);
+      const V3d nb = crs3(sub3(pf, mk3(rl[0], rl[1], rl[2])), fw);
+      SV fj = ws_ld_sv(W, WS_F, jb);
+      fj.a = sub3(fj.a, mul3(El, nb)); fj.l = sub3(fj.l, mul3(El, fw));
+      ws_st_sv(W, WS_F, jb, fj);
+    }
+  }
+  for (int i = RB_NB - 1; i >= 0; --i) {
+    const SV fi = ws_ld_sv(W, WS_F, i);
+    W(WS_C + i) = sdot(M.jtype[i], fi);
+    const int pa = M.parent[i];
+    if (pa != 0) {
+      ws_ld_xf(W, i, Ei, ri);
+      const SV t = xforceT(Ei, ri, fi);
+      SV fp = ws_ld_sv(W, WS_F, pa - 1);
+      fp.a = add3(fp.a, t.a); fp.l = add3(fp.l, t.l);
+      ws_st_sv(W, WS_F, pa - 1, fp);
+    }
+  }
+  // composite inertias in the region of the (dead) accelerations: cm at WS_U + i, ch at WS_U + 18 + 3 i, cI at WS_U + 72 + 6 i
+  constexpr int CM = WS_U, CH = WS_U + 18, CI = WS_U + 72;
+  for (int i = 0; i < RB_NB; ++i) { W(CM + i) = M.m[i]; for (int j = 0; j < 3; ++j) W(CH + 3 * i + j) = M.h[i][j]; for (int j = 0; j < 6; ++j) W(CI + 6 * i + j) = M.I[i][j]; }
+  for (int i = RB_NB - 1; i >= 0; --i) {
+    const int pa = M.parent[i];
+    if (pa == 0) continue;
+    ws_ld_xf(W, i, Ei, ri);
+    const double cmi = W(CM + i);
+    const V3d hp = mulT3(Ei, mk3(W(CH + 3 * i), W(CH + 3 * i + 1), W(CH + 3 * i + 2))), rr = mk3(ri[0], ri[1], ri[2]);
+    const V3d hn = add3(hp, scl3(cmi, rr));
+    double T[9];
+    { double I6[6];
+      for (int j = 0; j < 6; ++j) I6[j] = W(CI + 6 * i + j);
+      const double Is[9] = {I6[0], I6[1], I6[2], I6[1], I6[3], I6[4], I6[2], I6[4], I6[5]};
+      double A[9];
+      for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) A[3 * a + b] = Is[3 * a] * Ei[b] + Is[3 * a + 1] * Ei[3 + b] + Is[3 * a + 2] * Ei[6 + b];
+      for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) T[3 * a + b] = Ei[a] * A[b] + Ei[3 + a] * A[3 + b] + Ei[6 + a] * A[6 + b];
+    }
+    auto add_ss = [&](V3d a, V3d b, double sgn) {
+      const double d = a.x * b.x + a.y * b.y + a.z * b.z;
+      const double av[3] = {a.x, a.y, a.z}, bv[3] = {b.x, b.y, b.z};
+      for (int x = 0; x < 3; ++x) for (int y = 0; y < 3; ++y) T[3 * x + y] += sgn * (bv[x] * av[y] - (x == y ? d : 0.0));
+    };
+    add_ss(rr, hp, -1.0); add_ss(hn, rr, -1.0);
+    const int ip = CI + 6 * (pa - 1);
+    W(ip) += T[0]; W(ip + 1) += 0.5 * (T[1] + T[3]); W(ip + 2) += 0.5 * (T[2] + T[6]); W(ip + 3) += T[4]; W(ip + 4) += 0.5 * (T[5] + T[7]); W(ip + 5) += T[8];
+    W(CM + pa - 1) += cmi; W(CH + 3 * (pa - 1)) += hn.x; W(CH + 3 * (pa - 1) + 1) += hn.y; W(CH + 3 * (pa - 1) + 2) += hn.z;
+  }
+  for (int i = 0; i < RB_NB * RB_NB; ++i) W(WS_H + i) = 0.0;
+  for (int i = 0; i < RB_NB; ++i) {
+    double hh[3], II[6];
+    for (int j = 0; j < 3; ++j) hh[j] = W(CH + 3 * i + j);
+    for (int j = 0; j < 6; ++j) II[j] = W(CI + 6 * i + j);
+    SV fh = inertia_mul(W(CM + i), hh, II, sunit(M.jtype[i], 1.0));
+    W(WS_H + i * RB_NB + i) = sdot(M.jtype[i], fh);
+    int j = i;
+    while (M.parent[j] > 0) {
+      ws_ld_xf(W, j, Ei, ri);
+      fh = xforceT(Ei, ri, fh);
+      j = M.parent[j] - 1;
+      const double hij = sdot(M.jtype[j], fh);
+      W(WS_H + i * RB_NB + j) = hij; W(WS_H + j * RB_NB + i) = hij;
+    }
+  }
+}
+// chol_solve18 on W(WS_H ..), W(WS_RHS ..)
+__device__ bool chol_solve18_lds(const WsView& W) {
+  for (int j = 0; j < RB_NB; ++j) {
+    double d = W(WS_H + j * RB_NB + j);
+    for (int k = 0; k < j; ++k) { const double l = W(WS_H + j * RB_NB + k); d -= l * l; }
+    if (!(d > 0.0)) return false;
+    d = sqrt(d); W(WS_H + j * RB_NB + j) = d;
+    for (int i = j + 1; i < RB_NB; ++i) {
+      double s = W(WS_H + i * RB_NB + j);
+      for (int k = 0; k < j; ++k) s -= W(WS_H + i * RB_NB + k) * W(WS_H + j * RB_NB + k);
+      W(WS_H + i * RB_NB + j) = s / d;
+    }
+  }
+  for (int i = 0; i < RB_NB; ++i) { double s = W(WS_RHS + i); for (int k = 0; k < i; ++k) s -= W(WS_H + i * RB_NB + k) * W(WS_RHS + k); W(WS_RHS + i) = s / W(WS_H + i * RB_NB + i); }
+  for (int i = RB_NB - 1; i >= 0; --i) { double s = W(WS_RHS + i); for (int k = i + 1; k < RB_NB; ++k) s -= W(WS_H + k * RB_NB + i) * W(WS_RHS + k); W(WS_RHS + i) = s / W(WS_H + i * RB_NB + i); }
+  return true;
+}
+// The joint-space inertia of the quadruped is block-arrow: the six base coordinates couple with everything, the 3 x 3 blocks of the four
+// legs only with the base and themselves (different branches of the tree).  Solve H x = rhs by eliminating the legs first -- the Cholesky
+// factorisation in the order legs, base has no fill-in: per leg a 3 x 3 factor, Y = A^-1 [B | r] (3 x 7), Schur update of the 6 x 6 base
+// block; then the base; then x_leg = y - Y x_base.  Every loop has constant bounds (registers, pipelined LDS loads): ~1000 flops against
+// the 2700 of the dense factorisation with its ~2000 dependent LDS round trips, which was 80 % of a forward-dynamics evaluation.
+// x -> W(WS_RHS ..); false = a pivot was not positive.
+__device__ bool arrow_solve18_lds(const WsView& W) {
+  double S[6][6], rb[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) { rb[i] = W(WS_RHS + i);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) S[i][j] = W(WS_H + i * RB_NB + j); }
+  bool ok = true;
+  double Y[4][3][7];
+#pragma unroll
+  for (int l = 0; l < 4; ++l) {
+    const int o = 6 + 3 * l;
+    double A[3][3], Bm[3][7];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+      for (int b = 0; b < 3; ++b) A[a][b] = W(WS_H + (o + a) * RB_NB + o + b);
+#pragma unroll
+      for (int b = 0; b < 6; ++b) Bm[a][b] = W(WS_H + (o + a) * RB_NB + b);
+      Bm[a][6] = W(WS_RHS + o + a);
+    }
+    // A = L L'
+    const double d0 = A[0][0]; ok = ok && (d0 > 0.0); const double l00 = sqrt(d0 > 0.0 ? d0 : 1.0);
+    const double l10 = A[1][0] / l00, l20 = A[2][0] / l00;
+    const double d1 = A[1][1] - l10 * l10; ok = ok && (d1 > 0.0); const double l11 = sqrt(d1 > 0.0 ? d1 : 1.0);
+    const double l21 = (A[2][1] - l20 * l10) / l11;
+    const double d2 = A[2][2] - l20 * l20 - l21 * l21; ok = ok && (d2 > 0.0); const double l22 = sqrt(d2 > 0.0 ? d2 : 1.0);
+#pragma unroll
+    for (int cix = 0; cix < 7; ++cix) {
+      const double z0 = Bm[0][cix] / l00, z1 = (Bm[1][cix] - l10 * z0) / l11, z2 = (Bm[2][cix] - l20 * z0 - l21 * z1) / l22;
+      const double y2 = z2 / l22, y1 = (z1 - l21 * y2) / l11, y0 = (z0 - l10 * y1 - l20 * y2) / l00;
+      Y[l][0][cix] = y0; Y[l][1][cix] = y1; Y[l][2][cix] = y2;
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+#pragma unroll
+      for (int j = 0; j < 6; ++j) S[i][j] -= Bm[0][i] * Y[l][0][j] + Bm[1][i] * Y[l][1][j] + Bm[2][i] * Y[l][2][j];
+      rb[i] -= Bm[0][i] * Y[l][0][6] + Bm[1][i] * Y[l][1][6] + Bm[2][i] * Y[l][2][6];
+    }
+  }
+  // base block: dense 6 x 6 Cholesky in registers
+  double Lb[6][6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    double d = S[j][j];
+#pragma unroll
+    for (int k = 0; k < j; ++k) d -= Lb[j][k] * Lb[j][k];
+    ok = ok && (d > 0.0);
+    d = sqrt(d > 0.0 ? d : 1.0); Lb[j][j] = d;
+#pragma unroll
+    for (int i = j + 1; i < 6; ++i) {
+      double s = 0.5 * (S[i][j] + S[j][i]);
+#pragma unroll
+      for (int k = 0; k < j; ++k) s -= Lb[i][k] * Lb[j][k];
+      Lb[i][j] = s / d;
+    }
+  }
+  double xb[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) { double s = rb[i];
+#pragma unroll
+    for (int k = 0; k < i; ++k) s -= Lb[i][k] * xb[k];
+    xb[i] = s / Lb[i][i]; }
+#pragma unroll
+  for (int i = 5; i >= 0; --i) { double s = xb[i];
+#pragma unroll
+    for (int k = i + 1; k < 6; ++k) s -= Lb[k][i] * xb[k];
+    xb[i] = s / Lb[i][i]; }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) W(WS_RHS + i) = xb[i];
+#pragma unroll
+  for (int l = 0; l < 4; ++l)
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      double s = Y[l][a][6];
+#pragma unroll
+      for (int j = 0; j < 6; ++j) s -= Y[l][a][j] * xb[j];
+      W(WS_RHS + 6 + 3 * l + a) = s;
+    }
+  return ok;
+}
+
+__global__ void __launch_bounds__(64) landing_wb_rollout_lds_kernel(WbRollArgs a) {
+  __shared__ double ws[WB_TPB * WS_PER];
+  __shared__ RbdModel Ms;                       // the model (3.5 KB) next to the arrays: the recursion reads parent / jtype / Xtree / inertia of every body
+  {
+    static_assert(sizeof(RbdModel) % 4 == 0, "word copy");
+    const unsigned* src = reinterpret_cast<const unsigned*>(a.model); unsigned* dst = reinterpret_cast<unsigned*>(&Ms);
+    for (int e = threadIdx.x; e < (int)(sizeof(RbdModel) / 4); e += blockDim.x) dst[e] = src[e];
+  }
+  __syncthreads();
+  const int idx = blockIdx.x * WB_TPB + threadIdx.x;
+  if ((int)threadIdx.x >= WB_TPB || idx >= a.nalpha * a.B) return;
+  const WsView W{ws + threadIdx.x};
+  const int ia = idx / a.B, b = idx % a.B, N = a.N;
+  const RbdModel& M = Ms;
+  const double alpha = a.alphas[ia];
+  const double* xb = a.x + (size_t)b * (N + 1) * WB_NX; const double* ub = a.u + (size_t)b * N * WB_NU;
+  const double* rb = a.xref + (size_t)b * (N + 1) * WB_NX;
+  double* xo = a.xnew + ((size_t)ia * a.B + b) * (N + 1) * WB_NX; double* uo = a.unew + ((size_t)ia * a.B + b) * N * WB_NU;
+  for (int i = 0; i < WB_NX; ++i) { const double v = xb[i]; W(WS_X + i) = v; xo[i] = v; }
+  double cost = 0.0; bool ok = true;
+  for (int k = 0; k < N; ++k) {
+    for (int c = 0; c < WB_NU; ++c) {
+      double s = ub[k * WB_NU + c];
+      if (a.K) {
+        s += alpha * a.kff[((size_t)b * N + k) * WB_NU + c];
+        const double* Kr = a.K + (((size_t)b * N + k) * WB_NU + c) * WB_NX;
+        for (int j = 0; j < WB_NX; ++j) s += Kr[j] * (W(WS_X + j) - xb[k * WB_NX + j]);
+      }
+      W(WS_UN + c) = s; uo[k * WB_NU + c] = s;
+      cost += 0.5 * a.R[c] * s * s;
+    }
+    for (int i = 0; i < WB_NX; ++i) { const double d = W(WS_X + i) - rb[k * WB_NX + i]; cost += 0.5 * a.Q[i] * d * d; }
+    hand_c_lds(M, a.f_foot ? a.f_foot + ((size_t)b * N + k) * 12 : nullptr, W);
+    for (int i = 0; i < RB_NB; ++i) W(WS_RHS + i) = (i >= 6 ? W(WS_UN + i - 6) : 0.0) - W(WS_C + i);
+    ok = (a.arrow ? arrow_solve18_lds(W) : chol_solve18_lds(W)) && ok;
+    for (int i = 0; i < 18; ++i) { const double qd = W(WS_X + 18 + i); W(WS_X + i) += a.dt * qd; W(WS_X + 18 + i) = qd + a.dt * W(WS_RHS + i); }
+    for (int i = 0; i < WB_NX; ++i) xo[(k + 1) * WB_NX + i] = W(WS_X + i);
+  }
+  for (int i = 0; i < WB_NX; ++i) { const double d = W(WS_X + i) - rb[N * WB_NX + i]; cost += 0.5 * a.QN[i] * d * d; }
   a.cost[(size_t)ia * a.B + b] = (ok && cost == cost) ? cost : INFINITY;
 }
 
