@@ -419,6 +419,19 @@ int landing_leg_ik_batch(landing_ctx* ctx, int npts, const double* d_q6, const d
 int landing_kinodyn_rows_batch(landing_ctx* ctx, int npts, const double* d_q6, const double* d_c, const double* d_f, const double* d_jpos,
                                double* d_fk, double* d_fk_err, double* d_tau, void* stream);
 
+/* ---- function layer of the kinodynamic refinement NLP (landing_optimization.m:38-189) -------------------------------
+ * x = [X(:) (12 x (N+1)); jpos(:) (12 x N); U(:) (24 x N, c then f_grf per column)] -- the script's declaration order (:39-42), nx = 48 N + 12;
+ * g = [q(:,1); qdot(:,1); c(:,1) | q(:,N), q(:,N), qdot(:,N), qdot(:,N) | per interval the rows of :113-189 in the script's order], every
+ * expression the script bounds twice appears twice: ng = 48 + 141 (N - 1) + 117.  N here = number of intervals (the script's N - 1 = 20).
+ * landing_kinodyn_nlp_eval: d_g [B][ng] and / or d_jac [B][N][141][72] -- the Jacobian block of interval k over
+ *   w = [X_k (12), c_k (12), f_k (12), jpos_k (12), X_k+1 (12), c_k+1 (12)] (rows beyond 117 of the last interval and its c_k+1 columns are not
+ *   written / zero); the 48 boundary rows are coordinate picks.  Exact derivatives (forward mode, one tangent per thread), the way the
+ *   reference gets them from CasADi.  Needs landing_rbd_set_model (forward kinematics of get_forward_kin_foot.m, leg lengths of
+ *   get_foot_jacobians_mc.m).  Bounds and the solve itself are not part of this entry point.                          */
+typedef struct { double dt[64]; double mass, Ib[3], Ib_inv[3], mu; } landing_kinodyn_params;
+int landing_kinodyn_nlp_dims(int N, long long* nx, long long* ng);
+int landing_kinodyn_nlp_eval(landing_ctx* ctx, int B, int N, const double* d_x, const landing_kinodyn_params* prm, double* d_g, double* d_jac, void* stream);
+
 /* ---- SQP (Gauss-Newton / iLQR) loop on the 18-DoF model (BASELINE configs[3]) --------------------------------
  * Trajectory-tracking problem per member: state x = [q; qd] (36), control u = the 12 joint torques (base unactuated), known foot
  * forces f_k, explicit Euler  q+ = q + dt qd, qd+ = qd + dt qdd(q, qd, [0; u], f)  (the discretisation of the SRBM NLP,

@@ -457,6 +457,172 @@ __global__ void __launch_bounds__(64) landing_kinodyn_rows_kernel(KdArgs a) {
 }
 
 
+// ---- function layer of the kinodynamic refinement NLP ------------------------------------------------------------
+// g(x) and its Jacobian for the NLP of optimizations/landing/main_scripts/landing_optimization.m:38-189 (N+1 knots, N intervals):
+//   x = [X(:) (12 x (N+1): pos, rpy, omega_body, v_world); jpos(:) (12 x N); U(:) (24 x N: c; f_grf)]   -- the script's declaration order (:39-42)
+//   g = [q(:,1); qdot(:,1); c(:,1)  (24, :89-91) | q(:,N) twice, qdot(:,N) twice (24, :94-97) | per interval k the rows of :113-189 in the
+//        script's order: v / omega / pos / rpy Euler defects (12), f_z (4), per leg [c_z, f_z c_z, f_z (c+ - c) twice (k < N-1), p_rel x y z,
+//        |p_rel|^2, leg torques (3)], friction (16), z (1), c - FK twice (24), jpos twice (24)]:  141 rows (117 in the last interval)
+// Rows that the script states twice (two one-sided inequalities on the same expression) appear twice, so that lbg / ubg can be the script's.
+// One stage function, templated on the scalar: double for g, Dual for one tangent direction -- the Jacobian block of a stage
+// (rows x 72 columns over w = [X_k, c_k, f_k, jpos_k, X_k+1, c_k+1]) is produced exactly, one thread per (member, interval, column),
+// the way the reference gets it from CasADi's algorithmic differentiation.
+struct KdNlpParams { double dt[64]; double mass, Ib[3], Ibi[3], mu; };
+constexpr int KD_NW = 72, KD_ROWS = 141, KD_ROWS_LAST = 117, KD_BND = 48;
+__host__ __device__ inline int kd_ng(int N) { return KD_BND + (N - 1) * KD_ROWS + KD_ROWS_LAST; }
+__host__ __device__ inline int kd_nx(int N) { return 12 * (N + 1) + 12 * N + 24 * N; }
+
+__device__ __forceinline__ Dual operator/(Dual a, Dual b) { const double q = a.v / b.v; return D_(q, (a.d - q * b.d) / b.v); }
+__device__ __forceinline__ Dual operator*(Dual a, double b) { return D_(a.v * b, a.d * b); }
+__device__ __forceinline__ Dual operator+(Dual a, double b) { return D_(a.v + b, a.d); }
+__device__ __forceinline__ Dual operator-(Dual a, double b) { return D_(a.v - b, a.d); }
+__device__ __forceinline__ void sincos_t(double x, double& s, double& c) { sincos(x, &s, &c); }
+__device__ __forceinline__ void sincos_t(Dual x, Dual& s, Dual& c) { double sv, cv; sincos(x.v, &sv, &cv); s = D_(sv, cv * x.d); c = D_(cv, -sv * x.d); }
+__device__ __forceinline__ double lit(double, double v) { return v; }
+__device__ __forceinline__ Dual lit(Dual, double v) { return D_(v); }
+__device__ __forceinline__ V3D mk3(Dual x, Dual y, Dual z) { return mk3D(x, y, z); }
+template <class T> struct KdVec { typedef V3d type; };
+template <> struct KdVec<Dual> { typedef V3D type; };
+
+template <class T>
+__device__ void kd_compose(const T* Eu, const T* ru, T* Ea, T* ra) {      // (Ea, ra) <- plux(Eu, ru) * plux(Ea, ra)
+  const typename KdVec<T>::type t = mulT3(Ea, mk3(ru[0], ru[1], ru[2]));
+  T En[9];
+  for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) En[3 * a + b] = Eu[3 * a] * Ea[b] + Eu[3 * a + 1] * Ea[3 + b] + Eu[3 * a + 2] * Ea[6 + b];
+  for (int j = 0; j < 9; ++j) Ea[j] = En[j];
+  ra[0] = ra[0] + t.x; ra[1] = ra[1] + t.y; ra[2] = ra[2] + t.z;
+}
+
+template <class T>
+__device__ void kd_stage_rows(const KdNlpParams& P, const RbdModel& M, int k, bool last, const T* w, T* out) {
+  typedef typename KdVec<T>::type V;
+  const T zero = lit(w[0], 0.0);
+  const T* X = w; const T* c = w + 12; const T* f = w + 24; const T* jp = w + 36; const T* Xn = w + 48; const T* cn = w + 60;
+  const double dt = P.dt[k];
+  const V pos = mk3(X[0], X[1], X[2]), om = mk3(X[6], X[7], X[8]), v = mk3(X[9], X[10], X[11]);
+  T sr, cr, sp, cp, sy, cy;
+  sincos_t(X[3], sr, cr); sincos_t(X[4], sp, cp); sincos_t(X[5], sy, cy);
+  // R_body_to_world = rx(r)' ry(p)' rz(y)'  (rpyToRotMat_xyz.m:2), row-major
+  const T R[9] = {cp * cy, zero - cp * sy, sp,
+                  cr * sy + sr * sp * cy, cr * cy - sr * sp * sy, zero - sr * cp,
+                  sr * sy - cr * sp * cy, sr * cy + cr * sp * sy, cr * cp};
+  V fs = mk3(zero, zero, zero), tw = mk3(zero, zero, zero);
+  for (int l = 0; l < 4; ++l) {
+    const V fl = mk3(f[3 * l], f[3 * l + 1], f[3 * l + 2]);
+    fs = add3(fs, fl);
+    tw = add3(tw, crs3(sub3(mk3(c[3 * l], c[3 * l + 1], c[3 * l + 2]), pos), fl));
+  }
+  const V tb = mulT3(R, tw);                                                        // R_world_to_body * torque
+  const V Iw = mk3(om.x * P.Ib[0], om.y * P.Ib[1], om.z * P.Ib[2]);
+  const V nn = crs3(om, Iw);
+  const V omd = mk3((tb.x - nn.x) * P.Ibi[0], (tb.y - nn.y) * P.Ibi[1], (tb.z - nn.z) * P.Ibi[2]);
+  const double im = 1.0 / P.mass;
+  const V rdd = mk3(fs.x * im, fs.y * im, fs.z * im - 9.81);
+  const V Rw = mul3(R, om);
+  // Binv(rpy) (Binv.m:13-17), psi = yaw, theta = pitch
+  const T ict = lit(w[0], 1.0) / cp, tt = sp * ict;
+  const V ed = mk3((cy * Rw.x + sy * Rw.y) * ict, cy * Rw.y - sy * Rw.x, (cy * Rw.x + sy * Rw.y) * tt + Rw.z);
+  int r = 0;
+  out[r++] = Xn[9] - X[9] - rdd.x * dt; out[r++] = Xn[10] - X[10] - rdd.y * dt; out[r++] = Xn[11] - X[11] - rdd.z * dt;       // :125
+  out[r++] = Xn[6] - X[6] - omd.x * dt; out[r++] = Xn[7] - X[7] - omd.y * dt; out[r++] = Xn[8] - X[8] - omd.z * dt;          // :126
+  out[r++] = Xn[0] - X[0] - v.x * dt; out[r++] = Xn[1] - X[1] - v.y * dt; out[r++] = Xn[2] - X[2] - v.z * dt;                // :127
+  out[r++] = Xn[3] - X[3] - ed.x * dt; out[r++] = Xn[4] - X[4] - ed.y * dt; out[r++] = Xn[5] - X[5] - ed.z * dt;             // :128
+  for (int l = 0; l < 4; ++l) out[r++] = f[3 * l + 2];                                                                       // :131
+  // world -> base transform of the tree (the six base joints take pos, rpy), for the forward kinematics of :182
+  T E0[9], r0[3], Ej[9], rj[3];
+  for (int j = 0; j < 9; ++j) E0[j] = lit(w[0], (j % 4 == 0) ? 1.0 : 0.0);
+  r0[0] = r0[1] = r0[2] = zero;
+  for (int i = 0; i < 6; ++i) { joint_xform(M.jtype[i], X[i], M.E[i], M.r[i], Ej, rj); kd_compose(Ej, rj, E0, r0); }
+  T fkv[12];
+  const double l14 = M.l1 + M.l4;
+  for (int l = 0; l < 4; ++l) {
+    const T cz = c[3 * l + 2], fz = f[3 * l + 2];
+    out[r++] = cz;                                                                                                           // :138
+    out[r++] = fz * cz;                                                                                                      // :139
+    if (!last) {
+      for (int a = 0; a < 3; ++a) out[r++] = fz * (cn[3 * l + a] - c[3 * l + a]);                                              // :142
+      for (int a = 0; a < 3; ++a) out[r++] = fz * (cn[3 * l + a] - c[3 * l + a]);                                              // :143
+    }
+    const double hx = l < 2 ? 0.19 : -0.19, hy = (l & 1) ? 0.1 : -0.1;        // params.hipSrbmLocation (get_robot_params.m:90-91)
+    const V pr = sub3(mk3(c[3 * l], c[3 * l + 1], c[3 * l + 2]), add3(pos, mk3(R[0] * hx + R[1] * hy, R[3] * hx + R[4] * hy, R[6] * hx + R[7] * hy)));
+    out[r++] = pr.x; out[r++] = pr.y; out[r++] = pr.z;                                                                       // :157-163
+    out[r++] = pr.x * pr.x + pr.y * pr.y + pr.z * pr.z;                                                                      // :164
+    // leg torques J_f'(-R_world_to_body f)  (:167-171, get_foot_jacobians_mc.m:12-24)
+    T s1, c1, s2, c2, s3, c3;
+    sincos_t(jp[3 * l], s1, c1); sincos_t(jp[3 * l + 1], s2, c2); sincos_t(jp[3 * l + 2], s3, c3);
+    const T c23 = c2 * c3 - s2 * s3, s23 = s2 * c3 + c2 * s3;
+    const double ss = (l & 1) ? 1.0 : -1.0;
+    const T J[3][3] = {{zero, c23 * M.l3 + c2 * M.l2, c23 * M.l3},
+                       {c1 * c23 * M.l3 + c1 * c2 * M.l2 - s1 * (l14 * ss), zero - s1 * s23 * M.l3 - s1 * s2 * M.l2, zero - s1 * s23 * M.l3},
+                       {s1 * c23 * M.l3 + c2 * s1 * M.l2 + c1 * (l14 * ss), c1 * s23 * M.l3 + c1 * s2 * M.l2, c1 * s23 * M.l3}};
+    const V fb = mulT3(R, mk3(zero - f[3 * l], zero - f[3 * l + 1], zero - f[3 * l + 2]));
+    for (int j = 0; j < 3; ++j) out[r++] = J[0][j] * fb.x + J[1][j] * fb.y + J[2][j] * fb.z;
+    // foot position of the tree (get_forward_kin_foot.m)
+    T El[9], rl[3];
+    for (int j = 0; j < 9; ++j) El[j] = E0[j];
+    for (int j = 0; j < 3; ++j) rl[j] = r0[j];
+    const int jb = M.b_foot[l] - 1;
+    for (int i = jb - 2; i <= jb; ++i) { joint_xform(M.jtype[i], jp[3 * l + (i - (jb - 2))], M.E[i], M.r[i], Ej, rj); kd_compose(Ej, rj, El, rl); }
+    const V pf = add3(mk3(rl[0], rl[1], rl[2]), mulT3(El, mk3(lit(w[0], M.foot_r[l][0]), lit(w[0], M.foot_r[l][1]), lit(w[0], M.foot_r[l][2]))));
+    fkv[3 * l] = pf.x; fkv[3 * l + 1] = pf.y; fkv[3 * l + 2] = pf.z;
+  }
+  const double km = 0.71 * P.mu;
+  for (int l = 0; l < 4; ++l) out[r++] = f[3 * l] - f[3 * l + 2] * km;                                                         // :175
+  for (int l = 0; l < 4; ++l) out[r++] = f[3 * l] + f[3 * l + 2] * km;                                                         // :176
+  for (int l = 0; l < 4; ++l) out[r++] = f[3 * l + 1] - f[3 * l + 2] * km;                                                     // :177
+  for (int l = 0; l < 4; ++l) out[r++] = f[3 * l + 1] + f[3 * l + 2] * km;                                                     // :178
+  out[r++] = X[2];                                                                                                           // :181
+  for (int j = 0; j < 12; ++j) out[r++] = c[j] - fkv[j];                                                                     // :186
+  for (int j = 0; j < 12; ++j) out[r++] = c[j] - fkv[j];                                                                     // :187
+  for (int j = 0; j < 12; ++j) out[r++] = jp[j];                                                                             // :188
+  for (int j = 0; j < 12; ++j) out[r++] = jp[j];                                                                             // :189
+}
+
+struct KdNlpArgs { const RbdModel* model; KdNlpParams P; int B, N; const double* x; double* g; double* jac; };
+// index of w[j] of interval k in x
+__device__ __forceinline__ int kd_w_index(int N, int k, int j) {
+  const int oJ = 12 * (N + 1), oU = oJ + 12 * N;
+  if (j < 12) return 12 * k + j;
+  if (j < 24) return oU + 24 * k + (j - 12);
+  if (j < 36) return oU + 24 * k + 12 + (j - 24);
+  if (j < 48) return oJ + 12 * k + (j - 36);
+  if (j < 60) return 12 * (k + 1) + (j - 48);
+  return k + 1 < N ? oU + 24 * (k + 1) + (j - 60) : -1;          // c of the next interval (the last interval has none)
+}
+// g: one thread per (member, interval); the thread of interval 0 also writes the 48 boundary rows
+__global__ void __launch_bounds__(64) landing_kinodyn_nlp_g_kernel(KdNlpArgs a) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= a.B * a.N) return;
+  const int b = idx / a.N, k = idx % a.N, N = a.N;
+  const double* x = a.x + (size_t)b * kd_nx(N);
+  double* g = a.g + (size_t)b * kd_ng(N);
+  double w[KD_NW], out[KD_ROWS];
+  for (int j = 0; j < KD_NW; ++j) { const int i = kd_w_index(N, k, j); w[j] = i >= 0 ? x[i] : 0.0; }
+  const bool last = k == N - 1;
+  kd_stage_rows<double>(a.P, *a.model, k, last, w, out);
+  const int nr = last ? KD_ROWS_LAST : KD_ROWS;
+  for (int r = 0; r < nr; ++r) g[KD_BND + k * KD_ROWS + r] = out[r];
+  if (k == 0) {
+    for (int i = 0; i < 12; ++i) g[i] = x[i];                                            // q(:,1), qdot(:,1)
+    for (int i = 0; i < 12; ++i) g[12 + i] = x[12 * (N + 1) + 12 * N + i];               // c(:,1)
+    for (int i = 0; i < 6; ++i) { g[24 + i] = x[12 * N + i]; g[30 + i] = x[12 * N + i]; g[36 + i] = x[12 * N + 6 + i]; g[42 + i] = x[12 * N + 6 + i]; }
+  }
+}
+// Jacobian blocks: jac[b][k][row][col], col over w (72), one thread per (member, interval, column)
+__global__ void __launch_bounds__(64) landing_kinodyn_nlp_jac_kernel(KdNlpArgs a) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long long)a.B * a.N * KD_NW) return;
+  const int col = (int)(idx % KD_NW); const int k = (int)((idx / KD_NW) % a.N); const int b = (int)(idx / ((long long)KD_NW * a.N)), N = a.N;
+  const double* x = a.x + (size_t)b * kd_nx(N);
+  Dual w[KD_NW], out[KD_ROWS];
+  for (int j = 0; j < KD_NW; ++j) { const int i = kd_w_index(N, k, j); w[j] = D_(i >= 0 ? x[i] : 0.0, j == col ? 1.0 : 0.0); }
+  const bool last = k == N - 1;
+  kd_stage_rows<Dual>(a.P, *a.model, k, last, w, out);
+  const int nr = last ? KD_ROWS_LAST : KD_ROWS;
+  double* J = a.jac + (((size_t)b * N + k) * KD_ROWS) * KD_NW;
+  for (int r = 0; r < nr; ++r) J[(size_t)r * KD_NW + col] = (last && col >= 60) ? 0.0 : out[r].d;
+}
+
 // Leg inverse kinematics for the kinodynamic screen: joint angles of every leg such that FK([q6; jpos]) = c (the foot positions of an
 // SRBM solution), by damped Newton steps on the tree FK with a central-difference 3 x 3 Jacobian, clamped to the joint limits of
 // landing_optimization.m:246-247 (the reference seeds its kinodynamic NLP the same way, through quadInverseKinematics / fsolve,

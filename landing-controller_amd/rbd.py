@@ -65,6 +65,11 @@ JPOS_MIN = np.tile([-np.pi / 3, -np.pi / 2, 0.0], 4)       # landing_optimizatio
 JPOS_MAX = np.tile([np.pi / 3, np.pi / 2, 3 * np.pi / 4], 4)
 
 
+class KinodynParams(C.Structure):
+    """landing_kinodyn_params of include/landing_nlp.h"""
+    _fields_ = [("dt", C.c_double * 64), ("mass", C.c_double), ("Ib", C.c_double * 3), ("Ib_inv", C.c_double * 3), ("mu", C.c_double)]
+
+
 class Rbd:
     """binds the three entry points on an existing LandingLib (its context owns the uploaded model)"""
 
@@ -76,6 +81,8 @@ class Rbd:
         lib.lib.landing_kinodyn_rows_batch.argtypes = [vp, C.c_int] + [vp] * 7 + [vp]
         dp = C.POINTER(C.c_double)
         lib.lib.landing_leg_ik_batch.argtypes = [vp, C.c_int, vp, vp, dp, dp, C.c_int, vp, vp, vp]
+        lib.lib.landing_kinodyn_nlp_dims.argtypes = [C.c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
+        lib.lib.landing_kinodyn_nlp_eval.argtypes = [vp, C.c_int, C.c_int, vp, C.POINTER(KinodynParams), vp, vp, vp]
         self.model = quad3d_model()
         lib._check(lib.lib.landing_rbd_set_model(lib.ctx, C.byref(self.model)), "landing_rbd_set_model")
 
@@ -88,6 +95,22 @@ class Rbd:
     def kinodyn_rows(self, npts, d_q6, d_c, d_f, d_jpos, d_fk=0, d_fk_err=0, d_tau=0, stream=0):
         n = lambda v: v or None
         self.L._check(self.L.lib.landing_kinodyn_rows_batch(self.L.ctx, npts, d_q6, n(d_c), n(d_f), d_jpos, n(d_fk), n(d_fk_err), n(d_tau), n(stream)), "landing_kinodyn_rows_batch")
+
+    def kinodyn_nlp_dims(self, N):
+        nx, ng = C.c_longlong(), C.c_longlong()
+        self.L._check(self.L.lib.landing_kinodyn_nlp_dims(N, C.byref(nx), C.byref(ng)), "landing_kinodyn_nlp_dims")
+        return nx.value, ng.value
+
+    def kinodyn_nlp_eval(self, B, N, d_x, dt, mass, Ib, Ib_inv, mu, d_g=0, d_jac=0, stream=0):
+        """function layer of the kinodynamic refinement NLP (include/landing_nlp.h): g [B, ng] and / or the Jacobian blocks [B, N, 141, 72]"""
+        prm = KinodynParams()
+        for k in range(N):
+            prm.dt[k] = float(dt[k])
+        prm.mass = float(mass); prm.mu = float(mu)
+        for i in range(3):
+            prm.Ib[i] = float(Ib[i]); prm.Ib_inv[i] = float(Ib_inv[i])
+        n = lambda v: v or None
+        self.L._check(self.L.lib.landing_kinodyn_nlp_eval(self.L.ctx, B, N, d_x, C.byref(prm), n(d_g), n(d_jac), n(stream)), "landing_kinodyn_nlp_eval")
 
     def leg_ik(self, npts, d_q6, d_c, d_jpos, d_res=0, iters=12, jmin=None, jmax=None, stream=0):
         jmin = np.ascontiguousarray(JPOS_MIN[:3] if jmin is None else jmin, float); jmax = np.ascontiguousarray(JPOS_MAX[:3] if jmax is None else jmax, float)

@@ -71,3 +71,73 @@ def kinematic_rows(X, U, jpos):
     for k in range(N):
         _, fk_err[k], tau[k] = ro.kinodyn_rows(X[:6, k], U[:12, k], U[12:, k], jpos[:, k])
     return fk_err, tau
+
+
+# ---- the whole NLP in the layout of include/landing_nlp.h (landing_kinodyn_nlp_eval): x = [X(:); jpos(:); U(:)], rows in the script's order ----
+def nlp_dims(N):
+    return 48 * N + 12, 48 + 141 * (N - 1) + 117
+
+
+def stage_rows(w, dt, last, mass, Ib, Ib_inv, mu):
+    """rows of one interval (landing_optimization.m:113-189) for w = [X_k, c_k, f_k, jpos_k, X_k+1, c_k+1] (72): 141 values, 117 when `last`"""
+    X, c, f, jp, Xn, cn = w[:12], w[12:24], w[24:36], w[36:48], w[48:60], w[60:72]
+    pos, rpy, om, v = X[0:3], X[3:6], X[6:9], X[9:12]
+    R = ro.rpy_to_rot_xyz(rpy)
+    cf, ff = c.reshape(4, 3), f.reshape(4, 3)
+    rdd = ff.sum(axis=0) / mass + np.array([0.0, 0.0, -9.81])
+    tau = sum(np.cross(cf[l] - pos, ff[l]) for l in range(4))
+    omd = Ib_inv * (R.T @ tau - np.cross(om, Ib * om))
+    out = [Xn[9:12] - v - rdd * dt, Xn[6:9] - om - omd * dt, Xn[0:3] - pos - v * dt, Xn[3:6] - rpy - binv(rpy) @ (R @ om) * dt, ff[:, 2]]
+    fk, fk_err, tq = ro.kinodyn_rows(X[:6], c, f, jp)
+    for l in range(4):
+        out.append([cf[l, 2], ff[l, 2] * cf[l, 2]])
+        if not last:
+            d = ff[l, 2] * (cn[3 * l:3 * l + 3] - cf[l])
+            out += [d, d]
+        pr = cf[l] - (pos + R @ HIP[l])
+        out += [pr, [pr @ pr], tq[3 * l:3 * l + 3]]
+    km = 0.71 * mu
+    out += [ff[:, 0] - km * ff[:, 2], ff[:, 0] + km * ff[:, 2], ff[:, 1] - km * ff[:, 2], ff[:, 1] + km * ff[:, 2], [pos[2]], fk_err, fk_err, jp, jp]
+    return np.concatenate([np.atleast_1d(np.asarray(o, float)) for o in out])
+
+
+def w_index(N, k, j):
+    oJ, oU = 12 * (N + 1), 12 * (N + 1) + 12 * N
+    if j < 12: return 12 * k + j
+    if j < 24: return oU + 24 * k + (j - 12)
+    if j < 36: return oU + 24 * k + 12 + (j - 24)
+    if j < 48: return oJ + 12 * k + (j - 36)
+    if j < 60: return 12 * (k + 1) + (j - 48)
+    return oU + 24 * (k + 1) + (j - 60) if k + 1 < N else -1
+
+
+def gather_w(x, N, k):
+    return np.array([x[w_index(N, k, j)] if w_index(N, k, j) >= 0 else 0.0 for j in range(72)])
+
+
+def nlp_g(x, N, dt, mass, Ib, Ib_inv, mu):
+    nx, ng = nlp_dims(N)
+    assert x.shape == (nx,)
+    oU = 12 * (N + 1) + 12 * N
+    g = [x[0:12], x[oU:oU + 12], x[12 * N:12 * N + 6], x[12 * N:12 * N + 6], x[12 * N + 6:12 * N + 12], x[12 * N + 6:12 * N + 12]]
+    for k in range(N):
+        g.append(stage_rows(gather_w(x, N, k), dt[k], k == N - 1, mass, Ib, Ib_inv, mu))
+    g = np.concatenate(g)
+    assert g.shape == (ng,)
+    return g
+
+
+def stage_jacobian(w, dt, last, mass, Ib, Ib_inv, mu, h=2e-3):
+    """d rows / d w [rows, 72] by Richardson-extrapolated central differences (steps h, h/2: error O(h^4))"""
+    def cd(hh):
+        J = np.zeros((117 if last else 141, 72))
+        for j in range(72):
+            e = np.zeros(72); e[j] = hh
+            J[:, j] = (stage_rows(w + e, dt, last, mass, Ib, Ib_inv, mu) - stage_rows(w - e, dt, last, mass, Ib, Ib_inv, mu)) / (2 * hh)
+        return J
+    return (4.0 * cd(0.5 * h) - cd(h)) / 3.0
+
+
+def pack_x(X, U, J):
+    """X [12, N+1], U [24, N] (c; f), jpos [12, N] -> x in the layout above"""
+    return np.concatenate([X.flatten(order="F"), J.flatten(order="F"), U.flatten(order="F")])

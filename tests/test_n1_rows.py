@@ -82,3 +82,100 @@ def test_kinodyn_rows_kernel_on_stored_solutions_gpu():
     L = lc("capi").LandingLib(20, device=0)
     _check_rows(_rows_through(L, "cuda"))
     L.close()
+
+
+# ---- function layer of the whole refinement NLP (landing_kinodyn_nlp_eval): g and the exact Jacobian blocks --------------------------------
+def _nlp_check(L, dev, N, B, seed, n_jac=2):
+    """random points around a plausible posture: g vs the numpy oracle (1e-12), Jacobian blocks vs Richardson-extrapolated differences of the
+    ORACLE's rows (1e-7 relative: the kernel differentiates exactly, the tolerance is the oracle's)"""
+    import torch
+    from oracle import kinodyn_oracle as ko
+    mass, Ib, Ibi = lc("constants").robot_constants()
+    Ib, Ibi = np.asarray(Ib), np.asarray(Ibi)
+    R = lc("rbd").Rbd(L)
+    nx, ng = R.kinodyn_nlp_dims(N)
+    assert (nx, ng) == ko.nlp_dims(N)
+    rng = np.random.default_rng(seed)
+    dt = 0.02 + 0.03 * rng.random(N); mu = 0.75
+    xs = np.zeros((B, nx))
+    for b in range(B):
+        X = np.zeros((12, N + 1)); U = np.zeros((24, N)); J = np.zeros((12, N))
+        X[2] = 0.3 + 0.05 * rng.normal(size=N + 1); X[3:6] = 0.3 * rng.normal(size=(3, N + 1)); X[6:] = rng.normal(size=(6, N + 1)); X[:2] = 0.1 * rng.normal(size=(2, N + 1))
+        U[:12] = (np.tile([0.2, -0.15, 0.0, 0.2, 0.15, 0.0, -0.2, -0.15, 0.0, -0.2, 0.15, 0.0], (N, 1)).T + 0.05 * rng.normal(size=(12, N)))
+        U[12:] = 20.0 * rng.normal(size=(12, N)); U[14::3] = np.abs(U[14::3])
+        J[:] = (np.tile([0.0, -0.8, 1.6], 4)[:, None] + 0.2 * rng.normal(size=(12, N)))
+        xs[b] = ko.pack_x(X, U, J)
+    dx = torch.tensor(xs, dtype=torch.float64, device=dev)
+    g = torch.zeros(B, ng, dtype=torch.float64, device=dev); jac = torch.zeros(B, N, 141, 72, dtype=torch.float64, device=dev)
+    st = torch.cuda.current_stream().cuda_stream if dev == "cuda" else 0
+    R.kinodyn_nlp_eval(B, N, dx.data_ptr(), dt, mass, Ib, Ibi, mu, g.data_ptr(), jac.data_ptr(), st)
+    if dev == "cuda":
+        torch.cuda.synchronize()
+    g, jac = g.cpu().numpy(), jac.cpu().numpy()
+    for b in range(B):
+        go = ko.nlp_g(xs[b], N, dt, mass, Ib, Ibi, mu)
+        assert np.abs(g[b] - go).max() <= 1e-12 * max(1.0, np.abs(go).max()), np.abs(g[b] - go).max()
+    for b in range(min(B, n_jac)):
+        for k in (0, N - 1):
+            last = k == N - 1
+            Jo = ko.stage_jacobian(ko.gather_w(xs[b], N, k), dt[k], last, mass, Ib, Ibi, mu)
+            Jk = jac[b, k, :Jo.shape[0]]
+            assert np.abs(Jk - Jo).max() <= 1e-7 * max(1.0, np.abs(Jo).max()), (k, np.abs(Jk - Jo).max())
+            if last:
+                assert (Jk[:, 60:] == 0.0).all()
+    return R
+
+
+def test_kinodyn_nlp_function_layer_emulated():
+    subprocess.run(["make", "-C", os.path.join(PKG, "csrc"), "emu"], check=True, capture_output=True)
+    L = lc("capi").LandingLib(20, lib_path=os.path.join(ROOT, "tests", "emu", "liblanding_emu.so"))
+    _nlp_check(L, "cpu", N=3, B=2, seed=1, n_jac=1)
+
+
+def _stored_solution_rows(L, dev):
+    """the reference's stored kinodynamic solutions through the kernel: every row group inside the script's bounds"""
+    import torch
+    from oracle import kinodyn_oracle as ko
+    mass, Ib, Ibi = lc("constants").robot_constants()
+    R = lc("rbd").Rbd(L)
+    N = 20
+    for tag, mu, band in (("a", 0.5, 1e-3), ("b", 1.0, 1e-2)):
+        X, U, J = _sol(tag)
+        x = ko.pack_x(X, U, J)
+        dx = torch.tensor(x[None], dtype=torch.float64, device=dev)
+        g = torch.zeros(1, ko.nlp_dims(N)[1], dtype=torch.float64, device=dev)
+        st = torch.cuda.current_stream().cuda_stream if dev == "cuda" else 0
+        R.kinodyn_nlp_eval(1, N, dx.data_ptr(), DT, mass, np.asarray(Ib), np.asarray(Ibi), mu, g.data_ptr(), 0, st)
+        if dev == "cuda":
+            torch.cuda.synchronize()
+        g = g.cpu().numpy()[0]
+        assert np.abs(g - ko.nlp_g(x, N, DT, mass, np.asarray(Ib), np.asarray(Ibi), mu)).max() <= 1e-12
+        for k in range(N):
+            last = k == N - 1
+            r = g[48 + 141 * k: 48 + 141 * k + (117 if last else 141)]
+            assert np.abs(r[:12]).max() <= 5e-5                                       # Euler defects
+            assert r[12:16].min() >= -1e-6                                            # f_z >= 0
+            S = 9 if last else 15
+            for l in range(4):
+                q = r[16 + S * l: 16 + S * (l + 1)]
+                assert q[0] >= -1e-5 and q[1] <= 1e-3 * 1.001                         # c_z >= 0, LCP
+                if not last:
+                    assert np.abs(q[2:8]).max() <= 1e-3 * 1.001                       # no slip
+                assert (np.abs(q[-3:]) <= ko.TAU_MAX).all()                           # leg torques
+            o = 16 + 4 * S
+            assert r[o + 4:o + 8].min() >= -1e-5 and r[o:o + 4].max() <= 1e-5 and r[o + 12:o + 16].min() >= -1e-5 and r[o + 8:o + 12].max() <= 1e-5      # friction pyramid
+            assert np.abs(r[o + 17:o + 29]).max() <= band * 1.002                     # FK band
+
+
+def test_kinodyn_nlp_rows_on_stored_solutions_emulated():
+    L = lc("capi").LandingLib(20, lib_path=os.path.join(ROOT, "tests", "emu", "liblanding_emu.so"))
+    _stored_solution_rows(L, "cpu")
+
+
+@pytest.mark.gpu
+def test_kinodyn_nlp_function_layer_gpu():
+    """N = 20 intervals (the script's size), 1024 members: g of every member and sampled Jacobian blocks against the oracle; the stored solutions"""
+    L = lc("capi").LandingLib(20, device=0)
+    _nlp_check(L, "cuda", N=20, B=1024, seed=2, n_jac=2)
+    _stored_solution_rows(L, "cuda")
+    L.close()
