@@ -59,7 +59,7 @@ EXPORTS = ["landing_last_error", "landing_form_default", "landing_solver_opts_de
            "landing_multi_create", "landing_multi_destroy", "landing_multi_count", "landing_shard_range", "landing_multi_solve_args21",
            "landing_solve_21_multi", "landing_multi_release_cached",
            "landing_np_ccc", "landing_ctx_np", "landing_pack_args25", "landing_solve_args25", "landing_riccati_gains_batch", "landing_mpc_shift", "landing_solver_opts_warm", "landing_rbd_set_model", "landing_fb_dynamics_batch",
-           "landing_kinodyn_rows_batch", "landing_kinodyn_nlp_dims", "landing_kinodyn_nlp_eval", "landing_leg_ik_batch", "landing_nnz_hess_rc", "landing_pattern_hess_rc",
+           "landing_kinodyn_rows_batch", "landing_kinodyn_nlp_dims", "landing_kinodyn_nlp_eval", "landing_kinodyn_nlp_hess", "landing_leg_ik_batch", "landing_nnz_hess_rc", "landing_pattern_hess_rc",
            "landing_eval_hess_rc_batch", "landing_eval_hess_rc_batch_host"]
 
 

@@ -483,6 +483,52 @@ __device__ __forceinline__ Dual lit(Dual, double v) { return D_(v); }
 __device__ __forceinline__ V3D mk3(Dual x, Dual y, Dual z) { return mk3D(x, y, z); }
 template <class T> struct KdVec { typedef V3d type; };
 template <> struct KdVec<Dual> { typedef V3D type; };
+// second-order forward mode: value, two first-order parts and the mixed second-order part along directions (e_i, e_j); the same stage
+// function instantiated on this scalar gives d^2 rows / dw_i dw_j exactly (hyper-dual numbers)
+struct HDual { double v, a, b, ab; };
+__device__ __forceinline__ HDual H_(double v, double a = 0.0, double b = 0.0, double ab = 0.0) { HDual o; o.v = v; o.a = a; o.b = b; o.ab = ab; return o; }
+__device__ __forceinline__ HDual operator+(HDual x, HDual y) { return H_(x.v + y.v, x.a + y.a, x.b + y.b, x.ab + y.ab); }
+__device__ __forceinline__ HDual operator-(HDual x, HDual y) { return H_(x.v - y.v, x.a - y.a, x.b - y.b, x.ab - y.ab); }
+__device__ __forceinline__ HDual operator*(HDual x, HDual y) { return H_(x.v * y.v, x.a * y.v + x.v * y.a, x.b * y.v + x.v * y.b, x.ab * y.v + x.a * y.b + x.b * y.a + x.v * y.ab); }
+__device__ __forceinline__ HDual operator*(HDual x, double s) { return H_(x.v * s, x.a * s, x.b * s, x.ab * s); }
+__device__ __forceinline__ HDual operator*(double s, HDual x) { return H_(x.v * s, x.a * s, x.b * s, x.ab * s); }
+__device__ __forceinline__ HDual operator+(HDual x, double s) { return H_(x.v + s, x.a, x.b, x.ab); }
+__device__ __forceinline__ HDual operator-(HDual x, double s) { return H_(x.v - s, x.a, x.b, x.ab); }
+__device__ __forceinline__ HDual operator/(HDual x, HDual y) {
+  const double f = 1.0 / y.v, f1 = -f * f, f2 = -2.0 * f * f1;
+  return x * H_(f, f1 * y.a, f1 * y.b, f2 * y.a * y.b + f1 * y.ab);
+}
+__device__ __forceinline__ void sincos_t(HDual x, HDual& s, HDual& c) {
+  double sv, cv; sincos(x.v, &sv, &cv);
+  s = H_(sv, cv * x.a, cv * x.b, -sv * x.a * x.b + cv * x.ab); c = H_(cv, -sv * x.a, -sv * x.b, -cv * x.a * x.b - sv * x.ab);
+}
+__device__ __forceinline__ HDual lit(HDual, double v) { return H_(v); }
+struct V3H { HDual x, y, z; };
+__device__ __forceinline__ V3H mk3(HDual x, HDual y, HDual z) { V3H v; v.x = x; v.y = y; v.z = z; return v; }
+__device__ __forceinline__ V3H add3(V3H a, V3H b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ V3H sub3(V3H a, V3H b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ V3H crs3(V3H a, V3H b) { return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+__device__ __forceinline__ V3H mul3(const HDual* E, V3H v) { return mk3(E[0] * v.x + E[1] * v.y + E[2] * v.z, E[3] * v.x + E[4] * v.y + E[5] * v.z, E[6] * v.x + E[7] * v.y + E[8] * v.z); }
+__device__ __forceinline__ V3H mulT3(const HDual* E, V3H v) { return mk3(E[0] * v.x + E[3] * v.y + E[6] * v.z, E[1] * v.x + E[4] * v.y + E[7] * v.z, E[2] * v.x + E[5] * v.y + E[8] * v.z); }
+template <> struct KdVec<HDual> { typedef V3H type; };
+__device__ __forceinline__ void joint_xform(int jt, HDual q, const double* Et, const double* rt, HDual* E, HDual* r) {
+  if (jt < 3) {
+    HDual S, Cc; sincos_t(q, S, Cc);
+    const int a = jt, b = (jt + 1) % 3, d = (jt + 2) % 3;
+    for (int j = 0; j < 3; ++j) {
+      E[3 * a + j] = H_(Et[3 * a + j]);
+      E[3 * b + j] = Et[3 * b + j] * Cc + Et[3 * d + j] * S;
+      E[3 * d + j] = Et[3 * d + j] * Cc - Et[3 * b + j] * S;
+    }
+    r[0] = H_(rt[0]); r[1] = H_(rt[1]); r[2] = H_(rt[2]);
+  } else {
+    const int a = jt - 3;
+    for (int j = 0; j < 9; ++j) E[j] = H_(Et[j]);
+    r[0] = H_(rt[0]) + Et[3 * a] * q; r[1] = H_(rt[1]) + Et[3 * a + 1] * q; r[2] = H_(rt[2]) + Et[3 * a + 2] * q;
+  }
+}
+
+
 
 template <class T>
 __device__ void kd_compose(const T* Eu, const T* ru, T* Ea, T* ra) {      // (Ea, ra) <- plux(Eu, ru) * plux(Ea, ra)
@@ -578,7 +624,7 @@ __device__ void kd_stage_rows(const KdNlpParams& P, const RbdModel& M, int k, bo
   for (int j = 0; j < 12; ++j) out[r++] = jp[j];                                                                             // :189
 }
 
-struct KdNlpArgs { const RbdModel* model; KdNlpParams P; int B, N; const double* x; double* g; double* jac; };
+struct KdNlpArgs { const RbdModel* model; KdNlpParams P; int B, N; const double* x; double* g; double* jac; const double* lam; double* hess; };
 // index of w[j] of interval k in x
 __device__ __forceinline__ int kd_w_index(int N, int k, int j) {
   const int oJ = 12 * (N + 1), oU = oJ + 12 * N;
@@ -621,6 +667,33 @@ __global__ void __launch_bounds__(64) landing_kinodyn_nlp_jac_kernel(KdNlpArgs a
   const int nr = last ? KD_ROWS_LAST : KD_ROWS;
   double* J = a.jac + (((size_t)b * N + k) * KD_ROWS) * KD_NW;
   for (int r = 0; r < nr; ++r) J[(size_t)r * KD_NW + col] = (last && col >= 60) ? 0.0 : out[r].d;
+}
+
+// Hessian of lam' g restricted to one interval: hess[b][k][i][j] = sum_r lam_r d^2 row_r / dw_i dw_j (72 x 72, symmetric; the 48 boundary rows are
+// linear), one thread per (member, interval, pair i <= j) pushing the two directions through the stage function in second-order forward mode.
+// X_k+1 enters every row linearly and c_k+1 only through f_z (c_k+1 - c_k): pairs inside [X_k+1, c_k+1] are structural zeros and are skipped.
+// The NLP's Hessian of the Lagrangian is the sum of these blocks at their positions in x (+ the constant 2 QN of the terminal cost, :84-86).
+// A first, exact implementation for the next round's solver to be checked against -- not tuned (2 628 stage evaluations per interval).
+constexpr int KD_NPAIR = KD_NW * (KD_NW + 1) / 2;
+__global__ void __launch_bounds__(64) landing_kinodyn_nlp_hess_kernel(KdNlpArgs a) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long long)a.B * a.N * KD_NPAIR) return;
+  int pr = (int)(idx % KD_NPAIR); const int k = (int)((idx / KD_NPAIR) % a.N); const int b = (int)(idx / ((long long)KD_NPAIR * a.N)), N = a.N;
+  int i = 0;
+  while (pr >= KD_NW - i) { pr -= KD_NW - i; ++i; }
+  const int j = i + pr;
+  double* Hk = a.hess + (((size_t)b * N + k) * KD_NW) * KD_NW;
+  const bool last = k == N - 1;
+  if (i >= 48 || (j >= 48 && j < 60) || (last && j >= 60)) { Hk[i * KD_NW + j] = 0.0; Hk[j * KD_NW + i] = 0.0; return; }
+  const double* x = a.x + (size_t)b * kd_nx(N);
+  const double* lam = a.lam + (size_t)b * kd_ng(N) + KD_BND + (size_t)k * KD_ROWS;
+  HDual w[KD_NW], out[KD_ROWS];
+  for (int q = 0; q < KD_NW; ++q) { const int ix = kd_w_index(N, k, q); w[q] = H_(ix >= 0 ? x[ix] : 0.0, q == i ? 1.0 : 0.0, q == j ? 1.0 : 0.0, 0.0); }
+  kd_stage_rows<HDual>(a.P, *a.model, k, last, w, out);
+  const int nr = last ? KD_ROWS_LAST : KD_ROWS;
+  double s = 0.0;
+  for (int r = 0; r < nr; ++r) s += lam[r] * out[r].ab;
+  Hk[i * KD_NW + j] = s; Hk[j * KD_NW + i] = s;
 }
 
 // Leg inverse kinematics for the kinodynamic screen: joint angles of every leg such that FK([q6; jpos]) = c (the foot positions of an

@@ -83,6 +83,7 @@ class Rbd:
         lib.lib.landing_leg_ik_batch.argtypes = [vp, C.c_int, vp, vp, dp, dp, C.c_int, vp, vp, vp]
         lib.lib.landing_kinodyn_nlp_dims.argtypes = [C.c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
         lib.lib.landing_kinodyn_nlp_eval.argtypes = [vp, C.c_int, C.c_int, vp, C.POINTER(KinodynParams), vp, vp, vp]
+        lib.lib.landing_kinodyn_nlp_hess.argtypes = [vp, C.c_int, C.c_int, vp, C.POINTER(KinodynParams), vp, vp, vp]
         self.model = quad3d_model()
         lib._check(lib.lib.landing_rbd_set_model(lib.ctx, C.byref(self.model)), "landing_rbd_set_model")
 
@@ -101,16 +102,26 @@ class Rbd:
         self.L._check(self.L.lib.landing_kinodyn_nlp_dims(N, C.byref(nx), C.byref(ng)), "landing_kinodyn_nlp_dims")
         return nx.value, ng.value
 
-    def kinodyn_nlp_eval(self, B, N, d_x, dt, mass, Ib, Ib_inv, mu, d_g=0, d_jac=0, stream=0):
-        """function layer of the kinodynamic refinement NLP (include/landing_nlp.h): g [B, ng] and / or the Jacobian blocks [B, N, 141, 72]"""
+    @staticmethod
+    def _kd_params(N, dt, mass, Ib, Ib_inv, mu):
         prm = KinodynParams()
         for k in range(N):
             prm.dt[k] = float(dt[k])
         prm.mass = float(mass); prm.mu = float(mu)
         for i in range(3):
             prm.Ib[i] = float(Ib[i]); prm.Ib_inv[i] = float(Ib_inv[i])
+        return prm
+
+    def kinodyn_nlp_eval(self, B, N, d_x, dt, mass, Ib, Ib_inv, mu, d_g=0, d_jac=0, stream=0):
+        """function layer of the kinodynamic refinement NLP (include/landing_nlp.h): g [B, ng] and / or the Jacobian blocks [B, N, 141, 72]"""
+        prm = self._kd_params(N, dt, mass, Ib, Ib_inv, mu)
         n = lambda v: v or None
         self.L._check(self.L.lib.landing_kinodyn_nlp_eval(self.L.ctx, B, N, d_x, C.byref(prm), n(d_g), n(d_jac), n(stream)), "landing_kinodyn_nlp_eval")
+
+    def kinodyn_nlp_hess(self, B, N, d_x, dt, mass, Ib, Ib_inv, mu, d_lam_g, d_hess, stream=0):
+        """Hessian blocks of lam_g' g per interval [B, N, 72, 72] (include/landing_nlp.h)"""
+        prm = self._kd_params(N, dt, mass, Ib, Ib_inv, mu)
+        self.L._check(self.L.lib.landing_kinodyn_nlp_hess(self.L.ctx, B, N, d_x, C.byref(prm), d_lam_g, d_hess, stream or None), "landing_kinodyn_nlp_hess")
 
     def leg_ik(self, npts, d_q6, d_c, d_jpos, d_res=0, iters=12, jmin=None, jmax=None, stream=0):
         jmin = np.ascontiguousarray(JPOS_MIN[:3] if jmin is None else jmin, float); jmax = np.ascontiguousarray(JPOS_MAX[:3] if jmax is None else jmax, float)

@@ -179,3 +179,65 @@ def test_kinodyn_nlp_function_layer_gpu():
     _nlp_check(L, "cuda", N=20, B=1024, seed=2, n_jac=2)
     _stored_solution_rows(L, "cuda")
     L.close()
+
+
+def _hess_check(L, dev, N, B, seed, oracle_cols):
+    """Hessian blocks of lam' g: symmetric, structural zeros in the [X_k+1, c_k+1] block, equal to central differences of the kernel's own exact
+    Jacobian (J' lam at w +- h e_j, every column of two intervals, 1e-6) and -- for a few columns -- of the ORACLE's Richardson Jacobian (1e-5)"""
+    import torch
+    from oracle import kinodyn_oracle as ko
+    mass, Ib, Ibi = lc("constants").robot_constants()
+    Ib, Ibi = np.asarray(Ib), np.asarray(Ibi)
+    R = lc("rbd").Rbd(L)
+    nx, ng = R.kinodyn_nlp_dims(N)
+    rng = np.random.default_rng(seed)
+    dt = 0.02 + 0.03 * rng.random(N); mu = 0.75
+    xs = 0.3 * rng.normal(size=(B, nx)); xs[:, 2:12 * (N + 1):12] += 0.3
+    lam = rng.normal(size=(B, ng))
+    t = lambda a_: torch.tensor(np.ascontiguousarray(a_), dtype=torch.float64, device=dev)
+    st = torch.cuda.current_stream().cuda_stream if dev == "cuda" else 0
+    sync = (lambda: torch.cuda.synchronize()) if dev == "cuda" else (lambda: None)
+    dx, dl = t(xs), t(lam)
+    H = torch.zeros(B, N, 72, 72, dtype=torch.float64, device=dev)
+    R.kinodyn_nlp_hess(B, N, dx.data_ptr(), dt, mass, Ib, Ibi, mu, dl.data_ptr(), H.data_ptr(), st); sync()
+    H = H.cpu().numpy()
+    assert np.array_equal(H, H.transpose(0, 1, 3, 2)) and np.isfinite(H).all()
+    assert (H[:, :, 48:, 48:] == 0.0).all() and (H[:, :, :, 48:60] == 0.0).all() and (H[:, N - 1, :, 60:] == 0.0).all()
+    assert np.abs(H[:, :, :48, :48]).max() > 1e-3
+    h = 1e-5
+    def jt_lam(xp):      # J_k' lam_k of every interval at the points xp [n, nx] (kernel Jacobian)
+        n = xp.shape[0]
+        J = torch.zeros(n, N, 141, 72, dtype=torch.float64, device=dev)
+        dxp = t(xp)
+        R.kinodyn_nlp_eval(n, N, dxp.data_ptr(), dt, mass, Ib, Ibi, mu, 0, J.data_ptr(), st); sync()
+        return J.cpu().numpy()
+    b = 0
+    for k in (0, N - 1):
+        nr = 117 if k == N - 1 else 141
+        lk = lam[b, 48 + 141 * k: 48 + 141 * k + nr]
+        cols = [j for j in range(72) if ko.w_index(N, k, j) >= 0]
+        xp = np.repeat(xs[b:b + 1], 2 * len(cols), axis=0)
+        for q, j in enumerate(cols):
+            xp[2 * q, ko.w_index(N, k, j)] += h; xp[2 * q + 1, ko.w_index(N, k, j)] -= h
+        J = jt_lam(xp)[:, k, :nr]
+        for q, j in enumerate(cols):
+            col = ((J[2 * q] - J[2 * q + 1]) / (2 * h)).T @ lk
+            assert np.abs(H[b, k, :, j] - col).max() <= 1e-6 * max(1.0, np.abs(col).max()), (k, j, np.abs(H[b, k, :, j] - col).max())
+    k = 0
+    w = ko.gather_w(xs[b], N, k); lk = lam[b, 48:48 + 141]
+    for j in oracle_cols:
+        e = np.zeros(72); e[j] = 1e-3
+        col = (ko.stage_jacobian(w + e, dt[k], False, mass, Ib, Ibi, mu) - ko.stage_jacobian(w - e, dt[k], False, mass, Ib, Ibi, mu)).T @ lk / 2e-3
+        assert np.abs(H[b, k, :, j] - col).max() <= 1e-5 * max(1.0, np.abs(col).max()), (j, np.abs(H[b, k, :, j] - col).max())
+
+
+def test_kinodyn_nlp_hessian_emulated():
+    L = lc("capi").LandingLib(20, lib_path=os.path.join(ROOT, "tests", "emu", "liblanding_emu.so"))
+    _hess_check(L, "cpu", N=2, B=1, seed=3, oracle_cols=(4, 26, 38))      # a rotation angle, a vertical force, a hip joint
+
+
+@pytest.mark.gpu
+def test_kinodyn_nlp_hessian_gpu():
+    L = lc("capi").LandingLib(20, device=0)
+    _hess_check(L, "cuda", N=20, B=64, seed=4, oracle_cols=(3, 8, 14, 26, 40, 71))
+    L.close()

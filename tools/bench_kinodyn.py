@@ -22,6 +22,13 @@ for name, pg, pj in (("g", g.data_ptr(), 0), ("jacobian", 0, jac.data_ptr())):
     for _ in range(a.steps): run()
     e1.record(); torch.cuda.synchronize()
     out[name + "_ms"] = e0.elapsed_time(e1) / a.steps
+lam = torch.randn(a.B, ng, device="cuda", dtype=torch.float64); H = torch.zeros(a.B, a.N, 72, 72, device="cuda", dtype=torch.float64)
+run = lambda: R.kinodyn_nlp_hess(a.B, a.N, x.data_ptr(), dt, mass, Ib, Ibi, 0.75, lam.data_ptr(), H.data_ptr(), st)
+run(); torch.cuda.synchronize(); e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(3): run()
+e1.record(); torch.cuda.synchronize()
+out["hessian_ms"] = e0.elapsed_time(e1) / 3
 out.update({"workload": "kinodynamic refinement NLP function layer, N=%d intervals, batch=%d: nx %d, ng %d, Jacobian blocks %d x 141 x 72" % (a.N, a.B, nx, ng, a.N),
             "jacobian_bytes_written": int(a.B) * a.N * 141 * 72 * 8, "jacobian_GBps": a.B * a.N * 141 * 72 * 8 / out["jacobian_ms"] / 1e6})
 print(json.dumps(out))
