@@ -1,0 +1,91 @@
+"""Host side of the kinodynamic refinement NLP (optimizations/landing/main_scripts/landing_optimization.m): the variable
+layout, the bounds lbg / ubg in the row order of landing_kinodyn_nlp_eval (include/landing_nlp.h) with the script's values, its parameter
+code (velocity-dependent kinematic box, :251 with test_scripts/kin_box_limits.m) and the terminal cost (:83-86).  g, Jacobian and Hessian
+blocks come from the GPU (rbd.Rbd.kinodyn_nlp_eval / kinodyn_nlp_hess); the solve of this NLP is not built yet."""
+import numpy as np
+
+INF = np.inf
+SIDE_SIGN = (-1.0, 1.0, -1.0, 1.0)                                  # :156
+TAU_MAX = np.array([18.0, 18.0, 28.0])                              # model.tauMax = gr .* motorTauMax (get_robot_model.m:237-241)
+JPOS_MIN = np.tile([-np.pi / 3, -np.pi / 2, 0.0], 4)                # :246
+JPOS_MAX = np.tile([np.pi / 3, np.pi / 2, 3 * np.pi / 4], 4)        # :247
+
+
+def dims(N):
+    """N intervals (the script's N - 1): nx, ng"""
+    return 48 * N + 12, 48 + 141 * (N - 1) + 117
+
+
+def pack_x(X, U, jpos):
+    """X [12, N+1], U [24, N] = [c; f_grf], jpos [12, N] -> x (the script's declaration order X, jpos, U, :39-42)"""
+    return np.concatenate([np.asarray(X).flatten(order="F"), np.asarray(jpos).flatten(order="F"), np.asarray(U).flatten(order="F")])
+
+
+def unpack_x(x, N):
+    x = np.asarray(x)
+    a, b = 12 * (N + 1), 12 * (N + 1) + 12 * N
+    return x[:a].reshape(12, N + 1, order="F"), x[b:].reshape(24, N, order="F"), x[a:b].reshape(12, N, order="F")
+
+
+def kin_box_limits(v, direction):
+    """test_scripts/kin_box_limits.m: adjustment of the kinematic box with the body-frame velocity"""
+    box_max = 0.15 if direction == "x" else 0.25
+    return abs(v * (box_max / 2.0)) if abs(v) < 2.0 else box_max
+
+
+def kin_box_of(rpy0, v_world0):
+    """:249-251  kin_box_val from the initial attitude and velocity"""
+    r, p, y = rpy0
+    rx = np.array([[1, 0, 0], [0, np.cos(r), np.sin(r)], [0, -np.sin(r), np.cos(r)]])
+    ry = np.array([[np.cos(p), 0, -np.sin(p)], [0, 1, 0], [np.sin(p), 0, np.cos(p)]])
+    rz = np.array([[np.cos(y), np.sin(y), 0], [-np.sin(y), np.cos(y), 0], [0, 0, 1]])
+    vb = (rx.T @ ry.T @ rz.T).T @ np.asarray(v_world0, float)
+    return kin_box_limits(vb[0], "x"), kin_box_limits(vb[1], "y")
+
+
+def bounds(N, q_init, qd_init, c_init, kin_box, q_term_min=(-10, -10, 0.15, -0.1, -0.1, -10), q_term_max=(10, 10, 5, 0.1, 0.1, 10),
+           qd_term_min=(-10, -10, -10, -.5, -.5, -.5), qd_term_max=(10, 10, 10, .5, .5, .5), z_min=0.075, l_leg_max=0.4,
+           jpos_min=JPOS_MIN, jpos_max=JPOS_MAX, tau_max=TAU_MAX, comp_eps=1e-3, slip_eps=1e-3, fk_band=0.01):
+    """lbg, ubg [ng] in the row order of landing_kinodyn_nlp_eval; defaults = the script's values (:208-258)"""
+    ng = dims(N)[1]
+    lb, ub = np.zeros(ng), np.zeros(ng)
+    lb[0:6] = ub[0:6] = q_init; lb[6:12] = ub[6:12] = qd_init; lb[12:24] = ub[12:24] = c_init
+    lb[24:30] = q_term_min; ub[24:30] = INF; lb[30:36] = -INF; ub[30:36] = q_term_max
+    lb[36:42] = qd_term_min; ub[36:42] = INF; lb[42:48] = -INF; ub[42:48] = qd_term_max
+    kbx, kby = 0.125 + kin_box[0], 0.10 + kin_box[1]
+    for k in range(N):
+        last = k == N - 1
+        o = 48 + 141 * k
+        r = o + 12                                                  # (Euler defects: 0 = 0)
+        lb[r:r + 4] = 0.0; ub[r:r + 4] = INF; r += 4                 # f_z >= 0
+        for l in range(4):
+            lb[r] = 0.0; ub[r] = INF; r += 1                         # c_z >= 0
+            lb[r] = -INF; ub[r] = comp_eps; r += 1                   # f_z c_z <= 1e-3
+            if not last:
+                lb[r:r + 3] = -INF; ub[r:r + 3] = slip_eps; r += 3
+                lb[r:r + 3] = -slip_eps; ub[r:r + 3] = INF; r += 3
+            lb[r] = -kbx; ub[r] = kbx; r += 1
+            if SIDE_SIGN[l] < 0: lb[r], ub[r] = -kby, 0.05
+            else: lb[r], ub[r] = -0.05, kby
+            r += 1
+            lb[r] = -0.4; ub[r] = -0.075; r += 1
+            lb[r] = -INF; ub[r] = l_leg_max ** 2; r += 1
+            lb[r:r + 3] = -np.asarray(tau_max); ub[r:r + 3] = tau_max; r += 3
+        for s in range(4):                                           # friction: <= 0, >= 0, <= 0, >= 0
+            if s % 2 == 0: lb[r:r + 4] = -INF; ub[r:r + 4] = 0.0
+            else: lb[r:r + 4] = 0.0; ub[r:r + 4] = INF
+            r += 4
+        lb[r] = z_min; ub[r] = INF; r += 1
+        lb[r:r + 12] = -fk_band; ub[r:r + 12] = INF; r += 12
+        lb[r:r + 12] = -INF; ub[r:r + 12] = fk_band; r += 12
+        lb[r:r + 12] = jpos_min; ub[r:r + 12] = INF; r += 12
+        lb[r:r + 12] = -INF; ub[r:r + 12] = jpos_max; r += 12
+        assert r == o + (117 if last else 141)
+    return lb, ub
+
+
+def terminal_cost(x, N, x_ref_end, QN=(0, 0, 100, 10, 10, 0, 10, 10, 10, 10, 10, 10)):
+    """:83-86  (X(:,end) - Xref(:,end))' diag(QN) (...)  and its gradient in x (Hessian: 2 diag(QN) on X(:, N+1))"""
+    e = np.asarray(x)[12 * N:12 * N + 12] - np.asarray(x_ref_end, float)
+    g = np.zeros(dims(N)[0]); g[12 * N:12 * N + 12] = 2.0 * np.asarray(QN, float) * e
+    return float(e @ (np.asarray(QN, float) * e)), g

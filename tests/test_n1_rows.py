@@ -241,3 +241,27 @@ def test_kinodyn_nlp_hessian_gpu():
     L = lc("capi").LandingLib(20, device=0)
     _hess_check(L, "cuda", N=20, B=64, seed=4, oracle_cols=(3, 8, 14, 26, 40, 71))
     L.close()
+
+
+def test_kinodyn_bounds_hold_on_the_stored_solution():
+    """host side (landing-controller_amd/kinodyn.py): lbg / ubg in the kernel's row order with the script's values -- the stored solution of the
+    CURRENT formulation (prevSoln.mat: FK band 1e-2) lies inside them to the producing solver's tolerance, rows through the oracle"""
+    from oracle import kinodyn_oracle as ko
+    kd = lc("kinodyn")
+    mass, Ib, Ibi = lc("constants").robot_constants()
+    X, U, J = _sol("b")
+    N = 20
+    assert kd.dims(N) == ko.nlp_dims(N) and np.array_equal(kd.pack_x(X, U, J), ko.pack_x(X, U, J))
+    Xr, Ur, Jr = kd.unpack_x(kd.pack_x(X, U, J), N)
+    assert np.array_equal(Xr, X) and np.array_equal(Ur, U) and np.array_equal(Jr, J)
+    x = kd.pack_x(X, U, J)
+    g = ko.nlp_g(x, N, DT, mass, np.asarray(Ib), np.asarray(Ibi), 1.0)
+    kb = kd.kin_box_of(X[3:6, 0], X[9:12, 0])
+    lb, ub = kd.bounds(N, X[:6, 0], X[6:, 0], U[:12, 0], kb)
+    viol = np.maximum(np.maximum(lb - g, g - ub), 0.0)
+    # the friction rows depend on the run's mu (1.0 reproduces the file), the terminal box on that run's settings: every other row group holds
+    stage = np.arange(48, g.size)
+    assert viol[stage].max() <= 2e-3, (viol[stage].max(), int(np.argmax(viol[stage])))
+    assert viol[:24].max() == 0.0
+    f, gr = kd.terminal_cost(x, N, [0, 0, 0.25, 0, 0, 0, 0, 0, 0, 0, 0, 0])
+    assert f >= 0.0 and np.count_nonzero(gr) <= 12
