@@ -263,5 +263,7 @@ def test_kinodyn_bounds_hold_on_the_stored_solution():
     stage = np.arange(48, g.size)
     assert viol[stage].max() <= 2e-3, (viol[stage].max(), int(np.argmax(viol[stage])))
     assert viol[:24].max() == 0.0
+    # known answer: the stored trajectory ends ON the script's terminal reference (q_term_ref z = 0.25, :222-223): f* = 0 for this instance, the
+    # point is a feasible global minimiser of the NLP as defined here (gradient of f ~ 1e-5: stationary with zero multipliers)
     f, gr = kd.terminal_cost(x, N, [0, 0, 0.25, 0, 0, 0, 0, 0, 0, 0, 0, 0])
-    assert f >= 0.0 and np.count_nonzero(gr) <= 12
+    assert 0.0 <= f <= 1e-10 and np.abs(gr).max() <= 1e-4 and np.count_nonzero(gr) <= 12
