@@ -56,6 +56,7 @@ struct landing_ctx {
   // every scratch block above is re-used by the next call of its entry point, possibly on another stream: the launches that use it are
   // fenced by this event (recorded behind them, waited for before the next writer / reader touches the block) -- ADVICE r2
   hipEvent_t scratch_done = nullptr;
+  unsigned char* d_kd_pairs = nullptr;      // structurally non-zero pairs of a Hessian block of the kinodynamic NLP (rbd_kernels.hip)
   bool rbd_arrow = false;      // the model set by landing_rbd_set_model is "six base joints + four 3-joint legs on the base": H is block-arrow (wb_kernels.hip)
   std::mutex mu;      // serialises landing_solve_batch calls on one context (the workspace belongs to the context)
 };
@@ -283,6 +284,7 @@ void landing_destroy(landing_ctx* ctx) {
   if (ctx->d_fb_scratch) (void)hipFree(ctx->d_fb_scratch);
   for (int i = 0; i < 3; ++i) { if (ctx->aux[i]) (void)hipStreamDestroy(ctx->aux[i]); if (ctx->ev_join[i]) (void)hipEventDestroy(ctx->ev_join[i]); }
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+  if (ctx->d_kd_pairs) (void)hipFree(ctx->d_kd_pairs);
   if (ctx->scratch_done) { (void)hipEventSynchronize(ctx->scratch_done); (void)hipEventDestroy(ctx->scratch_done); }
   if (ctx->host_stream) (void)hipStreamDestroy(ctx->host_stream);
   delete ctx;

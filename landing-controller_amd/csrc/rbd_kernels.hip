@@ -674,17 +674,34 @@ __global__ void __launch_bounds__(64) landing_kinodyn_nlp_jac_kernel(KdNlpArgs a
 // X_k+1 enters every row linearly and c_k+1 only through f_z (c_k+1 - c_k): pairs inside [X_k+1, c_k+1] are structural zeros and are skipped.
 // The NLP's Hessian of the Lagrangian is the sum of these blocks at their positions in x (+ the constant 2 QN of the terminal cost, :84-86).
 // A first, exact implementation for the next round's solver to be checked against -- not tuned (2 628 stage evaluations per interval).
-constexpr int KD_NPAIR = KD_NW * (KD_NW + 1) / 2;
-__global__ void __launch_bounds__(64) landing_kinodyn_nlp_hess_kernel(KdNlpArgs a) {
+// Structural non-zeros of the block (the rest is written as zeros by a memset): the velocity X[9..11] and X_k+1 enter linearly; the variables
+// of a leg (c_l, f_l, jpos_l) couple with themselves and with the base (pos, rpy, omega) only; c_k+1 of a leg only with that leg's f_z:
+// 45 + 4 x 81 + 4 x 45 + 12 = 561 pairs instead of 2 628.
+__host__ __device__ inline int kd_pair_list(unsigned char* pi, unsigned char* pj) {      // fills (i <= j) pairs, returns their number (561)
+  int n = 0;
+  auto leg_of = [](int v) { return v < 12 ? -1 : (v < 48 ? ((v - 12) % 12) / 3 : -2); };      // base = -1, leg 0..3 for c / f / jpos entries
+  for (int i = 0; i < 48; ++i) {
+    if (i >= 9 && i < 12) continue;
+    for (int j = i; j < 48; ++j) {
+      if (j >= 9 && j < 12) continue;
+      const int li = leg_of(i), lj = leg_of(j);
+      if (li >= 0 && lj >= 0 && li != lj) continue;
+      if (pi) { pi[n] = (unsigned char)i; pj[n] = (unsigned char)j; }
+      ++n;
+    }
+  }
+  for (int l = 0; l < 4; ++l) for (int a = 0; a < 3; ++a) { if (pi) { pi[n] = (unsigned char)(24 + 3 * l + 2); pj[n] = (unsigned char)(60 + 3 * l + a); } ++n; }
+  return n;
+}
+constexpr int KD_NPAIR = 561;
+__global__ void __launch_bounds__(64) landing_kinodyn_nlp_hess_kernel(KdNlpArgs a, const unsigned char* __restrict__ pair_i, const unsigned char* __restrict__ pair_j) {
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (long long)a.B * a.N * KD_NPAIR) return;
-  int pr = (int)(idx % KD_NPAIR); const int k = (int)((idx / KD_NPAIR) % a.N); const int b = (int)(idx / ((long long)KD_NPAIR * a.N)), N = a.N;
-  int i = 0;
-  while (pr >= KD_NW - i) { pr -= KD_NW - i; ++i; }
-  const int j = i + pr;
+  const int pr = (int)(idx % KD_NPAIR); const int k = (int)((idx / KD_NPAIR) % a.N); const int b = (int)(idx / ((long long)KD_NPAIR * a.N)), N = a.N;
+  const int i = pair_i[pr], j = pair_j[pr];
   double* Hk = a.hess + (((size_t)b * N + k) * KD_NW) * KD_NW;
   const bool last = k == N - 1;
-  if (i >= 48 || (j >= 48 && j < 60) || (last && j >= 60)) { Hk[i * KD_NW + j] = 0.0; Hk[j * KD_NW + i] = 0.0; return; }
+  if (last && j >= 60) return;
   const double* x = a.x + (size_t)b * kd_nx(N);
   const double* lam = a.lam + (size_t)b * kd_ng(N) + KD_BND + (size_t)k * KD_ROWS;
   HDual w[KD_NW], out[KD_ROWS];
