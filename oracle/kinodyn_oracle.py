@@ -141,3 +141,35 @@ def stage_jacobian(w, dt, last, mass, Ib, Ib_inv, mu, h=2e-3):
 def pack_x(X, U, J):
     """X [12, N+1], U [24, N] (c; f), jpos [12, N] -> x in the layout above"""
     return np.concatenate([X.flatten(order="F"), J.flatten(order="F"), U.flatten(order="F")])
+
+
+def nlp_jacobian(x, N, dt, mass, Ib, Ib_inv, mu):
+    """dense Jacobian [ng, nx] of nlp_g from the Richardson stage blocks (boundary rows: coordinate picks)"""
+    nx, ng = nlp_dims(N)
+    Jf = np.zeros((ng, nx))
+    oU = 12 * (N + 1) + 12 * N
+    for i in range(12):
+        Jf[i, i] = 1.0; Jf[12 + i, oU + i] = 1.0
+    for i in range(6):
+        Jf[24 + i, 12 * N + i] = 1.0; Jf[30 + i, 12 * N + i] = 1.0; Jf[36 + i, 12 * N + 6 + i] = 1.0; Jf[42 + i, 12 * N + 6 + i] = 1.0
+    for k in range(N):
+        last = k == N - 1
+        Jk = stage_jacobian(gather_w(x, N, k), dt[k], last, mass, Ib, Ib_inv, mu)
+        for j in range(72):
+            ix = w_index(N, k, j)
+            if ix >= 0:
+                Jf[48 + 141 * k:48 + 141 * k + Jk.shape[0], ix] += Jk[:, j]
+    return Jf
+
+
+def kkt(x, lam_g, N, dt, mass, Ib, Ib_inv, mu, lbg, ubg, grad_f):
+    """unscaled KKT residuals of (x, lam_g) in the convention of the SRBM oracle (lo_kkt: lam > 0 pushes against ubg, lam < 0 against lbg):
+    (primal infeasibility, dual infeasibility |grad f + J' lam|_inf, complementarity max |lam_r| * distance to the bound it pushes against)"""
+    g = nlp_g(x, N, dt, mass, Ib, Ib_inv, mu)
+    pr = float(np.maximum(np.maximum(lbg - g, g - ubg), 0.0).max())
+    du = float(np.abs(np.asarray(grad_f) + nlp_jacobian(x, N, dt, mass, Ib, Ib_inv, mu).T @ lam_g).max())
+    eq = lbg == ubg
+    dist = np.where(lam_g > 0, np.where(np.isfinite(ubg), np.maximum(ubg - g, 0.0), np.inf), np.where(np.isfinite(lbg), np.maximum(g - lbg, 0.0), np.inf))
+    with np.errstate(invalid="ignore"):
+        co = np.where(eq | (lam_g == 0.0), 0.0, np.abs(lam_g) * dist)
+    return pr, du, float(np.nanmax(co))

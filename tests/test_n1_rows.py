@@ -267,3 +267,17 @@ def test_kinodyn_bounds_hold_on_the_stored_solution():
     # point is a feasible global minimiser of the NLP as defined here (gradient of f ~ 1e-5: stationary with zero multipliers)
     f, gr = kd.terminal_cost(x, N, [0, 0, 0.25, 0, 0, 0, 0, 0, 0, 0, 0, 0])
     assert 0.0 <= f <= 1e-10 and np.abs(gr).max() <= 1e-4 and np.count_nonzero(gr) <= 12
+
+
+def test_kinodyn_oracle_kkt_of_the_stored_solution():
+    """the certificate the next round's solver will be held to (oracle/kinodyn_oracle.py::kkt, convention of the SRBM oracle): the reference's stored
+    solution with zero multipliers is a KKT point of the NLP as defined here up to the producing solver's feasibility tolerance"""
+    from oracle import kinodyn_oracle as ko
+    kd = lc("kinodyn")
+    mass, Ib, Ibi = lc("constants").robot_constants()
+    X, U, J = _sol("b"); N = 20
+    x = kd.pack_x(X, U, J)
+    lb, ub = kd.bounds(N, X[:6, 0], X[6:, 0], U[:12, 0], kd.kin_box_of(X[3:6, 0], X[9:12, 0]))
+    f, gf = kd.terminal_cost(x, N, [0, 0, 0.25, 0, 0, 0, 0, 0, 0, 0, 0, 0])
+    pr, du, co = ko.kkt(x, np.zeros(lb.size), N, DT, mass, np.asarray(Ib), np.asarray(Ibi), 1.0, lb, ub, gf)
+    assert pr <= 2e-3 and du <= 1e-4 and co == 0.0, (pr, du, co)
