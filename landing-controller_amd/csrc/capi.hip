@@ -42,6 +42,7 @@ struct landing_ctx {
   landing::SolverWorkspace ws;
   double* d_prof = nullptr;
   double* d_vbl = nullptr;
+  double* h_vbl = nullptr; hipEvent_t vbl_copied = nullptr;      // pinned staging block of landing_riccati_gains_batch and the event behind its copy
   landing::RbdModel* d_rbd = nullptr;     // uploaded by landing_rbd_set_model
   int2* d_rc_map = nullptr;               // landing_eval_hess_rc_batch: source nonzero + running-cost code of every entry of the extended pattern
   double* d_fb_scratch = nullptr; size_t fb_scratch_n = 0;   // qdd and H^-1 per knot of the exact floating-base linearisation
@@ -278,6 +279,7 @@ void landing_destroy(landing_ctx* ctx) {
   ctx->ws.release();
   if (ctx->d_edge_map) (void)hipFree(ctx->d_edge_map);
   if (ctx->d_vbl) (void)hipFree(ctx->d_vbl);
+  if (ctx->h_vbl) { (void)hipEventSynchronize(ctx->vbl_copied); (void)hipHostFree(ctx->h_vbl); (void)hipEventDestroy(ctx->vbl_copied); }
   if (ctx->d_rbd) (void)hipFree(ctx->d_rbd);
   if (ctx->d_rc_map) (void)hipFree(ctx->d_rc_map);
   if (ctx->d_h4) (void)hipFree(ctx->d_h4);

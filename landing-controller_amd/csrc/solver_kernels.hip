@@ -1420,9 +1420,9 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
           else if (K.f_vmax <= 1e-9 && pr <= o.tol) act = ACT_BACK;
           else if (conv && K.f_v1 > o.feas_cert) { K.status = LANDING_INFEASIBLE; act = ACT_STOP; }
           else if (conv) act = ACT_BACK;
-          else if (it == K.lim) act = ACT_STOP;
+          else if (it >= K.lim) act = ACT_STOP;
           if (act == ACT_BACK) {
-            K.feas = 0; K.lim = it + o.max_iter; K.status = LANDING_MAX_ITER;
+            K.feas = 0; K.lim = it + (o.max_iter > 1 ? o.max_iter : 1); K.status = LANDING_MAX_ITER;
             K.mu = o.mu_init; K.nfilt = 0; K.delta_last = 0.0; K.need_reg_streak = 0; K.wd_count = 0; K.th_max = 0.0; K.nreset = 0; K.last_reset_it = it; K.ncrawl = 0;
             K.cutstreak = 0; K.force_step = 0;
             K.it = it + 1;
@@ -1431,7 +1431,7 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
         else if (K.fact_failed) { K.status = LANDING_NUMERICAL; K.fact_failed = 0; give_up = true; }      // no regularisation made the last step computable
         else if (!(du < 1e300) || !(pr < 1e300) || !(co < 1e300)) { K.status = LANDING_NUMERICAL; give_up = true; }
         else if (fmax(du, fmax(pr, co)) <= o.tol) { K.status = LANDING_CONVERGED; act = ACT_STOP; }
-        else if (it == K.lim) give_up = true;
+        else if (it >= K.lim) give_up = true;      // (>=: K.it runs ahead of a limit set from a max_iter < 1)
         else if (du > o.reset_du && nreset >= o.max_resets && o.max_resets > 0) { K.status = LANDING_NUMERICAL; give_up = true; }   // jammed again: give up
         else {
           // crawling: still in the first barrier problem (mu never decreased) restart_period iterations after the last (re)start
@@ -1458,7 +1458,7 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
         }
         if (give_up) {
           // the solve would end here as NUMERICAL / MAX_ITER: enter the feasibility phase once (landing_solver_opts::feas_phase)
-          if (o.feas_phase && !K.feas_used) {
+          if (o.feas_phase && !K.feas_used && o.max_iter > 0) {      // (max_iter < 1: the caller asked for no iteration at all, the phase would get none either)
             act = ACT_FEAS;
             K.feas = 1; K.feas_used = 1; K.status = LANDING_MAX_ITER; K.lim = it + o.max_iter;
             K.mu = o.mu_init; K.nfilt = 0; K.th_max = 0.0; K.delta_last = 0.0; K.need_reg_streak = 0; K.cutstreak = 0; K.force_step = 0; K.wd_count = 0;

@@ -281,12 +281,12 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
       if (vmax <= 1e-9 && pr <= op->tol) back = 1;                       /* a feasible point: back to the interior-point solve from here */
       else if (fmax(du, fmax(pr, co)) <= op->tol) { if (v1 > op->feas_cert) { status = 3; break; } back = 1; }
       if (back) {
-        feas = 0; W->feas = 0; lim = it + op->max_iter;
+        feas = 0; W->feas = 0; lim = it + (op->max_iter > 1 ? op->max_iter : 1);
         init_slacks(W, op); mu = op->mu_init; nfilt = 0; delta_last = 0.0; streak = 0; wd_count = 0; th_max = 0.0; nreset = 0; last_reset_it = it; ncrawl = 0; cutstreak = 0; force_step = 0;
         for (r = 12; r < ng; ++r) if (W->lb[r] == W->ub[r]) W->y[r] = 0.0;
         continue;
       }
-      if (it == lim) break;
+      if (it >= lim) break;
       goto no_reset;
     }
     {
@@ -294,10 +294,10 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
       if (fact_failed) { status = 2; fact_failed = 0; give_up = 1; }      /* no regularisation made the last step computable */
       else if (!(du < 1e300) || !(pr < 1e300) || !(co < 1e300)) { status = 2; give_up = 1; }
       else if (fmax(du, fmax(pr, co)) <= op->tol) { status = 0; break; }
-      else if (it == lim) give_up = 1;
+      else if (it >= lim) give_up = 1;
       else if (du > op->reset_du && nreset >= op->max_resets && op->max_resets > 0) { status = 2; give_up = 1; }
       if (give_up) {
-        if (!op->feas_phase || feas_used) break;
+        if (!op->feas_phase || feas_used || op->max_iter < 1) break;
         /* feasibility phase: from the current point (from the caller's initial guess when the iterate is not finite) */
         feas = 1; W->feas = 1; feas_used = 1; status = 1; nfilt = 0; th_max = 0.0; delta_last = 0.0; streak = 0; lim = it + op->max_iter; cutstreak = 0; force_step = 0; wd_count = 0;
         { int bad = 0; for (i = 0; i < nx; ++i) if (!(fabs(W->x[i]) < 1e6)) bad = 1;

@@ -129,3 +129,27 @@ def test_multi_device_entry_points_shard_ranges_and_identity(libs):
             assert np.array_equal(r[k], ref[k]), (devs, k)
         assert np.array_equal(r["lam_g"], lam_ref)
     lib.landing_multi_release_cached()
+
+
+def test_multi_device_rejects_the_25_argument_formulation_and_null_arguments(libs):
+    """a context built with the N=41 script's own parameter vector (run_cost = 2, np = 37N+112) must not be fed the 21-argument
+    p (13N+94 values: a heap over-read); NULL arguments are reported for every shard, not dereferenced by shards with lo > 0"""
+    capi, P = lc("capi"), lc("problem")
+    N, B = 6, 4
+    args = P.make_args21(B, N, 0.6, seed=2)
+    Lc = capi.LandingLib(N, lib_path=libs[1], kin_box=(0.05, 0.05, 0.27), run_cost=dict(QX=[1.0] * 12, Qc=[1.0] * 3, Qf=[1e-3] * 3, f_ref=[0, 0, 20.0]), ccc_params=True)
+    with pytest.raises(RuntimeError, match="25 arguments"):
+        Lc.solve_args21_multi(args, [0, 0])
+    L = capi.LandingLib(N, lib_path=libs[1])
+    bad = dict(args); bad.pop("mass")
+    a, keep, _ = capi.matlab_args21(N, args)
+    a.mass = None
+    x = np.zeros((B, L.nx))
+    dev = (C.c_int * 2)(0, 0)
+    L.lib.landing_multi_create.restype = C.c_void_p
+    m = L.lib.landing_multi_create(N, dev, 2, C.byref(L.form))
+    assert m
+    o = L.default_opts()
+    rc = L.lib.landing_multi_solve_args21(C.c_void_p(m), B, C.byref(a), C.byref(o), x.ctypes.data_as(C.POINTER(C.c_double)), None, None, None, None, None)
+    L.lib.landing_multi_destroy(C.c_void_p(m))
+    assert rc == -1 and b"NULL argument" in L.lib.landing_last_error()

@@ -126,8 +126,8 @@ def test_solver_is_deterministic_and_batch_independent(libs):
 
 def test_solver_full_size_batch_properties(libs, oracle_mod):
     """BASELINE configs[1] size (N=40, B=1024), device-pointer entry point: >= 93 % converge within 300 iterations,
-    every converged member satisfies the reported KKT bound, initial state rows are met exactly, a sample is
-    re-certified with the oracle's functions."""
+    every converged member satisfies the reported KKT bound, initial state rows are met exactly, every
+    converged member is re-certified with the oracle's functions."""
     import torch
     N, B = 40, 1024
     L = libs[N]
@@ -151,13 +151,13 @@ def test_solver_full_size_batch_properties(libs, oracle_mod):
     assert ith.mean() <= 44 and np.percentile(ith, 99) <= 65 and ith.max() <= 120, (ith.mean(), np.percentile(ith, 99), ith.max())
     po = O.param_offsets()
     assert np.array_equal(xh[:, :6], P[:, po["q_init"]:po["q_init"] + 6]) and np.array_equal(xh[:, 6:12], P[:, po["qd_init"]:po["qd_init"] + 6])
-    for b in np.nonzero(ok)[0][::97]:
-        assert O.kkt(xh[b], P[b], lh[b]).max() <= KKT_TOL * 1.0001
+    for b in np.nonzero(ok)[0]:      # EVERY converged member re-certified under the oracle's (reference-pinned) functions (was every 97th)
+        assert O.kkt(xh[b], P[b], lh[b]).max() <= KKT_TOL * 1.0001, b
 
 
 def test_solver_config3_shard_size_on_one_gpu(libs, oracle_mod):
     """BASELINE configs[2]'s total (B = 8192, N = 40) on ONE GPU: the workspace (9 GB of the 288 GB), the dispatch of 8192
-    workgroups over 512 resident slots and failure isolation at that size.  >= 99 % converge within 300 iterations; a sample of
+    workgroups over 512 resident slots and failure isolation at that size.  >= 99 % converge within 300 iterations; every one of
     the converged members is re-certified under the oracle's functions; member i equals member i of the 1024-batch with the
     same seed (batch independence at full size)."""
     import torch
@@ -181,8 +181,8 @@ def test_solver_config3_shard_size_on_one_gpu(libs, oracle_mod):
     ok = sth == 0
     assert ok.mean() >= 0.999, f"{ok.sum()}/{B}"      # measured: 8192 / 8192
     assert kh[ok].max() <= KKT_TOL * 1.0001
-    for b in np.nonzero(ok)[0][::701]:
-        assert O.kkt(xh[b], P[b], lh[b]).max() <= KKT_TOL * 1.0001
+    for b in np.nonzero(ok)[0]:      # every converged member of the 8192 (a C call each: a few seconds in total)
+        assert O.kkt(xh[b], P[b], lh[b]).max() <= KKT_TOL * 1.0001, b
     x1 = mk(1024, L.nx)
     L.solve_device(1024, dP.data_ptr(), dX0.data_ptr(), o, x1.data_ptr(), 0, 0, 0, 0, 0, torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()

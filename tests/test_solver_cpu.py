@@ -72,6 +72,28 @@ def test_emulated_kernel_follows_cpu_port(emu_lib, oracle_mod, clip_k, theta_flo
     assert np.allclose(g["kkt"][0], O.kkt(g["x"][0], P[0], g["lam_g"][0]), rtol=1e-6, atol=1e-12)
 
 
+def test_max_iter_zero_stops_at_once_in_kernel_and_port(emu_lib, oracle_mod):
+    """with max_iter <= 0 the feasibility phase used to set its iteration limit BEHIND the counter (lim = it + max_iter, it + 1
+    next) and the kernel's `it == lim` test could never fire: an unbounded loop on the GPU.  Both solvers now stop at once -- status
+    MAX_ITER, no iteration, the initial guess returned -- with the default options (feasibility phase on)."""
+    N = 20
+    O = oracle_mod.Oracle(N)
+    P, X0, _, _ = lc("problem").make_batch(2, N, 0.6, seed=3)
+    L = lc("capi").LandingLib(N, lib_path=emu_lib)
+    for mi in (0, -5):
+        o = L.default_opts(); o.max_iter = mi
+        assert o.feas_phase == 1
+        g = L.solve_host(P, X0, o)
+        c = oracle_mod.cpu_solve_batch(O, P, X0, threads=1, max_iter=mi)
+        assert (g["status"] == 1).all() and (c["status"] == 1).all()
+        assert (g["iters"] == 0).all() and (c["iters"] == 0).all()
+        assert np.array_equal(g["x"][:, 12:], X0[:, 12:])
+    o = L.default_opts(); o.max_iter = 1      # one iteration, then the phase gets one iteration as well and the solve ends
+    g = L.solve_host(P, X0, o)
+    c = oracle_mod.cpu_solve_batch(O, P, X0, threads=1, max_iter=1)
+    assert (g["status"] == 1).all() and np.array_equal(g["iters"], c["iters"]) and (g["iters"] <= 3).all()
+
+
 RUN_COST = dict(QX=[0, 0, 10, 1, 1, 0, .1, .1, .1, .1, .1, .1], Qc=[1.0, 1.0, 0.5], Qf=[1e-4, 1e-4, 1e-3], f_ref=[0, 0, 20.0])
 
 

@@ -14,7 +14,7 @@ for lib in "$@"; do
       rm -rf /tmp/pmc_$c
       rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_$c -- python3 $GRAFT_REPO_ROOT/tools/dev/ab_one.py $lib 1 --noprof > /dev/null 2> $out/pmc_${tag}_$c.err
     done
-    python3 - $tag <<'PY' | tee -a $out/ab_$1.traffic
+    python3 - $tag <<'PY' | tee -a $out/ab_$tag.traffic
 import csv, glob, sys, collections
 tot = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
