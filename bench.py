@@ -485,7 +485,7 @@ def measure_details(a, lib, np, torch, dev, mk, B, N, P, X0, dP, dX0, st, it, kk
         orc.cpu_solve_batch(O, P[:min(B, cores)], X0[:min(B, cores)], threads=cores, max_iter=3)
         t1 = time.perf_counter(); r1 = orc.cpu_solve_batch(O, P[:2], X0[:2], threads=1, max_iter=a.max_iter); t1 = time.perf_counter() - t1
         per_nlp = max(t1 / 2, 1e-3)
-        ns = int(min(B, max(cores, min(4 * cores, cores * max(1.0, 15.0 / per_nlp)))))      # about 15 s of wall time at most, one to four rounds per thread
+        ns = int(min(B, cores * max(1, min(64, int(15.0 / per_nlp)))))      # about 15 s of wall time at most (10-30 s of CPU work per core is the contract's sample size)
         tc = time.perf_counter()
         r = orc.cpu_solve_batch(O, P[:ns], X0[:ns], threads=cores, max_iter=a.max_iter)
         tcpu = time.perf_counter() - tc
