@@ -437,6 +437,45 @@ int landing_kinodyn_nlp_eval(landing_ctx* ctx, int B, int N, const double* d_x, 
  * checked against: 60 ms per 1024 members at N = 20 on an MI355X. */
 int landing_kinodyn_nlp_hess(landing_ctx* ctx, int B, int N, const double* d_x, const landing_kinodyn_params* prm, const double* d_lam_g, double* d_hess, void* stream);
 
+/* ---- the kinodynamic refinement SOLVE ---------------------------------------------------------------------------------
+ * The step after the SRBM solve in every production caller (main_scripts/landing_optimization.m:300-322 SRBM solution as the initial guess,
+ * :360-376 / :398-435 the solves; generate_data/generate_training_data_automated.m:125-175).  The reference hands this NLP to KNITRO through
+ * the solver function of generate_solver/generate_landingCtrller_KNITRO.m:365-377,
+ *   [x*, f*] = landingCtrller_KNITRO(Xref, Uref, dt, q_min, q_max, qd_min, qd_max, q_init, qd_init, c_init, q_term_min, q_term_max, qd_term_min,
+ *                                    qd_term_max, QN, x0, jpos_min, jpos_max, kin_box, mu, l_leg_max, mass, Ib, Ib_inv)
+ * (KNITRO is a commercial solver; its generated artefacts are missing blobs of the reference tree).  Here: the interior-point method of
+ * landing_solve_batch on this NLP's stage structure (state (X_k, c_k), controls (f_k, jpos_k, c_k+1): the joint angles are stage-local and are
+ * eliminated inside the stage), exact first and second derivatives from landing_kinodyn_nlp_eval / _hess, B members per call.
+ *   landing_kinodyn_form     the literals of the script's constraint set (:139-189)
+ *   landing_kinodyn_bounds   lbg / ubg [ng x B] from the script's arguments (host arrays, trailing batch axis; Opti's canonicalisation)
+ *   landing_kinodyn_solve_batch   device pointers: d_lbg, d_ubg [B][ng]; d_cost [B][24] = QN (12) | Xref(:, end) (12) (terminal cost :83-86);
+ *                            d_x0 [B][nx]; dt, mass, Ib, Ib_inv, mu shared by the batch (prm).  Outputs as landing_solve_batch: d_x [B][nx],
+ *                            d_f [B], d_lam_g [B][ng] (CasADi sign), d_status [B] (LANDING_*), d_iters [B], d_kkt [B][3] (pr, du, compl unscaled)
+ *   landing_solve_kinodyn_24 the 24 arguments in the reference's order, HOST pointers, column-major with a trailing batch axis
+ *                            (Xref 12 x (N+1) x B, Uref 24 x N x B (inactive, may be NULL), dt 1 x N x B, 6-vectors 6 x B, c_init 12 x B, QN 12 x B,
+ *                            x0 nx x B, jpos_min / jpos_max 12 x B, kin_box 2 x B, mu / l_leg_max / mass 1 x B, Ib / Ib_inv 3 x B); dt, mu, mass, Ib,
+ *                            Ib_inv must be the same for every member of one call (they are constants of every caller in the reference).
+ * Needs landing_rbd_set_model.  N = number of intervals (the script's N - 1 = 20), N <= 64.                                                 */
+typedef struct {
+  double comp_eps, slip_eps;      /* :139  f_z c_z <= 1e-3;  :142-143  |f_z (c+ - c)| <= 1e-3 */
+  double fk_band;                 /* :186-187  |c - FK(q, jpos)| <= 0.01 */
+  double kin_box_x0, kin_box_y0;  /* :151-152  0.125 + kin_box(1), 0.10 + kin_box(2)  (generate_landingCtrller_KNITRO.m:110 uses 0.125 for y as well) */
+  double kin_box_y_in;            /* :159-163  inner lateral bound 0.05 */
+  double kin_box_z_lo, kin_box_z_hi;  /* :153-154  -0.4, -0.075 */
+  double tau_max[3];              /* model.tauMax = gr .* motorTauMax (get_robot_model.m:236-240): 18, 18, 27.99 */
+} landing_kinodyn_form;
+void landing_kinodyn_form_default(landing_kinodyn_form* f);
+void landing_kinodyn_solver_opts_default(landing_solver_opts* o);
+int landing_kinodyn_bounds(int N, int B, const landing_kinodyn_form* form, const double* q_init, const double* qd_init, const double* c_init,
+                           const double* q_min, const double* q_term_min, const double* q_term_max, const double* qd_term_min, const double* qd_term_max,
+                           const double* jpos_min, const double* jpos_max, const double* kin_box, const double* l_leg_max, double* lbg, double* ubg);
+int landing_kinodyn_solve_batch(landing_ctx* ctx, int B, int N, const landing_kinodyn_params* prm, const double* d_lbg, const double* d_ubg,
+                                const double* d_cost, const double* d_x0, const landing_solver_opts* opts,
+                                double* d_x, double* d_f, double* d_lam_g, int* d_status, int* d_iters, double* d_kkt, void* stream);
+int landing_kinodyn_solve_batch_host(landing_ctx* ctx, int B, int N, const landing_kinodyn_params* prm, const double* lbg, const double* ubg,
+                                     const double* cost, const double* x0, const landing_solver_opts* opts,
+                                     double* x, double* f, double* lam_g, int* status, int* iters, double* kkt);
+
 /* ---- SQP (Gauss-Newton / iLQR) loop on the 18-DoF model (BASELINE configs[3]) --------------------------------
  * Trajectory-tracking problem per member: state x = [q; qd] (36), control u = the 12 joint torques (base unactuated), known foot
  * forces f_k, explicit Euler  q+ = q + dt qd, qd+ = qd + dt qdd(q, qd, [0; u], f)  (the discretisation of the SRBM NLP,

@@ -24,6 +24,7 @@
 #include "vbl_kernels.hip"
 #include "rbd_kernels.hip"
 #include "wb_kernels.hip"
+#include "kd_solver_kernels.hip"
 
 using landing::Layout;
 
@@ -57,6 +58,7 @@ struct landing_ctx {
   // every scratch block above is re-used by the next call of its entry point, possibly on another stream: the launches that use it are
   // fenced by this event (recorded behind them, waited for before the next writer / reader touches the block) -- ADVICE r2
   hipEvent_t scratch_done = nullptr;
+  double* d_kd_ws = nullptr; size_t kd_cap = 0; int* d_kd_active = nullptr; int* d_kd_done = nullptr; int kd_done_cap = 0;      // workspace of landing_kinodyn_solve_batch (kd_capi.inc), count of members still iterating
   unsigned char* d_kd_pairs = nullptr;      // structurally non-zero pairs of a Hessian block of the kinodynamic NLP (rbd_kernels.hip)
   bool rbd_arrow = false;      // the model set by landing_rbd_set_model is "six base joints + four 3-joint legs on the base": H is block-arrow (wb_kernels.hip)
   std::mutex mu;      // serialises landing_solve_batch calls on one context (the workspace belongs to the context)
@@ -287,6 +289,9 @@ void landing_destroy(landing_ctx* ctx) {
   for (int i = 0; i < 3; ++i) { if (ctx->aux[i]) (void)hipStreamDestroy(ctx->aux[i]); if (ctx->ev_join[i]) (void)hipEventDestroy(ctx->ev_join[i]); }
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
   if (ctx->d_kd_pairs) (void)hipFree(ctx->d_kd_pairs);
+  if (ctx->d_kd_ws) (void)hipFree(ctx->d_kd_ws);
+  if (ctx->d_kd_active) (void)hipFree(ctx->d_kd_active);
+  if (ctx->d_kd_done) (void)hipFree(ctx->d_kd_done);
   if (ctx->scratch_done) { (void)hipEventSynchronize(ctx->scratch_done); (void)hipEventDestroy(ctx->scratch_done); }
   if (ctx->host_stream) (void)hipStreamDestroy(ctx->host_stream);
   delete ctx;
@@ -459,3 +464,4 @@ int landing_bounds_batch(landing_ctx* ctx, int B, const double* d_p, double* d_l
 
 #include "solver_capi.inc"
 #include "multi_capi.inc"
+#include "kd_capi.inc"

@@ -1,0 +1,777 @@
+// kd_solver_kernels.hip -- batched interior-point solver of the KINODYNAMIC REFINEMENT NLP (gfx950, fp64).
+//
+// The NLP: optimizations/landing/main_scripts/landing_optimization.m:38-201 (= generate_solver/generate_landingCtrller_KNITRO.m:45-215),
+// the step after the SRBM solve in every production caller (:300-322 SRBM solution as the initial guess, :360-376 / :398-435 the solves,
+// which the reference hands to KNITRO -- a commercial solver whose artefacts are absent from the tree).  Variables
+//   x = [X (12 x (N+1)); jpos (12 x N); U (24 x N: c; f_grf)],  rows g in the script's order (rbd_kernels.hip, kd_stage_rows).
+// What is solved here is the same primal-dual interior-point iteration as the SRBM solver's (solver_kernels.hip): slack + bound
+// multiplier pair on every inequality row, fraction-to-the-boundary rule, filter line search, monotone barrier update, inertia correction
+// by delta_w -- on this NLP's stage structure:
+//   state   sigma_k = (X_k, c_k)            24      (X_0 and c_0 are fixed by the script's initial conditions, :89-91)
+//   control u_k     = (f_k, jpos_k, c_k+1)  36      (24 in the last interval: there is no c_N)
+//   dynamics X_k+1 = X_k + dt (...)  (the Euler defects :125-128 are linear in X_k+1 with unit coefficient), c_k+1 = part of u_k
+// The joint angles are stage-local (they enter the FK band, the leg-torque rows and their own limits of interval k only), so they are
+// eliminated with the forces inside the stage: the Riccati recursion runs on the 24-dimensional state.
+//
+// Division of work per interior-point iteration (host loop in kd_capi.inc, all members of the batch in lock step, finished members skip):
+//   landing_kinodyn_nlp_jac_kernel / _hess_kernel   (rbd_kernels.hip, whole batch)   exact J blocks (141 x 72) and Hessian blocks of lam' g
+//                                                    (72 x 72) of every interval by forward-mode AD, as CasADi provides them to the reference
+//   landing_kd_iter_kernel                          (this file, ONE WORKGROUP = ONE NLP)   error test, barrier update, condensation
+//       Q_k = H_k + J_k' Sigma J_k on the fp64 matrix cores (v_mfma_f64_16x16x4), Riccati sweep with inertia correction, forward sweep,
+//       step bounds, filter line search with g evaluated in the kernel (kd_stage_rows<double>, one lane per interval), acceptance.
+// The iteration state of a member (mu, delta_w, filter, counters) lives in its workspace between launches.
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+#include "../../include/landing_nlp.h"
+
+namespace landing {
+
+constexpr int KD_NSIG = 24, KD_NV = 60;          // state; stage variables v = (sigma, f, jpos, c+) of a middle interval (48 in the last one)
+constexpr int KD_MS = 62;                        // LDS row stride of the stage array [M | m] (column 60 = right-hand side)
+constexpr int KD_PS = 25;                        // LDS row stride of the cost-to-go P (24 x 24)
+constexpr int KD_AS = 37;                        // LDS row stride of [A^ | b] (12 x 37)
+constexpr int KD_JC_ROWS = 32, KD_JC_S = 65;     // rows per chunk of the staged Jacobian, LDS row stride (64 columns + pad)
+// per-interval record of the backward sweep (doubles): gains K (36 x 24) | kappa (36) | [A^ | b] (12 x 37) | state rows of the cost-to-go
+// P_k (12 x 24) | p_k (12)
+constexpr int KD_REC_K = 0, KD_REC_KAP = 864, KD_REC_AH = 900, KD_REC_PX = 1344, KD_REC_PV = 1632, KD_REC = 1648;
+constexpr int KD_FILT = 48;
+constexpr int KD_THREADS = 256;
+// row r (0..11) of the Euler defects (v, omega, pos, rpy -- the script's order :125-128) <-> entry of X_k+1 it is linear in
+__device__ __constant__ int KD_ROW2X[12] = {9, 10, 11, 6, 7, 8, 0, 1, 2, 3, 4, 5};
+
+struct KdState {
+  double mu, delta_last, th_max, c_pr, c_co, c_cm, c_ys, c_zs, c_nz, e_pr, e_du, e_co;
+  double tau, a_pr, a_du, th0, ph0, dphi, alpha, s_corr, delta, ft, fval, omt;
+  double filt_th[KD_FILT], filt_ph[KD_FILT];
+  int nfilt, it, status, done, need_reg_streak, first_failed, cutstreak, force_step, wd_count, last_mu_it;
+  int accepted, armijo_step, fact_ok, skipped_zero, attempt, flag, ls_done, need_corr, fallback, nfact, ntrial, pad_;
+};
+
+struct KdMem {
+  double *x, *xt, *dx, *gx;
+  double *g, *gt, *s, *ds, *zL, *zU, *y, *yn, *sig, *rho;
+  double *J, *H, *rec;
+  KdState* st;
+};
+__host__ __device__ inline size_t kd_ws_stride(int N) {
+  const size_t nx = (size_t)kd_nx(N), ng = (size_t)kd_ng(N);
+  return 4 * nx + 10 * ng + (size_t)N * KD_ROWS * KD_NW + (size_t)N * KD_NW * KD_NW + (size_t)(N + 1) * KD_REC + (sizeof(KdState) + 7) / 8 + 8;
+}
+__device__ __forceinline__ KdMem kd_carve(int N, double* w) {
+  const size_t nx = (size_t)kd_nx(N), ng = (size_t)kd_ng(N);
+  KdMem M;
+  M.x = w; w += nx; M.xt = w; w += nx; M.dx = w; w += nx; M.gx = w; w += nx;
+  M.g = w; w += ng; M.gt = w; w += ng; M.s = w; w += ng; M.ds = w; w += ng; M.zL = w; w += ng; M.zU = w; w += ng;
+  M.y = w; w += ng; M.yn = w; w += ng; M.sig = w; w += ng; M.rho = w; w += ng;
+  M.J = w; w += (size_t)N * KD_ROWS * KD_NW; M.H = w; w += (size_t)N * KD_NW * KD_NW; M.rec = w; w += (size_t)(N + 1) * KD_REC;
+  M.st = reinterpret_cast<KdState*>(w);
+  return M;
+}
+
+struct KdSolveArgs {
+  const RbdModel* model; KdNlpParams P; int B, N; landing_solver_opts o;
+  const double* x0;        // [B][nx]
+  const double* lb; const double* ub;      // [B][ng]  lbg / ubg (the script's values: kinodyn.py / landing_kinodyn_bounds)
+  const double* cost;      // [B][24]  QN (12) | Xref(:, end) (12)   -- the terminal cost of :83-86
+  double* ws; size_t ws_stride;
+  double* x_out; double* f_out; double* lam_out; int* status; int* iters; double* kkt;
+  int* n_active;           // number of members still iterating (written by the iteration kernel)
+  int* done;               // [B] 1 = the member has finished (read by the function-layer kernels: finished members are skipped)
+};
+
+// variable j of v = (X_k, c_k, f_k, jpos_k, c_k+1) -> column of the interval's block over w = (X_k, c_k, f_k, jpos_k, X_k+1, c_k+1)
+__host__ __device__ inline int kd_v2w(int j) { return j < 48 ? j : j + 12; }
+
+// g at x for one member: one lane per interval (callers pass every thread of the block; lanes >= N only write boundary rows / idle)
+__device__ __noinline__ void kd_member_eval_g(const KdNlpParams& P, const RbdModel& M, int N, const double* x, double* g) {
+  for (int k = threadIdx.x; k < N; k += blockDim.x) {
+    double w[KD_NW], out[KD_ROWS];
+    for (int j = 0; j < KD_NW; ++j) { const int i = kd_w_index(N, k, j); w[j] = i >= 0 ? x[i] : 0.0; }
+    const bool last = k == N - 1;
+    kd_stage_rows<double>(P, M, k, last, w, out);
+    const int nr = last ? KD_ROWS_LAST : KD_ROWS;
+    for (int r = 0; r < nr; ++r) g[KD_BND + k * KD_ROWS + r] = out[r];
+  }
+  if (threadIdx.x >= 64 && threadIdx.x < 64 + 48) {      // boundary rows (coordinate picks), by a wave that has no interval to evaluate
+    const int i = threadIdx.x - 64, oU = 12 * (N + 1) + 12 * N;
+    double v;
+    if (i < 12) v = x[i];
+    else if (i < 24) v = x[oU + (i - 12)];
+    else { const int j = i - 24; v = j < 12 ? x[12 * N + (j % 6)] : x[12 * N + 6 + (j % 6)]; }
+    g[i] = v;
+  }
+}
+
+// LDS of one member's workgroup
+struct KdLds {
+  double Ms[KD_NV * KD_MS];            // stage array [M | m]
+  double Pm[KD_NSIG * KD_PS];          // cost-to-go of the next stage
+  double pv[KD_NSIG];
+  double Ah[12 * KD_AS];               // [A^ | b]
+  double Y[KD_NSIG * KD_AS];           // P [A^ | b] (+ p): rows of sigma+
+  double Jc[KD_JC_ROWS * KD_JC_S];     // chunk of the interval's inequality rows (v columns, zero padded to 64)
+  double sgc[KD_JC_ROWS], rhc[KD_JC_ROWS];
+  double prow[KD_MS], pcol[KD_NV];
+  double dsg[KD_NSIG * 65];            // d sigma_k of every knot (N <= 64)
+  double dxw[KD_NW];
+  double red[(KD_THREADS / 64) * 6];
+  int flag;
+  KdState ks;
+};
+__shared__ KdLds KSH;
+
+#define KD_BEGIN() __syncthreads(); if (threadIdx.x == 0) {
+#define KD_BEGIN_SYNCED() if (threadIdx.x == 0) {
+#define KD_END() } __syncthreads()
+
+// ---- condensation of interval k into KSH.Ms (nv x nv + rhs), KSH.Ah ------------------------------------------------------------
+__device__ __noinline__ void kd_condense_stage(const KdMem& M, int N, int k, double delta) {
+  KdLds& S = KSH;
+  const int tid = threadIdx.x, NT = blockDim.x;
+  const bool last = k == N - 1;
+  const int nv = last ? 48 : KD_NV, nr = last ? KD_ROWS_LAST : KD_ROWS;
+  const double* __restrict__ Jk = M.J + (size_t)k * KD_ROWS * KD_NW;
+  const double* __restrict__ Hk = M.H + (size_t)k * KD_NW * KD_NW;
+  const int g0 = KD_BND + k * KD_ROWS;
+  // Hessian block of lam' g over v, delta_w on the diagonal, right-hand side cleared
+  for (int e = tid; e < KD_NV * KD_MS; e += NT) {
+    const int a = e / KD_MS, b = e % KD_MS;
+    double v = 0.0;
+    if (a < nv && b < nv) v = Hk[kd_v2w(a) * KD_NW + kd_v2w(b)] + (a == b ? delta : 0.0);
+    S.Ms[e] = v;
+  }
+  // [A^ | b] from the defect rows: X_k+1 = A^ (sigma_k, f_k) + b in step form  (rows in the order of X)
+  for (int e = tid; e < 12 * KD_AS; e += NT) {
+    const int r = e / KD_AS, c = e % KD_AS;
+    S.Ah[KD_ROW2X[r] * KD_AS + c] = c < 36 ? -Jk[r * KD_NW + c] : -M.g[g0 + r];
+  }
+  __syncthreads();
+  // + J_I' Sigma J_I and m = J_I' rho over the inequality rows 12 .. nr-1, in chunks of KD_JC_ROWS rows staged in LDS; the product runs on
+  // the fp64 matrix cores: wave w owns row tile w of M (16 rows), four column tiles
+  const int wave = tid >> 6, l = tid & 63, lj = l & 15, lk = l >> 4;
+  f64x4 acc[4];
+  for (int t = 0; t < 4; ++t) acc[t] = f64x4{0.0, 0.0, 0.0, 0.0};
+  double macc = 0.0;
+  for (int r0 = 12; r0 < nr; r0 += KD_JC_ROWS) {
+    for (int e = tid; e < KD_JC_ROWS * 64; e += NT) {
+      const int rr = e >> 6, c = e & 63, r = r0 + rr;
+      S.Jc[rr * KD_JC_S + c] = (r < nr && c < nv) ? Jk[r * KD_NW + kd_v2w(c)] : 0.0;
+    }
+    if (tid < KD_JC_ROWS) { const int r = r0 + tid; S.sgc[tid] = r < nr ? M.sig[g0 + r] : 0.0; S.rhc[tid] = r < nr ? M.rho[g0 + r] : 0.0; }
+    __syncthreads();
+    for (int t = 0; t < 4; ++t)
+      acc[t] = mfma_tile<KD_JC_ROWS / 4>(acc[t], [&](int i, int kk) { return S.Jc[kk * KD_JC_S + 16 * wave + i] * S.sgc[kk]; },
+                                         [&](int kk, int j) { return S.Jc[kk * KD_JC_S + 16 * t + j]; });
+    if (tid < nv) { for (int kk = 0; kk < KD_JC_ROWS; ++kk) macc += S.Jc[kk * KD_JC_S + tid] * S.rhc[kk]; }
+    __syncthreads();
+  }
+  for (int t = 0; t < 4; ++t)
+    for (int r = 0; r < 4; ++r) {
+      const int a = 16 * wave + lk + 4 * r, b = 16 * t + lj;
+      if (a < nv && b < nv) S.Ms[a * KD_MS + b] += acc[t][r];
+    }
+  if (tid < nv) S.Ms[tid * KD_MS + 60] = macc;
+  __syncthreads();
+}
+
+// ---- one backward step: adds T' P+ T, T'(P+ t0 + p+) of the next stage's cost-to-go, eliminates the controls (Gauss-Jordan, scalar pivots),
+// leaves gains / cost-to-go in the record and in KSH.Pm, KSH.pv.  ns_next = 24 (12 for the last interval: sigma_N = X_N).  false = a pivot
+// was not positive (wrong inertia).
+__device__ __noinline__ bool kd_riccati_stage(const KdMem& M, int N, int k) {
+  KdLds& S = KSH;
+  const int tid = threadIdx.x, NT = blockDim.x;
+  const bool last = k == N - 1;
+  const int nv = last ? 48 : KD_NV, nu = nv - KD_NSIG, nsn = last ? 12 : 24;
+  // Y = P+(:, X) [A^ | b] (+ p+ in the last column)
+  for (int e = tid; e < nsn * KD_AS; e += NT) {
+    const int i = e / KD_AS, c = e % KD_AS;
+    double a = c == 36 ? S.pv[i] : 0.0;
+    for (int t = 0; t < 12; ++t) a += S.Pm[i * KD_PS + t] * S.Ah[t * KD_AS + c];
+    S.Y[e] = a;
+  }
+  __syncthreads();
+  for (int e = tid; e < 36 * 37; e += NT) {
+    const int a = e / 37, b = e % 37;
+    double v = 0.0;
+    for (int t = 0; t < 12; ++t) v += S.Ah[t * KD_AS + a] * S.Y[t * KD_AS + b];
+    S.Ms[a * KD_MS + (b < 36 ? b : 60)] += v;
+  }
+  if (!last) {
+    for (int e = tid; e < 12 * 36; e += NT) {
+      const int i = e / 36, b = e % 36;
+      const double v = S.Y[(12 + i) * KD_AS + b];
+      S.Ms[(48 + i) * KD_MS + b] += v; S.Ms[b * KD_MS + 48 + i] += v;
+    }
+    for (int e = tid; e < 144; e += NT) { const int i = e / 12, j = e % 12; S.Ms[(48 + i) * KD_MS + 48 + j] += S.Pm[(12 + i) * KD_PS + 12 + j]; }
+    if (tid < 12) S.Ms[(48 + tid) * KD_MS + 60] += S.Y[(12 + tid) * KD_AS + 36];
+  }
+  __syncthreads();
+  // Gauss-Jordan on the control rows / columns 24 .. nv-1 of [M | m]
+  bool ok = true;
+  for (int p = KD_NSIG; p < nv; ++p) {
+    const double d = S.Ms[p * KD_MS + p];
+    if (!(d > 0.0) || !(d < 1e300)) { ok = false; break; }      // uniform: every thread reads the same LDS word
+    const double inv = 1.0 / d;
+    if (tid < KD_MS) S.prow[tid] = (tid < nv || tid == 60) ? S.Ms[p * KD_MS + tid] * inv : 0.0;
+    if (tid >= 64 && tid < 64 + nv) S.pcol[tid - 64] = S.Ms[(tid - 64) * KD_MS + p];
+    __syncthreads();
+    for (int e = tid; e < nv * KD_MS; e += NT) {
+      const int a = e / KD_MS, b = e % KD_MS;
+      if (b >= nv && b != 60) continue;
+      S.Ms[e] = (a == p) ? S.prow[b] : S.Ms[e] - S.pcol[a] * S.prow[b];
+    }
+    __syncthreads();
+  }
+  if (!ok) { __syncthreads(); return false; }
+  double* rec = M.rec + (size_t)k * KD_REC;
+  for (int e = tid; e < 36 * 24; e += NT) { const int a = e / 24, b = e % 24; rec[KD_REC_K + e] = a < nu ? S.Ms[(24 + a) * KD_MS + b] : 0.0; }
+  if (tid < 36) rec[KD_REC_KAP + tid] = tid < nu ? S.Ms[(24 + tid) * KD_MS + 60] : 0.0;
+  for (int e = tid; e < 12 * KD_AS; e += NT) rec[KD_REC_AH + e] = S.Ah[e];
+  for (int e = tid; e < 24 * 24; e += NT) {
+    const int i = e / 24, j = e % 24;
+    const double v = S.Ms[i * KD_MS + j];
+    S.Pm[i * KD_PS + j] = v;
+    if (i < 12) rec[KD_REC_PX + e] = v;
+  }
+  if (tid < 24) { const double v = S.Ms[tid * KD_MS + 60]; S.pv[tid] = v; if (tid < 12) rec[KD_REC_PV + tid] = v; }
+  __syncthreads();
+  return true;
+}
+
+// terminal cost-to-go on X_N: 2 QN (terminal cost :83-86) + Sigma of the four terminal row groups (:94-97) + delta
+__device__ __forceinline__ void kd_terminal(const KdMem& M, int N, const double* cost, double delta) {
+  KdLds& S = KSH;
+  const int tid = threadIdx.x, NT = blockDim.x;
+  for (int e = tid; e < KD_NSIG * KD_PS; e += NT) S.Pm[e] = 0.0;
+  if (tid < KD_NSIG) S.pv[tid] = 0.0;
+  __syncthreads();
+  if (tid < 12) {
+    const int i = tid, ra = i < 6 ? 24 + i : 36 + (i - 6), rb = i < 6 ? 30 + i : 42 + (i - 6);
+    const double qn2 = 2.0 * cost[i];
+    const double pd = qn2 + M.sig[ra] + M.sig[rb] + delta, pg = qn2 * (M.x[12 * N + i] - cost[12 + i]) + M.rho[ra] + M.rho[rb];
+    S.Pm[i * KD_PS + i] = pd; S.pv[i] = pg;
+    double* rec = M.rec + (size_t)N * KD_REC;
+    for (int j = 0; j < 24; ++j) rec[KD_REC_PX + i * 24 + j] = j == i ? pd : 0.0;
+    rec[KD_REC_PV + i] = pg;
+  }
+  __syncthreads();
+}
+
+// whole backward sweep with regularisation delta
+__device__ __noinline__ bool kd_backward(const KdMem& M, int N, const double* cost, double delta) {
+  kd_terminal(M, N, cost, delta);
+  for (int k = N - 1; k >= 0; --k) {
+    kd_condense_stage(M, N, k, delta);
+    if (!kd_riccati_stage(M, N, k)) return false;
+  }
+  return true;
+}
+
+// forward sweep: dx of every variable, multipliers of the defect rows (yn), ds of every inequality row
+__device__ __noinline__ void kd_forward(const KdMem& M, int N, const double* lbm) {
+  KdLds& S = KSH;
+  const int tid = threadIdx.x, NT = blockDim.x;
+  const int oJ = 12 * (N + 1), oU = oJ + 12 * N;
+  // sigma_0 is fixed by the initial conditions (rows 0..23: lb = ub = q_init, qd_init, c_init)
+  if (tid < 24) { const int xi = tid < 12 ? tid : oU + (tid - 12); S.dsg[tid] = lbm[tid] - M.x[xi]; }
+  __syncthreads();
+  for (int k = 0; k < N; ++k) {
+    const bool last = k == N - 1;
+    const int nu = last ? 24 : 36;
+    const double* rec = M.rec + (size_t)k * KD_REC;
+    const double* sk = S.dsg + 24 * k;
+    // du = -(K dsigma + kappa)
+    if (tid < nu) {
+      double a = rec[KD_REC_KAP + tid];
+      for (int t = 0; t < 24; ++t) a += rec[KD_REC_K + tid * 24 + t] * sk[t];
+      S.dxw[24 + tid] = -a;      // dxw[24..] = (df, djpos, dc+)
+    }
+    __syncthreads();
+    if (tid < 12) {              // dX+ = A^ (dsigma, df) + b
+      double a = rec[KD_REC_AH + tid * KD_AS + 36];
+      for (int t = 0; t < 24; ++t) a += rec[KD_REC_AH + tid * KD_AS + t] * sk[t];
+      for (int t = 0; t < 12; ++t) a += rec[KD_REC_AH + tid * KD_AS + 24 + t] * S.dxw[24 + t];
+      S.dsg[24 * (k + 1) + tid] = a;
+    } else if (tid < 24) S.dsg[24 * (k + 1) + tid] = last ? 0.0 : S.dxw[24 + 24 + (tid - 12)];
+    if (tid >= 64 && tid < 64 + 24) {          // steps of the stage variables into dx
+      const int j = tid - 64;
+      M.dx[j < 12 ? 12 * k + j : oU + 24 * k + (j - 12)] = sk[j];
+    }
+    if (tid >= 128 && tid < 128 + 24) {
+      const int j = tid - 128;
+      M.dx[j < 12 ? oU + 24 * k + 12 + j : oJ + 12 * k + (j - 12)] = S.dxw[24 + j];
+    }
+    __syncthreads();
+  }
+  if (tid < 12) M.dx[12 * N + tid] = S.dsg[24 * N + tid];
+  // multipliers of the defect rows of interval k: y = -(P_k+1 dsigma_k+1 + p_k+1)_X in the row order of the defects
+  for (int e = tid; e < 12 * N; e += NT) {
+    const int k = e / 12, r = e % 12, i = KD_ROW2X[r];
+    const double* recn = M.rec + (size_t)(k + 1) * KD_REC;
+    const double* sn = S.dsg + 24 * (k + 1);
+    double a = recn[KD_REC_PV + i];
+    for (int t = 0; t < 24; ++t) a += recn[KD_REC_PX + i * 24 + t] * sn[t];
+    M.yn[KD_BND + k * KD_ROWS + r] = -a;
+  }
+  __syncthreads();
+  // ds = J_I dx + (g - s): one wave per row, lanes over the 72 columns of the interval's block
+  const int wave = tid >> 6, l = tid & 63;
+  for (int k = 0; k < N; ++k) {
+    const int nr = k == N - 1 ? KD_ROWS_LAST : KD_ROWS, g0 = KD_BND + k * KD_ROWS;
+    if (tid < KD_NW) { const int i = kd_w_index(N, k, tid); S.dxw[tid] = i >= 0 ? M.dx[i] : 0.0; }
+    __syncthreads();
+    const double* Jk = M.J + (size_t)k * KD_ROWS * KD_NW;
+    for (int r = 12 + wave; r < nr; r += 4) {
+      double a = Jk[r * KD_NW + l] * S.dxw[l];
+      if (l < KD_NW - 64) a += Jk[r * KD_NW + 64 + l] * S.dxw[64 + l];
+#pragma unroll
+      for (int mask = 32; mask >= 1; mask >>= 1) a += __shfl_xor(a, mask);
+      if (l == 0) M.ds[g0 + r] = a + (M.g[g0 + r] - M.s[g0 + r]);
+    }
+    __syncthreads();
+  }
+  if (tid < 24) {      // terminal rows: copies of X_N
+    const int r = 24 + tid, xi = tid < 12 ? (tid % 6) : 6 + (tid % 6);
+    M.ds[r] = M.dx[12 * N + xi] + (M.g[r] - M.s[r]);
+  }
+  __syncthreads();
+}
+
+// gx = grad f + J' y over the free rows (rows 24 .. ng-1): one thread per variable, the (at most two) block columns that hold it
+__device__ __noinline__ void kd_grad_lag(const KdMem& M, int N, const double* cost) {
+  const int tid = threadIdx.x, NT = blockDim.x, nx = kd_nx(N);
+  const int oJ = 12 * (N + 1), oU = oJ + 12 * N;
+  for (int i = tid; i < nx; i += NT) {
+    int k, j0, j1 = -1;      // own interval and column, column in the previous interval's block
+    if (i < oJ) { k = i / 12; j0 = i % 12; j1 = 48 + j0; }
+    else if (i < oU) { k = (i - oJ) / 12; j0 = 36 + (i - oJ) % 12; }
+    else { k = (i - oU) / 24; const int q = (i - oU) % 24; j0 = 12 + q; if (q < 12) j1 = 60 + q; }
+    double a = 0.0;
+    if (k < N) {
+      const double* Jk = M.J + (size_t)k * KD_ROWS * KD_NW; const double* yk = M.y + KD_BND + k * KD_ROWS;
+      const int nr = k == N - 1 ? KD_ROWS_LAST : KD_ROWS;
+      for (int r = 0; r < nr; ++r) a += Jk[r * KD_NW + j0] * yk[r];
+    }
+    if (j1 >= 0 && k >= 1) {
+      const double* Jp = M.J + (size_t)(k - 1) * KD_ROWS * KD_NW; const double* yp = M.y + KD_BND + (k - 1) * KD_ROWS;
+      const int nrp = (k - 1 == N - 1) ? KD_ROWS_LAST : KD_ROWS;      // (X_N sits in the last interval's block)
+      for (int r = 0; r < nrp; ++r) a += Jp[r * KD_NW + j1] * yp[r];
+    }
+    if (i >= 12 * N && i < 12 * N + 12) {      // X_N: terminal cost and the four terminal row groups
+      const int q = i - 12 * N;
+      a += 2.0 * cost[q] * (M.x[i] - cost[12 + q]);
+      a += q < 6 ? M.y[24 + q] + M.y[30 + q] : M.y[36 + (q - 6)] + M.y[42 + (q - 6)];
+    }
+    M.gx[i] = a;
+  }
+  __syncthreads();
+}
+
+// primal / complementarity errors, Sigma and rho of the current point for barrier parameter mu_ -> K.c_*, M.sig, M.rho
+__device__ __noinline__ void kd_point_pass(const KdMem& M, int ng, const double* lbm, const double* ubm, double mu_) {
+  KdLds& S = KSH;
+  const int tid = threadIdx.x, NT = blockDim.x;
+  const double INF = INFINITY;
+  double pr = 0.0, co = 0.0, cm = 0.0, ys = 0.0, zs = 0.0, nz = 0.0;
+  for (int r = tid; r < ng; r += NT) {
+    const double lb = lbm[r], ub = ubm[r];
+    double sg = 0.0, rh = 0.0;
+    if (r >= 24) {
+      const double g = M.g[r];
+      ys += fabs(M.y[r]);
+      if (lb == ub) pr = fmax(pr, fabs(g - lb));
+      else {
+        const double s = M.s[r];
+        pr = fmax(pr, fabs(g - s));
+        if (lb > -INF) { const double d = s - lb, zl = M.zL[r]; co = fmax(co, d * zl); cm = fmax(cm, fabs(d * zl - mu_)); sg += zl / d; rh -= mu_ / d; zs += zl; nz += 1.0; }
+        if (ub < INF) { const double d = ub - s, zu = M.zU[r]; co = fmax(co, d * zu); cm = fmax(cm, fabs(d * zu - mu_)); sg += zu / d; rh += mu_ / d; zs += zu; nz += 1.0; }
+        rh += sg * (g - s);
+      }
+    }
+    M.sig[r] = sg; M.rho[r] = rh;
+  }
+  double v[6] = {pr, co, cm, ys, zs, nz}; const int op[6] = {RMAX, RMAX, RMAX, RSUM, RSUM, RSUM};
+  block_reduce<6>(v, op, S.red);
+  KD_BEGIN_SYNCED() S.ks.c_pr = v[0]; S.ks.c_co = v[1]; S.ks.c_cm = v[2]; S.ks.c_ys = v[3]; S.ks.c_zs = v[4]; S.ks.c_nz = fmax(v[5], 1.0); KD_END();
+}
+
+__device__ __noinline__ void kd_init_slacks(const KdMem& M, int ng, const double* lbm, const double* ubm, const landing_solver_opts& o) {
+  const double INF = INFINITY;
+  for (int r = threadIdx.x; r < ng; r += blockDim.x) {
+    const double lb = lbm[r], ub = ubm[r];
+    double sv = 0.0, zl = 0.0, zu = 0.0;
+    if (r >= 24 && lb != ub) {
+      const bool hL = lb > -INF, hU = ub < INF;
+      sv = M.g[r];
+      double pl, pu;
+      if (hL && hU) { pl = fmin(o.bound_push * fmax(1.0, fabs(lb)), o.bound_frac * (ub - lb)); pu = fmin(o.bound_push * fmax(1.0, fabs(ub)), o.bound_frac * (ub - lb)); }
+      else { pl = o.bound_push * fmax(1.0, hL ? fabs(lb) : 0.0); pu = o.bound_push * fmax(1.0, hU ? fabs(ub) : 0.0); }
+      if (hL) sv = fmax(sv, lb + pl);
+      if (hU) sv = fmin(sv, ub - pu);
+      zl = hL ? 1.0 : 0.0; zu = hU ? 1.0 : 0.0;
+    }
+    M.s[r] = sv; M.zL[r] = zl; M.zU[r] = zu; M.y[r] = zu - zl;
+  }
+  __syncthreads();
+}
+
+// ---- start of a solve: initial point, slacks, multipliers, iteration state ------------------------------------------------------
+__global__ void __launch_bounds__(KD_THREADS) landing_kd_init_kernel(KdSolveArgs A) {
+  const int m = blockIdx.x;
+  if (m >= A.B) return;
+  const int N = A.N, nx = kd_nx(N), ng = kd_ng(N), tid = threadIdx.x, NT = blockDim.x;
+  const KdMem M = kd_carve(N, A.ws + (size_t)m * A.ws_stride);
+  const double* lbm = A.lb + (size_t)m * ng; const double* ubm = A.ub + (size_t)m * ng;
+  const int oU = 12 * (N + 1) + 12 * N;
+  for (int i = tid; i < nx; i += NT) {
+    double v = A.x0[(size_t)m * nx + i];
+    if (i < 12) v = lbm[i];                                  // X(:,1) and c(:,1) are fixed (:89-91)
+    else if (i >= oU && i < oU + 12) v = lbm[12 + (i - oU)];
+    M.x[i] = v;
+  }
+  __syncthreads();
+  kd_member_eval_g(A.P, *A.model, N, M.x, M.g);
+  __syncthreads();
+  kd_init_slacks(M, ng, lbm, ubm, A.o);
+  KdState& K = KSH.ks;
+  if (tid == 0) {
+    K.mu = A.o.mu_init; K.delta_last = 0.0; K.th_max = 0.0; K.c_pr = K.c_co = K.c_cm = K.c_ys = K.c_zs = 0.0; K.c_nz = 1.0;
+    K.e_pr = K.e_du = K.e_co = 0.0; K.tau = 0.0; K.a_pr = K.a_du = 0.0; K.th0 = K.ph0 = K.dphi = K.alpha = K.s_corr = K.delta = K.ft = K.fval = 0.0; K.omt = -1.0;
+    K.nfilt = 0; K.it = 0; K.status = LANDING_MAX_ITER; K.done = 0; K.need_reg_streak = 0; K.first_failed = 0; K.cutstreak = 0; K.force_step = 0;
+    K.wd_count = 0; K.last_mu_it = 0; K.accepted = 0; K.armijo_step = 0; K.fact_ok = 0; K.skipped_zero = 0; K.attempt = 0; K.flag = 0; K.ls_done = 0;
+    K.need_corr = 0; K.fallback = 0; K.nfact = 0; K.ntrial = 0; K.pad_ = 0;
+  }
+  __syncthreads();
+  kd_point_pass(M, ng, lbm, ubm, K.mu);
+  // Presolve: rows of the first interval that depend on the FIXED variables X(:,1), c(:,1) only -- foot height, kinematic box, leg length of
+  // the initial stance (:138, :157-164) and the z bound (:181).  The script fixes c(:,1) to the nominal stance under the hips of the initial
+  // attitude (:232-236) and bounds p_rel in WORLD axes, so a steep initial pitch / roll with a small velocity-dependent box violates them
+  // whatever the solver does (190 of 1024 drop states of the callers' sampling law): such a member is reported as LANDING_INFEASIBLE at
+  // once, kkt[0] = the violation, instead of driving the interior-point iteration into a numerical failure.
+  double viol = 0.0;
+  if (tid < 21 && N >= 2) {
+    const int l = tid / 5, j = tid % 5;
+    const int r = tid == 20 ? KD_BND + 92 : KD_BND + 16 + 15 * l + (j == 0 ? 0 : 7 + j);      // per leg (15 rows): c_z (0) | p_rel x, y, z (8..10) | |p_rel|^2 (11); row 92 = z
+    const double g = M.g[r];
+    viol = fmax(fmax(lbm[r] - g, g - ubm[r]), 0.0);
+  }
+  viol = block_reduce1(viol, RMAX, KSH.red);
+  if (tid == 0) {
+    if (viol > A.o.tol) { K.status = LANDING_INFEASIBLE; K.done = 1; K.e_pr = viol; }
+    *M.st = K;
+    A.done[m] = K.done;
+  }
+}
+
+// ---- one interior-point iteration of one member (J and H blocks of the current (x, y) are in the workspace) ---------------------------
+__global__ void __launch_bounds__(KD_THREADS) landing_kd_iter_kernel(KdSolveArgs A) {
+  const int m = blockIdx.x;
+  if (m >= A.B) return;
+  const int N = A.N, nx = kd_nx(N), ng = kd_ng(N), tid = threadIdx.x, NT = blockDim.x;
+  const KdMem M = kd_carve(N, A.ws + (size_t)m * A.ws_stride);
+  if (M.st->done) return;                                   // (uniform: one global word per member)
+  const landing_solver_opts& o = A.o;
+  const double* lbm = A.lb + (size_t)m * ng; const double* ubm = A.ub + (size_t)m * ng;
+  const double* cost = A.cost + (size_t)m * 24;
+  const double INF = INFINITY;
+  KdLds& S = KSH;
+  KdState& K = S.ks;
+  if (tid == 0) K = *M.st;
+  __syncthreads();
+  const int oU = 12 * (N + 1) + 12 * N;
+  // ---------------------------------------------------------------- optimality error (unscaled), stop test
+  kd_grad_lag(M, N, cost);
+  {
+    double du = 0.0;
+    for (int i = tid; i < nx; i += NT) { const bool fixed = i < 12 || (i >= oU && i < oU + 12); if (!fixed) du = fmax(du, fabs(M.gx[i])); }
+    du = block_reduce1(du, RMAX, S.red);
+    KD_BEGIN_SYNCED()
+      const double pr = K.c_pr, co = K.c_co;
+      K.e_pr = pr; K.e_du = du; K.e_co = co;
+      K.flag = 0;
+      if (!(du < 1e300) || !(pr < 1e300) || !(co < 1e300)) { K.status = LANDING_NUMERICAL; K.flag = 1; }
+      else if (fmax(du, fmax(pr, co)) <= o.tol) { K.status = LANDING_CONVERGED; K.flag = 1; }
+      else if (K.it >= o.max_iter) { K.status = LANDING_MAX_ITER; K.flag = 1; }
+    KD_END();
+  }
+  if (K.flag) {
+    if (tid == 0) { K.done = 1; *M.st = K; A.done[m] = 1; }
+    return;
+  }
+  // ---------------------------------------------------------------- barrier parameter (monotone)
+  for (;;) {
+    KD_BEGIN()
+      double sd = 1.0, sc = 1.0;
+      if (o.barrier_smax > 0.0) {
+        sd = fmax(o.barrier_smax, (K.c_ys + K.c_zs) / ((double)(ng - 24) + K.c_nz)) / o.barrier_smax;
+        sc = fmax(o.barrier_smax, K.c_zs / K.c_nz) / o.barrier_smax;
+      }
+      const double mu = K.mu;
+      if (fmax(K.e_du / sd, fmax(K.c_pr, K.c_cm / sc)) <= o.kappa_eps * mu && mu > o.tol / 10.0) {
+        K.mu = fmax(o.tol / 10.0, fmin(o.kappa_mu * mu, pow(mu, o.theta_mu)));
+        K.nfilt = 0; K.last_mu_it = K.it; K.wd_count = 0;
+        K.flag = 1;
+      } else { K.flag = 0; K.tau = fmax(o.tau_min, 1.0 - mu); }
+    KD_END();
+    if (!K.flag) break;
+    kd_point_pass(M, ng, lbm, ubm, K.mu);
+  }
+  // ================================================================ Riccati factorisation with inertia correction (IPOPT's schedule)
+  KD_BEGIN()
+    const double dl = K.delta_last;
+    K.delta = (K.need_reg_streak >= 2 && dl > 0.0) ? fmax(1e-20, dl * o.delta_dec) : 0.0;
+    K.delta = fmax(K.delta, o.delta_floor);      // proximal term (the cost is terminal only: landing_nlp.h delta_floor)
+    K.skipped_zero = K.delta > 0.0; K.fact_ok = 0; K.attempt = 0; K.flag = 1; K.nfact++;
+  KD_END();
+  for (;;) {
+    const bool ok = kd_backward(M, N, cost, K.delta);
+    KD_BEGIN()
+      K.fact_ok = ok ? 1 : 0;
+      if (K.attempt == 0) K.first_failed = (K.skipped_zero && !ok) ? 1 : 0;
+      K.attempt++;
+      K.flag = 0;
+      if (!ok && K.attempt < 60) {
+        double d = K.delta; const double dl = K.delta_last;
+        if (d == 0.0) d = (dl == 0.0) ? o.delta_init : fmax(1e-20, dl * o.delta_dec);
+        else d *= (dl == 0.0 ? o.delta_inc_first : o.delta_inc);
+        if (!(d > 1e40)) { K.delta = d; K.flag = 1; K.nfact++; }
+      }
+    KD_END();
+    if (!K.flag) break;
+  }
+  if (!K.fact_ok) {
+    if (tid == 0) { K.status = LANDING_NUMERICAL; K.done = 1; *M.st = K; A.done[m] = 1; }
+    return;
+  }
+  KD_BEGIN()
+    if (K.delta > o.delta_floor) { K.delta_last = K.delta; K.need_reg_streak++; } else K.need_reg_streak = 0;
+    if (K.need_reg_streak > 8) K.need_reg_streak = 0;
+  KD_END();
+  kd_forward(M, N, lbm);
+  // ================================================================ dual steps, step bounds, merit data
+  {
+    const double mu = K.mu;
+    // clip_k rule (landing_nlp.h): while the point is far from feasible the step length comes from the clip_k-th largest ratio |ds| / distance;
+    // the slacks with a larger one stop at (1 - tau) of their distance (omt > 0 in the passes below).  Without it ONE slack after the other
+    // cuts the step by 1 - tau per iteration from the callers' guess (measured on the first GPU batch: a_pr 2e-1, 3e-2, 3e-3 ... 3e-15)
+    const bool clip_now = o.clip_k > 1 && K.c_pr > o.clip_until;
+    double top[4] = {0.0, 0.0, 0.0, 0.0};
+    double m_pr = 0.0, m_du = 0.0, th0 = 0.0, bar = 0.0, dphi = 0.0, f0 = 0.0;
+    for (int r = tid + 24; r < ng; r += NT) {
+      const double lb = lbm[r], ub = ubm[r], g = M.g[r];
+      if (lb == ub) { th0 += fabs(g - lb); continue; }
+      const double s = M.s[r], ds = M.ds[r];
+      th0 += fabs(g - s);
+      double dprod = 1.0;
+      if (lb > -INF) {
+        const double d = s - lb, rd = 1.0 / d, zl = M.zL[r];
+        const double dz = -zl * rd * ds + (mu * rd - zl);
+        m_pr = fmax(m_pr, -ds * rd); top4_push(top, -ds * rd); m_du = fmax(m_du, -dz / zl);
+        dprod = d; dphi -= mu * ds * rd;
+      }
+      if (ub < INF) {
+        const double d = ub - s, rd = 1.0 / d, zu = M.zU[r];
+        const double dz = zu * rd * ds + (mu * rd - zu);
+        m_pr = fmax(m_pr, ds * rd); top4_push(top, ds * rd); m_du = fmax(m_du, -dz / zu);
+        dprod *= d; dphi += mu * ds * rd;
+      }
+      bar -= log(dprod);
+    }
+    if (tid < 12) { const double d = M.x[12 * N + tid] - cost[12 + tid], qn = cost[tid]; f0 = qn * d * d; dphi += 2.0 * qn * d * M.dx[12 * N + tid]; }
+    double v[6] = {m_pr, m_du, th0, bar, dphi, f0}; const int op[6] = {RMAX, RMAX, RSUM, RSUM, RSUM, RSUM};
+    block_reduce<6>(v, op, S.red);
+    if (clip_now) block_top4(top, S.red);         // (uniform: clip_now comes from K)
+    KD_BEGIN_SYNCED()
+      const double tau = K.tau;
+      K.a_pr = (v[0] > tau) ? tau / v[0] : 1.0;
+      if (clip_now) { const double rk = top[(o.clip_k > 4 ? 4 : o.clip_k) - 1]; K.a_pr = (rk > tau) ? tau / rk : 1.0; }
+      K.omt = clip_now ? 1.0 - tau : -1.0;
+      K.a_du = (v[1] > tau) ? tau / v[1] : 1.0;
+      K.th0 = v[2]; K.dphi = v[4]; K.ph0 = v[5] + mu * v[3]; K.fval = v[5];
+      if (K.th_max == 0.0) K.th_max = 1e4 * fmax(1.0, v[2]);
+      K.alpha = K.a_pr; K.s_corr = 0.0; K.accepted = 0; K.armijo_step = 0; K.ls_done = K.a_pr > 1e-10 ? 0 : 1;
+    KD_END();
+  }
+  // ================================================================ filter line search
+  while (!K.ls_done) {
+    const double alpha = K.alpha, mu = K.mu, omt = K.omt;
+    for (int i = tid; i < nx; i += NT) M.xt[i] = M.x[i] + alpha * M.dx[i];
+    __syncthreads();
+    kd_member_eval_g(A.P, *A.model, N, M.xt, M.gt);
+    __syncthreads();
+    double tht = 0.0, bt = 0.0, ft = 0.0;
+    for (int r = tid + 24; r < ng; r += NT) {
+      const double lb = lbm[r], ub = ubm[r], g = M.gt[r];
+      if (lb == ub) { tht += fabs(g - lb); continue; }
+      double s = M.s[r] + alpha * M.ds[r];
+      if (omt > 0.0) { const double so = M.s[r]; if (lb > -INF) s = fmax(s, lb + omt * (so - lb)); if (ub < INF) s = fmin(s, ub - omt * (ub - so)); }
+      tht += fabs(g - s);
+      bt -= log((lb > -INF ? s - lb : 1.0) * (ub < INF ? ub - s : 1.0));
+    }
+    if (tid < 12) { const double d = M.xt[12 * N + tid] - cost[12 + tid]; ft = cost[tid] * d * d; }
+    { double v[3] = {tht, bt, ft}; const int op[3] = {RSUM, RSUM, RSUM}; block_reduce<3>(v, op, S.red); tht = v[0]; bt = v[1]; ft = v[2]; }
+    KD_BEGIN_SYNCED()
+      K.ntrial++;
+      const double th_min = 1e-4, th_floor = o.theta_floor * o.tol;
+      const double th0 = K.th0, ph0 = K.ph0, dphi = K.dphi;
+      const int nfilt = K.nfilt;
+      const double pht = ft + mu * bt;
+      bool ok_f = (tht <= K.th_max) && (pht < 1e300) && (pht > -1e300) && (tht < 1e300);
+      for (int e = 0; e < nfilt && ok_f; ++e) if (tht >= fmax(K.filt_th[e], th_floor) && pht >= K.filt_ph[e]) ok_f = false;
+      const bool switching = (dphi < 0.0) && (th0 <= th_min) && (alpha * pow(-dphi, 2.3) > 1.0 * pow(th0, 1.1));
+      bool accepted = false, done = false;
+      if (ok_f) {
+        if (switching) { if (pht <= ph0 + 1e-8 * alpha * dphi) { accepted = true; K.armijo_step = 1; } }
+        else if (tht <= fmax((1.0 - 1e-5) * th0, th_floor) || pht <= ph0 - 1e-8 * th0) accepted = true;
+      }
+      if (K.force_step && ok_f) { accepted = true; K.nfilt = 0; done = true; }      // watchdog: the step to the boundary is taken (it must still pass theta_max and the filter entries)
+      if (accepted) done = true;
+      K.need_corr = 0;
+      if (!done) {
+        if (o.slack_corr > 0.0 && alpha == K.a_pr && tht >= th0) { K.need_corr = 1; K.ft = ft; }
+        else { K.alpha = alpha * 0.5; if (!(K.alpha > 1e-10)) done = true; }
+      }
+      K.accepted = accepted ? 1 : 0; K.ls_done = done ? 1 : 0;
+    KD_END();
+    if (K.need_corr) {
+      // slack correction (landing_nlp.h): the rejected first trial point once more with the inequality slacks moved to g(x_trial)
+      double tht2 = 0.0, bt2 = 0.0;
+      for (int r = tid + 24; r < ng; r += NT) {
+        const double lb = lbm[r], ub = ubm[r], g = M.gt[r];
+        if (lb == ub) { tht2 += fabs(g - lb); continue; }
+        double s = M.s[r] + alpha * M.ds[r];
+        if (omt > 0.0) { const double so = M.s[r]; if (lb > -INF) s = fmax(s, lb + omt * (so - lb)); if (ub < INF) s = fmin(s, ub - omt * (ub - so)); }
+        const double lo = lb > -INF ? lb + o.slack_corr * (s - lb) : -INF, hi = ub < INF ? ub - o.slack_corr * (ub - s) : INF;
+        s = fmin(fmax(g, lo), hi);
+        tht2 += fabs(g - s);
+        bt2 -= log((lb > -INF ? s - lb : 1.0) * (ub < INF ? ub - s : 1.0));
+      }
+      { double v[2] = {tht2, bt2}; const int op[2] = {RSUM, RSUM}; block_reduce<2>(v, op, S.red); tht2 = v[0]; bt2 = v[1]; }
+      KD_BEGIN_SYNCED()
+        const double th_floor = o.theta_floor * o.tol, th0 = K.th0, ph0 = K.ph0;
+        const int nfilt = K.nfilt;
+        const double pht2 = K.ft + mu * bt2;
+        bool ok2 = (tht2 <= K.th_max) && (pht2 < 1e300) && (pht2 > -1e300);
+        for (int e = 0; e < nfilt && ok2; ++e) if (tht2 >= fmax(K.filt_th[e], th_floor) && pht2 >= K.filt_ph[e]) ok2 = false;
+        if (ok2 && (tht2 <= fmax((1.0 - 1e-5) * th0, th_floor) || pht2 <= ph0 - 1e-8 * th0)) { K.accepted = 1; K.s_corr = o.slack_corr; K.ls_done = 1; }
+        else { K.alpha = alpha * 0.5; if (!(K.alpha > 1e-10)) K.ls_done = 1; }
+      KD_END();
+    }
+  }
+  KD_BEGIN()
+    const double a_pr = K.a_pr;
+    K.force_step = 0;
+    if (o.watchdog > 0) {
+      if (K.accepted && K.alpha <= 0.0625 * a_pr) { if (++K.cutstreak >= o.watchdog) { K.force_step = 1; K.cutstreak = 0; K.wd_count++; } }
+      else K.cutstreak = 0;
+    }
+    K.fallback = 0;
+    if (!K.accepted) { K.nfilt = 0; K.alpha = fmin(a_pr, o.alpha_fallback); K.fallback = 1; }
+    else if (!K.armijo_step) {
+      int nfilt = K.nfilt;
+      if (nfilt == KD_FILT) { for (int e = 0; e + 1 < KD_FILT; ++e) { K.filt_th[e] = K.filt_th[e + 1]; K.filt_ph[e] = K.filt_ph[e + 1]; } nfilt = KD_FILT - 1; }
+      K.filt_th[nfilt] = (1.0 - 1e-5) * K.th0; K.filt_ph[nfilt] = K.ph0 - 1e-8 * K.th0;
+      K.nfilt = nfilt + 1;
+    }
+    if (o.dual_step_cap > 0.0) K.a_du = fmin(K.a_du, o.dual_step_cap * K.alpha);
+  KD_END();
+  if (K.fallback) {
+    const double alpha = K.alpha;
+    for (int i = tid; i < nx; i += NT) M.xt[i] = M.x[i] + alpha * M.dx[i];
+    __syncthreads();
+    kd_member_eval_g(A.P, *A.model, N, M.xt, M.gt);
+    __syncthreads();
+  }
+  // ================================================================ accept the trial point; errors, Sigma, rho of the new iterate
+  for (int i = tid; i < nx; i += NT) M.x[i] = M.xt[i];
+  {
+    const double alpha = K.alpha, a_du = K.a_du, mu = K.mu, s_corr = K.s_corr, omt = K.omt;
+    double npr = 0.0, nco = 0.0, ncm = 0.0, nys = 0.0, nzs = 0.0, nnz = 0.0;
+    for (int r = tid; r < ng; r += NT) {
+      const double lb = lbm[r], ub = ubm[r], g = M.gt[r];
+      M.g[r] = g;
+      double sg = 0.0, rh = 0.0;
+      if (r >= 24) {
+        if (lb == ub) { const double yn_ = M.y[r] + alpha * (M.yn[r] - M.y[r]); M.y[r] = yn_; nys += fabs(yn_); npr = fmax(npr, fabs(g - lb)); }
+        else {
+          const double so = M.s[r], ds = M.ds[r];
+          double s = so + alpha * ds;
+          if (omt > 0.0) { if (lb > -INF) s = fmax(s, lb + omt * (so - lb)); if (ub < INF) s = fmin(s, ub - omt * (ub - so)); }
+          if (s_corr > 0.0) { const double lo = lb > -INF ? lb + s_corr * (s - lb) : -INF, hi = ub < INF ? ub - s_corr * (ub - s) : INF; s = fmin(fmax(g, lo), hi); }
+          double zl = 0.0, zu = 0.0;
+          if (lb > -INF) {
+            const double dold = so - lb, zo = M.zL[r], dz = -zo / dold * ds + (mu / dold - zo), d = s - lb;
+            zl = fmin(fmax(zo + a_du * dz, 1e-10 * mu / d), 1e10 * mu / d);
+            nco = fmax(nco, d * zl); ncm = fmax(ncm, fabs(d * zl - mu)); sg += zl / d; rh -= mu / d; nzs += zl; nnz += 1.0;
+          }
+          if (ub < INF) {
+            const double dold = ub - so, zo = M.zU[r], dz = zo / dold * ds + (mu / dold - zo), d = ub - s;
+            zu = fmin(fmax(zo + a_du * dz, 1e-10 * mu / d), 1e10 * mu / d);
+            nco = fmax(nco, d * zu); ncm = fmax(ncm, fabs(d * zu - mu)); sg += zu / d; rh += mu / d; nzs += zu; nnz += 1.0;
+          }
+          npr = fmax(npr, fabs(g - s));
+          rh += sg * (g - s);
+          M.s[r] = s; M.zL[r] = zl; M.zU[r] = zu; M.y[r] = zu - zl; nys += fabs(zu - zl);
+        }
+      }
+      M.sig[r] = sg; M.rho[r] = rh;
+    }
+    double v[6] = {npr, nco, ncm, nys, nzs, nnz}; const int op[6] = {RMAX, RMAX, RMAX, RSUM, RSUM, RSUM};
+    block_reduce<6>(v, op, S.red);
+    KD_BEGIN_SYNCED()
+      K.c_pr = v[0]; K.c_co = v[1]; K.c_cm = v[2]; K.c_ys = v[3]; K.c_zs = v[4]; K.c_nz = fmax(v[5], 1.0);
+      K.it++;
+      *M.st = K;
+      atomicAdd(A.n_active, 1);
+    KD_END();
+  }
+}
+
+// ---- end of a solve: outputs (the J blocks of the final (x, y) are in the workspace) ------------------------------------------------
+__global__ void __launch_bounds__(KD_THREADS) landing_kd_finish_kernel(KdSolveArgs A) {
+  const int m = blockIdx.x;
+  if (m >= A.B) return;
+  const int N = A.N, nx = kd_nx(N), ng = kd_ng(N), tid = threadIdx.x, NT = blockDim.x;
+  const KdMem M = kd_carve(N, A.ws + (size_t)m * A.ws_stride);
+  const double* lbm = A.lb + (size_t)m * ng; const double* ubm = A.ub + (size_t)m * ng;
+  const double* cost = A.cost + (size_t)m * 24;
+  const double INF = INFINITY;
+  KdLds& S = KSH;
+  const int oU = 12 * (N + 1) + 12 * N;
+  kd_grad_lag(M, N, cost);
+  // multipliers of the fixed rows from stationarity of X(:,1), c(:,1): lam = -(grad f + J' y)
+  if (tid < 24) M.y[tid] = -M.gx[tid < 12 ? tid : oU + (tid - 12)];
+  double du = 0.0, fo = 0.0;
+  for (int i = tid; i < nx; i += NT) { const bool fixed = i < 12 || (i >= oU && i < oU + 12); if (!fixed) du = fmax(du, fabs(M.gx[i])); }
+  if (tid < 12) { const double d = M.x[12 * N + tid] - cost[12 + tid]; fo = cost[tid] * d * d; }
+  __syncthreads();
+  double kp = 0.0, kc = 0.0;
+  for (int r = tid; r < ng; r += NT) {
+    const double lb = lbm[r], ub = ubm[r], g = M.g[r], lam = M.y[r];
+    kp = fmax(kp, fmax(lb - g, fmax(g - ub, 0.0)));
+    if (lb != ub) {
+      const double dist = lam > 0.0 ? ub - g : g - lb;
+      if (lam != 0.0 && dist < INF) kc = fmax(kc, fabs(lam * dist));
+    }
+  }
+  { double v[4] = {kp, kc, du, fo}; const int op[4] = {RMAX, RMAX, RMAX, RSUM}; block_reduce<4>(v, op, S.red); kp = v[0]; kc = v[1]; du = v[2]; fo = v[3]; }
+  for (int i = tid; i < nx; i += NT) A.x_out[(size_t)m * nx + i] = M.x[i];
+  if (A.lam_out) for (int r = tid; r < ng; r += NT) A.lam_out[(size_t)m * ng + r] = M.y[r];
+  if (tid == 0) {
+    const KdState& K = *M.st;
+    int status = K.status;
+    if (!K.done) status = LANDING_MAX_ITER;
+    // the stop test of the iteration kernel used the slack-based primal error; the report is the reference-consistent residual
+    if (A.f_out) A.f_out[m] = fo;
+    if (A.status) A.status[m] = status;
+    if (A.iters) A.iters[m] = K.it;
+    if (A.kkt) { A.kkt[3 * m] = kp; A.kkt[3 * m + 1] = du; A.kkt[3 * m + 2] = kc; }
+  }
+}
+
+#undef KD_BEGIN
+#undef KD_BEGIN_SYNCED
+#undef KD_END
+
+}  // namespace landing

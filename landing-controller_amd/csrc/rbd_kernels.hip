@@ -624,7 +624,16 @@ __device__ void kd_stage_rows(const KdNlpParams& P, const RbdModel& M, int k, bo
   for (int j = 0; j < 12; ++j) out[r++] = jp[j];                                                                             // :189
 }
 
-struct KdNlpArgs { const RbdModel* model; KdNlpParams P; int B, N; const double* x; double* g; double* jac; const double* lam; double* hess; };
+struct KdNlpArgs {
+  const RbdModel* model; KdNlpParams P; int B, N; const double* x; double* g; double* jac; const double* lam; double* hess;
+  // member strides in doubles (0 = dense arrays [B][nx], [B][ng], [B][N][141][72], [B][N][72][72]) and an optional per-member skip flag: the
+  // interior-point solver (kd_solver_kernels.hip) evaluates straight into its per-member workspace and skips members that have finished
+  long long sx, sg, sj, sh; const int* skip;
+  __host__ __device__ size_t ox(int b) const { return (size_t)b * (sx ? (size_t)sx : (size_t)(12 * (N + 1) + 36 * N)); }
+  __host__ __device__ size_t og(int b) const { return (size_t)b * (sg ? (size_t)sg : (size_t)(48 + (N - 1) * 141 + 117)); }
+  __host__ __device__ size_t oj(int b) const { return (size_t)b * (sj ? (size_t)sj : (size_t)N * 141 * 72); }
+  __host__ __device__ size_t oh(int b) const { return (size_t)b * (sh ? (size_t)sh : (size_t)N * 72 * 72); }
+};
 // index of w[j] of interval k in x
 __device__ __forceinline__ int kd_w_index(int N, int k, int j) {
   const int oJ = 12 * (N + 1), oU = oJ + 12 * N;
@@ -640,8 +649,9 @@ __global__ void __launch_bounds__(64) landing_kinodyn_nlp_g_kernel(KdNlpArgs a) 
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= a.B * a.N) return;
   const int b = idx / a.N, k = idx % a.N, N = a.N;
-  const double* x = a.x + (size_t)b * kd_nx(N);
-  double* g = a.g + (size_t)b * kd_ng(N);
+  if (a.skip && a.skip[b]) return;
+  const double* x = a.x + a.ox(b);
+  double* g = a.g + a.og(b);
   double w[KD_NW], out[KD_ROWS];
   for (int j = 0; j < KD_NW; ++j) { const int i = kd_w_index(N, k, j); w[j] = i >= 0 ? x[i] : 0.0; }
   const bool last = k == N - 1;
@@ -659,13 +669,14 @@ __global__ void __launch_bounds__(64) landing_kinodyn_nlp_jac_kernel(KdNlpArgs a
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (long long)a.B * a.N * KD_NW) return;
   const int col = (int)(idx % KD_NW); const int k = (int)((idx / KD_NW) % a.N); const int b = (int)(idx / ((long long)KD_NW * a.N)), N = a.N;
-  const double* x = a.x + (size_t)b * kd_nx(N);
+  if (a.skip && a.skip[b]) return;
+  const double* x = a.x + a.ox(b);
   Dual w[KD_NW], out[KD_ROWS];
   for (int j = 0; j < KD_NW; ++j) { const int i = kd_w_index(N, k, j); w[j] = D_(i >= 0 ? x[i] : 0.0, j == col ? 1.0 : 0.0); }
   const bool last = k == N - 1;
   kd_stage_rows<Dual>(a.P, *a.model, k, last, w, out);
   const int nr = last ? KD_ROWS_LAST : KD_ROWS;
-  double* J = a.jac + (((size_t)b * N + k) * KD_ROWS) * KD_NW;
+  double* J = a.jac + a.oj(b) + ((size_t)k * KD_ROWS) * KD_NW;
   for (int r = 0; r < nr; ++r) J[(size_t)r * KD_NW + col] = (last && col >= 60) ? 0.0 : out[r].d;
 }
 
@@ -699,11 +710,12 @@ __global__ void __launch_bounds__(64) landing_kinodyn_nlp_hess_kernel(KdNlpArgs 
   if (idx >= (long long)a.B * a.N * KD_NPAIR) return;
   const int pr = (int)(idx % KD_NPAIR); const int k = (int)((idx / KD_NPAIR) % a.N); const int b = (int)(idx / ((long long)KD_NPAIR * a.N)), N = a.N;
   const int i = pair_i[pr], j = pair_j[pr];
-  double* Hk = a.hess + (((size_t)b * N + k) * KD_NW) * KD_NW;
+  if (a.skip && a.skip[b]) return;
+  double* Hk = a.hess + a.oh(b) + ((size_t)k * KD_NW) * KD_NW;
   const bool last = k == N - 1;
   if (last && j >= 60) return;
-  const double* x = a.x + (size_t)b * kd_nx(N);
-  const double* lam = a.lam + (size_t)b * kd_ng(N) + KD_BND + (size_t)k * KD_ROWS;
+  const double* x = a.x + a.ox(b);
+  const double* lam = a.lam + a.og(b) + KD_BND + (size_t)k * KD_ROWS;
   HDual w[KD_NW], out[KD_ROWS];
   for (int q = 0; q < KD_NW; ++q) { const int ix = kd_w_index(N, k, q); w[q] = H_(ix >= 0 ? x[ix] : 0.0, q == i ? 1.0 : 0.0, q == j ? 1.0 : 0.0, 0.0); }
   kd_stage_rows<HDual>(a.P, *a.model, k, last, w, out);

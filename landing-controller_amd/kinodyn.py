@@ -89,3 +89,40 @@ def terminal_cost(x, N, x_ref_end, QN=(0, 0, 100, 10, 10, 0, 10, 10, 10, 10, 10,
     e = np.asarray(x)[12 * N:12 * N + 12] - np.asarray(x_ref_end, float)
     g = np.zeros(dims(N)[0]); g[12 * N:12 * N + 12] = 2.0 * np.asarray(QN, float) * e
     return float(e @ (np.asarray(QN, float) * e)), g
+
+
+# ---- the solve (landing_kinodyn_solve_batch, include/landing_nlp.h) ---------------------------------------------------------------------
+QN_DEFAULT = (0, 0, 100, 10, 10, 0, 10, 10, 10, 10, 10, 10)          # :253
+Q_TERM_REF = (0, 0, 0.25, 0, 0, 0)                                   # :228
+C_REL_INIT = (0.2, 0.15, -0.3)                                       # :235  p_foot_rel of c_init
+SIDE_SIGN_C = np.array([1, -1, 1, 1, 1, 1, -1, -1, 1, -1, 1, 1], float)      # :204
+
+
+def rot_xyz(rpy):
+    """rpyToRotMat_xyz.m:2  R = rx(r)' ry(p)' rz(y)'  (body -> world)"""
+    r, p, y = rpy
+    rx = np.array([[1, 0, 0], [0, np.cos(r), np.sin(r)], [0, -np.sin(r), np.cos(r)]])
+    ry = np.array([[np.cos(p), 0, -np.sin(p)], [0, 1, 0], [np.sin(p), 0, np.cos(p)]])
+    rz = np.array([[np.cos(y), np.sin(y), 0], [-np.sin(y), np.cos(y), 0], [0, 0, 1]])
+    return rx.T @ ry.T @ rz.T
+
+
+def c_init_of(q_init):
+    """:232-236  initial foot positions under the hips of the initial pose"""
+    q = np.asarray(q_init, float)
+    R = rot_xyz(q[3:6])
+    return np.concatenate([q[:3] + R @ (SIDE_SIGN_C[3 * l:3 * l + 3] * np.asarray(C_REL_INIT)) for l in range(4)])
+
+
+def member_problem(N, q_init, qd_init, x_srbm, jpos_guess=None, **bound_kw):
+    """One member of the refinement batch as the production callers pose it (landing_optimization.m:203-322, generate_training_data_automated.m
+    :62-156): bounds, terminal cost data [QN | Xref(:, end)] and the initial guess x0 = [X*(:); jpos_guess; U*(:)] from the SRBM solution x_srbm
+    ([X(:); U(:)], nx = 36N + 12).  jpos_guess None -> the data-generation caller's constant guess (0, -pi/4, pi/2) per leg (:143)."""
+    q_init = np.asarray(q_init, float); qd_init = np.asarray(qd_init, float)
+    kb = kin_box_of(q_init[3:6], qd_init[3:6])
+    lb, ub = bounds(N, q_init, qd_init, c_init_of(q_init), kb, **bound_kw)
+    xs = np.asarray(x_srbm, float)
+    X = xs[:12 * (N + 1)].reshape(12, N + 1, order="F"); U = xs[12 * (N + 1):].reshape(24, N, order="F")
+    jp = np.tile(np.tile([0.0, -np.pi / 4, np.pi / 2], 4).reshape(12, 1), (1, N)) if jpos_guess is None else np.asarray(jpos_guess, float).reshape(12, N)
+    cost = np.concatenate([np.asarray(QN_DEFAULT, float), np.concatenate([Q_TERM_REF, np.zeros(6)])])
+    return lb, ub, cost, pack_x(X, U, jp)

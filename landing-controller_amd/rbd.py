@@ -84,6 +84,9 @@ class Rbd:
         lib.lib.landing_kinodyn_nlp_dims.argtypes = [C.c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
         lib.lib.landing_kinodyn_nlp_eval.argtypes = [vp, C.c_int, C.c_int, vp, C.POINTER(KinodynParams), vp, vp, vp]
         lib.lib.landing_kinodyn_nlp_hess.argtypes = [vp, C.c_int, C.c_int, vp, C.POINTER(KinodynParams), vp, vp, vp]
+        ip = C.POINTER(C.c_int)
+        lib.lib.landing_kinodyn_solve_batch_host.argtypes = [vp, C.c_int, C.c_int, C.POINTER(KinodynParams), dp, dp, dp, dp, vp, dp, dp, dp, ip, ip, dp]
+        lib.lib.landing_kinodyn_solve_batch.argtypes = [vp, C.c_int, C.c_int, C.POINTER(KinodynParams)] + [vp] * 4 + [vp] + [vp] * 6 + [vp]
         self.model = quad3d_model()
         lib._check(lib.lib.landing_rbd_set_model(lib.ctx, C.byref(self.model)), "landing_rbd_set_model")
 
@@ -122,6 +125,33 @@ class Rbd:
         """Hessian blocks of lam_g' g per interval [B, N, 72, 72] (include/landing_nlp.h)"""
         prm = self._kd_params(N, dt, mass, Ib, Ib_inv, mu)
         self.L._check(self.L.lib.landing_kinodyn_nlp_hess(self.L.ctx, B, N, d_x, C.byref(prm), d_lam_g, d_hess, stream or None), "landing_kinodyn_nlp_hess")
+
+    def kinodyn_default_opts(self):
+        from .capi import SolverOpts
+        o = SolverOpts()
+        self.L.lib.landing_kinodyn_solver_opts_default(C.byref(o))
+        return o
+
+    def kinodyn_solve_host(self, N, lbg, ubg, cost, x0, dt, mass, Ib, Ib_inv, mu, opts=None):
+        """landing_kinodyn_solve_batch_host: B kinodynamic refinement NLPs (host arrays [B, ng], [B, ng], [B, 24], [B, nx]) -> dict"""
+        lbg = np.ascontiguousarray(np.atleast_2d(lbg), float); ubg = np.ascontiguousarray(np.atleast_2d(ubg), float)
+        cost = np.ascontiguousarray(np.atleast_2d(cost), float); x0 = np.ascontiguousarray(np.atleast_2d(x0), float)
+        B = x0.shape[0]; nx, ng = self.kinodyn_nlp_dims(N)
+        assert x0.shape == (B, nx) and lbg.shape == (B, ng) and ubg.shape == (B, ng) and cost.shape == (B, 24)
+        prm = self._kd_params(N, dt, mass, Ib, Ib_inv, mu)
+        x = np.zeros((B, nx)); f = np.zeros(B); lam = np.zeros((B, ng)); st = np.zeros(B, np.int32); it = np.zeros(B, np.int32); kkt = np.zeros((B, 3))
+        dp = C.POINTER(C.c_double); ip = C.POINTER(C.c_int); P = lambda a: a.ctypes.data_as(dp)
+        rc = self.L.lib.landing_kinodyn_solve_batch_host(self.L.ctx, B, N, C.byref(prm), P(lbg), P(ubg), P(cost), P(x0), C.byref(opts) if opts is not None else None,
+                                                         P(x), P(f), P(lam), st.ctypes.data_as(ip), it.ctypes.data_as(ip), P(kkt))
+        self.L._check(rc, "landing_kinodyn_solve_batch_host")
+        return dict(x=x, f=f, lam_g=lam, status=st, iters=it, kkt=kkt)
+
+    def kinodyn_solve_device(self, B, N, d_lbg, d_ubg, d_cost, d_x0, dt, mass, Ib, Ib_inv, mu, opts, d_x, d_f=0, d_lam=0, d_status=0, d_iters=0, d_kkt=0, stream=0):
+        prm = self._kd_params(N, dt, mass, Ib, Ib_inv, mu)
+        n = lambda v: v or None
+        rc = self.L.lib.landing_kinodyn_solve_batch(self.L.ctx, B, N, C.byref(prm), d_lbg, d_ubg, d_cost, d_x0, C.byref(opts) if opts is not None else None,
+                                                    d_x, n(d_f), n(d_lam), n(d_status), n(d_iters), n(d_kkt), n(stream))
+        self.L._check(rc, "landing_kinodyn_solve_batch")
 
     def leg_ik(self, npts, d_q6, d_c, d_jpos, d_res=0, iters=12, jmin=None, jmax=None, stream=0):
         jmin = np.ascontiguousarray(JPOS_MIN[:3] if jmin is None else jmin, float); jmax = np.ascontiguousarray(JPOS_MAX[:3] if jmax is None else jmax, float)

@@ -173,3 +173,152 @@ def kkt(x, lam_g, N, dt, mass, Ib, Ib_inv, mu, lbg, ubg, grad_f):
     with np.errstate(invalid="ignore"):
         co = np.where(eq | (lam_g == 0.0), 0.0, np.abs(lam_g) * dist)
     return pr, du, float(np.nanmax(co))
+
+
+# ---- the same rows for MANY stages at once (numpy over a leading batch axis) -------------------------------------------------------------
+# Used to certify whole batches of solver results: the row functions above, restated with arrays [n, ...] in place of scalars, on any
+# numpy dtype.  On complex arguments they give the Jacobian by the complex-step method (every row is an analytic function of w: products,
+# sin, cos, tan): d row / d w_j = Im row(w + i h e_j) / h with h = 1e-30 is exact to rounding -- no difference quotient, no step-size error,
+# and a different derivative mechanism than the kernels' dual numbers.  tests/test_kd_solver_cpu.py pins the batch form to the scalar one.
+_CH = 1e-30
+
+
+def _rot_b(axis, t):
+    c, s = np.cos(t), np.sin(t)
+    o, z = np.ones_like(c), np.zeros_like(c)
+    if axis == 0: rows = [[o, z, z], [z, c, s], [z, -s, c]]
+    elif axis == 1: rows = [[c, z, -s], [z, o, z], [s, z, c]]
+    else: rows = [[c, s, z], [-s, c, z], [z, z, o]]
+    return np.stack([np.stack(r, axis=-1) for r in rows], axis=-2)
+
+
+def _skew_b(r):
+    z = np.zeros_like(r[..., 0])
+    return np.stack([np.stack([z, -r[..., 2], r[..., 1]], -1), np.stack([r[..., 2], z, -r[..., 0]], -1), np.stack([-r[..., 1], r[..., 0], z], -1)], -2)
+
+
+def _jcalc_b(jtype, q):
+    """jcalc.m:22-40 on an array of joint positions: XJ [n, 6, 6]"""
+    n = q.shape[0]
+    X = np.zeros((n, 6, 6), q.dtype)
+    if jtype[0] == "R":
+        E = _rot_b("xyz".index(jtype[1]), q)
+        X[:, :3, :3] = E; X[:, 3:, 3:] = E
+    else:
+        r = np.zeros((n, 3), q.dtype); r[:, "xyz".index(jtype[1])] = q
+        X[:, :3, :3] = np.eye(3); X[:, 3:, 3:] = np.eye(3); X[:, 3:, :3] = -_skew_b(r)
+    return X
+
+
+def fk_batch(q18):
+    """get_forward_kin_foot.m on rows of [q6, jpos] ([n, 18]): foot positions [n, 12] (6 x 6 Pluecker chain, as rbd_oracle.forward_kin_foot)"""
+    M = ro.quad3d_model()
+    X0 = [None] * ro.NB
+    for i in range(ro.NB):
+        Xup = _jcalc_b(M["jtype"][i], q18[:, i]) @ M["Xtree"][i]
+        pa = M["parent"][i]
+        X0[i] = Xup if pa == 0 else Xup @ X0[pa - 1]
+    out = []
+    for leg in range(4):
+        X = M["Xfoot"][leg] @ X0[M["b_foot"][leg] - 1]
+        E = X[:, :3, :3]
+        S = -(np.swapaxes(E, 1, 2) @ X[:, 3:, :3])
+        out.append(np.stack([S[:, 2, 1], S[:, 0, 2], S[:, 1, 0]], -1))
+    return np.concatenate(out, -1)
+
+
+def stage_rows_batch(W, dt, last, mass, Ib, Ib_inv, mu):
+    """stage_rows for n stages at once: W [n, 72], dt [n] -> [n, 141] (117 when `last`)"""
+    W = np.asarray(W); n = W.shape[0]; dt = np.asarray(dt, float).reshape(n, 1)
+    X, c, f, jp, Xn, cn = W[:, :12], W[:, 12:24], W[:, 24:36], W[:, 36:48], W[:, 48:60], W[:, 60:72]
+    pos, rpy, om, v = X[:, 0:3], X[:, 3:6], X[:, 6:9], X[:, 9:12]
+    R = np.swapaxes(_rot_b(0, rpy[:, 0]), 1, 2) @ np.swapaxes(_rot_b(1, rpy[:, 1]), 1, 2) @ np.swapaxes(_rot_b(2, rpy[:, 2]), 1, 2)     # rpyToRotMat_xyz.m:2
+    cf, ff = c.reshape(n, 4, 3), f.reshape(n, 4, 3)
+    rdd = ff.sum(axis=1) / mass + np.array([0.0, 0.0, -9.81])
+    tau = np.cross(cf - pos[:, None, :], ff).sum(axis=1)
+    omd = np.asarray(Ib_inv) * ((np.swapaxes(R, 1, 2) @ tau[:, :, None])[:, :, 0] - np.cross(om, np.asarray(Ib) * om))
+    th, ps = rpy[:, 1], rpy[:, 2]
+    z, o = np.zeros_like(th), np.ones_like(th)
+    Bi = np.stack([np.stack([np.cos(ps) / np.cos(th), np.sin(ps) / np.cos(th), z], -1), np.stack([-np.sin(ps), np.cos(ps), z], -1),
+                   np.stack([np.cos(ps) * np.tan(th), np.sin(ps) * np.tan(th), o], -1)], -2)                                 # Binv.m:13-17
+    ed = (Bi @ (R @ om[:, :, None]))[:, :, 0]
+    out = [Xn[:, 9:12] - v - rdd * dt, Xn[:, 6:9] - om - omd * dt, Xn[:, 0:3] - pos - v * dt, Xn[:, 3:6] - rpy - ed * dt, ff[:, :, 2]]
+    fk = fk_batch(np.concatenate([X[:, :6], jp], axis=1))
+    fk_err = c - fk
+    Rw2b = np.swapaxes(R, 1, 2)
+    l1, l2, l3, l4 = 0.062, 0.209, 0.195, 0.004                                                                              # get_foot_jacobians_mc.m:5-8
+    for l in range(4):
+        out.append(np.stack([cf[:, l, 2], ff[:, l, 2] * cf[:, l, 2]], -1))
+        if not last:
+            d = ff[:, l, 2:3] * (cn[:, 3 * l:3 * l + 3] - cf[:, l])
+            out += [d, d]
+        pr = cf[:, l] - (pos + (R @ HIP[l])[:, :])
+        out += [pr, (pr * pr).sum(axis=1, keepdims=True)]
+        q1, q2, q3 = jp[:, 3 * l], jp[:, 3 * l + 1], jp[:, 3 * l + 2]
+        s1, s2, s3, c1, c2, c3 = np.sin(q1), np.sin(q2), np.sin(q3), np.cos(q1), np.cos(q2), np.cos(q3)
+        c23 = c2 * c3 - s2 * s3; s23 = s2 * c3 + c2 * s3
+        ss = (-1.0, 1.0, -1.0, 1.0)[l]
+        zz = np.zeros_like(q1)
+        J = np.stack([np.stack([zz, l3 * c23 + l2 * c2, l3 * c23], -1),
+                      np.stack([l3 * c1 * c23 + l2 * c1 * c2 - (l1 + l4) * s1 * ss, -l3 * s1 * s23 - l2 * s1 * s2, -l3 * s1 * s23], -1),
+                      np.stack([l3 * s1 * c23 + l2 * c2 * s1 + (l1 + l4) * ss * c1, l3 * c1 * s23 + l2 * c1 * s2, l3 * c1 * s23], -1)], -2)
+        fb = -(Rw2b @ ff[:, l, :, None])
+        out.append((np.swapaxes(J, 1, 2) @ fb)[:, :, 0])
+    km = 0.71 * mu
+    out += [ff[:, :, 0] - km * ff[:, :, 2], ff[:, :, 0] + km * ff[:, :, 2], ff[:, :, 1] - km * ff[:, :, 2], ff[:, :, 1] + km * ff[:, :, 2], pos[:, 2:3], fk_err, fk_err, jp, jp]
+    return np.concatenate(out, axis=1)
+
+
+def _w_map(N):
+    """x index of w[j] of interval k ([N, 72]; -1 where the variable does not exist)"""
+    return np.array([[w_index(N, k, j) for j in range(72)] for k in range(N)])
+
+
+def nlp_g_batch(Xs, N, dt, mass, Ib, Ib_inv, mu):
+    """nlp_g for B members at once: Xs [B, nx] -> [B, ng]"""
+    Xs = np.asarray(Xs); B = Xs.shape[0]
+    wm = _w_map(N)
+    oU = 12 * (N + 1) + 12 * N
+    g = [Xs[:, 0:12], Xs[:, oU:oU + 12], Xs[:, 12 * N:12 * N + 6], Xs[:, 12 * N:12 * N + 6], Xs[:, 12 * N + 6:12 * N + 12], Xs[:, 12 * N + 6:12 * N + 12]]
+    for k in range(N):
+        W = np.where(wm[k] >= 0, Xs[:, np.maximum(wm[k], 0)], 0.0)
+        g.append(stage_rows_batch(W, np.full(B, dt[k]), k == N - 1, mass, Ib, Ib_inv, mu))
+    return np.concatenate(g, axis=1)
+
+
+def grad_lagrangian_batch(Xs, Lam, N, dt, mass, Ib, Ib_inv, mu, grad_f):
+    """grad f + J' lam for B members ([B, nx]), J by the complex-step method, interval by interval"""
+    Xs = np.asarray(Xs, float); Lam = np.asarray(Lam, float); B = Xs.shape[0]
+    nx, ng = nlp_dims(N)
+    wm = _w_map(N)
+    oU = 12 * (N + 1) + 12 * N
+    out = np.array(grad_f, float).reshape(B, nx).copy()
+    out[:, 0:12] += Lam[:, 0:12]; out[:, oU:oU + 12] += Lam[:, 12:24]
+    out[:, 12 * N:12 * N + 6] += Lam[:, 24:30] + Lam[:, 30:36]; out[:, 12 * N + 6:12 * N + 12] += Lam[:, 36:42] + Lam[:, 42:48]
+    for k in range(N):
+        last = k == N - 1
+        nr = 117 if last else 141
+        W = np.where(wm[k] >= 0, Xs[:, np.maximum(wm[k], 0)], 0.0)                      # [B, 72]
+        Wc = np.repeat(W[:, None, :], 72, axis=1).astype(complex)                      # [B, 72 directions, 72]
+        Wc[:, np.arange(72), np.arange(72)] += 1j * _CH
+        rows = stage_rows_batch(Wc.reshape(B * 72, 72), np.full(B * 72, dt[k]), last, mass, Ib, Ib_inv, mu)
+        Jk = (rows.imag / _CH).reshape(B, 72, nr)                                       # Jk[b, j, r] = d row_r / d w_j
+        lam_k = Lam[:, 48 + 141 * k:48 + 141 * k + nr]
+        contrib = np.einsum("bjr,br->bj", Jk, lam_k)
+        for j in range(72):
+            if wm[k, j] >= 0:
+                out[:, wm[k, j]] += contrib[:, j]
+    return out
+
+
+def kkt_batch(Xs, Lam, N, dt, mass, Ib, Ib_inv, mu, lbg, ubg, grad_f):
+    """kkt() for B members: [B, 3] = (pr_inf, du_inf, compl) in the convention of the SRBM oracle (lo_kkt)"""
+    Xs = np.asarray(Xs, float); Lam = np.asarray(Lam, float); lbg = np.asarray(lbg, float); ubg = np.asarray(ubg, float)
+    g = nlp_g_batch(Xs, N, dt, mass, Ib, Ib_inv, mu)
+    pr = np.maximum(np.maximum(lbg - g, g - ubg), 0.0).max(axis=1)
+    du = np.abs(grad_lagrangian_batch(Xs, Lam, N, dt, mass, Ib, Ib_inv, mu, grad_f)).max(axis=1)
+    eq = lbg == ubg
+    dist = np.where(Lam > 0, np.where(np.isfinite(ubg), np.maximum(ubg - g, 0.0), np.inf), np.where(np.isfinite(lbg), np.maximum(g - lbg, 0.0), np.inf))
+    with np.errstate(invalid="ignore"):
+        co = np.where(eq | (Lam == 0.0), 0.0, np.abs(Lam) * dist)
+    return np.stack([pr, du, np.nanmax(co, axis=1)], axis=1)

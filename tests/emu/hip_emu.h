@@ -21,6 +21,7 @@
 #define __host__
 #define __forceinline__ inline
 #define __shared__ static
+#define __constant__
 #define __launch_bounds__(...)
 #define __noinline__
 #define __restrict__
@@ -134,6 +135,7 @@ inline hip_emu_f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, hip_
   }
   return c;
 }
+inline int atomicAdd(int* p, int v) { const int o = *p; *p += v; return o; }      // (one block at a time, fibers never preempt)
 inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
 inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
 inline double __builtin_amdgcn_rcp(double x) { return 1.0 / x; }

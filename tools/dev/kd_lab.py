@@ -1,0 +1,73 @@
+"""dev: kinodynamic refinement solve through the host emulation (or the GPU library with --gpu): SRBM solve (CPU port) -> refinement"""
+import argparse, importlib, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+ap = argparse.ArgumentParser()
+ap.add_argument("--B", type=int, default=1); ap.add_argument("--seed", type=int, default=7); ap.add_argument("--law", default="main")
+ap.add_argument("--gpu", action="store_true"); ap.add_argument("--max-iter", type=int, default=200); ap.add_argument("--ik", action="store_true")
+ap.add_argument("--opt", action="append", default=[]); ap.add_argument("--pick", default=""); ap.add_argument("--configs", default=""); ap.add_argument("--certify", action="store_true")
+a = ap.parse_args()
+P_ = importlib.import_module("landing-controller_amd.problem"); capi = importlib.import_module("landing-controller_amd.capi")
+rbd = importlib.import_module("landing-controller_amd.rbd"); kd = importlib.import_module("landing-controller_amd.kinodyn")
+K = importlib.import_module("landing-controller_amd.constants")
+from oracle import oracle as orc
+N = 20
+consts = P_.production_constants(a.law)
+P, X0, q, qd = P_.make_batch(a.B, N, 0.6, seed=a.seed, consts=consts, dt_grid="reference", law=a.law)
+if a.pick:
+    idx = [int(v) for v in a.pick.split(",")]
+    P, X0, q, qd = P[idx], X0[idx], q[idx], qd[idx]; a.B = len(idx)
+O = orc.Oracle(N)
+t = time.time(); r = orc.cpu_solve_batch(O, P, X0, threads=8, max_iter=600); print("SRBM (CPU port): status", r["status"], "iters", r["iters"], "%.1fs" % (time.time() - t))
+lib_path = None if a.gpu else os.environ.get("KD_EMU", os.path.join(ROOT, "tests", "emu", "liblanding_emu.so"))
+L = capi.LandingLib(N, lib_path=lib_path) if lib_path else capi.LandingLib(N, device=0)
+R = rbd.Rbd(L)
+mass, Ib, Ibi = K.robot_constants()
+from oracle import kinodyn_oracle as ko
+ap2 = None
+def jpos_ik():
+    """joint angles by inverse kinematics on the SRBM solution's foot positions (landing_leg_ik_batch), [B, 12, N]"""
+    import torch
+    n = a.B * N
+    q6 = np.zeros((n, 6)); cc = np.zeros((n, 12))
+    for b in range(a.B):
+        X = r["x"][b][:12 * (N + 1)].reshape(12, N + 1, order="F"); U = r["x"][b][12 * (N + 1):].reshape(24, N, order="F")
+        q6[b * N:(b + 1) * N] = X[:6, :N].T; cc[b * N:(b + 1) * N] = U[:12].T
+        cc[b * N] = kd.c_init_of(q[b])
+    if a.gpu:
+        tq, tc = torch.tensor(q6, device="cuda"), torch.tensor(cc, device="cuda"); tj = torch.zeros(n, 12, device="cuda", dtype=torch.float64); tr = torch.zeros(n, 4, device="cuda", dtype=torch.float64)
+        R.leg_ik(n, tq.data_ptr(), tc.data_ptr(), tj.data_ptr(), tr.data_ptr(), iters=30); torch.cuda.synchronize()
+        jp, res = tj.cpu().numpy(), tr.cpu().numpy()
+    else:
+        jp = np.zeros((n, 12)); res = np.zeros((n, 4))
+        R.leg_ik(n, q6.ctypes.data, cc.ctypes.data, jp.ctypes.data, res.ctypes.data, iters=30)
+    print("IK residual max %.2e, 99%% %.2e" % (res.max(), np.percentile(res, 99)))
+    return jp.reshape(a.B, N, 12).transpose(0, 2, 1)
+JP = jpos_ik() if a.ik else None
+lbs, ubs, costs, x0s = [], [], [], []
+for b in range(a.B):
+    lb, ub, cost, x0 = kd.member_problem(N, q[b], qd[b], r["x"][b], None if JP is None else JP[b])
+    lbs.append(lb); ubs.append(ub); costs.append(cost); x0s.append(x0)
+lbs, ubs, costs, x0s = np.array(lbs), np.array(ubs), np.array(costs), np.array(x0s)
+for cfg in (a.configs.split(";") if a.configs else [""]):
+    o = R.kinodyn_default_opts(); o.max_iter = a.max_iter
+    for kv in [c for c in cfg.split(",") if c] + a.opt:
+        k_, v_ = kv.split("="); setattr(o, k_, type(getattr(o, k_))(float(v_)))
+    t = time.time()
+    s = R.kinodyn_solve_host(N, lbs, ubs, costs, x0s, P_.REFERENCE_DT_GRID, mass, Ib, Ibi, consts.mu, o)
+    ts = time.time() - t
+    ok = s["status"] == 0
+    line = "[%s] converged %d / %d  status counts %s  iters mean %.1f p99 %d max %d (converged: mean %.1f max %d)  %.1fs" % (
+        cfg, ok.sum(), a.B, np.bincount(s["status"], minlength=4).tolist(), s["iters"].mean(), np.percentile(s["iters"], 99), s["iters"].max(),
+        s["iters"][ok].mean() if ok.any() else 0, s["iters"][ok].max() if ok.any() else 0, ts)
+    if a.certify:
+        gf = np.zeros_like(s["x"])
+        for b in range(a.B):
+            gf[b] = kd.terminal_cost(s["x"][b], N, costs[b][12:], costs[b][:12])[1]
+        kk = ko.kkt_batch(s["x"][ok], s["lam_g"][ok], N, P_.REFERENCE_DT_GRID, mass, Ib, Ibi, consts.mu, lbs[ok], ubs[ok], gf[ok]) if ok.any() else np.zeros((0, 3))
+        line += "  oracle-certified %d (worst %.2e)" % ((kk.max(axis=1) <= 1.0001e-6).sum(), kk.max() if len(kk) else 0)
+    print(line, flush=True)
+    if not ok.all():
+        bad = np.nonzero(~ok & (s["status"] != 3))[0]
+        print("   undecided:", bad[:24].tolist(), s["status"][bad][:24].tolist(), s["iters"][bad][:24].tolist(), "f of converged: max %.2e" % (s["f"][ok].max() if ok.any() else 0))
