@@ -476,6 +476,17 @@ int landing_kinodyn_solve_batch_host(landing_ctx* ctx, int B, int N, const landi
                                      const double* cost, const double* x0, const landing_solver_opts* opts,
                                      double* x, double* f, double* lam_g, int* status, int* iters, double* kkt);
 
+int landing_solve_kinodyn_24(landing_ctx* ctx, int N, int B, const landing_kinodyn_form* form /* NULL = the script's literals */,
+                             const double* Xref, const double* Uref, const double* dt, const double* q_min, const double* q_max, const double* qd_min,
+                             const double* qd_max, const double* q_init, const double* qd_init, const double* c_init, const double* q_term_min,
+                             const double* q_term_max, const double* qd_term_min, const double* qd_term_max, const double* QN, const double* x0,
+                             const double* jpos_min, const double* jpos_max, const double* kin_box, const double* mu, const double* l_leg_max,
+                             const double* mass, const double* Ib, const double* Ib_inv, const landing_solver_opts* opts,
+                             double* x_star, double* f_star, double* lam_g, int* status, int* iters, double* kkt);
+/* CCS patterns of this NLP in CasADi's compressed form, which = 0: jac_g_x (ng x nx), 1: upper triangle of hess_gamma_x_x; colind [nx + 1],
+ * row [*nnz] (pass row = NULL to get the count first).  Derived from the derivative kernels themselves (device needed). */
+int landing_kinodyn_pattern(landing_ctx* ctx, int N, int which, long long* colind, long long* row, long long* nnz);
+
 /* ---- SQP (Gauss-Newton / iLQR) loop on the 18-DoF model (BASELINE configs[3]) --------------------------------
  * Trajectory-tracking problem per member: state x = [q; qd] (36), control u = the 12 joint torques (base unactuated), known foot
  * forces f_k, explicit Euler  q+ = q + dt qd, qd+ = qd + dt qdd(q, qd, [0; u], f)  (the discretisation of the SRBM NLP,

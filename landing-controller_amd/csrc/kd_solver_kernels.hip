@@ -45,7 +45,8 @@ struct KdState {
   double tau, a_pr, a_du, th0, ph0, dphi, alpha, s_corr, delta, ft, fval, omt;
   double filt_th[KD_FILT], filt_ph[KD_FILT];
   int nfilt, it, status, done, need_reg_streak, first_failed, cutstreak, force_step, wd_count, last_mu_it;
-  int accepted, armijo_step, fact_ok, skipped_zero, attempt, flag, ls_done, need_corr, fallback, nfact, ntrial, pad_;
+  int accepted, armijo_step, fact_ok, skipped_zero, attempt, flag, ls_done, need_corr, fallback, nfact, ntrial, nreset;
+  int last_reset_it, ncrawl, clip_k_cur, fresh;
 };
 
 struct KdMem {
@@ -440,7 +441,7 @@ __global__ void __launch_bounds__(KD_THREADS) landing_kd_init_kernel(KdSolveArgs
     K.e_pr = K.e_du = K.e_co = 0.0; K.tau = 0.0; K.a_pr = K.a_du = 0.0; K.th0 = K.ph0 = K.dphi = K.alpha = K.s_corr = K.delta = K.ft = K.fval = 0.0; K.omt = -1.0;
     K.nfilt = 0; K.it = 0; K.status = LANDING_MAX_ITER; K.done = 0; K.need_reg_streak = 0; K.first_failed = 0; K.cutstreak = 0; K.force_step = 0;
     K.wd_count = 0; K.last_mu_it = 0; K.accepted = 0; K.armijo_step = 0; K.fact_ok = 0; K.skipped_zero = 0; K.attempt = 0; K.flag = 0; K.ls_done = 0;
-    K.need_corr = 0; K.fallback = 0; K.nfact = 0; K.ntrial = 0; K.pad_ = 0;
+    K.need_corr = 0; K.fallback = 0; K.nfact = 0; K.ntrial = 0; K.nreset = 0; K.last_reset_it = 0; K.ncrawl = 0; K.clip_k_cur = A.o.clip_k; K.fresh = 0;
   }
   __syncthreads();
   kd_point_pass(M, ng, lbm, ubm, K.mu);
@@ -493,10 +494,48 @@ __global__ void __launch_bounds__(KD_THREADS) landing_kd_iter_kernel(KdSolveArgs
       if (!(du < 1e300) || !(pr < 1e300) || !(co < 1e300)) { K.status = LANDING_NUMERICAL; K.flag = 1; }
       else if (fmax(du, fmax(pr, co)) <= o.tol) { K.status = LANDING_CONVERGED; K.flag = 1; }
       else if (K.it >= o.max_iter) { K.status = LANDING_MAX_ITER; K.flag = 1; }
+      else if (du > o.reset_du && K.nreset >= o.max_resets && o.max_resets > 0) { K.status = LANDING_NUMERICAL; K.flag = 1; }      // jammed again: give up
+      else {
+        // restart rules of the SRBM solver (solver_kernels.hip, landing_nlp.h fresh_restart): a jammed iterate (multipliers blown up), a first
+        // barrier problem that crawls, a later one that has wandered off -> slacks, multipliers, barrier parameter and filter are re-initialised,
+        // at the current x or (after a jam) at the caller's initial guess with the step rule clip_k = 2
+        const int it = K.it, nreset = K.nreset; const double mu = K.mu;
+        const bool jam = du > o.reset_du && nreset < o.max_resets;
+        const bool stalled = o.restart_period > 0 && it - K.last_reset_it >= o.restart_period && mu >= o.mu_init && nreset < o.max_resets && K.ncrawl < ((o.fresh_restart & 4) ? 2 : 1);
+        const bool overreg = o.reset_delta > 0.0 && K.delta_last > o.reset_delta && nreset < o.max_resets;
+        const bool lost = (o.fresh_restart & 8) && o.restart_period > 0 && mu < o.mu_init && pr > 1e-3 && nreset < o.max_resets &&
+                          ((it - K.last_mu_it >= 2 * o.restart_period && it - K.last_reset_it >= o.restart_period) || K.wd_count >= 3);
+        if (jam || stalled || overreg || lost) {
+          K.flag = 2;
+          K.last_reset_it = it;
+          if (stalled) K.ncrawl++;
+          K.nreset = nreset + 1;
+          K.fresh = (((o.fresh_restart & 2) && nreset + 1 == 2) || ((o.fresh_restart & 1) && nreset + 1 == 1 && !stalled && !lost)) ? 1 : 0;
+          if (K.fresh) { if (K.clip_k_cur > 1) K.clip_k_cur = 2; K.th_max = 0.0; }
+          K.mu = o.mu_init; K.nfilt = 0; K.delta_last = 0.0; K.need_reg_streak = 0; K.wd_count = 0; K.cutstreak = 0; K.force_step = 0;
+          K.it = it + 1;
+        }
+      }
     KD_END();
   }
-  if (K.flag) {
+  if (K.flag == 1) {
     if (tid == 0) { K.done = 1; *M.st = K; A.done[m] = 1; }
+    return;
+  }
+  if (K.flag == 2) {      // restart: the next round of launches evaluates the derivatives at the re-initialised point
+    if (K.fresh) {
+      for (int i = tid; i < nx; i += NT) {
+        double v = A.x0[(size_t)m * nx + i];
+        if (i < 12) v = lbm[i]; else if (i >= oU && i < oU + 12) v = lbm[12 + (i - oU)];
+        M.x[i] = v;
+      }
+      __syncthreads();
+      kd_member_eval_g(A.P, *A.model, N, M.x, M.g);
+      __syncthreads();
+    }
+    kd_init_slacks(M, ng, lbm, ubm, o);
+    kd_point_pass(M, ng, lbm, ubm, K.mu);
+    if (tid == 0) { *M.st = K; atomicAdd(A.n_active, 1); }
     return;
   }
   // ---------------------------------------------------------------- barrier parameter (monotone)
@@ -555,7 +594,7 @@ __global__ void __launch_bounds__(KD_THREADS) landing_kd_iter_kernel(KdSolveArgs
     // clip_k rule (landing_nlp.h): while the point is far from feasible the step length comes from the clip_k-th largest ratio |ds| / distance;
     // the slacks with a larger one stop at (1 - tau) of their distance (omt > 0 in the passes below).  Without it ONE slack after the other
     // cuts the step by 1 - tau per iteration from the callers' guess (measured on the first GPU batch: a_pr 2e-1, 3e-2, 3e-3 ... 3e-15)
-    const bool clip_now = o.clip_k > 1 && K.c_pr > o.clip_until;
+    const bool clip_now = K.clip_k_cur > 1 && K.c_pr > o.clip_until;
     double top[4] = {0.0, 0.0, 0.0, 0.0};
     double m_pr = 0.0, m_du = 0.0, th0 = 0.0, bar = 0.0, dphi = 0.0, f0 = 0.0;
     for (int r = tid + 24; r < ng; r += NT) {
@@ -585,7 +624,7 @@ __global__ void __launch_bounds__(KD_THREADS) landing_kd_iter_kernel(KdSolveArgs
     KD_BEGIN_SYNCED()
       const double tau = K.tau;
       K.a_pr = (v[0] > tau) ? tau / v[0] : 1.0;
-      if (clip_now) { const double rk = top[(o.clip_k > 4 ? 4 : o.clip_k) - 1]; K.a_pr = (rk > tau) ? tau / rk : 1.0; }
+      if (clip_now) { const double rk = top[(K.clip_k_cur > 4 ? 4 : K.clip_k_cur) - 1]; K.a_pr = (rk > tau) ? tau / rk : 1.0; }
       K.omt = clip_now ? 1.0 - tau : -1.0;
       K.a_du = (v[1] > tau) ? tau / v[1] : 1.0;
       K.th0 = v[2]; K.dphi = v[4]; K.ph0 = v[5] + mu * v[3]; K.fval = v[5];

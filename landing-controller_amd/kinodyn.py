@@ -1,12 +1,13 @@
 """Host side of the kinodynamic refinement NLP (optimizations/landing/main_scripts/landing_optimization.m): the variable
 layout, the bounds lbg / ubg in the row order of landing_kinodyn_nlp_eval (include/landing_nlp.h) with the script's values, its parameter
 code (velocity-dependent kinematic box, :251 with test_scripts/kin_box_limits.m) and the terminal cost (:83-86).  g, Jacobian and Hessian
-blocks come from the GPU (rbd.Rbd.kinodyn_nlp_eval / kinodyn_nlp_hess); the solve of this NLP is not built yet."""
+blocks come from the GPU (rbd.Rbd.kinodyn_nlp_eval / kinodyn_nlp_hess), the solve from rbd.Rbd.kinodyn_solve_host / kinodyn_solve_24
+(landing_kinodyn_solve_batch, csrc/kd_solver_kernels.hip)."""
 import numpy as np
 
 INF = np.inf
 SIDE_SIGN = (-1.0, 1.0, -1.0, 1.0)                                  # :156
-TAU_MAX = np.array([18.0, 18.0, 28.0])                              # model.tauMax = gr .* motorTauMax (get_robot_model.m:237-241)
+TAU_MAX = np.array([18.0, 18.0, 3.0 * 9.33])                        # model.tauMax = gr .* motorTauMax = [6 6 9.33] * 3 (get_robot_model.m:237-241)
 JPOS_MIN = np.tile([-np.pi / 3, -np.pi / 2, 0.0], 4)                # :246
 JPOS_MAX = np.tile([np.pi / 3, np.pi / 2, 3 * np.pi / 4], 4)        # :247
 
@@ -126,3 +127,24 @@ def member_problem(N, q_init, qd_init, x_srbm, jpos_guess=None, **bound_kw):
     jp = np.tile(np.tile([0.0, -np.pi / 4, np.pi / 2], 4).reshape(12, 1), (1, N)) if jpos_guess is None else np.asarray(jpos_guess, float).reshape(12, N)
     cost = np.concatenate([np.asarray(QN_DEFAULT, float), np.concatenate([Q_TERM_REF, np.zeros(6)])])
     return lb, ub, cost, pack_x(X, U, jp)
+
+
+def make_args24(N, q_init, qd_init, x_srbm, dt, mass, Ib, Ib_inv, mu=0.75, l_leg_max=0.4, jpos_guess=None):
+    """The 24 arguments of the reference's kinodynamic solver function for B drop states (generate_training_data_automated.m:62-156), MATLAB-shaped
+    with a trailing batch axis; q_init, qd_init [B, 6], x_srbm [B, 36N+12] the SRBM solutions used as the initial guess."""
+    q_init = np.atleast_2d(np.asarray(q_init, float)); qd_init = np.atleast_2d(np.asarray(qd_init, float)); xs = np.atleast_2d(np.asarray(x_srbm, float))
+    B = q_init.shape[0]
+    rep = lambda v: np.repeat(np.asarray(v, float).reshape(-1, 1), B, axis=1)
+    Xref = np.zeros((12, N + 1, B)); x0 = np.zeros((48 * N + 12, B)); c_init = np.zeros((12, B)); kb = np.zeros((2, B))
+    for b in range(B):
+        for i in range(6):
+            Xref[i, :, b] = np.linspace(q_init[b, i], Q_TERM_REF[i], N + 1); Xref[6 + i, :, b] = np.linspace(qd_init[b, i], 0.0, N + 1)
+        c_init[:, b] = c_init_of(q_init[b]); kb[:, b] = kin_box_of(q_init[b, 3:6], qd_init[b, 3:6])
+        jp = None if jpos_guess is None else jpos_guess[b]
+        x0[:, b] = member_problem(N, q_init[b], qd_init[b], xs[b], jp)[3]
+    return dict(Xref=Xref, Uref=None, dt=np.repeat(np.asarray(dt, float).reshape(1, N, 1), B, axis=2), q_min=rep([-10, -10, 0.075, -10, -10, -10]),
+                q_max=rep([10, 10, 1.0, 10, 10, 10]), qd_min=rep([-10, -10, -10, -40, -40, -40]), qd_max=rep([10, 10, 10, 40, 40, 40]),
+                q_init=q_init.T.copy(), qd_init=qd_init.T.copy(), c_init=c_init, q_term_min=rep([-10, -10, 0.15, -0.1, -0.1, -10]),
+                q_term_max=rep([10, 10, 5, 0.1, 0.1, 10]), qd_term_min=rep([-10, -10, -10, -.5, -.5, -.5]), qd_term_max=rep([10, 10, 10, .5, .5, .5]),
+                QN=rep(QN_DEFAULT), x0=x0, jpos_min=rep(JPOS_MIN), jpos_max=rep(JPOS_MAX), kin_box=kb, mu=rep([mu]), l_leg_max=rep([l_leg_max]),
+                mass=rep([mass]), Ib=rep(Ib), Ib_inv=rep(Ib_inv))

@@ -153,6 +153,55 @@ class Rbd:
                                                     d_x, n(d_f), n(d_lam), n(d_status), n(d_iters), n(d_kkt), n(stream))
         self.L._check(rc, "landing_kinodyn_solve_batch")
 
+    ARGS24 = ("Xref", "Uref", "dt", "q_min", "q_max", "qd_min", "qd_max", "q_init", "qd_init", "c_init", "q_term_min", "q_term_max", "qd_term_min",
+              "qd_term_max", "QN", "x0", "jpos_min", "jpos_max", "kin_box", "mu", "l_leg_max", "mass", "Ib", "Ib_inv")
+
+    def kinodyn_solve_24(self, N, args, opts=None, form=None):
+        """landing_solve_kinodyn_24: the reference's 24-argument solver function (generate_landingCtrller_KNITRO.m:373-377), `args` = dict name ->
+        MATLAB-shaped array (column-major, batch = last axis; Uref may be None)"""
+        dp = C.POINTER(C.c_double); ip = C.POINTER(C.c_int)
+        keep = []
+        def conv(name):
+            v = args.get(name)
+            if v is None:
+                return None
+            a = np.asfortranarray(np.asarray(v, float)); keep.append(a)
+            return a.ctypes.data_as(dp)
+        ptrs = [conv(n) for n in self.ARGS24]
+        B = int(np.asarray(args["x0"]).reshape(48 * N + 12, -1, order="F").shape[1])
+        nx, ng = self.kinodyn_nlp_dims(N)
+        x = np.zeros((B, nx)); f = np.zeros(B); lam = np.zeros((B, ng)); st = np.zeros(B, np.int32); it = np.zeros(B, np.int32); kkt = np.zeros((B, 3))
+        P = lambda a: a.ctypes.data_as(dp)
+        fn = self.L.lib.landing_solve_kinodyn_24
+        fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p] + [dp] * 24 + [C.c_void_p, dp, dp, dp, ip, ip, dp]
+        rc = fn(self.L.ctx, N, B, C.byref(form) if form is not None else None, *ptrs, C.byref(opts) if opts is not None else None,
+                P(x), P(f), P(lam), st.ctypes.data_as(ip), it.ctypes.data_as(ip), P(kkt))
+        self.L._check(rc, "landing_solve_kinodyn_24")
+        return dict(x=x, f=f, lam_g=lam, status=st, iters=it, kkt=kkt)
+
+    def kinodyn_bounds(self, N, B, q_init, qd_init, c_init, q_min, q_term_min, q_term_max, qd_term_min, qd_term_max, jpos_min, jpos_max, kin_box, l_leg_max):
+        """landing_kinodyn_bounds (pure host code): arrays [B, n] -> lbg, ubg [B, ng]"""
+        dp = C.POINTER(C.c_double)
+        a = [np.ascontiguousarray(v, float) for v in (q_init, qd_init, c_init, q_min, q_term_min, q_term_max, qd_term_min, qd_term_max, jpos_min, jpos_max, kin_box, l_leg_max)]
+        ng = 48 + 141 * (N - 1) + 117
+        lb = np.zeros((B, ng)); ub = np.zeros((B, ng))
+        fn = self.L.lib.landing_kinodyn_bounds
+        fn.argtypes = [C.c_int, C.c_int, C.c_void_p] + [dp] * 14
+        self.L._check(fn(N, B, None, *[v.ctypes.data_as(dp) for v in a], lb.ctypes.data_as(dp), ub.ctypes.data_as(dp)), "landing_kinodyn_bounds")
+        return lb, ub
+
+    def kinodyn_pattern(self, N, which):
+        """landing_kinodyn_pattern: CCS (colind, row) of jac_g_x (which = 0) or triu(hess_gamma_x_x) (which = 1)"""
+        nx = 48 * N + 12
+        colind = np.zeros(nx + 1, np.int64); nnz = C.c_longlong()
+        lp = C.POINTER(C.c_longlong)
+        fn = self.L.lib.landing_kinodyn_pattern
+        fn.argtypes = [C.c_void_p, C.c_int, C.c_int, lp, lp, lp]
+        self.L._check(fn(self.L.ctx, N, which, colind.ctypes.data_as(lp), None, C.byref(nnz)), "landing_kinodyn_pattern")
+        row = np.zeros(nnz.value, np.int64)
+        self.L._check(fn(self.L.ctx, N, which, colind.ctypes.data_as(lp), row.ctypes.data_as(lp), C.byref(nnz)), "landing_kinodyn_pattern")
+        return colind, row
+
     def leg_ik(self, npts, d_q6, d_c, d_jpos, d_res=0, iters=12, jmin=None, jmax=None, stream=0):
         jmin = np.ascontiguousarray(JPOS_MIN[:3] if jmin is None else jmin, float); jmax = np.ascontiguousarray(JPOS_MAX[:3] if jmax is None else jmax, float)
         dp = C.POINTER(C.c_double)
