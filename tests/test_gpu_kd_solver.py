@@ -1,0 +1,131 @@
+"""GPU tests of the kinodynamic refinement solve (landing_optimization.m:38-201,300-322,360-376), through the C ABI:
+the production callers' pipeline -- SRBM solve (landing_solve_batch, N = 20, production grid) -> its solution as the initial guess of the
+refinement NLP -> landing_solve_kinodyn_24 -- on 1024 drop states, EVERY returned member re-certified under the oracle's rows and
+complex-step Jacobian (oracle/kinodyn_oracle.py, pinned by the reference's stored kinodynamic solutions, tests/test_n1_rows.py)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, lc
+
+pytestmark = pytest.mark.gpu
+N = 20
+KKT_TOL = 1e-6
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    L = lc("capi").LandingLib(N, device=0)
+    R = lc("rbd").Rbd(L)
+    yield L, R
+    L.close()
+
+
+def _consts():
+    mass, Ib, Ibi = lc("constants").robot_constants()
+    return mass, np.asarray(Ib), np.asarray(Ibi), lc("problem").REFERENCE_DT_GRID
+
+
+def _certify(x, lam, lb, ub, cost, dt, mu):
+    from oracle import kinodyn_oracle as ko
+    kd = lc("kinodyn")
+    mass, Ib, Ibi, _ = _consts()
+    out = np.zeros((x.shape[0], 3))
+    for lo in range(0, x.shape[0], 128):      # (chunks bound the size of the complex-step arrays)
+        sl = slice(lo, lo + 128)
+        gf = np.array([kd.terminal_cost(x[b], N, cost[b][12:], cost[b][:12])[1] for b in range(*sl.indices(x.shape[0]))])
+        out[sl] = ko.kkt_batch(x[sl], lam[sl], N, dt, mass, Ib, Ibi, mu, lb[sl], ub[sl], gf)
+    return out
+
+
+def test_refinement_of_1024_srbm_solutions_every_member_decided_and_certified(ctx):
+    """1024 drop states of the production sampling law (landing_optimization.m:207-218), f_max / grid of that caller.  Every member must be
+    DECIDED: a KKT point <= 1e-6 (unscaled, under the oracle -- every converged member is re-certified), or the presolve certificate: a row
+    of the first interval that holds FIXED variables only (the nominal stance under the hips of a steep initial attitude against the
+    velocity-dependent kinematic box, :157-164 with :232-236,249-251) is violated, which no solver can repair; at most 0.5 % undecided.
+    Measured on an MI355X (round 4): seeds 7 / 8 / 9: 834 + 190 + 0, 865 + 159 + 0, 860 + 163 + 1; f* <= 1e-9 for every converged member."""
+    L, R = ctx
+    P, kd = lc("problem"), lc("kinodyn")
+    from oracle import kinodyn_oracle as ko
+    B = 1024
+    consts = P.production_constants("main")
+    Pp, X0, q, qd = P.make_batch(B, N, 0.6, seed=20211, consts=consts, dt_grid="reference", law="main")
+    srbm = L.solve_host(Pp, X0)
+    assert (srbm["status"] == 0).mean() >= 0.99
+    mass, Ib, Ibi, dt = _consts()
+    args = kd.make_args24(N, q, qd, srbm["x"], dt, mass, Ib, Ibi, mu=consts.mu)
+    s = R.kinodyn_solve_24(N, args)
+    ok, cert = s["status"] == 0, s["status"] == 3
+    assert (ok | cert).mean() >= 0.995, np.bincount(s["status"], minlength=4)
+    assert ok.sum() >= 0.75 * B
+    prob = [kd.member_problem(N, q[b], qd[b], srbm["x"][b]) for b in range(B)]
+    lb, ub, cost = (np.array([p[i] for p in prob]) for i in range(3))
+    # every converged member: the oracle's KKT residual, and it is what the kernel reported
+    k = _certify(s["x"][ok], s["lam_g"][ok], lb[ok], ub[ok], cost[ok], dt, consts.mu)
+    assert k.max() <= KKT_TOL * 1.0001, (k.max(axis=0), int(np.argmax(k.max(axis=1))))
+    assert np.allclose(k, s["kkt"][ok], rtol=1e-3, atol=1e-9)
+    assert s["f"][ok].max() <= 1e-7                       # the terminal reference is reachable: f* = 0 (cf. the stored solution, tests/test_n1_rows.py)
+    oU = 12 * (N + 1) + 12 * N
+    assert np.array_equal(s["x"][ok][:, :6], q[ok]) and np.array_equal(s["x"][ok][:, 6:12], qd[ok])
+    assert np.array_equal(s["x"][ok][:, oU:oU + 12], args["c_init"].T[ok])
+    # every certificate: the oracle's rows of the first interval over the fixed variables are violated by what the kernel reports
+    g = ko.nlp_g_batch(s["x"][cert], N, dt, mass, Ib, Ibi, consts.mu)
+    rows = 48 + 16 + 15 * np.repeat(np.arange(4), 5) + np.tile([0, 8, 9, 10, 11], 4)
+    viol = np.maximum(np.maximum(lb[cert] - g, g - ub[cert]), 0.0)
+    assert (viol[:, rows].max(axis=1) > KKT_TOL).all() and (s["iters"][cert] == 0).all()
+    assert np.allclose(viol.max(axis=1), s["kkt"][cert][:, 0], rtol=1e-9, atol=1e-12)
+    print("refinement of 1024: converged %d, certified infeasible %d, undecided %d; iterations mean %.1f max %d" % (ok.sum(), cert.sum(), B - ok.sum() - cert.sum(), s["iters"][ok].mean(), s["iters"][ok].max()))
+
+
+def test_stored_drop_known_answer(ctx):
+    """the drop of test_scripts/1.5msDrop30Pitch.mat (pure pitch 30 deg, v_z = -1.5, uniform dt = 0.03; the file holds a kinodynamic solution of
+    an older variant of the script, FK band 1e-3): from ITS initial state and stance, with the current script's bounds (:208-258), the pipeline
+    returns a KKT point with f* <= 2e-5 (the terminal reference is reachable, f* = 0) that is feasible under those bounds."""
+    L, R = ctx
+    P, kd = lc("problem"), lc("kinodyn")
+    d = np.load(os.path.join(GOLDEN, "n1_kinodyn_solutions.npz"))
+    X, U = d["X_a"], d["U_a"]
+    q, qd = X[:6, 0].copy(), X[6:, 0].copy()
+    dt = np.full(N, 0.03)
+    consts = P.production_constants("main")
+    p, x0s, _, _ = P.make_member(N, 0.6, q, qd, consts, dt)
+    srbm = L.solve_host(p[None], x0s[None])
+    assert srbm["status"][0] == 0
+    mass, Ib, Ibi, _ = _consts()
+    args = kd.make_args24(N, q[None], qd[None], srbm["x"], dt, mass, Ib, Ibi, mu=consts.mu)
+    args["c_init"] = U[:12, 0].reshape(12, 1).copy()      # the stance the file starts from
+    args["x0"][12 * (N + 1) + 12 * N:12 * (N + 1) + 12 * N + 12, 0] = U[:12, 0]
+    s = R.kinodyn_solve_24(N, args)
+    assert s["status"][0] == 0 and s["f"][0] <= 2e-5, (s["status"], s["f"], s["kkt"])
+    lb, ub = kd.bounds(N, q, qd, U[:12, 0], kd.kin_box_of(q[3:6], qd[3:6]))
+    cost = np.concatenate([kd.QN_DEFAULT, kd.Q_TERM_REF, np.zeros(6)])
+    k = _certify(s["x"], s["lam_g"], lb[None], ub[None], cost[None], dt, consts.mu)
+    assert k.max() <= KKT_TOL * 1.0001, k
+
+
+def test_device_entry_point_is_deterministic_and_batch_independent(ctx):
+    """landing_kinodyn_solve_batch on device pointers: the same batch twice and a member alone give identical bits (fixed summation orders,
+    the only atomic is the integer count of members still iterating)"""
+    import torch
+    L, R = ctx
+    P, kd = lc("problem"), lc("kinodyn")
+    B = 8
+    consts = P.production_constants("main")
+    Pp, X0, q, qd = P.make_batch(B, N, 0.6, seed=8, consts=consts, dt_grid="reference", law="main")
+    srbm = L.solve_host(Pp, X0)
+    mass, Ib, Ibi, dt = _consts()
+    prob = [kd.member_problem(N, q[b], qd[b], srbm["x"][b]) for b in range(B)]
+    lb, ub, cost, x0 = (np.array([p[i] for p in prob]) for i in range(4))
+    a = R.kinodyn_solve_host(N, lb, ub, cost, x0, dt, mass, Ib, Ibi, consts.mu)
+    T = lambda v: torch.tensor(v, device="cuda")
+    dl, du_, dc, dx0 = T(lb), T(ub), T(cost), T(x0)
+    nx, ng = kd.dims(N)
+    x = torch.empty(B, nx, device="cuda", dtype=torch.float64); st = torch.empty(B, device="cuda", dtype=torch.int32); it = torch.empty(B, device="cuda", dtype=torch.int32)
+    R.kinodyn_solve_device(B, N, dl.data_ptr(), du_.data_ptr(), dc.data_ptr(), dx0.data_ptr(), dt, mass, Ib, Ibi, consts.mu, None, x.data_ptr(), d_status=st.data_ptr(),
+                           d_iters=it.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(x.cpu().numpy(), a["x"]) and np.array_equal(it.cpu().numpy(), a["iters"]) and np.array_equal(st.cpu().numpy(), a["status"])
+    b = int(np.nonzero(a["status"] == 0)[0][0])
+    c = R.kinodyn_solve_host(N, lb[b], ub[b], cost[b], x0[b], dt, mass, Ib, Ibi, consts.mu)
+    assert np.array_equal(c["x"][0], a["x"][b]) and c["iters"][0] == a["iters"][b]
