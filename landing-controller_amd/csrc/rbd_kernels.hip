@@ -539,8 +539,11 @@ __device__ void kd_compose(const T* Eu, const T* ru, T* Ea, T* ra) {      // (Ea
   ra[0] = ra[0] + t.x; ra[1] = ra[1] + t.y; ra[2] = ra[2] + t.z;
 }
 
+// legmask: bit l set = the rows of leg l that need the leg's kinematics (hip-relative position, leg torques, forward kinematics: the
+// expensive part of the function) are evaluated; a cleared bit writes zeros there.  The value / Jacobian kernels pass 15; the Hessian kernel
+// passes the one leg a pair of directions belongs to (second derivatives of the other legs' rows vanish for that pair).
 template <class T>
-__device__ void kd_stage_rows(const KdNlpParams& P, const RbdModel& M, int k, bool last, const T* w, T* out) {
+__device__ void kd_stage_rows(const KdNlpParams& P, const RbdModel& M, int k, bool last, const T* w, T* out, int legmask = 15) {
   typedef typename KdVec<T>::type V;
   const T zero = lit(w[0], 0.0);
   const T* X = w; const T* c = w + 12; const T* f = w + 24; const T* jp = w + 36; const T* Xn = w + 48; const T* cn = w + 60;
@@ -588,6 +591,11 @@ __device__ void kd_stage_rows(const KdNlpParams& P, const RbdModel& M, int k, bo
     if (!last) {
       for (int a = 0; a < 3; ++a) out[r++] = fz * (cn[3 * l + a] - c[3 * l + a]);                                              // :142
       for (int a = 0; a < 3; ++a) out[r++] = fz * (cn[3 * l + a] - c[3 * l + a]);                                              // :143
+    }
+    if (!((legmask >> l) & 1)) {      // rows of this leg's kinematics are not needed by the caller
+      for (int a = 0; a < 7; ++a) out[r++] = zero;
+      fkv[3 * l] = c[3 * l]; fkv[3 * l + 1] = c[3 * l + 1]; fkv[3 * l + 2] = c[3 * l + 2];
+      continue;
     }
     const double hx = l < 2 ? 0.19 : -0.19, hy = (l & 1) ? 0.1 : -0.1;        // params.hipSrbmLocation (get_robot_params.m:90-91)
     const V pr = sub3(mk3(c[3 * l], c[3 * l + 1], c[3 * l + 2]), add3(pos, mk3(R[0] * hx + R[1] * hy, R[3] * hx + R[4] * hy, R[6] * hx + R[7] * hy)));
@@ -688,20 +696,30 @@ __global__ void __launch_bounds__(64) landing_kinodyn_nlp_jac_kernel(KdNlpArgs a
 // Structural non-zeros of the block (the rest is written as zeros by a memset): the velocity X[9..11] and X_k+1 enter linearly; the variables
 // of a leg (c_l, f_l, jpos_l) couple with themselves and with the base (pos, rpy, omega) only; c_k+1 of a leg only with that leg's f_z:
 // 45 + 4 x 81 + 4 x 45 + 12 = 561 pairs instead of 2 628.
+// Order: the 45 pairs inside the base first (they need the rows of every leg), then leg by leg the pairs that involve a variable of that leg
+// (they need that leg's rows only: kd_stage_rows' legmask) -- the threads of a wavefront mostly share one mask.
+__host__ __device__ inline int kd_pair_leg(int i, int j) {      // -1: both directions in the base; else the leg the pair belongs to
+  auto leg_of = [](int v) { return v < 12 ? -1 : (v < 48 ? ((v - 12) % 12) / 3 : (v >= 60 ? (v - 60) / 3 : -1)); };
+  const int li = leg_of(i), lj = leg_of(j);
+  return li >= 0 ? li : lj;
+}
 __host__ __device__ inline int kd_pair_list(unsigned char* pi, unsigned char* pj) {      // fills (i <= j) pairs, returns their number (561)
   int n = 0;
   auto leg_of = [](int v) { return v < 12 ? -1 : (v < 48 ? ((v - 12) % 12) / 3 : -2); };      // base = -1, leg 0..3 for c / f / jpos entries
-  for (int i = 0; i < 48; ++i) {
-    if (i >= 9 && i < 12) continue;
-    for (int j = i; j < 48; ++j) {
-      if (j >= 9 && j < 12) continue;
-      const int li = leg_of(i), lj = leg_of(j);
-      if (li >= 0 && lj >= 0 && li != lj) continue;
-      if (pi) { pi[n] = (unsigned char)i; pj[n] = (unsigned char)j; }
-      ++n;
+  for (int pass = -1; pass < 4; ++pass) {
+    for (int i = 0; i < 48; ++i) {
+      if (i >= 9 && i < 12) continue;
+      for (int j = i; j < 48; ++j) {
+        if (j >= 9 && j < 12) continue;
+        const int li = leg_of(i), lj = leg_of(j);
+        if (li >= 0 && lj >= 0 && li != lj) continue;
+        if ((li >= 0 ? li : lj) != pass) continue;
+        if (pi) { pi[n] = (unsigned char)i; pj[n] = (unsigned char)j; }
+        ++n;
+      }
     }
+    if (pass >= 0) for (int a = 0; a < 3; ++a) { if (pi) { pi[n] = (unsigned char)(24 + 3 * pass + 2); pj[n] = (unsigned char)(60 + 3 * pass + a); } ++n; }
   }
-  for (int l = 0; l < 4; ++l) for (int a = 0; a < 3; ++a) { if (pi) { pi[n] = (unsigned char)(24 + 3 * l + 2); pj[n] = (unsigned char)(60 + 3 * l + a); } ++n; }
   return n;
 }
 constexpr int KD_NPAIR = 561;
@@ -718,7 +736,8 @@ __global__ void __launch_bounds__(64) landing_kinodyn_nlp_hess_kernel(KdNlpArgs 
   const double* lam = a.lam + a.og(b) + KD_BND + (size_t)k * KD_ROWS;
   HDual w[KD_NW], out[KD_ROWS];
   for (int q = 0; q < KD_NW; ++q) { const int ix = kd_w_index(N, k, q); w[q] = H_(ix >= 0 ? x[ix] : 0.0, q == i ? 1.0 : 0.0, q == j ? 1.0 : 0.0, 0.0); }
-  kd_stage_rows<HDual>(a.P, *a.model, k, last, w, out);
+  const int pl = kd_pair_leg(i, j);
+  kd_stage_rows<HDual>(a.P, *a.model, k, last, w, out, pl < 0 ? 15 : (1 << pl));
   const int nr = last ? KD_ROWS_LAST : KD_ROWS;
   double s = 0.0;
   for (int r = 0; r < nr; ++r) s += lam[r] * out[r].ab;
