@@ -47,6 +47,7 @@ constexpr int YS = 37;    // LDS row stride of 24x36 / 12x36 matrices
 constexpr int RIC_K = 0, RIC_KAP = 576, RIC_MT = 600, RIC_MV = 888, RIC_PX = 900, RIC_PV = 1188, RIC_STRIDE = 1200;
 constexpr int RIC_FWD0 = 288, RIC_FWDN = 612;   // forward chain reads rec[288, 900): K rows of c+ | kappa | Mt | mv
 constexpr int FILT_CAP = 64;
+constexpr int SOLVER_NMAX = 96;   // longest horizon the solver kernel takes: sigma_0..sigma_N of the forward sweep live in the 48 x 49 LDS array, one table row per stage
 constexpr int ES = 26;    // LDS row stride of the elimination side block [gamma_u | I] (24 x 25)
 constexpr int SOLVER_THREADS = 256;
 // condensed stage data (once per iteration): [G targets (table order) | gamma 48 | A^ values] per stage
@@ -214,7 +215,7 @@ struct Lds {
   int cab[COND_GAM]; int cat[COND_STRIDE - COND_AH]; int c_tab, c_nT, c_nA;
   // condensation: packed term table of the most frequent stage type (the others are read from L2) and, per stage, the
   // bases of the seven [J | H | Hc] segments + the type id (slot 7)
-  int segb[64 * 8];
+  int segb[SOLVER_NMAX * 8];
   // bounds of the rows: lbg/ubg depend on the row's position inside its stage only (boundary rows | rows of a stage |
   // rows of the last stage, which has another layout), so 244 (lb, ub) pairs in LDS replace two ng-long workspace arrays
   // that every row pass used to stream (6 of ~30 array passes per iteration)
@@ -979,10 +980,10 @@ __device__ LANDING_INL_FWD void forward_pass() {
   const Layout& L = S.L;
   const MemberMem& M = S.M;
   const int N = L.N, tid = threadIdx.x, NT = blockDim.x;
-  double* sg = S.G;                    // sigma_k, k = 0..N  at sg[24 k]           (N <= 64: 1560 doubles)
-  double* buf = S.G + 24 * 65;         // two stage slots of RIC_FWDN doubles       (up to 1560 + 1224 = 2784 > 48*GS: second slot in A1)
+  double* sg = S.G;                    // sigma_k, k = 0..N  at sg[24 k]           (N <= SOLVER_NMAX = 96: 2328 of the 2352 doubles of G)
+  double* buf = S.stg;                 // two stage slots of RIC_FWDN doubles: the staging area of the backward sweep (free here) and A1
   double* buf1 = S.A1;
-  static_assert(24 * 65 + RIC_FWDN <= 48 * GS && RIC_FWDN <= XCH * 2, "forward scratch fits");
+  static_assert(24 * (SOLVER_NMAX + 1) <= 48 * GS && RIC_FWDN <= COND_STRIDE + 12 && RIC_FWDN <= XCH * 2, "forward scratch fits");
   auto slot = [&](int k) { return (k & 1) ? buf1 : buf; };
   auto fetch = [&](int k, double (&r)[3]) {
     landing_gptr rec = (landing_gptr)(M.ric + (size_t)(k < N ? k : N - 1) * RIC_STRIDE + RIC_FWD0);   // global_load: a flat load would also tie up the LDS counter
@@ -1737,7 +1738,8 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
             accepted = true;
           }
         }
-        if (K.force_step && ok_f) { accepted = true; K.nfilt = 0; done = true; }      // watchdog (landing_nlp.h): the step to the boundary is taken whatever the filter says
+        if (K.force_step && ok_f) { accepted = true; K.nfilt = 0; done = true; }      // watchdog (landing_nlp.h): the step to the boundary is taken without the sufficient-decrease / switching tests;
+                                                                                      // it must still pass theta <= theta_max and must not be dominated by a filter entry (ok_f), then the filter restarts
         if (accepted) done = true;
         K.need_corr = 0;
         if (!done) {

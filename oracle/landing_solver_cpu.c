@@ -537,7 +537,7 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
         if (switching) { if (pht <= ph0 + 1e-8 * alpha * dphi) { accepted = 1; armijo = 1; } }
         else if (tht <= fmax((1.0 - 1e-5) * th0, th_floor) || pht <= ph0 - 1e-8 * th0) accepted = 1;
       }
-      if (force_step && ok_f) { accepted = 1; nfilt = 0; break; }      /* watchdog: the step to the boundary is taken whatever the filter says */
+      if (force_step && ok_f) { accepted = 1; nfilt = 0; break; }      /* watchdog: the step to the boundary is taken without the sufficient-decrease / switching tests (it passed theta_max and the filter entries: ok_f) */
       if (accepted) break;
       if (!feas && op->slack_corr > 0.0 && alpha == a_pr && tht >= th0) {   /* slack correction at the rejected first trial point (include/landing_nlp.h): no new solve */
         const double kk = op->slack_corr; double tht2 = 0, bt2 = 0, pht2; int okf2;

@@ -89,9 +89,9 @@ def test_warm_start_converges_faster(libs):
 
 
 def test_solver_other_horizons_and_limits(oracle_mod):
-    """N is a runtime parameter of the solver too (N <= 64: one lane per stage in the derivative phases)."""
+    """N is a runtime parameter of the solver too (N <= 96: the lane = stage phases loop over 64-stage chunks, the forward sweep keeps sigma_0..N in LDS)."""
     capi = lc("capi")
-    for N in (16, 30):
+    for N in (16, 30, 80):      # (80 > 64: two chunks of the lane = stage phases, round 4; CPU port: 6 of 6 in 45..51 iterations)
         O = oracle_mod.Oracle(N)
         L = capi.LandingLib(N, device=0)
         P, X0, _, _ = lc("problem").make_batch(6, N, 0.6, seed=4)
@@ -106,9 +106,9 @@ def test_solver_other_horizons_and_limits(oracle_mod):
             g = O.g(r["x"][b], P[b]); lb, ub = O.bounds(P[b]); eq = lb == ub
             assert np.abs(g[eq] - lb[eq]).max() <= 1e-6 and np.maximum(np.maximum(lb - g, g - ub), 0.0)[~eq].sum() > 1e-4
         L.close()
-    L = capi.LandingLib(80, device=0)
-    P, X0, _, _ = lc("problem").make_batch(1, 80, 0.6, seed=4)
-    with pytest.raises(RuntimeError, match="N <= 64"):
+    L = capi.LandingLib(100, device=0)
+    P, X0, _, _ = lc("problem").make_batch(1, 100, 0.6, seed=4)
+    with pytest.raises(RuntimeError, match="N <= 96"):
         L.solve_host(P, X0)
     L.close()
 

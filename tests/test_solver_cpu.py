@@ -94,6 +94,24 @@ def test_max_iter_zero_stops_at_once_in_kernel_and_port(emu_lib, oracle_mod):
     assert (g["status"] == 1).all() and np.array_equal(g["iters"], c["iters"]) and (g["iters"] <= 3).all()
 
 
+def test_emulated_kernel_long_horizon(emu_lib, oracle_mod):
+    """N = 80 (> 64 stages: the lane = stage phases run in two chunks, sigma_0..80 of the forward sweep fill the LDS array; limit 96): the
+    emulated kernel follows the CPU port"""
+    N, K = 80, 3
+    O = oracle_mod.Oracle(N)
+    P, X0, _, _ = lc("problem").make_batch(1, N, 0.6, seed=4)
+    L = lc("capi").LandingLib(N, lib_path=emu_lib)
+    o = L.default_opts(); o.max_iter = K; o.feas_phase = 0
+    g = L.solve_host(P, X0, o)
+    c = oracle_mod.cpu_solve_batch(O, P, X0, threads=1, max_iter=K, feas_phase=0)
+    assert g["iters"][0] == c["iters"][0] == K
+    assert np.max(np.abs(g["x"][0] - c["x"][0])) < 1e-9 and np.max(np.abs(g["lam_g"][0] - c["lam_g"][0])) < 1e-7
+    L100 = lc("capi").LandingLib(100, lib_path=emu_lib)
+    P, X0, _, _ = lc("problem").make_batch(1, 100, 0.6, seed=4)
+    with pytest.raises(RuntimeError, match="N <= 96"):
+        L100.solve_host(P, X0)
+
+
 RUN_COST = dict(QX=[0, 0, 10, 1, 1, 0, .1, .1, .1, .1, .1, .1], Qc=[1.0, 1.0, 0.5], Qf=[1e-4, 1e-4, 1e-3], f_ref=[0, 0, 20.0])
 
 
