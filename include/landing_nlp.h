@@ -509,6 +509,17 @@ int landing_wb_rollout(landing_ctx* ctx, int B, int N, int nalpha, const double*
                        const double* d_xref, const double* d_f_foot, const double* d_K, const double* d_kff, const double* Q36, const double* R12,
                        const double* QN36, double* d_xnew, double* d_unew, double* d_cost, void* stream);
 
+/* Integrator of landing_wb_backward / landing_wb_rollout: 0 (default) explicit Euler as above; 1 semi-implicit (symplectic) Euler,
+ *   qd+ = qd + dt qdd(q, qd, u),  q+ = q + dt qd+   (the scheme the reference compares with explicit Euler in
+ * test_scripts/test_integrationDifference.m:30-40).  Explicit Euler on this model is unstable beyond dt ~ 1.5 ms (light leg links under the foot
+ * forces); the semi-implicit scheme runs the loop on the landing NLP's own 15 ms grid.  The linearisation of the backward pass follows:
+ * A = [I 0; 0 0] + [dt A_qd; A_qd],  B = [dt B_qd; B_qd]  with A_qd = [dt dqdd/dq, I + dt dqdd/dqd], B_qd = dt Hinv(:, 6:18).
+ * landing_wb_select: after ONE landing_wb_rollout launch with all step lengths, every member keeps the first rollout of the list that lowers its
+ * cost (d_x, d_u, d_cost updated in place, d_step [B] = the step length taken, 0 = none; members with d_ok = 0 keep their trajectory). */
+int landing_wb_set_integrator(landing_ctx* ctx, int semi_implicit);
+int landing_wb_select(landing_ctx* ctx, int B, int N, int nalpha, const double* d_alphas, const int* d_ok, const double* d_xnew, const double* d_unew,
+                      const double* d_costnew, double* d_x, double* d_u, double* d_cost, double* d_step, void* stream);
+
 /* development aid: d_prof [B][16] doubles receives per-member phase timers of the next solves (100 MHz
  * wall-clock ticks: eval, error, sigma/rho, backward, forward, dual, line search, accept; then counts of
  * factorisations, trial points, iterations); NULL disables. */

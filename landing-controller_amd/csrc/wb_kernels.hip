@@ -18,7 +18,7 @@ namespace landing {
 constexpr int WB_NX = 36, WB_NU = 12, WB_LD = 37;     // LDS row stride 37: conflict-free column walks
 
 struct WbBackArgs {
-  int B, N; double dt, reg;
+  int B, N; double dt, reg; int semi;      // semi = 1: semi-implicit (symplectic) Euler, qd+ = qd + dt qdd, q+ = q + dt qd+ (landing_wb_set_integrator)
   const double* x; const double* u; const double* xref;          // [B][N+1][36], [B][N][12], [B][N+1][36]
   const double* A; const double* Hinv;                           // [B*N][18][36], [B*N][18][18] (knot index b*N + k)
   double Q[WB_NX], R[WB_NU], QN[WB_NX];                          // diagonal weights
@@ -42,17 +42,19 @@ __global__ void __launch_bounds__(64) landing_wb_backward_kernel(WbBackArgs a) {
   for (int k = N - 1; k >= 0; --k) {
     const double* Ad = a.A + ((size_t)b * N + k) * 18 * 36;
     const double* Hi = a.Hinv + ((size_t)b * N + k) * 18 * 18;
-    // A_k = [I, dt I; dt dqdd/dq, I + dt dqdd/dqd],  B_k = dt [0; Hinv(:, 6:18)] (only the lower 18 rows are stored)
+    // A_k = [I, dt I; dt dqdd/dq, I + dt dqdd/dqd],  B_k = dt [0; Hinv(:, 6:18)] (only the lower 18 rows Bl are stored).  Semi-implicit Euler:
+    // the q rows of both are [I 0] + dt x (their qd rows), i.e. B = [dt Bl; Bl] and B' w = Bl' (w_qd + dt w_q) -- the factor sd below
     for (int e = t; e < WB_NX * WB_NX; e += 64) {
       const int i = e / WB_NX, j = e % WB_NX;
       double val;
-      if (i < 18) val = (j == i ? 1.0 : 0.0) + (j == 18 + i ? a.dt : 0.0);
+      if (i < 18) val = (j == i ? 1.0 : 0.0) + (a.semi ? a.dt * (a.dt * Ad[i * 36 + j] + (j == 18 + i ? 1.0 : 0.0)) : (j == 18 + i ? a.dt : 0.0));      // semi: q rows = [I 0] + dt (qd rows)
       else val = a.dt * Ad[(i - 18) * 36 + j] + (j == i ? 1.0 : 0.0);
       Ak[i * WB_LD + j] = val;
     }
     for (int e = t; e < 18 * WB_NU; e += 64) { const int i = e / WB_NU, c = e % WB_NU; Bk[e] = a.dt * Hi[i * 18 + 6 + c]; }
     if (t < WB_NX) dx[t] = xb[(size_t)k * WB_NX + t] - rb[(size_t)k * WB_NX + t];
     __syncthreads();
+    const double sd = a.semi ? a.dt : 0.0;
     // VA = V A, VB = V B
     for (int e = t; e < WB_NX * WB_NX; e += 64) {
       const int i = e / WB_NX, j = e % WB_NX;
@@ -63,7 +65,7 @@ __global__ void __launch_bounds__(64) landing_wb_backward_kernel(WbBackArgs a) {
     for (int e = t; e < WB_NX * WB_NU; e += 64) {
       const int i = e / WB_NU, c = e % WB_NU;
       double s = 0.0;
-      for (int m = 0; m < 18; ++m) s += V[i * WB_LD + 18 + m] * Bk[m * WB_NU + c];
+      for (int m = 0; m < 18; ++m) s += (V[i * WB_LD + 18 + m] + sd * V[i * WB_LD + m]) * Bk[m * WB_NU + c];
       VB[e] = s;
     }
     __syncthreads();
@@ -71,18 +73,18 @@ __global__ void __launch_bounds__(64) landing_wb_backward_kernel(WbBackArgs a) {
     for (int e = t; e < WB_NU * WB_NX; e += 64) {
       const int c = e / WB_NX, j = e % WB_NX;
       double s = 0.0;
-      for (int m = 0; m < 18; ++m) s += Bk[m * WB_NU + c] * VA[(18 + m) * WB_LD + j];
+      for (int m = 0; m < 18; ++m) s += Bk[m * WB_NU + c] * (VA[(18 + m) * WB_LD + j] + sd * VA[m * WB_LD + j]);
       Qux[c * WB_LD + j] = s;
     }
     for (int e = t; e < WB_NU * WB_NU; e += 64) {
       const int c = e / WB_NU, d = e % WB_NU;
       double s = (c == d) ? a.R[c] + a.reg : 0.0;
-      for (int m = 0; m < 18; ++m) s += Bk[m * WB_NU + c] * VB[(18 + m) * WB_NU + d];
+      for (int m = 0; m < 18; ++m) s += Bk[m * WB_NU + c] * (VB[(18 + m) * WB_NU + d] + sd * VB[m * WB_NU + d]);
       Quu[c * (WB_NU + 1) + d] = s;
     }
     if (t < WB_NU) {
       double s = a.R[t] * a.u[((size_t)b * N + k) * WB_NU + t];
-      for (int m = 0; m < 18; ++m) s += Bk[m * WB_NU + t] * v[18 + m];
+      for (int m = 0; m < 18; ++m) s += Bk[m * WB_NU + t] * (v[18 + m] + sd * v[m]);
       Qu[t] = s;
     }
     if (t < WB_NX) {
@@ -161,7 +163,7 @@ __global__ void __launch_bounds__(64) landing_wb_backward_kernel(WbBackArgs a) {
 }
 
 struct WbRollArgs {
-  const RbdModel* model; int B, N, nalpha; double dt; int arrow;      // arrow: the model's H is block-arrow (base 6 + four 3-joint legs on the base): structured solve
+  const RbdModel* model; int B, N, nalpha; double dt; int semi; int arrow;      // semi: semi-implicit Euler (WbBackArgs); arrow: the model's H is block-arrow (base 6 + four 3-joint legs on the base): structured solve
   const double* alphas;                                          // [nalpha]
   const double* x; const double* u; const double* xref; const double* f_foot;   // current trajectory, reference, foot forces [B][N][12] or null
   const double* K; const double* kff;                            // null: open-loop rollout of u (initialisation)
@@ -197,7 +199,7 @@ __global__ void __launch_bounds__(64) landing_wb_rollout_kernel(WbRollArgs a) {
     hand_c(M, xs, xs + 18, a.f_foot ? a.f_foot + ((size_t)b * N + k) * 12 : nullptr, H, C);
     for (int i = 0; i < RB_NB; ++i) rhs[i] = (i >= 6 ? un[i - 6] : 0.0) - C[i];
     ok = chol_solve18(H, rhs) && ok;
-    for (int i = 0; i < 18; ++i) { const double qd = xs[18 + i]; xs[i] += a.dt * qd; xs[18 + i] = qd + a.dt * rhs[i]; }
+    for (int i = 0; i < 18; ++i) { const double qd = xs[18 + i], qn = qd + a.dt * rhs[i]; xs[i] += a.dt * (a.semi ? qn : qd); xs[18 + i] = qn; }
     for (int i = 0; i < WB_NX; ++i) xo[(k + 1) * WB_NX + i] = xs[i];
   }
   for (int i = 0; i < WB_NX; ++i) { const double d = xs[i] - rb[N * WB_NX + i]; cost += 0.5 * a.QN[i] * d * d; }
@@ -473,11 +475,32 @@ __global__ void __launch_bounds__(64) landing_wb_rollout_lds_kernel(WbRollArgs a
     hand_c_lds(M, a.f_foot ? a.f_foot + ((size_t)b * N + k) * 12 : nullptr, W);
     for (int i = 0; i < RB_NB; ++i) W(WS_RHS + i) = (i >= 6 ? W(WS_UN + i - 6) : 0.0) - W(WS_C + i);
     ok = (a.arrow ? arrow_solve18_lds(W) : chol_solve18_lds(W)) && ok;
-    for (int i = 0; i < 18; ++i) { const double qd = W(WS_X + 18 + i); W(WS_X + i) += a.dt * qd; W(WS_X + 18 + i) = qd + a.dt * W(WS_RHS + i); }
+    for (int i = 0; i < 18; ++i) { const double qd = W(WS_X + 18 + i), qn = qd + a.dt * W(WS_RHS + i); W(WS_X + i) += a.dt * (a.semi ? qn : qd); W(WS_X + 18 + i) = qn; }
     for (int i = 0; i < WB_NX; ++i) xo[(k + 1) * WB_NX + i] = W(WS_X + i);
   }
   for (int i = 0; i < WB_NX; ++i) { const double d = W(WS_X + i) - rb[N * WB_NX + i]; cost += 0.5 * a.QN[i] * d * d; }
   a.cost[(size_t)ia * a.B + b] = (ok && cost == cost) ? cost : INFINITY;
+}
+
+
+// Step-length selection on the device: member b keeps the FIRST of the nalpha rollouts (in the order of the list) whose cost is below its
+// current one -- trajectory, controls, cost and the step length taken (0 = none) -- unless its backward pass failed (ok = 0).  Replaces one
+// rollout launch + torch.where merges per step length of the host loop.
+struct WbSelArgs { int B, N, nalpha; const double* alphas; const int* ok; const double* xnew; const double* unew; const double* costnew; double* x; double* u; double* cost; double* step; };
+__global__ void __launch_bounds__(256) landing_wb_select_kernel(WbSelArgs a) {
+  const int b = blockIdx.x, t = threadIdx.x;
+  if (b >= a.B) return;
+  int pick = -1;
+  const double c0 = a.cost[b];
+  if (a.ok[b]) for (int ia = 0; ia < a.nalpha && pick < 0; ++ia) if (a.costnew[(size_t)ia * a.B + b] < c0) pick = ia;      // (uniform: every thread reads the same words)
+  __syncthreads();      // every thread has read cost[b] before thread 0 overwrites it
+  if (pick >= 0) {
+    const size_t nxs = (size_t)(a.N + 1) * WB_NX, nus = (size_t)a.N * WB_NU;
+    const double* xs = a.xnew + ((size_t)pick * a.B + b) * nxs; const double* us = a.unew + ((size_t)pick * a.B + b) * nus;
+    for (size_t e = t; e < nxs; e += blockDim.x) a.x[(size_t)b * nxs + e] = xs[e];
+    for (size_t e = t; e < nus; e += blockDim.x) a.u[(size_t)b * nus + e] = us[e];
+  }
+  if (t == 0) { if (pick >= 0) a.cost[b] = a.costnew[(size_t)pick * a.B + b]; if (a.step) a.step[b] = pick >= 0 ? a.alphas[pick] : 0.0; }
 }
 
 }  // namespace landing

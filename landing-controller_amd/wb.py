@@ -15,8 +15,15 @@ import torch
 
 
 class WholeBodySQP:
-    def __init__(self, lib, rbd, N, dt, Q, R, QN, device="cuda", alphas=(1.0, 0.5, 0.25, 0.1, 0.03)):
+    def __init__(self, lib, rbd, N, dt, Q, R, QN, device="cuda", alphas=(1.0, 0.5, 0.25, 0.1, 0.03), semi_implicit=False, fused=True):
+        """semi_implicit: qd+ = qd + dt qdd, q+ = q + dt qd+ (landing_wb_set_integrator; the scheme of test_scripts/test_integrationDifference.m:30-40)
+        instead of explicit Euler.  fused: ALL step lengths in one landing_wb_rollout launch and the choice per member on the device
+        (landing_wb_select) -- no host synchronisation inside an iteration; False = the round-3 loop (one launch + torch.where merges per step length)"""
         self.L, self.R_, self.N, self.dt, self.dev = lib, rbd, int(N), float(dt), torch.device(device)
+        self.fused = bool(fused)
+        lib.lib.landing_wb_set_integrator.argtypes = [C.c_void_p, C.c_int]
+        lib._check(lib.lib.landing_wb_set_integrator(lib.ctx, 1 if semi_implicit else 0), "landing_wb_set_integrator")
+        lib.lib.landing_wb_select.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 10
         self.Q = np.ascontiguousarray(Q, float); self.R = np.ascontiguousarray(R, float); self.QN = np.ascontiguousarray(QN, float)
         assert self.Q.shape == (36,) and self.R.shape == (12,) and self.QN.shape == (36,)
         self.alphas = torch.tensor(list(alphas), dtype=torch.float64, device=self.dev)
@@ -78,6 +85,16 @@ class WholeBodySQP:
             K, kff, dV, ok = self.backward(x, u, xref, A, Hinv, reg)
             # backtracking: the step lengths in decreasing order, one rollout launch each, a member keeps the FIRST one that lowers its
             # cost; the loop ends as soon as every member has one (normally after alpha = 1)
+            if self.fused:
+                xn, un, cn = self.rollout(x, u, xref, f_foot, K, kff, alphas=self.alphas)
+                step = torch.zeros_like(cost)
+                x = x.contiguous(); u = u.contiguous(); cost = cost.contiguous()
+                self.L._check(self.L.lib.landing_wb_select(self.L.ctx, B, self.N, int(self.alphas.shape[0]), self.alphas.data_ptr(), ok.data_ptr(), xn.data_ptr(), un.data_ptr(),
+                                                           cn.data_ptr(), x.data_ptr(), u.data_ptr(), cost.data_ptr(), step.data_ptr(), self._stream()), "landing_wb_select")
+                hist.append(cost.clone()); steps.append(step)
+                if rel_tol > 0.0 and float(((hist[-2] - hist[-1]) / hist[-1].clamp_min(1e-300)).max()) <= rel_tol:
+                    break
+                continue
             x_old, u_old = x, u
             done = ~ok.bool(); step = torch.zeros_like(cost)
             for ia in range(self.alphas.shape[0]):

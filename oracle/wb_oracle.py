@@ -8,10 +8,14 @@ import numpy as np
 from oracle import rbd_oracle as ro
 
 
+SEMI = False      # module switch: semi-implicit (symplectic) Euler, qd+ = qd + dt qdd, q+ = q + dt qd+ (test_scripts/test_integrationDifference.m:30-40)
+
+
 def step(x, u, f, dt):
     q, qd = x[:18], x[18:]
     qdd = ro.forward_dynamics(q, qd, np.concatenate([np.zeros(6), u]), None if f is None else f.reshape(4, 3))
-    return np.concatenate([q + dt * qd, qd + dt * qdd])
+    qn = qd + dt * qdd
+    return np.concatenate([q + dt * (qn if SEMI else qd), qn])
 
 
 def cost_of(xs, us, xref, Q, R, QN):
@@ -41,8 +45,12 @@ def backward(xs, us, xref, f_foot, dt, Q, R, QN, reg=0.0):
         Ad = ro.richardson_linearisation(q, qd, tau, ff)
         H, _ = ro.hand_c(q, qd, ff)
         Hinv = np.linalg.inv(H)
-        A = np.eye(36); A[:18, 18:] += dt * np.eye(18); A[18:, :] += dt * Ad
+        A = np.eye(36); A[18:, :] += dt * Ad
         Bm = np.zeros((36, 12)); Bm[18:, :] = dt * Hinv[:, 6:]
+        if SEMI:      # q+ = q + dt qd+: the q rows are [I 0] + dt x (the qd rows)
+            A[:18, :] += dt * A[18:, :]; Bm[:18, :] = dt * Bm[18:, :]
+        else:
+            A[:18, 18:] += dt * np.eye(18)
         Qx = Q * (xs[k] - xref[k]) + A.T @ v; Qu = R * us[k] + Bm.T @ v
         Qxx = np.diag(Q) + A.T @ V @ A; Quu = np.diag(R) + Bm.T @ V @ Bm + reg * np.eye(12); Qux = Bm.T @ V @ A
         K[k] = -np.linalg.solve(Quu, Qux); kff[k] = -np.linalg.solve(Quu, Qu)

@@ -38,26 +38,32 @@ def _problem(rng, B, N):
     return x0, u0, xref, f
 
 
-def _sqp(L, dev, N):
+def _sqp(L, dev, N, **kw):
     import torch  # noqa: F401
     R_ = lc("rbd").Rbd(L)
-    return lc("wb").WholeBodySQP(L, R_, N, DT, Q, R, QN, device=dev)
+    return lc("wb").WholeBodySQP(L, R_, N, DT, Q, R, QN, device=dev, **kw)
 
 
-def test_wb_sqp_emulated_follows_oracle():
+@pytest.mark.parametrize("semi,fused", [(False, True), (True, True), (False, False)])
+def test_wb_sqp_emulated_follows_oracle(semi, fused):
+    """explicit and semi-implicit Euler (landing_wb_set_integrator), step lengths chosen on the device (landing_wb_select) or by the round-3 host loop"""
     import torch
     from oracle import wb_oracle as wo
+    wo.SEMI = semi
     subprocess.run(["make", "-C", os.path.join(PKG, "csrc"), "emu"], check=True, capture_output=True)
     L = lc("capi").LandingLib(20, lib_path=os.path.join(ROOT, "tests", "emu", "liblanding_emu.so"))
     N, B, iters = 5, 2, 2
     x0, u0, xref, f = _problem(np.random.default_rng(3), B, N)
-    S = _sqp(L, "cpu", N)
+    S = _sqp(L, "cpu", N, semi_implicit=semi, fused=fused)
     t = lambda a: torch.tensor(a, dtype=torch.float64)
     out = S.solve(t(x0), t(u0), t(xref), t(f), iters=iters, K_init=KPD)
     cost = out["cost"].numpy()
     print(cost)
     for b in range(B):
-        xs, us, hist = wo.solve(x0[b], u0[b], xref[b], f[b], DT, Q, R, QN, iters, K_init=KPD)
+        try:
+            xs, us, hist = wo.solve(x0[b], u0[b], xref[b], f[b], DT, Q, R, QN, iters, K_init=KPD)
+        finally:
+            wo.SEMI = False if b == B - 1 else semi
         assert np.allclose(cost[:, b], hist, rtol=1e-6), (cost[:, b], hist)
         assert np.max(np.abs(out["x"][b].numpy() - xs)) <= 1e-6 * max(1.0, np.abs(xs).max())
         assert np.max(np.abs(out["u"][b].numpy() - us)) <= 1e-5 * max(1.0, np.abs(us).max())

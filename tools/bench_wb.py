@@ -7,10 +7,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 capi = importlib.import_module("landing-controller_amd.capi"); rbd = importlib.import_module("landing-controller_amd.rbd"); wb = importlib.import_module("landing-controller_amd.wb")
 import test_wb as T
-ap = argparse.ArgumentParser(); ap.add_argument("--members", type=int, default=1024); ap.add_argument("--iters", type=int, default=6); a = ap.parse_args()
+ap = argparse.ArgumentParser(); ap.add_argument("--members", type=int, default=1024); ap.add_argument("--iters", type=int, default=6); ap.add_argument("--host-loop", action="store_true", help="the round-3 loop: one rollout launch + torch.where merges per step length"); ap.add_argument("--semi", action="store_true"); a = ap.parse_args()
 N, B = 40, a.members
 L = capi.LandingLib(N, 0); R = rbd.Rbd(L)
-S = wb.WholeBodySQP(L, R, N, T.DT, T.Q, T.R, T.QN, device="cuda")
+S = wb.WholeBodySQP(L, R, N, T.DT, T.Q, T.R, T.QN, device="cuda", fused=not a.host_loop, semi_implicit=a.semi)
 nb = min(B, 64)
 x0, u0, xref, f = T._problem(np.random.default_rng(5), nb, N)
 rep = (B + nb - 1) // nb
@@ -33,10 +33,12 @@ def timed(fn, reps=5):
 t_lin, (A, Hinv) = timed(lambda: S.linearise(x, u, df))
 t_back, (K, kff, dV, ok) = timed(lambda: S.backward(x, u, dxr, A, Hinv))
 t_roll, _ = timed(lambda: S.rollout(x, u, dxr, df, K, kff, alphas=S.alphas[:1]))
+t_roll_all, _ = timed(lambda: S.rollout(x, u, dxr, df, K, kff, alphas=S.alphas))
 cost = out["cost"].cpu().numpy()
 print(json.dumps({"workload": "SQP (Gauss-Newton / iLQR) on the 18-DoF floating-base model, N=40, batch=%d, fp64 (BASELINE configs[3])" % B,
                   "iterations": a.iters, "wall_ms_per_iteration_incl_host": 1e3 * wall / (a.iters + 1),
-                  "linearise_ms": t_lin, "backward_ms": t_back, "rollouts_ms": t_roll, "kernel_ms_per_iteration": t_lin + t_back + t_roll,
+                  "linearise_ms": t_lin, "backward_ms": t_back, "rollouts_ms": t_roll, "rollout_all_step_lengths_ms": t_roll_all, "kernel_ms_per_iteration": t_lin + t_back + (t_roll if a.host_loop else t_roll_all),
+                  "step_length_choice": "host loop (one launch per step length, torch.where merges)" if a.host_loop else "one rollout launch with all step lengths + landing_wb_select on the device", "integrator": "semi-implicit Euler" if a.semi else "explicit Euler", "dt": T.DT,
                   "sqp_iterations_per_s_whole_batch": B / ((t_lin + t_back + t_roll) * 1e-3),
                   "cost_mean_by_iteration": [float(v) for v in cost.mean(axis=1)], "cost_decreased_members": int((cost[-1] < cost[0]).sum()),
                   "rollout_launches_per_iteration": "one per step length tried (backtracking 1, 0.5, 0.25, 0.1, 0.03); normally one", "alpha_mean_by_iteration": [float(v) for v in out["alpha"].mean(dim=1).cpu()]}))
