@@ -483,6 +483,15 @@ int landing_solve_kinodyn_24(landing_ctx* ctx, int N, int B, const landing_kinod
                              const double* jpos_min, const double* jpos_max, const double* kin_box, const double* mu, const double* l_leg_max,
                              const double* mass, const double* Ib, const double* Ib_inv, const landing_solver_opts* opts,
                              double* x_star, double* f_star, double* lam_g, int* status, int* iters, double* kkt);
+/* the reference's 'quad3D' tree with the 'mc3D' parameters as a landing_rbd_model (for C / mex callers; rbd.py builds the same in Python), and the
+ * one-call form of landing_solve_kinodyn_24 for FFI stubs: a context per (N, device) with that model is cached inside the library */
+void landing_rbd_model_mc3d(landing_rbd_model* model);
+int landing_solve_kinodyn_24_on(int device, int N, int B, const double* Xref, const double* Uref, const double* dt, const double* q_min, const double* q_max,
+                                const double* qd_min, const double* qd_max, const double* q_init, const double* qd_init, const double* c_init,
+                                const double* q_term_min, const double* q_term_max, const double* qd_term_min, const double* qd_term_max, const double* QN,
+                                const double* x0, const double* jpos_min, const double* jpos_max, const double* kin_box, const double* mu, const double* l_leg_max,
+                                const double* mass, const double* Ib, const double* Ib_inv, const landing_solver_opts* opts,
+                                double* x_star, double* f_star, double* lam_g, int* status, int* iters, double* kkt);
 /* CCS patterns of this NLP in CasADi's compressed form, which = 0: jac_g_x (ng x nx), 1: upper triangle of hess_gamma_x_x; colind [nx + 1],
  * row [*nnz] (pass row = NULL to get the count first).  Derived from the derivative kernels themselves (device needed). */
 int landing_kinodyn_pattern(landing_ctx* ctx, int N, int which, long long* colind, long long* row, long long* nnz);
@@ -517,6 +526,9 @@ int landing_wb_rollout(landing_ctx* ctx, int B, int N, int nalpha, const double*
  * landing_wb_select: after ONE landing_wb_rollout launch with all step lengths, every member keeps the first rollout of the list that lowers its
  * cost (d_x, d_u, d_cost updated in place, d_step [B] = the step length taken, 0 = none; members with d_ok = 0 keep their trajectory). */
 int landing_wb_set_integrator(landing_ctx* ctx, int semi_implicit);
+/* two-stage search: roll out the full step first (the usual winner), select, then landing_wb_skip_taken(d_step) + a rollout of the shorter step
+ * lengths, in which every member that already took a step returns at once, + landing_wb_select with nalpha NEGATED (= keep earlier choices) */
+int landing_wb_skip_taken(landing_ctx* ctx, const double* d_step);
 int landing_wb_select(landing_ctx* ctx, int B, int N, int nalpha, const double* d_alphas, const int* d_ok, const double* d_xnew, const double* d_unew,
                       const double* d_costnew, double* d_x, double* d_u, double* d_cost, double* d_step, void* stream);
 

@@ -169,6 +169,7 @@ struct WbRollArgs {
   const double* K; const double* kff;                            // null: open-loop rollout of u (initialisation)
   double Q[WB_NX], R[WB_NU], QN[WB_NX];
   double* xnew; double* unew; double* cost;                      // [nalpha][B][N+1][36], [nalpha][B][N][12], [nalpha][B]
+  const double* skip;                                            // [B] or null: members with skip[b] != 0 (a step length already taken, landing_wb_select) are not rolled out: cost = inf
 };
 
 // nonlinear rollout under u = u_k + alpha kff_k + K_k (x - x_k), one thread per (step length, member)
@@ -176,6 +177,7 @@ __global__ void __launch_bounds__(64) landing_wb_rollout_kernel(WbRollArgs a) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= a.nalpha * a.B) return;
   const int ia = idx / a.B, b = idx % a.B, N = a.N;
+  if (a.skip && a.skip[b] != 0.0) { a.cost[(size_t)ia * a.B + b] = INFINITY; return; }
   const RbdModel& M = *a.model;
   const double alpha = a.alphas[ia];
   const double* xb = a.x + (size_t)b * (N + 1) * WB_NX; const double* ub = a.u + (size_t)b * N * WB_NU;
@@ -453,6 +455,7 @@ __global__ void __launch_bounds__(64) landing_wb_rollout_lds_kernel(WbRollArgs a
   if ((int)threadIdx.x >= WB_TPB || idx >= a.nalpha * a.B) return;
   const WsView W{ws + threadIdx.x};
   const int ia = idx / a.B, b = idx % a.B, N = a.N;
+  if (a.skip && a.skip[b] != 0.0) { a.cost[(size_t)ia * a.B + b] = INFINITY; return; }
   const RbdModel& M = Ms;
   const double alpha = a.alphas[ia];
   const double* xb = a.x + (size_t)b * (N + 1) * WB_NX; const double* ub = a.u + (size_t)b * N * WB_NU;
@@ -486,13 +489,14 @@ __global__ void __launch_bounds__(64) landing_wb_rollout_lds_kernel(WbRollArgs a
 // Step-length selection on the device: member b keeps the FIRST of the nalpha rollouts (in the order of the list) whose cost is below its
 // current one -- trajectory, controls, cost and the step length taken (0 = none) -- unless its backward pass failed (ok = 0).  Replaces one
 // rollout launch + torch.where merges per step length of the host loop.
-struct WbSelArgs { int B, N, nalpha; const double* alphas; const int* ok; const double* xnew; const double* unew; const double* costnew; double* x; double* u; double* cost; double* step; };
+struct WbSelArgs { int B, N, nalpha, keep; const double* alphas; const int* ok; const double* xnew; const double* unew; const double* costnew; double* x; double* u; double* cost; double* step; };
 __global__ void __launch_bounds__(256) landing_wb_select_kernel(WbSelArgs a) {
   const int b = blockIdx.x, t = threadIdx.x;
   if (b >= a.B) return;
   int pick = -1;
   const double c0 = a.cost[b];
-  if (a.ok[b]) for (int ia = 0; ia < a.nalpha && pick < 0; ++ia) if (a.costnew[(size_t)ia * a.B + b] < c0) pick = ia;      // (uniform: every thread reads the same words)
+  const bool taken = a.keep && a.step && a.step[b] != 0.0;      // second stage of a two-stage search: the member already took a step length
+  if (a.ok[b] && !taken) for (int ia = 0; ia < a.nalpha && pick < 0; ++ia) if (a.costnew[(size_t)ia * a.B + b] < c0) pick = ia;      // (uniform: every thread reads the same words)
   __syncthreads();      // every thread has read cost[b] before thread 0 overwrites it
   if (pick >= 0) {
     const size_t nxs = (size_t)(a.N + 1) * WB_NX, nus = (size_t)a.N * WB_NU;
@@ -500,7 +504,7 @@ __global__ void __launch_bounds__(256) landing_wb_select_kernel(WbSelArgs a) {
     for (size_t e = t; e < nxs; e += blockDim.x) a.x[(size_t)b * nxs + e] = xs[e];
     for (size_t e = t; e < nus; e += blockDim.x) a.u[(size_t)b * nus + e] = us[e];
   }
-  if (t == 0) { if (pick >= 0) a.cost[b] = a.costnew[(size_t)pick * a.B + b]; if (a.step) a.step[b] = pick >= 0 ? a.alphas[pick] : 0.0; }
+  if (t == 0) { if (pick >= 0) a.cost[b] = a.costnew[(size_t)pick * a.B + b]; if (a.step && !taken) a.step[b] = pick >= 0 ? a.alphas[pick] : 0.0; }
 }
 
 }  // namespace landing

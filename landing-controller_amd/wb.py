@@ -24,6 +24,7 @@ class WholeBodySQP:
         lib.lib.landing_wb_set_integrator.argtypes = [C.c_void_p, C.c_int]
         lib._check(lib.lib.landing_wb_set_integrator(lib.ctx, 1 if semi_implicit else 0), "landing_wb_set_integrator")
         lib.lib.landing_wb_select.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 10
+        lib.lib.landing_wb_skip_taken.argtypes = [C.c_void_p, C.c_void_p]
         self.Q = np.ascontiguousarray(Q, float); self.R = np.ascontiguousarray(R, float); self.QN = np.ascontiguousarray(QN, float)
         assert self.Q.shape == (36,) and self.R.shape == (12,) and self.QN.shape == (36,)
         self.alphas = torch.tensor(list(alphas), dtype=torch.float64, device=self.dev)
@@ -86,11 +87,21 @@ class WholeBodySQP:
             # backtracking: the step lengths in decreasing order, one rollout launch each, a member keeps the FIRST one that lowers its
             # cost; the loop ends as soon as every member has one (normally after alpha = 1)
             if self.fused:
-                xn, un, cn = self.rollout(x, u, xref, f_foot, K, kff, alphas=self.alphas)
+                # two stages, no host synchronisation: the full step for everybody, then the shorter ones for the members that did not take it
+                # (the second rollout returns at once for all others -- normally for every member)
                 step = torch.zeros_like(cost)
+                x_base, u_base = x.clone(), u.clone()      # both stages roll out from the trajectory of the backward pass
                 x = x.contiguous(); u = u.contiguous(); cost = cost.contiguous()
-                self.L._check(self.L.lib.landing_wb_select(self.L.ctx, B, self.N, int(self.alphas.shape[0]), self.alphas.data_ptr(), ok.data_ptr(), xn.data_ptr(), un.data_ptr(),
-                                                           cn.data_ptr(), x.data_ptr(), u.data_ptr(), cost.data_ptr(), step.data_ptr(), self._stream()), "landing_wb_select")
+                na = int(self.alphas.shape[0])
+                for stage, (lo, hi) in enumerate(((0, 1), (1, na))):
+                    if hi <= lo:
+                        continue
+                    if stage == 1:
+                        self.L._check(self.L.lib.landing_wb_skip_taken(self.L.ctx, step.data_ptr()), "landing_wb_skip_taken")
+                    al = self.alphas[lo:hi].contiguous()
+                    xn, un, cn = self.rollout(x_base, u_base, xref, f_foot, K, kff, alphas=al)
+                    self.L._check(self.L.lib.landing_wb_select(self.L.ctx, B, self.N, (hi - lo) * (-1 if stage else 1), al.data_ptr(), ok.data_ptr(), xn.data_ptr(), un.data_ptr(),
+                                                               cn.data_ptr(), x.data_ptr(), u.data_ptr(), cost.data_ptr(), step.data_ptr(), self._stream()), "landing_wb_select")
                 hist.append(cost.clone()); steps.append(step)
                 if rel_tol > 0.0 and float(((hist[-2] - hist[-1]) / hist[-1].clamp_min(1e-300)).max()) <= rel_tol:
                     break

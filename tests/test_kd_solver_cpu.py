@@ -139,3 +139,25 @@ def test_presolve_certificate_and_patterns(emu):
 
 
 NNZ_JAC, NNZ_HESS = 13536, 5720      # N = 20 (three random points agree; the reference ships no generated code of this NLP to compare with)
+
+
+def test_c_model_builder_equals_python_model_and_gateway_compiles(tmp_path):
+    """landing_rbd_model_mc3d (what C / mex callers use) fills the struct exactly as rbd.quad3d_model does; matlab/landing_refine_mex.c compiles
+    against the mex.h stub and links to the product library"""
+    import ctypes as C
+    subprocess.run(["make", "-C", os.path.join(PKG, "csrc"), "all"], check=True, capture_output=True)
+    raw = lc("capi").load(os.path.join(PKG, "liblanding_mi355x.so"))
+    rbd = lc("rbd")
+    m = rbd.RbdModel()
+    raw.landing_rbd_model_mc3d.argtypes = [C.POINTER(rbd.RbdModel)]
+    raw.landing_rbd_model_mc3d.restype = None
+    raw.landing_rbd_model_mc3d(C.byref(m))
+    ref = rbd.quad3d_model()
+    for name, _ in rbd.RbdModel._fields_:
+        a, b = np.ctypeslib.as_array(getattr(m, name)) if hasattr(getattr(m, name), "_length_") else getattr(m, name), \
+               np.ctypeslib.as_array(getattr(ref, name)) if hasattr(getattr(ref, name), "_length_") else getattr(ref, name)
+        assert np.allclose(a, b, rtol=1e-13, atol=1e-19), name      # (the inertia about the link origin is formed in another order of operations: last-bit differences)
+    so = os.path.join(str(tmp_path), "refine_gateway.so")
+    subprocess.run(["gcc", "-O1", "-std=c99", "-D_POSIX_C_SOURCE=200809L", "-fPIC", "-shared", "-Wall", "-Werror", "-Wno-unused-function", "-I", os.path.join(ROOT, "tests", "stubs"),
+                    "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "matlab", "landing_refine_mex.c"), "-o", so, "-L", PKG, "-llanding_mi355x", "-Wl,-rpath," + PKG], check=True)
+    assert "mexFunction" in subprocess.run(["nm", "-D", so], capture_output=True, text=True).stdout
