@@ -483,7 +483,7 @@ int landing_solve_kinodyn_24(landing_ctx* ctx, int N, int B, const landing_kinod
                              const double* jpos_min, const double* jpos_max, const double* kin_box, const double* mu, const double* l_leg_max,
                              const double* mass, const double* Ib, const double* Ib_inv, const landing_solver_opts* opts,
                              double* x_star, double* f_star, double* lam_g, int* status, int* iters, double* kkt);
-/* the reference's 'quad3D' tree with the 'mc3D' parameters as a landing_rbd_model (for C / mex callers; rbd.py builds the same in Python), and the
+/* the reference's 'quad3D' tree with the 'mc3D' parameters in the model struct above, for C / mex callers (rbd.py builds the same in Python), and the
  * one-call form of landing_solve_kinodyn_24 for FFI stubs: a context per (N, device) with that model is cached inside the library */
 void landing_rbd_model_mc3d(landing_rbd_model* model);
 int landing_solve_kinodyn_24_on(int device, int N, int B, const double* Xref, const double* Uref, const double* dt, const double* q_min, const double* q_max,
