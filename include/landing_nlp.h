@@ -89,7 +89,11 @@ typedef struct {
                             1024..2048 drop states (N=40, tools/dev/fracsweep.py): 0.5 -> 97.6 % solved, mean 80 iterations;
                             any value in 0.02..0.2 -> 100 % solved, mean 64 iterations.                                          */
   double kappa_eps;      /* barrier-subproblem tolerance factor (IPOPT's barrier_tol_factor, default there 10): a barrier problem counts as
-                            solved when its scaled optimality error is <= kappa_eps mu.  Default 80 (round 3).  IPOPT's 10 belongs to its
+                            solved when its scaled optimality error is <= kappa_eps mu.  Default 0 = AUTOMATIC (round 4): 80 for the
+                            terminal-cost form (below), IPOPT's 10 for the forms with a running cost (landing_form.run_cost 1 / 2) -- on the
+                            17 stored N = 40 solutions of the reference, which are solutions of the running-cost form, 10 ends in the stored
+                            local minimum or a better one 13 times, 80 only 11 times (tests/test_gpu_solver.py), and the bench workload is
+                            the terminal-cost form.  A positive value is taken as given.  The 80 of round 3:  IPOPT's 10 belongs to its
                             monotone mode, which the reference does not use (mu_strategy adaptive, :244): this solver's mu schedule IS the
                             monotone one, and with 10 a member spends 30-40 of its ~48 iterations polishing the first barrier problem
                             (mu = 0.1) before mu may fall.  MI355X, 64 fresh batches of 1024 (N = 40, delta_floor on): 5 / 10 / 20 / 40 /

@@ -59,12 +59,12 @@ struct KdState {
 struct KdMem {
   double *x, *xt, *dx, *gx;
   double *g, *gt, *s, *ds, *zL, *zU, *y, *yn, *sig, *rho;
-  double *J, *H, *rec;
+  double *J, *H, *rec, *wbuf;      // wbuf [N][72]: gathered stage variables of the in-kernel row evaluation
   KdState* st;
 };
 __host__ __device__ inline size_t kd_ws_stride(int N) {
   const size_t nx = (size_t)kd_nx(N), ng = (size_t)kd_ng(N);
-  return 4 * nx + 10 * ng + (size_t)N * KD_ROWS * KD_NW + (size_t)N * KD_NW * KD_NW + (size_t)(N + 1) * KD_REC + (sizeof(KdState) + 7) / 8 + 8;
+  return 4 * nx + 10 * ng + (size_t)N * KD_ROWS * KD_NW + (size_t)N * KD_NW * KD_NW + (size_t)(N + 1) * KD_REC + (size_t)N * KD_NW + (sizeof(KdState) + 7) / 8 + 8;
 }
 __device__ __forceinline__ KdMem kd_carve(int N, double* w) {
   const size_t nx = (size_t)kd_nx(N), ng = (size_t)kd_ng(N);
@@ -73,6 +73,7 @@ __device__ __forceinline__ KdMem kd_carve(int N, double* w) {
   M.g = w; w += ng; M.gt = w; w += ng; M.s = w; w += ng; M.ds = w; w += ng; M.zL = w; w += ng; M.zU = w; w += ng;
   M.y = w; w += ng; M.yn = w; w += ng; M.sig = w; w += ng; M.rho = w; w += ng;
   M.J = w; w += (size_t)N * KD_ROWS * KD_NW; M.H = w; w += (size_t)N * KD_NW * KD_NW; M.rec = w; w += (size_t)(N + 1) * KD_REC;
+  M.wbuf = w; w += (size_t)N * KD_NW;
   M.st = reinterpret_cast<KdState*>(w);
   return M;
 }
@@ -92,14 +93,15 @@ struct KdSolveArgs {
 __host__ __device__ inline int kd_v2w(int j) { return j < 48 ? j : j + 12; }
 
 // g at x for one member: one lane per interval (callers pass every thread of the block; lanes >= N only write boundary rows / idle)
-KD_PHASE void kd_member_eval_g(const KdNlpParams& P, const RbdModel& M, int N, const double* x, double* g) {
+KD_PHASE void kd_member_eval_g(const KdNlpParams& P, const RbdModel& M, int N, const double* x, double* g, double* wbuf) {
   for (int k = threadIdx.x; k < N; k += blockDim.x) {
-    double w[KD_NW], out[KD_ROWS];
+    // the 72 stage variables are gathered into the member's workspace and read from there where they are used: as a local array they are
+    // promoted to 144 VGPRs and, with the rows' temporaries, put the phase at 253 VGPRs + 32 AGPRs of spill (one workgroup per CU)
+    double* w = wbuf + (size_t)k * KD_NW;
     for (int j = 0; j < KD_NW; ++j) { const int i = kd_w_index(N, k, j); w[j] = i >= 0 ? x[i] : 0.0; }
-    const bool last = k == N - 1;
-    kd_stage_rows<double>(P, M, k, last, w, out);
-    const int nr = last ? KD_ROWS_LAST : KD_ROWS;
-    for (int r = 0; r < nr; ++r) g[KD_BND + k * KD_ROWS + r] = out[r];
+    // the rows go straight to the member's g array (a local out[141] is promoted to registers by the unrolled row code: 255 VGPRs + AGPR spills,
+    // one workgroup per CU); the last interval writes its 117 rows only
+    kd_stage_rows<double>(P, M, k, k == N - 1, w, g + KD_BND + k * KD_ROWS);
   }
   if (threadIdx.x >= 64 && threadIdx.x < 64 + 48) {      // boundary rows (coordinate picks), by a wave that has no interval to evaluate
     const int i = threadIdx.x - 64, oU = 12 * (N + 1) + 12 * N;
@@ -171,6 +173,9 @@ KD_PHASE void kd_condense_stage(const KdMem& M, int N, int k, double delta) {
     for (int t = 0; t < 4; ++t)
       acc[t] = mfma_tile<KD_JC_ROWS / 4>(acc[t], [&](int i, int kk) { return S.Jc[kk * KD_JC_S + 16 * wave + i] * S.sgc[kk]; },
                                          [&](int kk, int j) { return S.Jc[kk * KD_JC_S + 16 * t + j]; });
+#if defined(__HIP_DEVICE_COMPILE__)
+    for (int t = 0; t < 4; ++t) asm volatile("" : "+v"(acc[t]));      // accumulators in VGPRs: AGPRs of this phase would add to the VGPR maximum of the
+#endif                                                                  // row-evaluation phase (253) and cost the kernel its second workgroup per CU
     if (tid < nv) { for (int kk = 0; kk < KD_JC_ROWS; ++kk) macc += S.Jc[kk * KD_JC_S + tid] * S.rhc[kk]; }
     __syncthreads();
   }
@@ -462,7 +467,7 @@ __global__ void __launch_bounds__(KD_THREADS) landing_kd_init_kernel(KdSolveArgs
     M.x[i] = v;
   }
   __syncthreads();
-  kd_member_eval_g(A.P, *A.model, N, M.x, M.g);
+  kd_member_eval_g(A.P, *A.model, N, M.x, M.g, M.wbuf);
   __syncthreads();
   kd_init_slacks(M, ng, lbm, ubm, A.o);
   KdState& K = KSH.ks;
@@ -562,7 +567,7 @@ __global__ void __launch_bounds__(KD_THREADS, 2) landing_kd_iter_kernel(KdSolveA
         M.x[i] = v;
       }
       __syncthreads();
-      kd_member_eval_g(A.P, *A.model, N, M.x, M.g);
+      kd_member_eval_g(A.P, *A.model, N, M.x, M.g, M.wbuf);
       __syncthreads();
     }
     kd_init_slacks(M, ng, lbm, ubm, o);
@@ -673,7 +678,7 @@ __global__ void __launch_bounds__(KD_THREADS, 2) landing_kd_iter_kernel(KdSolveA
     const double alpha = K.alpha, mu = K.mu, omt = K.omt;
     for (int i = tid; i < nx; i += NT) M.xt[i] = M.x[i] + alpha * M.dx[i];
     __syncthreads();
-    kd_member_eval_g(A.P, *A.model, N, M.xt, M.gt);
+    kd_member_eval_g(A.P, *A.model, N, M.xt, M.gt, M.wbuf);
     __syncthreads();
     double tht = 0.0, bt = 0.0, ft = 0.0;
     for (int r = tid + 24; r < ng; r += NT) {
@@ -755,7 +760,7 @@ __global__ void __launch_bounds__(KD_THREADS, 2) landing_kd_iter_kernel(KdSolveA
     const double alpha = K.alpha;
     for (int i = tid; i < nx; i += NT) M.xt[i] = M.x[i] + alpha * M.dx[i];
     __syncthreads();
-    kd_member_eval_g(A.P, *A.model, N, M.xt, M.gt);
+    kd_member_eval_g(A.P, *A.model, N, M.xt, M.gt, M.wbuf);
     __syncthreads();
   }
   KD_PROF(5);

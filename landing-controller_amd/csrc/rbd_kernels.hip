@@ -14,6 +14,7 @@
 // memory; the linearisation is a central-difference sweep of the forward dynamics with one thread per (knot, column).
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <type_traits>
 
 namespace landing {
 
@@ -539,6 +540,46 @@ __device__ void kd_compose(const T* Eu, const T* ru, T* Ea, T* ra) {      // (Ea
   ra[0] = ra[0] + t.x; ra[1] = ra[1] + t.y; ra[2] = ra[2] + t.z;
 }
 
+// Kinematic rows of one leg of an interval (landing_optimization.m:148-171, 182): p_rel x y z, |p_rel|^2, the three leg torques -> o7[0..6];
+// foot position of the tree -> fk3.  Everything it needs comes through pointers (w = the interval's 72 variables, R body -> world, (E0, r0) the
+// world -> base transform of the tree).  For T = double the function is called out of line (kd_leg_kin_d): inlined four times into the row
+// code it put the in-kernel row evaluation of the interior-point solver at 253 VGPRs + 32 AGPRs of spill, one workgroup per CU.
+template <class T>
+__device__ __forceinline__ void kd_leg_kin(const RbdModel& M, int l, const T* w, const T* R, const T* E0, const T* r0, T* o7, T* fk3) {
+  typedef typename KdVec<T>::type V;
+  const T zero = lit(w[0], 0.0);
+  const T* X = w; const T* c = w + 12; const T* f = w + 24; const T* jp = w + 36;
+  const V pos = mk3(X[0], X[1], X[2]);
+  const double l14 = M.l1 + M.l4;
+  T Ej[9], rj[3];
+  int q = 0;
+    const double hx = l < 2 ? 0.19 : -0.19, hy = (l & 1) ? 0.1 : -0.1;        // params.hipSrbmLocation (get_robot_params.m:90-91)
+    const V pr = sub3(mk3(c[3 * l], c[3 * l + 1], c[3 * l + 2]), add3(pos, mk3(R[0] * hx + R[1] * hy, R[3] * hx + R[4] * hy, R[6] * hx + R[7] * hy)));
+    o7[q++] = pr.x; o7[q++] = pr.y; o7[q++] = pr.z;                                                                       // :157-163
+    o7[q++] = pr.x * pr.x + pr.y * pr.y + pr.z * pr.z;                                                                      // :164
+    // leg torques J_f'(-R_world_to_body f)  (:167-171, get_foot_jacobians_mc.m:12-24)
+    T s1, c1, s2, c2, s3, c3;
+    sincos_t(jp[3 * l], s1, c1); sincos_t(jp[3 * l + 1], s2, c2); sincos_t(jp[3 * l + 2], s3, c3);
+    const T c23 = c2 * c3 - s2 * s3, s23 = s2 * c3 + c2 * s3;
+    const double ss = (l & 1) ? 1.0 : -1.0;
+    const T J[3][3] = {{zero, c23 * M.l3 + c2 * M.l2, c23 * M.l3},
+                       {c1 * c23 * M.l3 + c1 * c2 * M.l2 - s1 * (l14 * ss), zero - s1 * s23 * M.l3 - s1 * s2 * M.l2, zero - s1 * s23 * M.l3},
+                       {s1 * c23 * M.l3 + c2 * s1 * M.l2 + c1 * (l14 * ss), c1 * s23 * M.l3 + c1 * s2 * M.l2, c1 * s23 * M.l3}};
+    const V fb = mulT3(R, mk3(zero - f[3 * l], zero - f[3 * l + 1], zero - f[3 * l + 2]));
+    for (int j = 0; j < 3; ++j) o7[q++] = J[0][j] * fb.x + J[1][j] * fb.y + J[2][j] * fb.z;
+    // foot position of the tree (get_forward_kin_foot.m)
+    T El[9], rl[3];
+    for (int j = 0; j < 9; ++j) El[j] = E0[j];
+    for (int j = 0; j < 3; ++j) rl[j] = r0[j];
+    const int jb = M.b_foot[l] - 1;
+    for (int i = jb - 2; i <= jb; ++i) { joint_xform(M.jtype[i], jp[3 * l + (i - (jb - 2))], M.E[i], M.r[i], Ej, rj); kd_compose(Ej, rj, El, rl); }
+    const V pf = add3(mk3(rl[0], rl[1], rl[2]), mulT3(El, mk3(lit(w[0], M.foot_r[l][0]), lit(w[0], M.foot_r[l][1]), lit(w[0], M.foot_r[l][2]))));
+  fk3[0] = pf.x; fk3[1] = pf.y; fk3[2] = pf.z;
+}
+__device__ __noinline__ void kd_leg_kin_d(const RbdModel& M, int l, const double* w, const double* R, const double* E0, const double* r0, double* o7, double* fk3) {
+  kd_leg_kin<double>(M, l, w, R, E0, r0, o7, fk3);
+}
+
 // legmask: bit l set = the rows of leg l that need the leg's kinematics (hip-relative position, leg torques, forward kinematics: the
 // expensive part of the function) are evaluated; a cleared bit writes zeros there.  The value / Jacobian kernels pass 15; the Hessian kernel
 // passes the one leg a pair of directions belongs to (second derivatives of the other legs' rows vanish for that pair).
@@ -597,6 +638,9 @@ __device__ void kd_stage_rows(const KdNlpParams& P, const RbdModel& M, int k, bo
       fkv[3 * l] = c[3 * l]; fkv[3 * l + 1] = c[3 * l + 1]; fkv[3 * l + 2] = c[3 * l + 2];
       continue;
     }
+    // hip-relative foot position (4 rows), leg torques (3 rows), foot position of the tree: kd_leg_kin (out of line for T = double)
+    if constexpr (std::is_same<T, double>::value) { kd_leg_kin_d(M, l, w, R, E0, r0, out + r, fkv + 3 * l); r += 7; continue; }
+    // (the dual / hyper-dual instantiations of the derivative kernels keep the rows inline: the same code as kd_leg_kin, in place)
     const double hx = l < 2 ? 0.19 : -0.19, hy = (l & 1) ? 0.1 : -0.1;        // params.hipSrbmLocation (get_robot_params.m:90-91)
     const V pr = sub3(mk3(c[3 * l], c[3 * l + 1], c[3 * l + 2]), add3(pos, mk3(R[0] * hx + R[1] * hy, R[3] * hx + R[4] * hy, R[6] * hx + R[7] * hy)));
     out[r++] = pr.x; out[r++] = pr.y; out[r++] = pr.z;                                                                       // :157-163

@@ -261,7 +261,9 @@ def test_n40_reference_solutions_known_answer(oracle_mod):
     # or clip_k 8 give 9 / 8 -- the reason those faster settings are not the defaults (profiles/r03_delta_floor.txt)
     # (non-convex NLP: which KKT point a run reaches depends on the regularisation path; every returned point is certified above)
     print("N=40 stored reference solutions: converged %d of %d, same local minimum %d, same or better objective %d" % (ok.sum(), len(Ps), same, better))
-    assert same >= 4 and better >= 11, (same, better, ok.sum())
+    # round 4: kappa_eps chosen by formulation (0 = automatic: IPOPT's 10 for the forms with a running cost, which these stored solutions are;
+    # 80 for the terminal-cost form of the bench): 17 of 17, 5 coincide, 13 same or better -- the round-2 level, assertion restored
+    assert same >= 5 and better >= 13, (same, better, ok.sum())
 
 
 def test_reference_bound_frac_is_a_supported_configuration(libs, oracle_mod):
