@@ -131,6 +131,7 @@ namespace {
 struct RecJ {
   std::vector<long long>* rows; std::vector<long long>* colind; long long base_own, base_prev; bool first;
   void col() { colind->push_back((long long)rows->size()); }
+  void end() {}
   void put(int r, double) {
     long long g;
     if (r >= 0) g = base_own + r;
@@ -245,7 +246,7 @@ landing_ctx* landing_create(int N, int device, const landing_form* form) {
   // 36-38 % of 8 TB/s against 39.5-41.7 % with the single stream on the same box, profiles/r03_sweep_timeline.txt)
   { const char* e = getenv("LANDING_SWEEP_HSPLIT"); c->hess_split = (e && e[0] == '1'); }
   {  // positions of the U_k Jacobian entries of stages 0 / N-1 inside the uniform (middle-stage) emission sequence
-    struct RecCodes { std::vector<int>* v; void col() {} void put(int r, double) { v->push_back(r); } };
+    struct RecCodes { std::vector<int>* v; void col() {} void end() {} void put(int r, double) { v->push_back(r); } };
     std::vector<int> cx, cu;
     srbm::StageVars z; srbm::StageParams P;
     memset(&z, 0, sizeof(z)); memset(&P, 0, sizeof(P)); P.mass = 1.0;
@@ -322,10 +323,7 @@ int landing_eval_batch(landing_ctx* ctx, int B, const double* d_x, const double*
     HIP_TRY(hipEventRecord(ctx->ev_fork, s0));
     HIP_TRY(hipStreamWaitEvent(sj, ctx->ev_fork, 0)); HIP_TRY(hipStreamWaitEvent(sh, ctx->ev_fork, 0)); HIP_TRY(hipStreamWaitEvent(sh2, ctx->ev_fork, 0));
   }
-  if (d_hess && ctx->hess_split) {
-    hipLaunchKernelGGL(landing::landing_sweep_kernel<3>, dim3(B), dim3(64), 0, sh, ctx->L, B, A);
-    hipLaunchKernelGGL(landing::landing_sweep_kernel<4>, dim3(B), dim3(64), 0, sh2, ctx->L, B, A);
-  } else if (d_hess) hipLaunchKernelGGL(landing::landing_sweep_kernel<1>, dim3(B), dim3(64), 0, sh, ctx->L, B, A);
+  if (d_hess) hipLaunchKernelGGL(landing::landing_sweep_kernel<1>, dim3(B), dim3(64), 0, sh, ctx->L, B, A);
   if (d_jac) hipLaunchKernelGGL(landing::landing_sweep_kernel<0>, dim3(B), dim3(64), 0, sj, ctx->L, B, A);
   if (d_g) hipLaunchKernelGGL(landing::landing_sweep_kernel<2>, dim3(B), dim3(64), 0, s0, ctx->L, B, A);
   // the part of the sweep that needs no stage evaluation has its own light instantiation (eval_kernels.hip)

@@ -73,14 +73,15 @@ __device__ __forceinline__ void load_stage(const Layout& L, const double* x, con
 }
 
 struct RowStore { double* g; __device__ __forceinline__ void put(int r, double v) { g[r] = v; } };
-struct SeqStoreJ { double* q; __device__ __forceinline__ void col() {} __device__ __forceinline__ void put(int, double v) { *q++ = v; } };
-struct SeqStoreH { double* q; __device__ __forceinline__ void put(double v) { *q++ = v; } };
+struct SeqStoreJ { double* q; __device__ __forceinline__ void col() {} __device__ __forceinline__ void end() {} __device__ __forceinline__ void put(int, double v) { *q++ = v; } };
+struct SeqStoreH { double* q; __device__ __forceinline__ void end() {} __device__ __forceinline__ void put(double v) { *q++ = v; } };
 struct LamStage { const double* l; __device__ __forceinline__ double operator()(int r) const { return l[r]; } };
 
 // column-wise accumulation of J^T lam (grad_gamma_x)
 struct DotLam {
   const double* lam_own; const double* lam_prev; bool first; double* out; double acc; bool open;
   __device__ __forceinline__ void col() { if (open) *out++ = acc; acc = 0.0; open = true; }
+  __device__ __forceinline__ void end() {}
   __device__ __forceinline__ void put(int r, double v) {
     double l;
     if (r >= 0) l = lam_own[r];
@@ -91,22 +92,27 @@ struct DotLam {
   __device__ __forceinline__ void finish() { if (open) *out++ = acc; open = false; }
 };
 
-// Sequential store of one CCS segment per lane, coalesced through a 64x16 LDS tile: every lane of the wavefront
-// appends its value to its own tile row; every 16 values the wave writes the tile out row by row, so that one store
-// instruction covers four 128-byte runs instead of 64 scattered 8-byte words (the direct per-lane stores are bound
-// by the L2 request rate, not by bytes: profiles/README.md).  All lanes emit the SAME sequence -- stages 0 and N-1,
-// whose segments lack the entries of the neighbouring stage's no-slip rows, emit placeholders there and the
+// Sequential store of one CCS segment per lane, coalesced through an LDS tile: every lane of the wavefront appends its value to its own
+// tile row; every 16 values the wave writes 16-value runs out row by row, so that one store instruction covers four 128-byte runs instead of 64
+// scattered 8-byte words (the direct per-lane stores are bound by the L2 request rate, not by bytes: profiles/README.md).  All lanes emit the
+// SAME sequence -- stages 0 and N-1, whose segments lack the entries of the neighbouring stage's no-slip rows, emit placeholders there and the
 // write-out compacts them through `map` (position in the uniform sequence -> position in the segment, -1 = absent).
-constexpr int TILE_LD = 17;
+//
+// Round 4: the runs are ALIGNED to 128-byte lines.  The CCS segments start wherever the reference's nonzero order puts them (157 k, 228 k + ...
+// doubles, members 15 364 doubles apart), so a run of the 16 values emitted last straddles two lines; measured with the store pattern alone
+// (tools/dev/wbench.hip, 4096 waves x 40 rows): 3.4 TB/s against 6.7 TB/s for line-aligned runs.  A tile row is therefore a RING of the last 32
+// values: at the F-th write-out a lane row writes the aligned block that became complete one round earlier, positions [h + 16 (F - 2), h + 16 (F - 1))
+// with h = 1..16 the distance of the segment start to the next line boundary (the head [0, h) goes out at F = 1, the tail at finish()).  Only the head
+// and the tail of a segment remain partial lines.  The rows of the edge stages, whose positions go through the compaction maps, keep the immediate
+// write-out.  X_k and U_k columns of a stage are emitted one after the other (srbm_stage.hpp), so both parts share ONE tile: the second emitter
+// takes the tile over at end() of the first.
+constexpr int TILE_LD = 33;
 // hides a wave-uniform value from the optimiser (empty asm on an SGPR); a no-op for the g++ host emulation of tests/emu
 #if defined(__HIP__)
 #define LANDING_OPAQUE_UNIFORM(x) asm volatile("" : "+s"(x))
 #else
 #define LANDING_OPAQUE_UNIFORM(x) ((void)0)
 #endif
-// write-out of one tile.  Inlined (an out-of-line call makes every write-out wait for its stores at the return), but
-// the position counter is laundered through an empty asm so that the 25 call sites of a stage are not specialised
-// and hoisted into one giant live range (that version spilled 1.9 KB per lane).
 // tile rows whose LDS reads are issued together in the write-out (1 = round 2's loop: one LDS round trip per row).  The Jacobian stream
 // sits at its 256-VGPR bound (2 waves per SIMD): 2; the Hessian stream runs at 1 wave per SIMD with room in the AGPRs and nothing to hide
 // an LDS round trip behind: more; the residual stream has registers to spare.
@@ -119,64 +125,108 @@ constexpr int TILE_LD = 17;
 #ifndef LANDING_FLUSH_GROUP_G
 #define LANDING_FLUSH_GROUP_G 4
 #endif
+// KIND 0: Jacobian X_k columns, 1: Jacobian U_k columns, 2: Hessian X_k columns, 3: Hessian U_k columns, 4: g rows.
+// start of stage k's segment in the member's array, and the position of emitted value `pos` inside it (-1: a placeholder of an edge stage)
 template <int KIND>
-__device__ __forceinline__ void tile_flush(const double* tile, double* gbase, const Layout* L, const int* map, int k0, int nrow, int cnt_, int n_) {
-  int cnt = cnt_, n = n_;
-  LANDING_OPAQUE_UNIFORM(cnt); LANDING_OPAQUE_UNIFORM(n);
+__device__ __forceinline__ int tile_seg(const Layout* L, int k) {
+  return KIND == 0 ? L->jx(k) : (KIND == 1 ? L->ju(k) : (KIND == 2 ? L->hx(k) : (KIND == 3 ? L->hu(k) : L->g_stage(k))));
+}
+#ifndef LANDING_TILE_IMM_MASK
+#define LANDING_TILE_IMM_MASK 0      // bit KIND set: that part is written in the emitted windows, unaligned (dev knob)
+#endif
+template <int KIND>
+__device__ __forceinline__ bool tile_edge(int k, int N) {      // rows whose positions are compacted: immediate write-out
+  if ((LANDING_TILE_IMM_MASK >> KIND) & 1) return true;
+  return KIND == 1 ? (k == 0 || k == N - 1) : (KIND == 3 ? k == 0 : (KIND == 4 ? k == N - 1 : false));
+}
+template <int KIND>
+__device__ __forceinline__ int tile_pos(const int* map, int k, int N, int pos) {
+  if (KIND == 1) { if (k == 0) pos = map[pos]; else if (k == N - 1) pos = map[228 + pos]; }
+  else if (KIND == 3) { if (k == 0) pos = (pos < 72) ? ((pos % 6 == 4) ? -1 : pos - (pos / 6) - (pos % 6 > 4 ? 1 : 0)) : pos - 12; }
+  else if (KIND == 4) {   // residual rows; the last stage has no no-slip rows (80 instead of 104 rows)
+    if (k == N - 1) {
+      if (pos >= 64) pos -= 24;
+      else if (pos >= 16) { const int l = (pos - 16) / 12, t = (pos - 16) % 12; pos = t < 2 ? 16 + 6 * l + t : (t < 8 ? -1 : 16 + 6 * l + t - 6); }
+    }
+  }
+  return pos;
+}
+// write-out of one tile; FIN = false: regular round (cnt is a multiple of 16), true: the rest of the sequence.  Inlined (an
+// out-of-line call makes every write-out wait for its stores at the return), but the position counter is laundered through an empty asm so
+// that the call sites of a stage are not specialised and hoisted into one giant live range (that version spilled 1.9 KB per lane).
+// ga = (address of gbase / 8) mod 16: with it the distance of a segment start to the next 128-byte line is 32-bit arithmetic.
+template <int KIND, bool FIN>
+__device__ __forceinline__ void tile_flush(const double* tile, double* gbase, int ga, const Layout* L, const int* map, int k0, int nrow, int cnt_) {
+  int cnt = cnt_;
+  LANDING_OPAQUE_UNIFORM(cnt);
   __builtin_amdgcn_wave_barrier();
   const int lane = threadIdx.x & 63, c = lane & 15, N = L->N;
   constexpr int FG = KIND <= 1 ? LANDING_FLUSH_GROUP_J : (KIND <= 3 ? LANDING_FLUSH_GROUP_H : LANDING_FLUSH_GROUP_G);
-  if (c < n) {
-    // a lane writes column c of the tile rows lane>>4, +4, +8, ...; the rows are taken FG at a time with their LDS reads issued
-    // together (round 2 read, waited and stored one row per trip: the write-out was a chain of exposed LDS round trips, as long as the
-    // arithmetic of the stage itself)
+  const int F = cnt >> 4;
+  const int lag = 16 * (F - 2) + c;                    // regular round, interior row: position h + lag (negative: not yet there)
+  const int done0 = F >= 1 ? 16 * (F - 1) : -16;       // rest: positions below h + done0 are written (F = 0: none, see below)
+  // a lane writes column c of the tile rows lane>>4, +4, +8, ...; the rows are taken FG at a time with their LDS reads issued together
 #pragma unroll 1
-    for (int row0 = lane >> 4; row0 < nrow; row0 += 4 * FG) {
-      double v[FG];
+  for (int row0 = lane >> 4; row0 < nrow; row0 += 4 * FG) {
+    double v[FG], v2[FG]; int q[FG], q2[FG];
 #pragma unroll
-      for (int j = 0; j < FG; ++j) { const int row = row0 + 4 * j; v[j] = tile[(row < nrow ? row : row0) * TILE_LD + c]; }
-#pragma unroll
-      for (int j = 0; j < FG; ++j) {
-        const int row = row0 + 4 * j;
-        if (row >= nrow) continue;
-        const int k = k0 + row;
-        int pos = cnt - n + c;
-        int seg;
-        if (KIND == 0) seg = L->jx(k);
-        else if (KIND == 1) { seg = L->ju(k); if (k == 0) pos = map[pos]; else if (k == N - 1) pos = map[228 + pos]; }
-        else if (KIND == 2) seg = L->hx(k);
-        else if (KIND == 3) { seg = L->hu(k); if (k == 0) pos = (pos < 72) ? ((pos % 6 == 4) ? -1 : pos - (pos / 6) - (pos % 6 > 4 ? 1 : 0)) : pos - 12; }
-        else {   // KIND 4: residual rows; the last stage has no no-slip rows (80 instead of 104 rows)
-          seg = L->g_stage(k);
-          if (k == N - 1) {
-            if (pos >= 64) pos -= 24;
-            else if (pos >= 16) { const int l = (pos - 16) / 12, t = (pos - 16) % 12; pos = t < 2 ? 16 + 6 * l + t : (t < 8 ? -1 : 16 + 6 * l + t - 6); }
-          }
-        }
-        if (pos >= 0) gbase[seg + pos] = v[j];
+    for (int j = 0; j < FG; ++j) {
+      const int row = row0 + 4 * j < nrow ? row0 + 4 * j : row0;
+      const int k = k0 + row;
+      const int seg = tile_seg<KIND>(L, k);
+      const double* tr = tile + row * TILE_LD;
+      int p1, p2 = -1;      // positions of the emitted sequence this lane writes for the row (p2: second block of the rest)
+      if (tile_edge<KIND>(k, N)) {      // immediate: the window emitted since the last round
+        if (!FIN) p1 = cnt - 16 + c; else p1 = c < (cnt & 15) ? (cnt & ~15) + c : -1;
+      } else {
+        const int h = 16 - ((ga + seg) & 15);      // 1..16
+        if (!FIN) p1 = h + lag;
+        else { p1 = (F >= 1 ? h + done0 : 0) + c; p2 = p1 + 16; if (p1 >= cnt) p1 = -1; if (p2 >= cnt) p2 = -1; }
       }
+      v[j] = tr[(p1 < 0 ? 0 : p1) & 31];
+      if (FIN) v2[j] = tr[(p2 < 0 ? 0 : p2) & 31];
+      const int d1 = p1 < 0 ? -1 : tile_pos<KIND>(map, k, N, p1);
+      q[j] = d1 < 0 ? -1 : seg + d1;
+      if (FIN) { const int d2 = p2 < 0 ? -1 : tile_pos<KIND>(map, k, N, p2); q2[j] = d2 < 0 ? -1 : seg + d2; }
+    }
+#pragma unroll
+    for (int j = 0; j < FG; ++j) {
+      if (row0 + 4 * j >= nrow) continue;
+      if (q[j] >= 0) gbase[q[j]] = v[j];
+      if (FIN) if (q2[j] >= 0) gbase[q2[j]] = v2[j];
     }
   }
   __builtin_amdgcn_wave_barrier();
 }
-// LO, HI: window of the emitted sequence this instance really writes (positions [LO, HI), multiples of 16 or the ends).  The position
-// counter is a compile-time constant at every put() of the unrolled stage code, so outside the window the store AND the arithmetic that
-// produced the value are dead code: the two halves of the split Hessian stream (landing_sweep_kernel<3>, <4>) each compute only their own part.
-template <int KIND, int LO = 0, int HI = (1 << 30)>   // 0: Jacobian X_k columns, 1: Jacobian U_k columns, 2: Hessian X_k columns, 3: Hessian U_k columns, 4: g rows
-struct TileStore {
-  double* tile;          // LDS, 64 x TILE_LD
-  double* gbase;         // member's J or H array
+__device__ __forceinline__ int tile_ga(const double* g) { return (int)((((unsigned long long)g) >> 3) & 15ull); }
+// the two emitters of a stage (X_k columns, then U_k columns) over ONE tile: end() of the X part (srbm_stage.hpp) writes its rest out
+template <int KX, int KU>
+struct TilePair {
+  double* tile;          // LDS, 64 x TILE_LD: per lane a ring of the last 32 emitted values
+  double* gbase;         // member's J / H / g array
+  int ga;                // (gbase / 8) mod 16
   const Layout* L;
   const int* map;        // edge_map (KIND 1) or nullptr
-  int k0, nrow, cnt;     // stage of tile row 0, rows really written
-  __device__ __forceinline__ void col() {}
-  __device__ __forceinline__ void put(int, double v) { put(v); }
-  __device__ __forceinline__ void put(double v) {
-    if (cnt >= LO && cnt < HI) tile[(threadIdx.x & 63) * TILE_LD + (cnt & 15)] = v;
-    ++cnt;
-    if ((cnt & 15) == 0 && cnt > LO && cnt <= HI) tile_flush<KIND>(tile, gbase, L, map, k0, nrow, cnt, 16);
+  int k0, nrow;          // stage of tile row 0, rows really written
+  int cx = 0, cu = 0;
+  bool xdone = false;
+  __device__ __forceinline__ void putx(double v) {
+    tile[(threadIdx.x & 63) * TILE_LD + (cx & 31)] = v;
+    ++cx;
+    if ((cx & 15) == 0) tile_flush<KX, false>(tile, gbase, ga, L, map, k0, nrow, cx);
   }
-  __device__ __forceinline__ void finish() { if ((cnt & 15) && cnt > LO && cnt <= HI) tile_flush<KIND>(tile, gbase, L, map, k0, nrow, cnt, cnt & 15); }
+  __device__ __forceinline__ void endx() { tile_flush<KX, true>(tile, gbase, ga, L, map, k0, nrow, cx); xdone = true; }
+  __device__ __forceinline__ void putu(double v) {
+    tile[(threadIdx.x & 63) * TILE_LD + (cu & 31)] = v;
+    ++cu;
+    if ((cu & 15) == 0) tile_flush<KU, false>(tile, gbase, ga, L, map, k0, nrow, cu);
+  }
+  __device__ __forceinline__ void finish() {
+    if (!xdone) tile_flush<KX, true>(tile, gbase, ga, L, map, k0, nrow, cx);
+    else tile_flush<KU, true>(tile, gbase, ga, L, map, k0, nrow, cu);
+  }
+  struct X { TilePair& t; __device__ __forceinline__ void col() {} __device__ __forceinline__ void end() { t.endx(); } __device__ __forceinline__ void put(int, double v) { t.putx(v); } __device__ __forceinline__ void put(double v) { t.putx(v); } };
+  struct U { TilePair& t; __device__ __forceinline__ void col() {} __device__ __forceinline__ void end() {} __device__ __forceinline__ void put(int, double v) { t.putu(v); } __device__ __forceinline__ void put(double v) { t.putu(v); } };
 };
 
 // Jacobian (FAM 0), Hessian (FAM 1) nonzeros or residual rows (FAM 2) of every stage of one member: one wavefront per member, lane = stage,
@@ -185,7 +235,7 @@ struct TileStore {
 // (register budget: the Jacobian stream fits 256 VGPRs -> 2 waves/SIMD; the Hessian stream needs the AGPR overflow
 // of the default bound, capping it costs 750 B of scratch per lane and doubles its time)
 #ifndef LANDING_SWEEP_H_WAVES
-#define LANDING_SWEEP_H_WAVES(FAM) (((FAM) == 1 || (FAM) == 3) ? 1 : 2)
+#define LANDING_SWEEP_H_WAVES(FAM) ((FAM) == 1 ? 1 : 2)
 #endif
 template <int FAM>
 __global__ void __launch_bounds__(64, LANDING_SWEEP_H_WAVES(FAM)) landing_sweep_kernel(Layout L, int B, EvalArgs A) {
@@ -195,7 +245,7 @@ __global__ void __launch_bounds__(64, LANDING_SWEEP_H_WAVES(FAM)) landing_sweep_
   const double* x = A.x + (size_t)m * L.nx;
   const double* p = A.p + (size_t)m * L.np;
   const double* lam_g = A.lam_g ? A.lam_g + (size_t)m * L.ng : nullptr;
-  __shared__ double tileX[64 * TILE_LD], tileU[64 * TILE_LD];
+  __shared__ double tile[64 * TILE_LD];
   __shared__ int emap[456];      // compaction maps of the edge stages (FAM 0): read at every U-column write-out -- from LDS, not through a dependent global load
   if (FAM == 0) { for (int i = ln; i < 456; i += 64) emap[i] = A.edge_map[i]; __builtin_amdgcn_wave_barrier(); }
   for (int k0 = 0; k0 < N; k0 += 64) {
@@ -208,19 +258,17 @@ __global__ void __launch_bounds__(64, LANDING_SWEEP_H_WAVES(FAM)) landing_sweep_
       double fz_prev[4] = {0, 0, 0, 0};
       if (k > 0) { const double* Up = x + L.x_U(k - 1); for (int l = 0; l < 4; ++l) fz_prev[l] = Up[12 + 3 * l + 2]; }
       double* J = A.jac + (size_t)m * L.nnz_jac;
-      TileStore<0> ex{tileX, J, &L, nullptr, k0, rows_here, 0};
-      TileStore<1> eu{tileU, J, &L, emap, k0, rows_here, 0};
+      TilePair<0, 1> t{tile, J, tile_ga(J), &L, emap, k0, rows_here};
+      TilePair<0, 1>::X ex{t}; TilePair<0, 1>::U eu{t};
       srbm::stage_jac(z, P, false, false, fz_prev, ex, eu);
-      ex.finish(); eu.finish();
+      t.finish();
     } else if (FAM == 2) {
-      TileStore<4> og{tileX, A.g + (size_t)m * L.ng, &L, nullptr, k0, rows_here, 0};
+      double* G = A.g + (size_t)m * L.ng;
+      TilePair<4, 4> t{tile, G, tile_ga(G), &L, nullptr, k0, rows_here};
+      TilePair<4, 4>::X og{t};
       srbm::stage_g(z, P, false, og);
-      og.finish();
+      t.finish();
     } else {
-      // FAM 1: the whole Hessian segment of the stage; FAM 3 / 4: its two halves as separate launches (X_k columns + the first 80 positions
-      // of the U_k columns | the last 80) -- the Hessian stream runs at one wave per SIMD and was the critical path of every sweep call
-      // (347 of 382 us at 4096 members, profiles/r03_sweep_timeline.txt); two shorter streams halve the per-member latency
-      constexpr int XHI = FAM == 4 ? 0 : (1 << 30), ULO = FAM == 4 ? 80 : 0, UHI = FAM == 3 ? 80 : (1 << 30);
       double* H = A.hess + (size_t)m * L.nnz_hess;
       double lps[12];
       for (int i = 0; i < 12; ++i) lps[i] = 0.0;
@@ -229,12 +277,12 @@ __global__ void __launch_bounds__(64, LANDING_SWEEP_H_WAVES(FAM)) landing_sweep_
         for (int l = 0; l < 4; ++l) for (int i = 0; i < 3; ++i) lps[3 * l + i] = lp[16 + 12 * l + 2 + i] + lp[16 + 12 * l + 5 + i];
       }
       LamStage lam{lam_g + L.g_stage(k)};
-      TileStore<2, 0, XHI> hx{tileX, H, &L, nullptr, k0, rows_here, 0};
-      TileStore<3, ULO, UHI> hu{tileU, H, &L, nullptr, k0, rows_here, 0};
+      TilePair<2, 3> t{tile, H, tile_ga(H), &L, nullptr, k0, rows_here};
+      TilePair<2, 3>::X hx{t}; TilePair<2, 3>::U hu{t};
       // the last stage reads its multipliers through its own row numbering (80 rows); the emitted sequence is the same
       // for every lane (runtime `last` only selects row offsets), so the tile write-outs stay convergent
       srbm::stage_hess(z, P, false, k == N - 1, lam, lps, hx, hu);
-      hx.finish(); hu.finish();
+      t.finish();
     }
   }
 }
@@ -451,22 +499,6 @@ __device__ LANDING_INL_TASK void eval_task_jac(const Layout& L, const srbm::Stag
   SeqStoreJ ex{J + L.jx(k)}, eu{J + L.ju(k)};
   srbm::stage_jac(z, P, k == 0, k == L.N - 1, fz_prev, ex, eu);
 }
-// Jacobian nonzeros of ALL stages by one wavefront with the coalesced tile write-out of landing_sweep_kernel<0> (every lane runs
-// the middle-stage instruction stream, the edge stages' placeholders are dropped through the compaction map): the solver's
-// per-lane sequential stores were 64 scattered 8-byte words per store instruction.  tileX / tileU: LDS, 64 x TILE_LD each.
-__device__ __noinline__ void eval_task_jac_tiled(const Layout& L, const double* x, const double* p, double* J, double* tileX, double* tileU, const int* edge_map) {
-  const int N = L.N, ln = threadIdx.x & 63;
-  int k = ln;
-  if (k > N - 1) k = N - 1;                       // idle lanes replay the last stage (never written out)
-  srbm::StageVars z; srbm::StageParams P;
-  load_stage(L, x, p, k, z, P);
-  double fz_prev[4] = {0, 0, 0, 0};
-  if (k > 0) { const double* Up = x + L.x_U(k - 1); for (int l = 0; l < 4; ++l) fz_prev[l] = Up[12 + 3 * l + 2]; }
-  TileStore<0> ex{tileX, J, &L, nullptr, 0, N, 0};
-  TileStore<1> eu{tileU, J, &L, edge_map, 0, N, 0};
-  srbm::stage_jac(z, P, false, false, fz_prev, ex, eu);
-  ex.finish(); eu.finish();
-}
 __device__ LANDING_INL_TASK void eval_task_jty(const Layout& L, const srbm::StageVars& z, const srbm::StageParams& P, int k,
                                            const double* fz_prev, const double* y, double* gx) {
   const bool first = (k == 0);
@@ -506,11 +538,9 @@ __device__ LANDING_INL_EVAL_JH void member_eval_jh(const Layout& L, const double
   // one wavefront per task (no divergent calls): wave 0 -> Jacobian, wave 1 -> J^T y, wave 2 -> Hessian; with fewer
   // than 3 waves the tasks are looped
   const int nwave = (blockDim.x + 63) >> 6, wave = threadIdx.x >> 6;
-  const bool tiled = tiles && edge_map && N <= 64 && N >= 3;
-  if (tiled && wave == 0) eval_task_jac_tiled(L, x, p, J, tiles, tiles + 64 * TILE_LD, edge_map);
+  (void)tiles; (void)edge_map;      // (round 2's tiled write-out of the Jacobian task inside the solver: measured slower, removed)
   for (int task = wave; task < 3; task += nwave)
   for (int k = threadIdx.x & 63; k < N; k += 64) {
-    if (tiled && task == 0) break;
     const bool first = (k == 0);
     srbm::StageVars z; srbm::StageParams P;
     load_stage(L, x, p, k, z, P);

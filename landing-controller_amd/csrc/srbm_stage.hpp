@@ -284,6 +284,7 @@ __host__ __device__ __forceinline__ void stage_jac(const StageVars& z, const Sta
     ex.col();
     ex.put(PREV_ID(9 + j), 1.0); ex.put(j, -dt); ex.put(6 + j, -1.0); ex.put(box + 15 + j, 1.0); ex.put(box + 21 + j, 1.0);
   }
+  ex.end();                                      // X part complete (emitters that share a buffer between the parts switch here)
   // ---- U_k columns: feet ----
 #pragma unroll
   for (int l = 0; l < 4; ++l) {
@@ -412,6 +413,7 @@ __host__ __device__ __forceinline__ void stage_hess(const StageVars& z, const St
     hx.put(hew[0][1]); hx.put(hew[1][1]); hx.put(hew[2][1]); hx.put(hw01);
     hx.put(hew[0][2]); hx.put(hew[1][2]); hx.put(hew[2][2]); hx.put(hw02); hx.put(hw12);
   }
+  hx.end();
   // ---- U_k columns: feet ----
 #pragma unroll
   for (int l = 0; l < 4; ++l) {
