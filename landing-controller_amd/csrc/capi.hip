@@ -53,7 +53,7 @@ struct landing_ctx {
   hipStream_t host_stream = nullptr;  // stream of the *_host entry points (copies + launch), created on first use
   hipStream_t aux[3] = {nullptr, nullptr, nullptr};
   hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
-  bool hess_split = false;           // LANDING_SWEEP_HSPLIT=1: the Hessian stream as two launches (landing_sweep_kernel<3>, <4>) -- measured slower, see below
+  int sweep_split = 0;               // dev (LANDING_SWEEP_SPLIT=<n>): bit 0: the Jacobian stream as two launches (X_k columns, U_k columns), bit 1: the Hessian stream too -- measured, no gain
   bool sweep_concurrent = true;      // Q (576) | F (576) | 1/diag(R) (12) of the last landing_riccati_gains_batch call
   // every scratch block above is re-used by the next call of its entry point, possibly on another stream: the launches that use it are
   // fenced by this event (recorded behind them, waited for before the next writer / reader touches the block) -- ADVICE r2
@@ -244,7 +244,7 @@ landing_ctx* landing_create(int N, int device, const landing_form* form) {
   // (round 3: the forces half needs 154 VGPRs instead of 256 + 198 and finishes in 190 us, but the other half still takes as long as the
   // whole stream did and the Jacobian stream slows down -- the sweep is bound by the aggregate of resident waves, not by one stream's latency:
   // 36-38 % of 8 TB/s against 39.5-41.7 % with the single stream on the same box, profiles/r03_sweep_timeline.txt)
-  { const char* e = getenv("LANDING_SWEEP_HSPLIT"); c->hess_split = (e && e[0] == '1'); }
+  { const char* e = getenv("LANDING_SWEEP_SPLIT"); if (e && e[0] >= '0' && e[0] <= '3') c->sweep_split = e[0] - '0'; }
   {  // positions of the U_k Jacobian entries of stages 0 / N-1 inside the uniform (middle-stage) emission sequence
     struct RecCodes { std::vector<int>* v; void col() {} void end() {} void put(int r, double) { v->push_back(r); } };
     std::vector<int> cx, cu;
@@ -323,9 +323,16 @@ int landing_eval_batch(landing_ctx* ctx, int B, const double* d_x, const double*
     HIP_TRY(hipEventRecord(ctx->ev_fork, s0));
     HIP_TRY(hipStreamWaitEvent(sj, ctx->ev_fork, 0)); HIP_TRY(hipStreamWaitEvent(sh, ctx->ev_fork, 0)); HIP_TRY(hipStreamWaitEvent(sh2, ctx->ev_fork, 0));
   }
-  if (d_hess) hipLaunchKernelGGL(landing::landing_sweep_kernel<1>, dim3(B), dim3(64), 0, sh, ctx->L, B, A);
-  if (d_jac) hipLaunchKernelGGL(landing::landing_sweep_kernel<0>, dim3(B), dim3(64), 0, sj, ctx->L, B, A);
-  if (d_g) hipLaunchKernelGGL(landing::landing_sweep_kernel<2>, dim3(B), dim3(64), 0, s0, ctx->L, B, A);
+  const size_t lds = (size_t)landing::landing_sweep_tile_rows(ctx->L.N) * landing::TILE_LD * sizeof(double);
+  if (d_hess && ctx->sweep_split & 2) {
+    hipLaunchKernelGGL((landing::landing_sweep_kernel<1, 2>), dim3(B), dim3(64), lds, sh, ctx->L, B, A);
+    hipLaunchKernelGGL((landing::landing_sweep_kernel<1, 1>), dim3(B), dim3(64), lds, sh, ctx->L, B, A);
+  } else if (d_hess) hipLaunchKernelGGL((landing::landing_sweep_kernel<1, 0>), dim3(B), dim3(64), lds, sh, ctx->L, B, A);
+  if (d_jac && ctx->sweep_split & 1) {      // the Jacobian stream as two launches: U_k columns, X_k columns
+    hipLaunchKernelGGL((landing::landing_sweep_kernel<0, 2>), dim3(B), dim3(64), lds + 456 * sizeof(int), sj, ctx->L, B, A);
+    hipLaunchKernelGGL((landing::landing_sweep_kernel<0, 1>), dim3(B), dim3(64), lds, sh2, ctx->L, B, A);
+  } else if (d_jac) hipLaunchKernelGGL((landing::landing_sweep_kernel<0, 0>), dim3(B), dim3(64), lds + 456 * sizeof(int), sj, ctx->L, B, A);
+  if (d_g) hipLaunchKernelGGL((landing::landing_sweep_kernel<2, 0>), dim3(B), dim3(64), lds, s0, ctx->L, B, A);
   // the part of the sweep that needs no stage evaluation has its own light instantiation (eval_kernels.hip)
   const bool heavy = (ctx->L.run_cost && (d_f || d_grad_f)) || (d_g && !A.g_staged) || d_ggx || d_ggp;
   if (heavy) hipLaunchKernelGGL(landing::landing_sweep_misc_kernel<false>, dim3(B), dim3(64), 0, s0, ctx->L, B, A);
@@ -383,7 +390,7 @@ int landing_eval_hess_rc_batch(landing_ctx* ctx, int B, const double* d_x, const
   hipStream_t s0 = (hipStream_t)stream;
   HIP_TRY(scratch_acquire(ctx, s0));
   landing::EvalArgs A{d_x, d_p, d_lam_f, d_lam_g, nullptr, nullptr, nullptr, nullptr, ctx->d_h4, nullptr, nullptr, ctx->d_edge_map, 0};
-  hipLaunchKernelGGL(landing::landing_sweep_kernel<1>, dim3(B), dim3(64), 0, s0, L, B, A);
+  hipLaunchKernelGGL((landing::landing_sweep_kernel<1, 0>), dim3(B), dim3(64), (size_t)landing::landing_sweep_tile_rows(L.N) * landing::TILE_LD * sizeof(double), s0, L, B, A);
   hipLaunchKernelGGL(landing::landing_sweep_misc_kernel<true>, dim3(B), dim3(64), 0, s0, L, B, A);     // terminal-cost block of the Hessian
   hipLaunchKernelGGL(landing::landing_hess_rc_kernel, dim3((nrc + 255) / 256, B), dim3(256), 0, s0, L, B, nrc, ctx->d_rc_map, ctx->d_h4, d_p, d_lam_f, d_hess_rc);
   HIP_TRY(hipGetLastError());

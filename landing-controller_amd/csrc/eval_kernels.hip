@@ -98,32 +98,35 @@ struct DotLam {
 // SAME sequence -- stages 0 and N-1, whose segments lack the entries of the neighbouring stage's no-slip rows, emit placeholders there and the
 // write-out compacts them through `map` (position in the uniform sequence -> position in the segment, -1 = absent).
 //
-// Round 4: the runs are ALIGNED to 128-byte lines.  The CCS segments start wherever the reference's nonzero order puts them (157 k, 228 k + ...
-// doubles, members 15 364 doubles apart), so a run of the 16 values emitted last straddles two lines; measured with the store pattern alone
-// (tools/dev/wbench.hip, 4096 waves x 40 rows): 3.4 TB/s against 6.7 TB/s for line-aligned runs.  A tile row is therefore a RING of the last 32
-// values: at the F-th write-out a lane row writes the aligned block that became complete one round earlier, positions [h + 16 (F - 2), h + 16 (F - 1))
-// with h = 1..16 the distance of the segment start to the next line boundary (the head [0, h) goes out at F = 1, the tail at finish()).  Only the head
-// and the tail of a segment remain partial lines.  The rows of the edge stages, whose positions go through the compaction maps, keep the immediate
-// write-out.  X_k and U_k columns of a stage are emitted one after the other (srbm_stage.hpp), so both parts share ONE tile: the second emitter
-// takes the tile over at end() of the first.
-constexpr int TILE_LD = 33;
+// Round 4: the runs are ALIGNED to 128-byte lines and written 16 bytes per lane.  The CCS segments start wherever the reference's nonzero order
+// puts them (157 k, 228 k + ... doubles, members 15 364 doubles apart), so a run of the 16 values emitted last straddles two lines; measured with the
+// store pattern alone (tools/dev/wbench.hip, 4096 waves x 40 rows): 3.4 TB/s against 6.7 TB/s for line-aligned runs.  And the write-out of round 3
+// (one 8-byte word per lane and row visit, ~30 instructions each) was 2.5 x the arithmetic of the Jacobian stream in issued instructions.  A tile
+// row is therefore a RING of the last 32 values (slot 32 mirrors slot 0, so that a pair of consecutive positions is always contiguous): from the
+// second round on a row writes the aligned block that became complete one round earlier, positions [h + 16 (F - 2), h + 16 (F - 1)) with h = 1..16
+// the distance of the segment start to the next line boundary -- eight lanes per row, one global_store_dwordx4 each (tile_round).  The head [0, h)
+// and the tail (<= 30 values) go out at the end of the part by 8-byte words (tile_rest: in full lines too).  The rows of the edge
+// stages, whose positions go through the compaction maps, are written by words in the emitted windows as before.  X_k and U_k columns of a stage
+// are emitted one after the other (srbm_stage.hpp), so both parts share ONE tile: the second emitter takes the tile over at end() of the first.
+constexpr int TILE_LD = 49;      // ring of 32 + mirror of slot 0 + the first 16 values of the part (TILE_HEAD)
+constexpr int TILE_HEAD = 33;
 // hides a wave-uniform value from the optimiser (empty asm on an SGPR); a no-op for the g++ host emulation of tests/emu
 #if defined(__HIP__)
 #define LANDING_OPAQUE_UNIFORM(x) asm volatile("" : "+s"(x))
+#define LANDING_OPAQUE_LANE(x) asm volatile("" : "+v"(x))
 #else
 #define LANDING_OPAQUE_UNIFORM(x) ((void)0)
+#define LANDING_OPAQUE_LANE(x) ((void)0)
 #endif
-// tile rows whose LDS reads are issued together in the write-out (1 = round 2's loop: one LDS round trip per row).  The Jacobian stream
-// sits at its 256-VGPR bound (2 waves per SIMD): 2; the Hessian stream runs at 1 wave per SIMD with room in the AGPRs and nothing to hide
-// an LDS round trip behind: more; the residual stream has registers to spare.
+// tile rows (per lane) whose LDS reads are issued together in the block write-out: a lane visits rows lane>>3, +8, ... -- 5 visits at N = 40
 #ifndef LANDING_FLUSH_GROUP_J
-#define LANDING_FLUSH_GROUP_J 2
+#define LANDING_FLUSH_GROUP_J 3
 #endif
 #ifndef LANDING_FLUSH_GROUP_H
 #define LANDING_FLUSH_GROUP_H 5
 #endif
 #ifndef LANDING_FLUSH_GROUP_G
-#define LANDING_FLUSH_GROUP_G 4
+#define LANDING_FLUSH_GROUP_G 5
 #endif
 // KIND 0: Jacobian X_k columns, 1: Jacobian U_k columns, 2: Hessian X_k columns, 3: Hessian U_k columns, 4: g rows.
 // start of stage k's segment in the member's array, and the position of emitted value `pos` inside it (-1: a placeholder of an edge stage)
@@ -131,13 +134,11 @@ template <int KIND>
 __device__ __forceinline__ int tile_seg(const Layout* L, int k) {
   return KIND == 0 ? L->jx(k) : (KIND == 1 ? L->ju(k) : (KIND == 2 ? L->hx(k) : (KIND == 3 ? L->hu(k) : L->g_stage(k))));
 }
-#ifndef LANDING_TILE_IMM_MASK
-#define LANDING_TILE_IMM_MASK 0      // bit KIND set: that part is written in the emitted windows, unaligned (dev knob)
-#endif
+template <int KIND> constexpr bool tile_first_edge() { return KIND == 1 || KIND == 3; }      // stage 0 is compacted
+template <int KIND> constexpr bool tile_last_edge() { return KIND == 1 || KIND == 4; }       // stage N-1 is compacted
 template <int KIND>
-__device__ __forceinline__ bool tile_edge(int k, int N) {      // rows whose positions are compacted: immediate write-out
-  if ((LANDING_TILE_IMM_MASK >> KIND) & 1) return true;
-  return KIND == 1 ? (k == 0 || k == N - 1) : (KIND == 3 ? k == 0 : (KIND == 4 ? k == N - 1 : false));
+__device__ __forceinline__ bool tile_edge(int k, int N) {      // rows whose positions are compacted: written by words, window by window
+  return (tile_first_edge<KIND>() && k == 0) || (tile_last_edge<KIND>() && k == N - 1);
 }
 template <int KIND>
 __device__ __forceinline__ int tile_pos(const int* map, int k, int N, int pos) {
@@ -151,49 +152,108 @@ __device__ __forceinline__ int tile_pos(const int* map, int k, int N, int pos) {
   }
   return pos;
 }
-// write-out of one tile; FIN = false: regular round (cnt is a multiple of 16), true: the rest of the sequence.  Inlined (an
-// out-of-line call makes every write-out wait for its stores at the return), but the position counter is laundered through an empty asm so
-// that the call sites of a stage are not specialised and hoisted into one giant live range (that version spilled 1.9 KB per lane).
+struct alignas(16) TilePairOfDoubles { double a, b; };
+// Regular round (cnt = 16 F): the line-aligned block [h + 16 (F - 2), + 16) of every interior row, two values per lane (F >= 2; at F = 2 also
+// the head [0, h), by words), and the window emitted since the last round of the edge rows (by words; lanes 0-15 stage 0, lanes 16-31 stage N-1).
+// Inlined (an out-of-line call makes every write-out wait for its stores at the return), but the position counter is laundered through an
+// empty asm so that the call sites of a stage are not specialised and hoisted into one giant live range (that version spilled 1.9 KB per lane);
+// ONE function for the whole round: the stage functions' loops are only unrolled (and the round tests resolved) while their body stays small.
 // ga = (address of gbase / 8) mod 16: with it the distance of a segment start to the next 128-byte line is 32-bit arithmetic.
-template <int KIND, bool FIN>
-__device__ __forceinline__ void tile_flush(const double* tile, double* gbase, int ga, const Layout* L, const int* map, int k0, int nrow, int cnt_) {
+template <int KIND>
+__device__ __forceinline__ void tile_round(const double* tile, double* gbase, int ga, const Layout* L, const int* map, int k0, int nrow, int cnt_) {
   int cnt = cnt_;
   LANDING_OPAQUE_UNIFORM(cnt);
   __builtin_amdgcn_wave_barrier();
-  const int lane = threadIdx.x & 63, c = lane & 15, N = L->N;
+  // the lane number is laundered too: everything derived from it is recomputed in every round (a few integer operations) instead of living in
+  // registers across the stage's arithmetic -- at the 256-register bound those were SPILLED, and their reload at the start of a round
+  // (s_waitcnt vmcnt(0)) also waited for every store of the previous round: the rounds were serialised on the store latency
+  int lane = threadIdx.x & 63;
+  LANDING_OPAQUE_LANE(lane);
+  const int N = L->N;
   constexpr int FG = KIND <= 1 ? LANDING_FLUSH_GROUP_J : (KIND <= 3 ? LANDING_FLUSH_GROUP_H : LANDING_FLUSH_GROUP_G);
+  if (cnt >= 32) {
+    const int lag = cnt - 32 + 2 * (lane & 7);
+#pragma unroll 1
+    for (int row0 = lane >> 3; row0 < nrow; row0 += 8 * FG) {
+      double va[FG], vb[FG]; int q[FG];
+#pragma unroll
+      for (int j = 0; j < FG; ++j) {
+        const bool in = row0 + 8 * j < nrow;
+        const int row = in ? row0 + 8 * j : row0;
+        const int k = k0 + row;
+        const int seg = tile_seg<KIND>(L, k);
+        const int p = 16 - ((ga + seg) & 15) + lag;
+        const double* tr = tile + row * TILE_LD;
+        va[j] = tr[p & 31]; vb[j] = tr[(p & 31) + 1];
+        q[j] = in && !tile_edge<KIND>(k, N) ? seg + p : -1;
+      }
+#pragma unroll
+      for (int j = 0; j < FG; ++j)
+        if (q[j] >= 0) *reinterpret_cast<TilePairOfDoubles*>(gbase + q[j]) = TilePairOfDoubles{va[j], vb[j]};
+    }
+  }
+  if (tile_first_edge<KIND>() || tile_last_edge<KIND>()) {
+    const int k = (lane >> 4) == 0 ? (tile_first_edge<KIND>() ? 0 : -1) : ((lane >> 4) == 1 && tile_last_edge<KIND>() ? N - 1 : -1);
+    const int row = k - k0;
+    if (k >= 0 && row >= 0 && row < nrow) {
+      const int p = cnt - 16 + (lane & 15), d = tile_pos<KIND>(map, k, N, p);
+      if (d >= 0) gbase[tile_seg<KIND>(L, k) + d] = tile[row * TILE_LD + (p & 31)];
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+// The rest of a part, by 8-byte words, 16 lanes per row: the tail of every row (<= 30 values of an interior row, <= 15 of an edge row) and the
+// heads.  A segment ends where the next stage's begins, so the tail of row r and the head [0, h) of row r + 1 share a 128-byte line: the lanes
+// past the end of row r write the head of row r + 1 (kept in the TILE_HEAD slots) IN THE SAME STORE -- a full line instead of two partial
+// ones at different times (the store pattern alone: 4.2 -> 5.2 TB/s, tools/dev/wbench2.hip).  A row whose predecessor cannot do that (first row
+// of the tile, or the predecessor is an edge row) writes its own head.
+template <int KIND>
+__device__ __forceinline__ void tile_rest(const double* tile, double* gbase, int ga, const Layout* L, const int* map, int k0, int nrow, int cnt_) {
+  int cnt = cnt_;
+  LANDING_OPAQUE_UNIFORM(cnt);
+  __builtin_amdgcn_wave_barrier();
+  int lane = threadIdx.x & 63;
+  LANDING_OPAQUE_LANE(lane);
+  const int c = lane & 15, N = L->N;
+  constexpr int FG = 2;
   const int F = cnt >> 4;
-  const int lag = 16 * (F - 2) + c;                    // regular round, interior row: position h + lag (negative: not yet there)
-  const int done0 = F >= 1 ? 16 * (F - 1) : -16;       // rest: positions below h + done0 are written (F = 0: none, see below)
-  // a lane writes column c of the tile rows lane>>4, +4, +8, ...; the rows are taken FG at a time with their LDS reads issued together
 #pragma unroll 1
   for (int row0 = lane >> 4; row0 < nrow; row0 += 4 * FG) {
-    double v[FG], v2[FG]; int q[FG], q2[FG];
+    double v[FG], v2[FG], v3[FG]; int q[FG], q2[FG], q3[FG];
 #pragma unroll
     for (int j = 0; j < FG; ++j) {
-      const int row = row0 + 4 * j < nrow ? row0 + 4 * j : row0;
+      const bool in = row0 + 4 * j < nrow;
+      const int row = in ? row0 + 4 * j : row0;
       const int k = k0 + row;
       const int seg = tile_seg<KIND>(L, k);
+      const int h = 16 - ((ga + seg) & 15);      // 1..16
       const double* tr = tile + row * TILE_LD;
-      int p1, p2 = -1;      // positions of the emitted sequence this lane writes for the row (p2: second block of the rest)
-      if (tile_edge<KIND>(k, N)) {      // immediate: the window emitted since the last round
-        if (!FIN) p1 = cnt - 16 + c; else p1 = c < (cnt & 15) ? (cnt & ~15) + c : -1;
-      } else {
-        const int h = 16 - ((ga + seg) & 15);      // 1..16
-        if (!FIN) p1 = h + lag;
-        else { p1 = (F >= 1 ? h + done0 : 0) + c; p2 = p1 + 16; if (p1 >= cnt) p1 = -1; if (p2 >= cnt) p2 = -1; }
+      int p1, p2 = -1, p3 = -1;
+      bool n1 = false, n2 = false;      // the position belongs to the head of the next row
+      if (tile_edge<KIND>(k, N)) p1 = c < (cnt & 15) ? (cnt & ~15) + c : -1;
+      else if (F < 2) { p1 = c; p2 = 16 + c; if (p1 >= cnt) p1 = -1; if (p2 >= cnt) p2 = -1; }      // short part: nothing written yet, the row writes all of itself
+      else {
+        p1 = h + 16 * (F - 1) + c; p2 = p1 + 16;
+        // the next row's head: allowed when that row is in the tile, not an edge row and really contiguous
+        const bool join = row + 1 < nrow && !tile_edge<KIND>(k + 1, N) && tile_seg<KIND>(L, k + 1) == seg + cnt;
+        if (p1 >= cnt) { n1 = join && p1 - cnt < 16 - ((ga + seg + cnt) & 15); if (!n1) p1 = -1; }
+        if (p2 >= cnt) { n2 = join && p2 - cnt < 16 - ((ga + seg + cnt) & 15); if (!n2) p2 = -1; }
+        if ((row == 0 || tile_edge<KIND>(k - 1, N) || tile_seg<KIND>(L, k - 1) + cnt != seg) && c < h) p3 = c;      // own head
       }
-      v[j] = tr[(p1 < 0 ? 0 : p1) & 31];
-      if (FIN) v2[j] = tr[(p2 < 0 ? 0 : p2) & 31];
-      const int d1 = p1 < 0 ? -1 : tile_pos<KIND>(map, k, N, p1);
+      if (!in) p1 = p2 = p3 = -1;
+      v[j] = n1 ? tr[TILE_LD + TILE_HEAD + p1 - cnt] : tr[(p1 < 0 ? 0 : p1) & 31];
+      v2[j] = n2 ? tr[TILE_LD + TILE_HEAD + p2 - cnt] : tr[(p2 < 0 ? 0 : p2) & 31];
+      v3[j] = tr[TILE_HEAD + (p3 < 0 ? 0 : p3)];
+      const int d1 = p1 < 0 ? -1 : (n1 ? p1 : tile_pos<KIND>(map, k, N, p1));
       q[j] = d1 < 0 ? -1 : seg + d1;
-      if (FIN) { const int d2 = p2 < 0 ? -1 : tile_pos<KIND>(map, k, N, p2); q2[j] = d2 < 0 ? -1 : seg + d2; }
+      q2[j] = p2 < 0 ? -1 : seg + p2;      // p2, p3 only on interior rows: no compaction
+      q3[j] = p3 < 0 ? -1 : seg + p3;
     }
 #pragma unroll
     for (int j = 0; j < FG; ++j) {
-      if (row0 + 4 * j >= nrow) continue;
       if (q[j] >= 0) gbase[q[j]] = v[j];
-      if (FIN) if (q2[j] >= 0) gbase[q2[j]] = v2[j];
+      if (q2[j] >= 0) gbase[q2[j]] = v2[j];
+      if (q3[j] >= 0) gbase[q3[j]] = v3[j];
     }
   }
   __builtin_amdgcn_wave_barrier();
@@ -202,7 +262,7 @@ __device__ __forceinline__ int tile_ga(const double* g) { return (int)((((unsign
 // the two emitters of a stage (X_k columns, then U_k columns) over ONE tile: end() of the X part (srbm_stage.hpp) writes its rest out
 template <int KX, int KU>
 struct TilePair {
-  double* tile;          // LDS, 64 x TILE_LD: per lane a ring of the last 32 emitted values
+  double* tile;          // LDS, 64 x TILE_LD: per lane a ring of the last 32 emitted values (+ the mirror of slot 0)
   double* gbase;         // member's J / H / g array
   int ga;                // (gbase / 8) mod 16
   const Layout* L;
@@ -210,20 +270,21 @@ struct TilePair {
   int k0, nrow;          // stage of tile row 0, rows really written
   int cx = 0, cu = 0;
   bool xdone = false;
-  __device__ __forceinline__ void putx(double v) {
-    tile[(threadIdx.x & 63) * TILE_LD + (cx & 31)] = v;
-    ++cx;
-    if ((cx & 15) == 0) tile_flush<KX, false>(tile, gbase, ga, L, map, k0, nrow, cx);
+  template <int KIND>
+  __device__ __forceinline__ void put_(double v, int& cnt) {
+    double* t = tile + ((int)(threadIdx.x & 63) < nrow ? (int)(threadIdx.x & 63) : nrow) * TILE_LD;      // (stays live: 385 uses per stage); idle lanes share the spare row
+    t[cnt & 31] = v;
+    if ((cnt & 31) == 0) t[32] = v;
+    if (cnt < 16) t[TILE_HEAD + cnt] = v;
+    ++cnt;      // cnt is a compile-time constant at every call site (the stage functions are straight-line code): the tests below cost nothing
+    if ((cnt & 15) == 0 && (cnt >= 32 || tile_first_edge<KIND>() || tile_last_edge<KIND>())) tile_round<KIND>(tile, gbase, ga, L, map, k0, nrow, cnt);
   }
-  __device__ __forceinline__ void endx() { tile_flush<KX, true>(tile, gbase, ga, L, map, k0, nrow, cx); xdone = true; }
-  __device__ __forceinline__ void putu(double v) {
-    tile[(threadIdx.x & 63) * TILE_LD + (cu & 31)] = v;
-    ++cu;
-    if ((cu & 15) == 0) tile_flush<KU, false>(tile, gbase, ga, L, map, k0, nrow, cu);
-  }
+  __device__ __forceinline__ void putx(double v) { put_<KX>(v, cx); }
+  __device__ __forceinline__ void putu(double v) { put_<KU>(v, cu); }
+  __device__ __forceinline__ void endx() { tile_rest<KX>(tile, gbase, ga, L, map, k0, nrow, cx); xdone = true; }
   __device__ __forceinline__ void finish() {
-    if (!xdone) tile_flush<KX, true>(tile, gbase, ga, L, map, k0, nrow, cx);
-    else tile_flush<KU, true>(tile, gbase, ga, L, map, k0, nrow, cu);
+    if (!xdone) tile_rest<KX>(tile, gbase, ga, L, map, k0, nrow, cx);
+    else tile_rest<KU>(tile, gbase, ga, L, map, k0, nrow, cu);
   }
   struct X { TilePair& t; __device__ __forceinline__ void col() {} __device__ __forceinline__ void end() { t.endx(); } __device__ __forceinline__ void put(int, double v) { t.putx(v); } __device__ __forceinline__ void put(double v) { t.putx(v); } };
   struct U { TilePair& t; __device__ __forceinline__ void col() {} __device__ __forceinline__ void end() {} __device__ __forceinline__ void put(int, double v) { t.putu(v); } __device__ __forceinline__ void put(double v) { t.putu(v); } };
@@ -232,22 +293,45 @@ struct TilePair {
 // Jacobian (FAM 0), Hessian (FAM 1) nonzeros or residual rows (FAM 2) of every stage of one member: one wavefront per member, lane = stage,
 // every lane runs the middle-stage instruction stream (first = last = false) and the tile write-out drops the
 // placeholders of the two edge stages.  Reported by landing_kernel_name_sweep() for profilers.
-// (register budget: the Jacobian stream fits 256 VGPRs -> 2 waves/SIMD; the Hessian stream needs the AGPR overflow
-// of the default bound, capping it costs 750 B of scratch per lane and doubles its time)
-#ifndef LANDING_SWEEP_H_WAVES
-#define LANDING_SWEEP_H_WAVES(FAM) ((FAM) == 1 ? 1 : 2)
+// Occupancy: the tile is dynamic LDS of (min(N, 64) + 1) x TILE_LD doubles (the extra row takes the puts of the idle lanes) -- 16 KB at
+// N = 40, 9 wavefronts per CU -- and the registers allow 2 wavefronts per SIMD for the Jacobian and residual streams (256 VGPRs), 1 for the
+// Hessian stream (AGPR overflow of the default bound; capping it costs 750 B of scratch per lane and doubles its time).  Measured in round 4:
+// compiling the streams for 3 wavefronts per SIMD (smaller tile, <= 168 registers, ~100 B of spills) is slower, and so is launching the X_k and
+// U_k columns of a stream as two kernels (PART 1, 2: half the instruction stream each) -- the streams are bound by the write path, not by issue.
+#ifndef LANDING_SWEEP_WAVES
+#define LANDING_SWEEP_WAVES(FAM, PART) ((FAM) == 1 && (PART) == 0 ? 1 : 2)
 #endif
-template <int FAM>
-__global__ void __launch_bounds__(64, LANDING_SWEEP_H_WAVES(FAM)) landing_sweep_kernel(Layout L, int B, EvalArgs A) {
+__host__ __device__ inline int landing_sweep_tile_rows(int N) { return (N < 64 ? N : 64) + 1; }
+struct NullEmit {      // the part of a stage another launch writes: its arithmetic is dead code here
+  __device__ __forceinline__ void col() {}
+  __device__ __forceinline__ void end() {}
+  __device__ __forceinline__ void put(int, double) {}
+  __device__ __forceinline__ void put(double) {}
+};
+// PART 0: both parts of a stage by one wavefront; 1: the X_k columns only; 2: the U_k columns only (the Jacobian stream is launched as 1 + 2:
+// half the instruction stream and fewer live values per wavefront, twice the wavefronts)
+template <int FAM, int PART = 0>
+__global__ void __launch_bounds__(64, LANDING_SWEEP_WAVES(FAM, PART)) landing_sweep_kernel(Layout L, int B, EvalArgs A) {
   const int m = blockIdx.x;
   if (m >= B) return;
   const int N = L.N, ln = threadIdx.x;
   const double* x = A.x + (size_t)m * L.nx;
   const double* p = A.p + (size_t)m * L.np;
   const double* lam_g = A.lam_g ? A.lam_g + (size_t)m * L.ng : nullptr;
-  __shared__ double tile[64 * TILE_LD];
-  __shared__ int emap[456];      // compaction maps of the edge stages (FAM 0): read at every U-column write-out -- from LDS, not through a dependent global load
-  if (FAM == 0) { for (int i = ln; i < 456; i += 64) emap[i] = A.edge_map[i]; __builtin_amdgcn_wave_barrier(); }
+#if defined(__HIP__)
+  extern __shared__ double tile[];      // landing_sweep_tile_rows(N) x TILE_LD doubles, then (FAM 0) the compaction maps
+#else
+  static double tile[65 * TILE_LD + 228];      // host emulation (tests/emu): no dynamic LDS
+#endif
+  int* emap = reinterpret_cast<int*>(tile + landing_sweep_tile_rows(N) * TILE_LD);      // of the edge stages: read at every U-column write-out -- from LDS, not through a dependent global load
+  if (FAM == 0 && PART != 1) {
+    int e[8];      // all eight loads in flight before the first is waited for
+#pragma unroll
+    for (int j = 0; j < 8; ++j) e[j] = ln + 64 * j < 456 ? A.edge_map[ln + 64 * j] : 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) if (ln + 64 * j < 456) emap[ln + 64 * j] = e[j];
+    __builtin_amdgcn_wave_barrier();
+  }
   for (int k0 = 0; k0 < N; k0 += 64) {
     const int rows_here = N - k0 < 64 ? N - k0 : 64;
     int k = k0 + ln;
@@ -256,12 +340,24 @@ __global__ void __launch_bounds__(64, LANDING_SWEEP_H_WAVES(FAM)) landing_sweep_
     load_stage(L, x, p, k, z, P);
     if (FAM == 0) {
       double fz_prev[4] = {0, 0, 0, 0};
-      if (k > 0) { const double* Up = x + L.x_U(k - 1); for (int l = 0; l < 4; ++l) fz_prev[l] = Up[12 + 3 * l + 2]; }
+      if (PART != 1 && k > 0) { const double* Up = x + L.x_U(k - 1); for (int l = 0; l < 4; ++l) fz_prev[l] = Up[12 + 3 * l + 2]; }
       double* J = A.jac + (size_t)m * L.nnz_jac;
-      TilePair<0, 1> t{tile, J, tile_ga(J), &L, emap, k0, rows_here};
-      TilePair<0, 1>::X ex{t}; TilePair<0, 1>::U eu{t};
-      srbm::stage_jac(z, P, false, false, fz_prev, ex, eu);
-      t.finish();
+      if (PART == 0) {
+        TilePair<0, 1> t{tile, J, tile_ga(J), &L, emap, k0, rows_here};
+        TilePair<0, 1>::X ex{t}; TilePair<0, 1>::U eu{t};
+        srbm::stage_jac(z, P, false, false, fz_prev, ex, eu);
+        t.finish();
+      } else if (PART == 1) {
+        TilePair<0, 0> t{tile, J, tile_ga(J), &L, nullptr, k0, rows_here};
+        TilePair<0, 0>::X ex{t}; NullEmit eu;
+        srbm::stage_jac(z, P, false, false, fz_prev, ex, eu);
+        t.finish();
+      } else {
+        TilePair<1, 1> t{tile, J, tile_ga(J), &L, emap, k0, rows_here};
+        NullEmit ex; TilePair<1, 1>::X eu{t};
+        srbm::stage_jac(z, P, false, false, fz_prev, ex, eu);
+        t.finish();
+      }
     } else if (FAM == 2) {
       double* G = A.g + (size_t)m * L.ng;
       TilePair<4, 4> t{tile, G, tile_ga(G), &L, nullptr, k0, rows_here};
@@ -277,12 +373,24 @@ __global__ void __launch_bounds__(64, LANDING_SWEEP_H_WAVES(FAM)) landing_sweep_
         for (int l = 0; l < 4; ++l) for (int i = 0; i < 3; ++i) lps[3 * l + i] = lp[16 + 12 * l + 2 + i] + lp[16 + 12 * l + 5 + i];
       }
       LamStage lam{lam_g + L.g_stage(k)};
-      TilePair<2, 3> t{tile, H, tile_ga(H), &L, nullptr, k0, rows_here};
-      TilePair<2, 3>::X hx{t}; TilePair<2, 3>::U hu{t};
       // the last stage reads its multipliers through its own row numbering (80 rows); the emitted sequence is the same
       // for every lane (runtime `last` only selects row offsets), so the tile write-outs stay convergent
-      srbm::stage_hess(z, P, false, k == N - 1, lam, lps, hx, hu);
-      t.finish();
+      if (PART == 0) {
+        TilePair<2, 3> t{tile, H, tile_ga(H), &L, nullptr, k0, rows_here};
+        TilePair<2, 3>::X hx{t}; TilePair<2, 3>::U hu{t};
+        srbm::stage_hess(z, P, false, k == N - 1, lam, lps, hx, hu);
+        t.finish();
+      } else if (PART == 1) {
+        TilePair<2, 2> t{tile, H, tile_ga(H), &L, nullptr, k0, rows_here};
+        TilePair<2, 2>::X hx{t}; NullEmit hu;
+        srbm::stage_hess(z, P, false, k == N - 1, lam, lps, hx, hu);
+        t.finish();
+      } else {
+        TilePair<3, 3> t{tile, H, tile_ga(H), &L, nullptr, k0, rows_here};
+        NullEmit hx; TilePair<3, 3>::X hu{t};
+        srbm::stage_hess(z, P, false, k == N - 1, lam, lps, hx, hu);
+        t.finish();
+      }
     }
   }
 }

@@ -1,5 +1,5 @@
 """dev probe: static count of scratch (private-segment) loads / stores per function of the gfx950 code object.
-   hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -enable-ipra=0 --cuda-device-only -c landing-controller_amd/csrc/capi.hip -o /tmp/capi_dev.o
+   hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -enable-ipra=0 -mllvm -pragma-unroll-threshold=1000000 --cuda-device-only -c landing-controller_amd/csrc/capi.hip -o /tmp/capi_dev.o
    /opt/rocm/lib/llvm/bin/llvm-objdump -d --no-show-raw-insn /tmp/capi_dev.o > /tmp/capi.s ;  python tools/dev/scratch_count.py /tmp/capi.s [filter]"""
 import re, subprocess, sys
 cur, cnt, tot = None, {}, {}

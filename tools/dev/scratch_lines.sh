@@ -1,7 +1,7 @@
 #!/bin/bash
 # dev probe: scratch accesses of landing_ipm_kernel by source line (device-only build with line tables)   tools/dev/scratch_lines.sh [-DFLAG ...]
 cd "$(dirname "$0")/../../landing-controller_amd/csrc"
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -enable-ipra=0 --cuda-device-only -gline-tables-only -c capi.hip -o /tmp/devb/lines.o "$@" 2>/dev/null || exit 1
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -enable-ipra=0 -mllvm -pragma-unroll-threshold=1000000 --cuda-device-only -gline-tables-only -c capi.hip -o /tmp/devb/lines.o "$@" 2>/dev/null || exit 1
 /opt/rocm/lib/llvm/bin/clang-offload-bundler --unbundle --type=o --input=/tmp/devb/lines.o --targets=hip-amdgcn-amd-amdhsa--gfx950 --output=/tmp/devb/lines.co
 /opt/rocm/lib/llvm/bin/llvm-objdump -d -l --no-show-raw-insn /tmp/devb/lines.co > /tmp/devb/lines.s
 python3 - <<'PY'
