@@ -76,6 +76,19 @@ struct RowStore { double* g; __device__ __forceinline__ void put(int r, double v
 struct SeqStoreJ { double* q; __device__ __forceinline__ void col() {} __device__ __forceinline__ void end() {} __device__ __forceinline__ void put(int, double v) { *q++ = v; } };
 struct SeqStoreH { double* q; __device__ __forceinline__ void end() {} __device__ __forceinline__ void put(double v) { *q++ = v; } };
 struct LamStage { const double* l; __device__ __forceinline__ double operator()(int r) const { return l[r]; } };
+// the multipliers of a stage addressed by the row numbers of a MIDDLE stage (104 rows); `last`: the lane holds the last stage (80 rows: the six
+// no-slip rows of every foot are absent -> 0, the rows behind them move up).  r is a compile-time constant at every call site.
+struct LamRemap {
+  const double* l; bool last;
+  __device__ __forceinline__ double operator()(int r) const {
+    const double xm = l[r];
+    if (r < 16) return xm;
+    const int t = (r - 16) % 12, leg = (r - 16) / 12;
+    if (t >= 2 && t < 8) return last ? 0.0 : xm;
+    const double xl = l[t < 2 ? 16 + 6 * leg + t : 16 + 6 * leg + t - 6];
+    return last ? xl : xm;
+  }
+};
 
 // column-wise accumulation of J^T lam (grad_gamma_x)
 struct DotLam {
@@ -366,29 +379,35 @@ __global__ void __launch_bounds__(64, LANDING_SWEEP_WAVES(FAM, PART)) landing_sw
       t.finish();
     } else {
       double* H = A.hess + (size_t)m * L.nnz_hess;
+      // Multipliers: no branches around the loads.  (Read through LamStage with a runtime `last`, the twelve no-slip sums of stage_hess became
+      // twelve conditional blocks of two loads and an s_waitcnt vmcnt(0) each -- a chain of ~15 memory round trips per wavefront, at one
+      // wavefront per SIMD a large part of the stream's time.)  Every lane runs stage_hess with last = false (the emitted sequence is the
+      // same for every lane anyway); the lane of the last stage, whose 80 rows are numbered differently and have no no-slip rows, reads
+      // through LamRemap: both numberings are loaded unconditionally (all rows lie inside the 80 rows of the shortest stage) and selected.
+      const LamRemap lam{lam_g + L.g_stage(k), k == N - 1};
       double lps[12];
-      for (int i = 0; i < 12; ++i) lps[i] = 0.0;
-      if (k > 0) {
-        const double* lp = lam_g + L.g_stage(k - 1);
-        for (int l = 0; l < 4; ++l) for (int i = 0; i < 3; ++i) lps[3 * l + i] = lp[16 + 12 * l + 2 + i] + lp[16 + 12 * l + 5 + i];
+      {
+        const double* lp = lam_g + L.g_stage(k > 0 ? k - 1 : 0);      // stage 0: loaded from its own rows, multiplied away
+        const double on = k > 0 ? 1.0 : 0.0;
+#pragma unroll
+        for (int l = 0; l < 4; ++l)
+#pragma unroll
+          for (int i = 0; i < 3; ++i) lps[3 * l + i] = on * (lp[16 + 12 * l + 2 + i] + lp[16 + 12 * l + 5 + i]);
       }
-      LamStage lam{lam_g + L.g_stage(k)};
-      // the last stage reads its multipliers through its own row numbering (80 rows); the emitted sequence is the same
-      // for every lane (runtime `last` only selects row offsets), so the tile write-outs stay convergent
       if (PART == 0) {
         TilePair<2, 3> t{tile, H, tile_ga(H), &L, nullptr, k0, rows_here};
         TilePair<2, 3>::X hx{t}; TilePair<2, 3>::U hu{t};
-        srbm::stage_hess(z, P, false, k == N - 1, lam, lps, hx, hu);
+        srbm::stage_hess(z, P, false, false, lam, lps, hx, hu);
         t.finish();
       } else if (PART == 1) {
         TilePair<2, 2> t{tile, H, tile_ga(H), &L, nullptr, k0, rows_here};
         TilePair<2, 2>::X hx{t}; NullEmit hu;
-        srbm::stage_hess(z, P, false, k == N - 1, lam, lps, hx, hu);
+        srbm::stage_hess(z, P, false, false, lam, lps, hx, hu);
         t.finish();
       } else {
         TilePair<3, 3> t{tile, H, tile_ga(H), &L, nullptr, k0, rows_here};
         NullEmit hx; TilePair<3, 3>::X hu{t};
-        srbm::stage_hess(z, P, false, k == N - 1, lam, lps, hx, hu);
+        srbm::stage_hess(z, P, false, false, lam, lps, hx, hu);
         t.finish();
       }
     }
