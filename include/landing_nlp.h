@@ -78,12 +78,32 @@ typedef struct {
 typedef struct {
   double tol;            /* unscaled KKT tolerance on pr/du/compl (default 1e-6)   */
   int max_iter;          /* default 3000 (:232)                                    */
-  double mu_init;        /* 0.1 (:247)                                             */
-  double bound_push;     /* 0.5 (:242), the reference's value.  1.0 is faster on every family tried (MI355X, 64 fresh batches of 1024, N = 40,
-                            kappa_eps 80: 40.1 -> 36.7 iterations, 72.0 -> 68.1 ms per batch; CPU port: N = 20 production grid 42.6 -> 38.6 /
-                            58.5 -> 50.2, running cost 60.0 -> 56.1) but ends at a WORSE local minimum than the reference's stored N = 40
-                            solutions more often (same-or-better objective on 9 of 17 instead of 11..13, tests/test_gpu_solver.py) -- the
-                            reference's value stays the default (profiles/r03_delta_floor.txt)                                          */
+  double mu_init;        /* first barrier parameter.  Default 0 = AUTOMATIC (round 4), like kappa_eps below: the reference's 0.1 (:247) for the
+                            forms with a running cost -- on the 17 stored N = 40 solutions of the reference, which are of that form, 0.1 ends in
+                            the stored local minimum or a better one 13 times, 0.2 / 0.3 / 0.5 / 1.0 only 10 / 12 / 11 / 11 times
+                            (tools/dev/quality17.py) -- and 0.5 for the terminal-cost form: with this solver's monotone schedule a member
+                            leaves the first barrier problem better centred.  MI355X, 32 fresh batches of 1024 (N = 40, tools/dev/musweep.py):
+                            0.1 / 0.3 / 0.5 / 0.7 / 1.0 -> 40.1 / 36.8 / 36.5 / 35.8 / 35.1 iterations on average, slowest member 89 / 115 / 80 /
+                            86 / 85, 79.8 / 75.3 / 72.2 / 71.5 / 71.8 ms per batch through the host path; 2.0 loses one member in 8192.
+                            A positive value is taken as given (the warm-start options set 1e-4).
+                            Hold-out of 128 fresh batches (tools/soak.py): 131 072 / 131 072 converged with both, iterations mean 40.1 -> 36.5,
+                            p99.9 62 -> 57, 72.7 -> 66.8 ms per batch.  On the reference's N = 20 production grid (16 x 1024 drop states, law
+                            main) the mean falls too (43.9 -> 38.4) but the slow tail is longer: within 300 iterations 16 346 + 33 certified +
+                            5 undecided with 0.1, 16 337 + 34 + 13 with 0.5; within 1500 iterations 16 346 + 37 + 1 against 16 348 + 35 + 1
+                            (the members 0.5 leaves for later converge, where 0.1 certifies some of them infeasible) -- a caller of that
+                            problem who caps the iterations tightly sets 0.1.                                                                  */
+  double bound_push;     /* slack initialisation: distance a slack is pushed off its bounds.  Default 0 = AUTOMATIC (round 4): the reference's 0.5
+                            (:242) for the forms with a running cost, 1.0 for the terminal-cost form.  1.0 is faster on every family tried
+                            (round 3, MI355X, 64 fresh batches of 1024, N = 40, kappa_eps 80: 40.1 -> 36.7 iterations, 72.0 -> 68.1 ms per batch;
+                            CPU port: N = 20 production grid 42.6 -> 38.6, running cost 60.0 -> 56.1) but ends at a WORSE local minimum than
+                            the reference's stored N = 40 solutions -- which are of the running-cost form -- more often (same-or-better
+                            objective on 9 of 17 instead of 11..13, tests/test_gpu_solver.py): there the reference's value stays.  The
+                            terminal-cost form has no such question: its minimum is f* = 0 (the terminal reference is reachable), every
+                            KKT point found is the global minimum (tools/dev/fstar_cmp.py: f* ~ 1e-10 under any setting).  With the automatic
+                            mu_init, MI355X, two hold-out sets of 128 fresh batches (tools/soak.py): 262 144 / 262 144 converged, iterations
+                            mean 34.1 (reference values 40.1), p99.9 53 (62), slowest member 112, 64.0 ms per batch (72.7); N = 20 production
+                            grid, law main, within 300 iterations: 16 350 converged + 32 certified + 2 undecided (reference values 16 346 + 33 + 5),
+                            law datagen 15 920 + 412 + 52 (15 950 + 410 + 24).  A positive value is taken as given.                          */
   double bound_frac;     /* default 0.1.  The reference sets 0.5 for IPOPT (:241); with 0.5 the slack of every two-sided row starts at
                             the mid-point of its interval whatever the initial guess says.  Measured on three seeded batches of
                             1024..2048 drop states (N=40, tools/dev/fracsweep.py): 0.5 -> 97.6 % solved, mean 80 iterations;

@@ -195,11 +195,12 @@ def test_feasibility_phase_rescues_or_certifies(oracle_mod):
     P, X0, _, _ = lc("problem").make_batch(B, N, 0.6, seed=3)
     keep = [1, 3, 5]; P, X0, B = P[keep], X0[keep], 3      # (one member of each kind: certified, rescued, converged anyway -- the emulation is slow)
     o = L.default_opts(); o.max_iter = 150
+    o.mu_init = 0.1; o.bound_push = 0.5      # the three members were picked under the reference's values (the defaults are automatic since round 4)
     assert o.feas_phase == 1 and o.feas_rho == 1000.0
     r1 = L.solve_host(P, X0, o)
     o.feas_phase = 0
     r0 = L.solve_host(P, X0, o)
-    c1 = oracle_mod.cpu_solve_batch(O, P, X0, threads=4, max_iter=150, feas_phase=1)
+    c1 = oracle_mod.cpu_solve_batch(O, P, X0, threads=4, max_iter=150, feas_phase=1, mu_init=0.1, bound_push=0.5)
     assert (r0["status"] != 0).sum() == 2                                    # two of the three fail without the phase
     assert np.array_equal(r1["status"], c1["status"]), (r1["status"], c1["status"])
     assert (r1["status"] == 0).sum() > (r0["status"] == 0).sum() and (r1["status"] == 3).sum() >= 1
