@@ -254,6 +254,15 @@ typedef struct {
                             equivalent (72.7 / 71.3 ms per batch): the default is 3e-4, a factor 3 below that cliff (two hold-out sets of
                             131 072 drop states: all converged, worst member 167 iterations).  0 = the plain IPOPT schedule (first trial
                             delta_w = 0)                                                                                                 */
+  int jam_clip;          /* (round 4) the clip_k rule also NEAR feasibility once the classic fraction-to-the-boundary rule has allowed a step
+                            to the boundary below 0.02 in this many iterations in a row (default 2; 0 = never): the slow members left after
+                            the option changes of round 4 (65..78 iterations against a mean of 34) sit in a later barrier problem with
+                            pr ~ 1e-3, where clip_until has switched the rule off, behind one or two slacks that allow steps of 1e-6..1e-2
+                            for 25 iterations.  The rule ends with the first iteration whose classic step bound is >= 0.02 again.      */
+  int stag_relief;       /* (round 4) delta_floor is divided by 10 per iteration once this many FULL steps (alpha = alpha_dual = 1, first
+                            factorisation accepted) in the last barrier problem have not halved max(pr, du) (default 3; 0 = never): against a
+                            curvature of ~1e-5 the proximal term turns Newton's method into a linear iteration of rate delta / (sigma + delta)
+                            -- one member of the bench batch needed 45 full steps from pr 1e-5 to 1e-6.  Any other step resets it.      */
 } landing_solver_opts;
 
 /* status codes written per batch member by landing_solve_batch */

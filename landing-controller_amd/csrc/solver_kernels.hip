@@ -177,6 +177,8 @@ struct IpmState {
   long long tp;
   int nfilt, it, status, need_reg_streak, nreset, last_reset_it, ncrawl, clip_k_cur, last_mu_it, cutstreak, wd_count, first_failed, force_step;
   int clip_now, accepted, armijo_step, fact_ok, skipped_zero, attempt;
+  int jamrun, stag, full_prev;      // jam_clip / stag_relief (landing_nlp.h): iterations in a row with a tiny step to the boundary; full steps of the last barrier problem that did not halve the error
+  double e_prev;
   int action, flag, fresh, ls_done, need_corr, fallback;
   // feasibility (restoration) phase, landing_nlp.h: 1 while the elastic problem is being solved; lim = iteration limit in force
   int feas, feas_used, lim, fact_failed;
@@ -1382,6 +1384,7 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
     K.nfilt = 0; K.it = 0; K.status = LANDING_MAX_ITER; K.need_reg_streak = 0; K.nreset = 0; K.first_failed = 0;
     K.last_reset_it = 0; K.ncrawl = 0; K.clip_k_cur = o.clip_k; K.last_mu_it = 0; K.cutstreak = 0; K.wd_count = 0; K.force_step = 0;
     K.e_pr = 0; K.e_du = 0; K.e_co = 0;
+    K.jamrun = 0; K.stag = 0; K.full_prev = 0; K.e_prev = 1e300;
     K.feas = 0; K.feas_used = 0; K.fact_failed = 0; K.lim = o.max_iter; K.c_rn = 0.0; K.f_vmax = 0.0; K.f_v1 = 0.0;
   }
   __syncthreads();
@@ -1411,6 +1414,11 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
         const int it = K.it, nreset = K.nreset;
         if (K.feas) du = fmax(du, K.c_rn);      // the elastic problem has the extra stationarity rows rho_pen - z - w = 0
         K.e_pr = pr; K.e_du = du; K.e_co = co;
+        if (o.stag_relief > 0) {      // full Newton steps in the last barrier problem that do not halve the error: the proximal term is what holds them back
+          const double E = fmax(pr, du);
+          K.stag = (!K.feas && mu <= o.tol / 10.0 * 1.0000001 && K.full_prev && E > 0.5 * K.e_prev) ? K.stag + 1 : 0;
+          K.e_prev = E;
+        }
         int act = ACT_GO;
         bool give_up = false;
         if (K.feas) {
@@ -1560,7 +1568,14 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
     KS_BEGIN()
       const double dl = K.delta_last;
       K.delta = (K.need_reg_streak >= 2 && dl > 0.0) ? fmax(1e-20, dl * ((o.sticky_delta && K.first_failed) ? 1.0 : o.delta_dec)) : 0.0;
-      if (!L.run_cost && !K.feas) K.delta = fmax(K.delta, o.delta_floor);      // proximal term of the terminal-cost form (landing_nlp.h)
+      if (!L.run_cost && !K.feas) {      // proximal term of the terminal-cost form (landing_nlp.h)
+        double fl = o.delta_floor;
+        if (o.stag_relief > 0 && K.stag >= o.stag_relief) {      // ... a tenth of it per stagnating iteration
+          for (int e = K.stag - o.stag_relief; e >= 0; --e) fl *= 0.1;
+          if (fl < 1e-12) fl = 0.0;
+        }
+        K.delta = fmax(K.delta, fl);
+      }
       K.skipped_zero = K.delta > 0.0;
       K.fact_ok = 0; K.attempt = 0; K.flag = 1;
       S.prof[PH_NFACT] += 1.0;
@@ -1604,7 +1619,7 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
     {
       const double mu = K.mu;
       const bool feas = K.feas != 0;
-      const bool clip_now = !feas && K.clip_k_cur > 1 && K.c_pr > o.clip_until;
+      const bool clip_now = !feas && K.clip_k_cur > 1 && (K.c_pr > o.clip_until || (o.jam_clip > 0 && K.jamrun >= o.jam_clip));      // far from feasible, or jammed (landing_nlp.h)
       double top[4] = {0.0, 0.0, 0.0, 0.0};
       double m_pr = 0.0, m_du = 0.0, th0 = 0.0, bar = 0.0, dphi = 0.0;
       double f0 = 0.0;
@@ -1804,6 +1819,8 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
         K.nfilt = nfilt + 1;
       }
       if (o.dual_step_cap > 0.0) K.a_du = fmin(K.a_du, o.dual_step_cap * K.alpha);      // the multipliers do not run ahead of a blocked primal step (landing_nlp.h)
+      if (o.jam_clip > 0) K.jamrun = (!K.clip_now && K.a_pr < 0.02) ? K.jamrun + 1 : 0;
+      K.full_prev = (K.accepted && K.alpha == 1.0 && K.a_du == 1.0 && K.attempt <= 1) ? 1 : 0;
     KS_END();
     if (K.fallback) {
       const double alpha = K.alpha;

@@ -44,6 +44,7 @@ typedef struct {
   double feas_rho;       /* price of a unit of violation (IPOPT's restoration phase: 1000)                                                   */
   double feas_cert;      /* l1 violation above which the elastic KKT point counts as a certificate                                           */
   double delta_floor;    /* first regularisation tried in an iteration of the terminal-cost form (include/landing_nlp.h)                     */
+  int jam_clip, stag_relief;      /* include/landing_nlp.h */
 } lo_solver_opts;
 
 void lo_solver_opts_default(lo_solver_opts* o) {
@@ -52,7 +53,7 @@ void lo_solver_opts_default(lo_solver_opts* o) {
   o->delta_init = 1e-4; o->delta_inc_first = 10.0; o->delta_inc = 4.0; o->delta_dec = 0.5; o->tau_min = 0.9; o->alpha_fallback = 1e-2; o->restart_period = 75; o->reset_delta = 1e5;
   o->barrier_smax = 1.0; o->watchdog = 3; o->slack_corr = 0.9; o->dual_step_cap = 1.0; o->fresh_restart = 9; o->theta_floor = 30.0; o->clip_k = 4; o->clip_until = 0.03;
   o->feas_phase = 1; o->feas_rho = 1000.0; o->feas_cert = 1e-4;
-  o->delta_floor = 3e-4;
+  o->delta_floor = 3e-4; o->jam_clip = 2; o->stag_relief = 3;
 }
 
 #define NW 48
@@ -222,6 +223,8 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
   lo_bounds(F, p, W->lb, W->ub);
   eval_g(F, W->x, p, W->g);
   init_slacks(W, op);
+  int stag = 0, full_prev = 0; double e_prev = 1e300; const int stag_k = op->stag_relief;      /* jam_clip / stag_relief: include/landing_nlp.h */
+  int jamrun = 0; const int jam_k = op->jam_clip; const double jam_a = 0.02;
   for (it = 0; it <= lim; ++it) {
     double du = 0, pr = 0, co = 0, tau, delta;
     int fact_ok = 0, attempt, clip_now; double use_reset = 0.0;
@@ -268,6 +271,11 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
       if (ub < INFINITY) co = fmax(co, (ub - W->s[r]) * W->zU[r]);
     }
     e_du = du;
+    if (stag_k > 0) {
+      const double E = fmax(pr, du);
+      if (!feas && mu <= op->tol / 10.0 * 1.0000001 && full_prev && E > 0.5 * e_prev) stag++; else stag = 0;
+      e_prev = E;
+    }
     if (getenv("LO_TRACE")) fprintf(stderr, "it %4d pr %9.2e du %9.2e co %9.2e mu %8.1e dlast %8.1e nreset %d nfilt %d\n", it, pr, du, co, mu, delta_last, nreset, nfilt);
     if (feas) {
       double vmax = 0.0, v1 = 0.0; int back = 0;
@@ -408,7 +416,11 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
     }
     /* factorisation with inertia correction (same schedule as the HIP kernel) */
     delta = (streak >= 2 && delta_last > 0.0) ? fmax(1e-20, delta_last * op->delta_dec) : 0.0;
-    if (!F->run_cost && !feas) delta = fmax(delta, op->delta_floor);
+    if (!F->run_cost && !feas) {
+      double fl = op->delta_floor;
+      if (stag_k > 0 && stag >= stag_k) { int e; for (e = stag - stag_k; e >= 0; --e) fl *= 0.1; if (fl < 1e-12) fl = 0.0; }
+      delta = fmax(delta, fl);
+    }
     for (attempt = 0; attempt < 60 && !fact_ok; ++attempt) {
       if (attempt > 0) {
         if (delta == 0.0) delta = (delta_last == 0.0) ? op->delta_init : fmax(1e-20, delta_last * op->delta_dec);
@@ -449,7 +461,7 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
     }
     /* dual steps, step bounds, merit data.  clip_now: the primal step length comes from the clip_k-th largest ratio
      * |ds| / distance (top[] holds the four largest); the slacks with a larger ratio are clipped in slack_step(). */
-    clip_now = !feas && clip_k_cur > 1 && pr > op->clip_until;
+    clip_now = !feas && clip_k_cur > 1 && (pr > op->clip_until || (jam_k > 0 && jamrun >= jam_k));
     top[0] = top[1] = top[2] = top[3] = 0.0;
     for (r = 12; r < ng; ++r) {
       const double lb = W->lb[r], ub = W->ub[r], g = W->g[r]; double s, ds, yn;
@@ -572,6 +584,8 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
     }
     if (getenv("LO_TRACE")) fprintf(stderr, "      alpha %9.2e a_pr %9.2e a_du %9.2e delta %8.1e acc %d armijo %d th0 %9.2e dphi %9.2e clip %d\n", alpha, a_pr, a_du, delta, accepted, armijo, th0, dphi, clip_now);
     if (op->dual_step_cap > 0.0) a_du = fmin(a_du, op->dual_step_cap * alpha);      /* the multipliers do not run ahead of a blocked primal step */
+    if (jam_k > 0) { if (!clip_now && a_pr < jam_a) jamrun++; else jamrun = 0; }
+    full_prev = accepted && alpha == 1.0 && a_du == 1.0 && attempt <= 1;
     memcpy(W->x, W->xt, sizeof(double) * nx);
     for (r = 0; r < ng; ++r) {
       const double lb = W->lb[r], ub = W->ub[r]; double s, zl = 0, zu = 0;
