@@ -372,3 +372,25 @@ def test_soak_failures_are_rescued(oracle_mod):
     r1 = L.solve_host(Ps, Xs, o)
     assert (r1["status"] == 0).sum() >= 7, r1["status"]          # the restart rules alone (measured: 8 of 8, 94..207 iterations)
     L.close()
+
+
+@pytest.mark.gpu
+def test_tail_rules_of_round4(libs, oracle_mod):
+    """jam_clip / stag_relief (include/landing_nlp.h) through the C ABI on the bench batch (seed 20211): the slowest member (304: 88 iterations, 45 of them
+    full Newton steps held back by the proximal term) ends within 60 iterations with the defaults, no member gets slower by more than 15 iterations, every
+    member of both runs is a KKT point under the oracle."""
+    N, B = 40, 1024
+    L = libs[N]
+    O = oracle_mod.Oracle(N)
+    P, X0, _, _ = lc("problem").make_batch(B, N, 0.6, seed=20211)
+    o = L.default_opts(); o.max_iter = 300
+    assert (o.jam_clip, o.stag_relief) == (2, 3)
+    r1 = L.solve_host(P, X0, o)
+    o.jam_clip = 0; o.stag_relief = 0
+    r0 = L.solve_host(P, X0, o)
+    assert (r0["status"] == 0).all() and (r1["status"] == 0).all()
+    assert r0["iters"][304] >= 80 and r1["iters"][304] <= 60, (r0["iters"][304], r1["iters"][304])
+    assert r1["iters"].max() < r0["iters"].max() and (r1["iters"] - r0["iters"]).max() <= 15
+    for r in (r0, r1):
+        for b in range(B):
+            assert O.kkt(r["x"][b], P[b], r["lam_g"][b]).max() <= KKT_TOL * 1.0001, b

@@ -215,3 +215,19 @@ def test_feasibility_phase_rescues_or_certifies(oracle_mod):
             assert np.abs(g[eq] - lb[eq]).max() <= 1e-6 and abs(viol.max() - r1["kkt"][b, 0]) <= 1e-12 and viol.sum() > 1e-4
             assert np.abs(r1["x"][b] - c1["x"][b]).max() <= 1e-6             # the CPU port ends at the same elastic KKT point
     L.close()
+
+
+def test_stag_relief_shortens_the_known_slow_member(oracle_mod):
+    """landing_solver_opts::stag_relief (round 4): member 304 of the bench batch (seed 20211) reaches pr ~ 1e-5 after 36 iterations and then takes 45 FULL
+    Newton steps to 1e-6 -- the proximal term delta_floor against a curvature of ~1e-5.  With the rule (default 3) the floor shrinks once three such steps have
+    not halved the error; both runs end at KKT points under the oracle's functions.  (CPU port = the kernel's algorithm, test_kernel_matches_cpu_port.)"""
+    N = 40
+    O = oracle_mod.Oracle(N)
+    P, X0, _, _ = lc("problem").make_batch(1024, N, 0.6, seed=20211)
+    P, X0 = P[304:305], X0[304:305]
+    a = oracle_mod.cpu_solve_batch(O, P, X0, threads=1, max_iter=300, stag_relief=0, jam_clip=0)
+    b = oracle_mod.cpu_solve_batch(O, P, X0, threads=1, max_iter=300)
+    assert a["status"][0] == 0 and b["status"][0] == 0
+    assert a["iters"][0] >= 80 and b["iters"][0] <= 60, (a["iters"], b["iters"])      # measured: 88 -> 52
+    for r in (a, b):
+        assert O.kkt(r["x"][0], P[0], r["lam_g"][0]).max() <= 1e-6 * 1.0001
