@@ -505,6 +505,9 @@ int landing_kinodyn_bounds(int N, int B, const landing_kinodyn_form* form, const
 int landing_kinodyn_solve_batch(landing_ctx* ctx, int B, int N, const landing_kinodyn_params* prm, const double* d_lbg, const double* d_ubg,
                                 const double* d_cost, const double* d_x0, const landing_solver_opts* opts,
                                 double* d_x, double* d_f, double* d_lam_g, int* d_status, int* d_iters, double* d_kkt, void* stream);
+/* Host arrays.  With opts = NULL (the defaults) the members the first pass leaves undecided -- iteration limit or numerical failure -- are solved
+   again from the same initial guess: pass 2 with bound_push = bound_frac = 0.1, pass 3 with mu_init = 0.02; a member keeps its first decided
+   outcome and iters counts all its passes (measured on 1024 drop states of the hard sampling law: 19 -> 5 undecided).  With options given: one pass. */
 int landing_kinodyn_solve_batch_host(landing_ctx* ctx, int B, int N, const landing_kinodyn_params* prm, const double* lbg, const double* ubg,
                                      const double* cost, const double* x0, const landing_solver_opts* opts,
                                      double* x, double* f, double* lam_g, int* status, int* iters, double* kkt);

@@ -6,7 +6,7 @@ sys.path.insert(0, ROOT)
 ap = argparse.ArgumentParser()
 ap.add_argument("--B", type=int, default=1); ap.add_argument("--seed", type=int, default=7); ap.add_argument("--law", default="main")
 ap.add_argument("--gpu", action="store_true"); ap.add_argument("--max-iter", type=int, default=200); ap.add_argument("--ik", action="store_true")
-ap.add_argument("--opt", action="append", default=[]); ap.add_argument("--pick", default=""); ap.add_argument("--configs", default=""); ap.add_argument("--certify", action="store_true")
+ap.add_argument("--opt", action="append", default=[]); ap.add_argument("--pick", default=""); ap.add_argument("--configs", default=""); ap.add_argument("--certify", action="store_true"); ap.add_argument("--default-opts", action="store_true", help="pass no options: the library defaults with its retry ladder (max_iter 500)")
 a = ap.parse_args()
 P_ = importlib.import_module("landing-controller_amd.problem"); capi = importlib.import_module("landing-controller_amd.capi")
 rbd = importlib.import_module("landing-controller_amd.rbd"); kd = importlib.import_module("landing-controller_amd.kinodyn")
@@ -55,7 +55,7 @@ for cfg in (a.configs.split(";") if a.configs else [""]):
     for kv in [c for c in cfg.split(",") if c] + a.opt:
         k_, v_ = kv.split("="); setattr(o, k_, type(getattr(o, k_))(float(v_)))
     t = time.time()
-    s = R.kinodyn_solve_host(N, lbs, ubs, costs, x0s, P_.REFERENCE_DT_GRID, mass, Ib, Ibi, consts.mu, o)
+    s = R.kinodyn_solve_host(N, lbs, ubs, costs, x0s, P_.REFERENCE_DT_GRID, mass, Ib, Ibi, consts.mu, None if a.default_opts else o)
     ts = time.time() - t
     ok = s["status"] == 0
     line = "[%s] converged %d / %d  status counts %s  iters mean %.1f p99 %d max %d (converged: mean %.1f max %d)  %.1fs" % (
