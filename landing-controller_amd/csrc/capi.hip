@@ -88,7 +88,7 @@ void landing_form_default(landing_form* f) {
 void landing_solver_opts_default(landing_solver_opts* o) {
   memset(o, 0, sizeof(*o));
   o->tol = 1e-6; o->max_iter = 3000; o->mu_init = 0.0 /* auto: 0.5 for the terminal-cost form, the reference's 0.1 for forms with a running cost (landing_nlp.h) */; o->bound_push = 0.0 /* auto: 1.0 / the reference's 0.5 */; o->bound_frac = 0.1;
-  o->kappa_eps = 0.0 /* auto: 80 for the terminal-cost form, 10 for forms with a running cost (landing_nlp.h) */; o->kappa_mu = 0.2; o->theta_mu = 1.5; o->max_soc = 0; o->max_resets = 8; o->reset_du = 1e9;
+  o->kappa_eps = 0.0 /* auto: 120 for the terminal-cost form, 10 for forms with a running cost (landing_nlp.h) */; o->kappa_mu = 0.2; o->theta_mu = 0.0 /* auto: 1.8 / IPOPT's 1.5 */; o->max_soc = 0; o->max_resets = 8; o->reset_du = 1e9;
   o->delta_init = 1e-4; o->delta_inc_first = 10.0; o->delta_inc = 4.0; o->delta_dec = 0.5; o->tau_min = 0.9; o->alpha_fallback = 1e-2;
   o->stage_local_reg = 0; o->sticky_delta = 0; o->restart_period = 75; o->reset_delta = 1e5; o->dispatch_order = 1;
   o->clip_k = 4; o->clip_until = 0.03; o->theta_floor = 30.0; o->fresh_restart = 9; o->dual_step_cap = 1.0; o->slack_corr = 0.9; o->watchdog = 3; o->barrier_smax = 1.0; o->factor_fp32 = 0; o->jam_clip = 2; o->stag_relief = 3;

@@ -49,7 +49,7 @@ typedef struct {
 
 void lo_solver_opts_default(lo_solver_opts* o) {
   o->tol = 1e-6; o->max_iter = 3000; o->mu_init = 0.0 /* auto: 0.5 terminal-cost form, 0.1 with a running cost */; o->bound_push = 0.0 /* auto: 1.0 / 0.5 */; o->bound_frac = 0.1;
-  o->kappa_eps = 0.0 /* auto: 80 terminal-cost form, 10 with a running cost */; o->kappa_mu = 0.2; o->theta_mu = 1.5; o->max_resets = 8; o->reset_du = 1e9;
+  o->kappa_eps = 0.0 /* auto: 120 terminal-cost form, 10 with a running cost */; o->kappa_mu = 0.2; o->theta_mu = 0.0 /* auto: 1.8 / 1.5 */; o->max_resets = 8; o->reset_du = 1e9;
   o->delta_init = 1e-4; o->delta_inc_first = 10.0; o->delta_inc = 4.0; o->delta_dec = 0.5; o->tau_min = 0.9; o->alpha_fallback = 1e-2; o->restart_period = 75; o->reset_delta = 1e5;
   o->barrier_smax = 1.0; o->watchdog = 3; o->slack_corr = 0.9; o->dual_step_cap = 1.0; o->fresh_restart = 9; o->theta_floor = 30.0; o->clip_k = 4; o->clip_until = 0.03;
   o->feas_phase = 1; o->feas_rho = 1000.0; o->feas_cert = 1e-4;
@@ -632,7 +632,8 @@ int lo_solve_batch(const lo_form* F, int B, const double* p, const double* x0, c
   const lo_int nx = lo_nx(F->N), ng = lo_ng(F->N), np = lo_np_form(F);
   lo_solver_opts o; long long c0 = 0, c1 = 0; int b;
   if (opts) o = *opts; else lo_solver_opts_default(&o);
-  if (!(o.kappa_eps > 0.0)) o.kappa_eps = F->run_cost ? 10.0 : 80.0;      /* automatic choice by formulation (include/landing_nlp.h) */
+  if (!(o.kappa_eps > 0.0)) o.kappa_eps = F->run_cost ? 10.0 : 120.0;     /* automatic choice by formulation (include/landing_nlp.h) */
+  if (!(o.theta_mu > 0.0)) o.theta_mu = F->run_cost ? 1.5 : 1.8;
   if (!(o.mu_init > 0.0)) o.mu_init = F->run_cost ? 0.1 : 0.5;
   if (!(o.bound_push > 0.0)) o.bound_push = F->run_cost ? 0.5 : 1.0;
 #ifdef _OPENMP

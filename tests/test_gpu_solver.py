@@ -365,7 +365,7 @@ def test_soak_failures_are_rescued(oracle_mod):
     o.fresh_restart = 0; o.dual_step_cap = 0.0; o.slack_corr = 0.0; o.watchdog = 0; o.barrier_smax = 0.0; o.feas_phase = 0
     r2 = L.solve_host(Ps, Xs, o)
     assert (r2["status"] == 0).sum() >= 7, r2["status"]          # the proximal term alone (delta_floor, round 3) un-jams them: measured 8 of 8
-    o.delta_floor = 0.0; o.kappa_eps = 10.0; o.mu_init = 0.1; o.bound_push = 0.5     # ... the round-2 schedule they were found with (round 4: with the automatic mu_init / bound_push of this form, 0.5 / 1.0, 7 of the 8 converge even so)
+    o.delta_floor = 0.0; o.kappa_eps = 10.0; o.mu_init = 0.1; o.bound_push = 0.5; o.theta_mu = 1.5     # ... the round-2 schedule they were found with (round 4: with the automatic mu_init / bound_push of this form, 0.5 / 1.0, 7 of the 8 converge even so)
     r0 = L.solve_host(Ps, Xs, o)
     assert (r0["status"] != 0).sum() >= 4, r0["status"]          # measured: 8 of 8 fail
     o.fresh_restart = 15
@@ -385,6 +385,7 @@ def test_tail_rules_of_round4(libs, oracle_mod):
     P, X0, _, _ = lc("problem").make_batch(B, N, 0.6, seed=20211)
     o = L.default_opts(); o.max_iter = 300
     assert (o.jam_clip, o.stag_relief) == (2, 3)
+    o.kappa_eps = 80.0; o.theta_mu = 1.5      # the barrier schedule the slow member was found with (the automatic one moved on: 120 / 1.8)
     r1 = L.solve_host(P, X0, o)
     o.jam_clip = 0; o.stag_relief = 0
     r0 = L.solve_host(P, X0, o)

@@ -195,12 +195,12 @@ def test_feasibility_phase_rescues_or_certifies(oracle_mod):
     P, X0, _, _ = lc("problem").make_batch(B, N, 0.6, seed=3)
     keep = [1, 3, 5]; P, X0, B = P[keep], X0[keep], 3      # (one member of each kind: certified, rescued, converged anyway -- the emulation is slow)
     o = L.default_opts(); o.max_iter = 150
-    o.mu_init = 0.1; o.bound_push = 0.5      # the three members were picked under the reference's values (the defaults are automatic since round 4)
+    o.mu_init = 0.1; o.bound_push = 0.5; o.theta_mu = 1.5; o.kappa_eps = 80.0      # the three members were picked under these values (the defaults are automatic since round 4)
     assert o.feas_phase == 1 and o.feas_rho == 1000.0
     r1 = L.solve_host(P, X0, o)
     o.feas_phase = 0
     r0 = L.solve_host(P, X0, o)
-    c1 = oracle_mod.cpu_solve_batch(O, P, X0, threads=4, max_iter=150, feas_phase=1, mu_init=0.1, bound_push=0.5)
+    c1 = oracle_mod.cpu_solve_batch(O, P, X0, threads=4, max_iter=150, feas_phase=1, mu_init=0.1, bound_push=0.5, theta_mu=1.5, kappa_eps=80.0)
     assert (r0["status"] != 0).sum() == 2                                    # two of the three fail without the phase
     assert np.array_equal(r1["status"], c1["status"]), (r1["status"], c1["status"])
     assert (r1["status"] == 0).sum() > (r0["status"] == 0).sum() and (r1["status"] == 3).sum() >= 1
@@ -225,8 +225,9 @@ def test_stag_relief_shortens_the_known_slow_member(oracle_mod):
     O = oracle_mod.Oracle(N)
     P, X0, _, _ = lc("problem").make_batch(1024, N, 0.6, seed=20211)
     P, X0 = P[304:305], X0[304:305]
-    a = oracle_mod.cpu_solve_batch(O, P, X0, threads=1, max_iter=300, stag_relief=0, jam_clip=0)
-    b = oracle_mod.cpu_solve_batch(O, P, X0, threads=1, max_iter=300)
+    sched = dict(kappa_eps=80.0, theta_mu=1.5)      # the barrier schedule the member was found with (the automatic one moved on: 120 / 1.8)
+    a = oracle_mod.cpu_solve_batch(O, P, X0, threads=1, max_iter=300, stag_relief=0, jam_clip=0, **sched)
+    b = oracle_mod.cpu_solve_batch(O, P, X0, threads=1, max_iter=300, **sched)
     assert a["status"][0] == 0 and b["status"][0] == 0
     assert a["iters"][0] >= 80 and b["iters"][0] <= 60, (a["iters"], b["iters"])      # measured: 88 -> 52
     for r in (a, b):
