@@ -377,7 +377,8 @@ def main():
 
     if rank == 0:
         cfg = {"workload": "3D-SRBM landing NLP, N=40 intervals, batch=%d random drop heights/attitudes per GPU, fp64 (BASELINE configs[1]%s)" % (B, "; x%d GPUs = configs[2]" % world if world > 1 else ""),
-               "global_batch": B * world, "distinct_batches": n_batches, "max_iter": a.max_iter, "kkt_tol": 1e-6, "parallelism": "batch-sharded x%d, RCCL all-gather of x*" % world}
+               "global_batch": B * world, "distinct_batches": n_batches, "max_iter": a.max_iter, "kkt_tol": 1e-6,
+               "solver_options": "library defaults; kappa_eps / theta_mu / mu_init / bound_push chosen by the formulation (terminal-cost form: 120 / 1.8 / 0.5 / 1.0; include/landing_nlp.h)", "parallelism": "batch-sharded x%d, RCCL all-gather of x*" % world}
         out = {"metric": "landing NLPs solved/sec (SRBM, N=40, batch)", "value": solved_per_step * a.steps / elapsed, "unit": "NLPs/s",
                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic", "config": cfg,
