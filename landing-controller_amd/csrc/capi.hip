@@ -242,9 +242,6 @@ landing_ctx* landing_create(int N, int device, const landing_form* form) {
   c->L = landing::make_layout(N);
   c->device = device;
   { const char* e = getenv("LANDING_SWEEP_SERIAL"); c->sweep_concurrent = !(e && e[0] == '1'); }
-  // (round 3: the forces half needs 154 VGPRs instead of 256 + 198 and finishes in 190 us, but the other half still takes as long as the
-  // whole stream did and the Jacobian stream slows down -- the sweep is bound by the aggregate of resident waves, not by one stream's latency:
-  // 36-38 % of 8 TB/s against 39.5-41.7 % with the single stream on the same box, profiles/r03_sweep_timeline.txt)
   { const char* e = getenv("LANDING_SWEEP_SPLIT"); if (e && e[0] >= '0' && e[0] <= '3') c->sweep_split = e[0] - '0'; }
   {  // positions of the U_k Jacobian entries of stages 0 / N-1 inside the uniform (middle-stage) emission sequence
     struct RecCodes { std::vector<int>* v; void col() {} void end() {} void put(int r, double) { v->push_back(r); } };
