@@ -40,11 +40,15 @@ __device__ __forceinline__ V3d sym3(const double* I, V3d v) { return mk3(I[0] * 
 struct SV { V3d a, l; };             // spatial vector: angular / linear (motion) or moment / force
 
 // joint transform applied on top of Xtree: Xup = XJ * plux(E, r)   (jcalc.m:22-40, plux.m)
-__device__ __forceinline__ void joint_xform(int jt, double q, const double* Et, const double* rt, double* E, double* r) {
-  if (jt < 3) {
+// The axis is a template parameter (joint_xform below dispatches): with a run-time axis the rows of E are addressed through computed indices, and
+// the callers' per-body E arrays then cannot live in registers (round 4: 8.9 KB -> 1.3 KB of scratch in the tangent kernel, 7.6 KB in the hyper-dual one).
+template <int JT>
+__device__ __forceinline__ void joint_xform_t(double q, const double* Et, const double* rt, double* E, double* r) {
+  if (JT < 3) {
     double s, c; sincos(q, &s, &c);
     // rows of rx/ry/rz (coordinate transforms): rx = [1 0 0; 0 c s; 0 -s c], ry = [c 0 -s; 0 1 0; s 0 c], rz = [c s 0; -s c 0; 0 0 1]
-    const int a = jt, b = (jt + 1) % 3, d = (jt + 2) % 3;
+    constexpr int a = JT < 3 ? JT : 0, b = (a + 1) % 3, d = (a + 2) % 3;
+#pragma unroll
     for (int j = 0; j < 3; ++j) {
       E[3 * a + j] = Et[3 * a + j];
       E[3 * b + j] = c * Et[3 * b + j] + s * Et[3 * d + j];
@@ -52,9 +56,20 @@ __device__ __forceinline__ void joint_xform(int jt, double q, const double* Et, 
     }
     r[0] = rt[0]; r[1] = rt[1]; r[2] = rt[2];
   } else {   // xlt(q e_a) * plux(E, r) = plux(E, r + E' (q e_a))
-    const int a = jt - 3;
+    constexpr int a = JT >= 3 ? JT - 3 : 0;
+#pragma unroll
     for (int j = 0; j < 9; ++j) E[j] = Et[j];
     r[0] = rt[0] + Et[3 * a] * q; r[1] = rt[1] + Et[3 * a + 1] * q; r[2] = rt[2] + Et[3 * a + 2] * q;
+  }
+}
+__device__ __forceinline__ void joint_xform(int jt, double q, const double* Et, const double* rt, double* E, double* r) {
+  switch (jt) {
+    case 0: joint_xform_t<0>(q, Et, rt, E, r); break;
+    case 1: joint_xform_t<1>(q, Et, rt, E, r); break;
+    case 2: joint_xform_t<2>(q, Et, rt, E, r); break;
+    case 3: joint_xform_t<3>(q, Et, rt, E, r); break;
+    case 4: joint_xform_t<4>(q, Et, rt, E, r); break;
+    default: joint_xform_t<5>(q, Et, rt, E, r); break;
   }
 }
 __device__ __forceinline__ SV xmotion(const double* E, const double* r, SV v) {      // X v
@@ -197,6 +212,7 @@ struct FbArgs {
   const double* q; const double* qd; const double* tau; const double* f_foot;   // [npts][18] x3, [npts][12] or null
   double* H; double* C; double* qdd; double* A; double* Hinv;                  // [npts][324], [npts][18], [npts][18], [npts][18*36], [npts][324]; any may be null
   double fd_h;
+  int arrow;      // the model has the quadruped topology rnea_tangent_quad is written for (landing_rbd_set_model)
 };
 
 // one thread per knot: H, C (and qdd when tau is given)
@@ -276,11 +292,15 @@ __device__ __forceinline__ V3D mulT3(const Dual* E, V3D v) { return mk3D(E[0] * 
 __device__ __forceinline__ V3D sym3(const double* I, V3D v) { return mk3D(I[0] * v.x + I[1] * v.y + I[2] * v.z, I[1] * v.x + I[3] * v.y + I[4] * v.z, I[2] * v.x + I[4] * v.y + I[5] * v.z); }
 struct SVD { V3D a, l; };
 __device__ __forceinline__ SVD addS(SVD p, SVD q) { SVD o; o.a = add3(p.a, q.a); o.l = add3(p.l, q.l); return o; }
-__device__ __forceinline__ void joint_xform(int jt, Dual q, const double* Et, const double* rt, Dual* E, Dual* r) {
-  if (jt < 3) {
+// (the axis is a template parameter: with a run-time axis the rows of E are addressed through computed indices and the callers' E arrays
+// cannot live in registers)
+template <int JT>
+__device__ __forceinline__ void joint_xform_t(Dual q, const double* Et, const double* rt, Dual* E, Dual* r) {
+  if (JT < 3) {
     double s, c; sincos(q.v, &s, &c);
     const Dual S = D_(s, c * q.d), Cc = D_(c, -s * q.d);
-    const int a = jt, b = (jt + 1) % 3, d = (jt + 2) % 3;
+    constexpr int a = JT < 3 ? JT : 0, b = (a + 1) % 3, d = (a + 2) % 3;
+#pragma unroll
     for (int j = 0; j < 3; ++j) {
       E[3 * a + j] = D_(Et[3 * a + j]);
       E[3 * b + j] = Et[3 * b + j] * Cc + Et[3 * d + j] * S;
@@ -288,9 +308,20 @@ __device__ __forceinline__ void joint_xform(int jt, Dual q, const double* Et, co
     }
     r[0] = D_(rt[0]); r[1] = D_(rt[1]); r[2] = D_(rt[2]);
   } else {
-    const int a = jt - 3;
+    constexpr int a = JT >= 3 ? JT - 3 : 0;
+#pragma unroll
     for (int j = 0; j < 9; ++j) E[j] = D_(Et[j]);
     r[0] = D_(rt[0]) + Et[3 * a] * q; r[1] = D_(rt[1]) + Et[3 * a + 1] * q; r[2] = D_(rt[2]) + Et[3 * a + 2] * q;
+  }
+}
+__device__ __forceinline__ void joint_xform(int jt, Dual q, const double* Et, const double* rt, Dual* E, Dual* r) {
+  switch (jt) {
+    case 0: joint_xform_t<0>(q, Et, rt, E, r); break;
+    case 1: joint_xform_t<1>(q, Et, rt, E, r); break;
+    case 2: joint_xform_t<2>(q, Et, rt, E, r); break;
+    case 3: joint_xform_t<3>(q, Et, rt, E, r); break;
+    case 4: joint_xform_t<4>(q, Et, rt, E, r); break;
+    default: joint_xform_t<5>(q, Et, rt, E, r); break;
   }
 }
 __device__ __forceinline__ SVD xmotion(const Dual* E, const Dual* r, SVD v) {
@@ -361,6 +392,96 @@ __device__ void rnea_tangent(const RbdModel& M, const double* q, const double* q
     if (pa != 0) fvp[pa - 1] = addS(fvp[pa - 1], xforceT(E[i], r[i], fvp[i]));
   }
 }
+// The same tangent for the reference's quadruped topology (landing_rbd_set_model checks it: six single-DoF base joints in a chain, bodies 0..5,
+// and four legs of three joints hanging off body 5 -- parent = [0 1 2 3 4 5 | 6 7 8 | 6 10 11 | 6 13 14 | 6 16 17]).  The generic recursion above
+// indexes its per-body arrays with the model's parent table: 1080 doubles of dual numbers per thread in private memory (8.9 KB of scratch, the
+// kernel's whole time).  Here every index is a compile-time constant and a leg is finished -- forward, foot force, backward into body 5 -- before
+// the next one starts; the base chain's transforms are formed again on the way back instead of being kept.  Same operations in the same order per
+// body as rnea_tangent: the results agree to rounding.
+__device__ void rnea_tangent_quad(const RbdModel& M, const double* q, const double* qd, const double* qdd, const double* f_foot, int dir, double* dtau) {
+  SVD fb[6], v, a;
+  Dual E0[9], r0[3];
+#pragma unroll
+  for (int j = 0; j < 9; ++j) E0[j] = D_((j % 4 == 0) ? 1.0 : 0.0);
+  r0[0] = r0[1] = r0[2] = D_(0.0);
+  auto compose = [](const Dual* Eu, const Dual* ru, Dual* Ea, Dual* ra) {
+    const V3D t = mulT3(Ea, mk3D(ru[0], ru[1], ru[2]));
+    Dual En[9];
+#pragma unroll
+    for (int aa = 0; aa < 3; ++aa)
+#pragma unroll
+      for (int bb = 0; bb < 3; ++bb) En[3 * aa + bb] = Eu[3 * aa] * Ea[bb] + Eu[3 * aa + 1] * Ea[3 + bb] + Eu[3 * aa + 2] * Ea[6 + bb];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) Ea[j] = En[j];
+    ra[0] = ra[0] + t.x; ra[1] = ra[1] + t.y; ra[2] = ra[2] + t.z;
+  };
+  // ---- base chain, forward
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    Dual E[9], r[3];
+    const Dual qi = D_(q[i], dir == i ? 1.0 : 0.0), qdi = D_(qd[i], dir == RB_NB + i ? 1.0 : 0.0);
+    joint_xform(M.jtype[i], qi, M.E[i], M.r[i], E, r);
+    const SVD vJ = sunit(M.jtype[i], qdi), aJ = sunit(M.jtype[i], D_(qdd[i]));
+    if (i == 0) {
+      SVD g; g.a = mk3D(0.0, 0.0, 0.0); g.l = mk3D(0.0, 0.0, 9.81);
+      v = vJ; a = addS(xmotion(E, r, g), aJ);
+    } else {
+      const SVD vn = addS(xmotion(E, r, v), vJ);
+      a = addS(addS(xmotion(E, r, a), crm_mul(vn, vJ)), aJ);
+      v = vn;
+    }
+    fb[i] = addS(inertia_mul(M.m[i], M.h[i], M.I[i], a), crf_mul(v, inertia_mul(M.m[i], M.h[i], M.I[i], v)));
+    if (f_foot) compose(E, r, E0, r0);
+  }
+  // ---- the four legs, one after the other
+#pragma unroll 1
+  for (int leg = 0; leg < 4; ++leg) {
+    Dual El[3][9], rl[3][3];
+    SVD fl[3], vv = v, aa = a;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int i = 6 + 3 * leg + j;
+      const Dual qi = D_(q[i], dir == i ? 1.0 : 0.0), qdi = D_(qd[i], dir == RB_NB + i ? 1.0 : 0.0);
+      joint_xform(M.jtype[i], qi, M.E[i], M.r[i], El[j], rl[j]);
+      const SVD vJ = sunit(M.jtype[i], qdi), aJ = sunit(M.jtype[i], D_(qdd[i]));
+      const SVD vn = addS(xmotion(El[j], rl[j], vv), vJ);
+      aa = addS(addS(xmotion(El[j], rl[j], aa), crm_mul(vn, vJ)), aJ);
+      vv = vn;
+      fl[j] = addS(inertia_mul(M.m[i], M.h[i], M.I[i], aa), crf_mul(vv, inertia_mul(M.m[i], M.h[i], M.I[i], vv)));
+    }
+    if (f_foot) {
+      Dual Ef[9], rf[3];
+#pragma unroll
+      for (int j = 0; j < 9; ++j) Ef[j] = E0[j];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) rf[j] = r0[j];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) compose(El[j], rl[j], Ef, rf);
+      const V3D rb = mk3D(rf[0], rf[1], rf[2]);
+      const V3D pf = add3(rb, mulT3(Ef, mk3D(M.foot_r[leg][0], M.foot_r[leg][1], M.foot_r[leg][2])));
+      const V3D fw = mk3D(f_foot[3 * leg], f_foot[3 * leg + 1], f_foot[3 * leg + 2]);
+      const V3D nb = crs3(sub3(pf, rb), fw);
+      fl[2].a = sub3(fl[2].a, mul3(Ef, nb)); fl[2].l = sub3(fl[2].l, mul3(Ef, fw));
+    }
+#pragma unroll
+    for (int j = 2; j >= 0; --j) {
+      const int i = 6 + 3 * leg + j;
+      dtau[i] = sdot(M.jtype[i], fl[j]).d;
+      if (j > 0) fl[j - 1] = addS(fl[j - 1], xforceT(El[j], rl[j], fl[j]));
+      else fb[5] = addS(fb[5], xforceT(El[0], rl[0], fl[0]));
+    }
+  }
+  // ---- base chain, backward (transforms formed again)
+#pragma unroll
+  for (int i = 5; i >= 0; --i) {
+    dtau[i] = sdot(M.jtype[i], fb[i]).d;
+    if (i > 0) {
+      Dual E[9], r[3];
+      joint_xform(M.jtype[i], D_(q[i], dir == i ? 1.0 : 0.0), M.E[i], M.r[i], E, r);
+      fb[i - 1] = addS(fb[i - 1], xforceT(E, r, fb[i]));
+    }
+  }
+}
 // pass 1 (one thread per knot): H, C, qdd and H^-1 (scratch or caller buffers); pass 2 (one thread per (knot, column)): A(:, col) = -H^-1 dtau
 __global__ void __launch_bounds__(64) landing_fb_lin_exact_prep_kernel(FbArgs a, double* qdd_out, double* hinv_out) {
   const int pt = blockIdx.x * blockDim.x + threadIdx.x;
@@ -394,13 +515,18 @@ __global__ void __launch_bounds__(64) landing_fb_lin_exact_prep_kernel(FbArgs a,
     for (int i = 0; i < RB_NB; ++i) hinv_out[((size_t)pt * RB_NB + i) * RB_NB + c] = ok ? e[i] : NAN;
   }
 }
-__global__ void __launch_bounds__(64) landing_fb_lin_exact_kernel(FbArgs a, const double* qdd_in, const double* hinv_in) {
+template <bool QUAD>      // QUAD: the model has the topology of rnea_tangent_quad (FbArgs::arrow); its own instantiation, so that it does not inherit the generic recursion's scratch
+#ifndef LANDING_FBLIN_WAVES
+#define LANDING_FBLIN_WAVES 1
+#endif
+__global__ void __launch_bounds__(64, QUAD ? LANDING_FBLIN_WAVES : 1) landing_fb_lin_exact_kernel(FbArgs a, const double* qdd_in, const double* hinv_in) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   const int pt = idx / 36, col = idx % 36;
   if (pt >= a.npts) return;
   const RbdModel& M = *a.model;
   double dtau[RB_NB];
-  rnea_tangent(M, a.q + (size_t)pt * RB_NB, a.qd + (size_t)pt * RB_NB, qdd_in + (size_t)pt * RB_NB, a.f_foot ? a.f_foot + (size_t)pt * 12 : nullptr, col, dtau);
+  if (QUAD) rnea_tangent_quad(M, a.q + (size_t)pt * RB_NB, a.qd + (size_t)pt * RB_NB, qdd_in + (size_t)pt * RB_NB, a.f_foot ? a.f_foot + (size_t)pt * 12 : nullptr, col, dtau);
+  else rnea_tangent(M, a.q + (size_t)pt * RB_NB, a.qd + (size_t)pt * RB_NB, qdd_in + (size_t)pt * RB_NB, a.f_foot ? a.f_foot + (size_t)pt * 12 : nullptr, col, dtau);
   const double* Hi = hinv_in + (size_t)pt * RB_NB * RB_NB;
   for (int i = 0; i < RB_NB; ++i) {
     double s = 0.0;
@@ -512,10 +638,12 @@ __device__ __forceinline__ V3H crs3(V3H a, V3H b) { return mk3(a.y * b.z - a.z *
 __device__ __forceinline__ V3H mul3(const HDual* E, V3H v) { return mk3(E[0] * v.x + E[1] * v.y + E[2] * v.z, E[3] * v.x + E[4] * v.y + E[5] * v.z, E[6] * v.x + E[7] * v.y + E[8] * v.z); }
 __device__ __forceinline__ V3H mulT3(const HDual* E, V3H v) { return mk3(E[0] * v.x + E[3] * v.y + E[6] * v.z, E[1] * v.x + E[4] * v.y + E[7] * v.z, E[2] * v.x + E[5] * v.y + E[8] * v.z); }
 template <> struct KdVec<HDual> { typedef V3H type; };
-__device__ __forceinline__ void joint_xform(int jt, HDual q, const double* Et, const double* rt, HDual* E, HDual* r) {
-  if (jt < 3) {
+template <int JT>
+__device__ __forceinline__ void joint_xform_t(HDual q, const double* Et, const double* rt, HDual* E, HDual* r) {
+  if (JT < 3) {
     HDual S, Cc; sincos_t(q, S, Cc);
-    const int a = jt, b = (jt + 1) % 3, d = (jt + 2) % 3;
+    constexpr int a = JT < 3 ? JT : 0, b = (a + 1) % 3, d = (a + 2) % 3;
+#pragma unroll
     for (int j = 0; j < 3; ++j) {
       E[3 * a + j] = H_(Et[3 * a + j]);
       E[3 * b + j] = Et[3 * b + j] * Cc + Et[3 * d + j] * S;
@@ -523,12 +651,22 @@ __device__ __forceinline__ void joint_xform(int jt, HDual q, const double* Et, c
     }
     r[0] = H_(rt[0]); r[1] = H_(rt[1]); r[2] = H_(rt[2]);
   } else {
-    const int a = jt - 3;
+    constexpr int a = JT >= 3 ? JT - 3 : 0;
+#pragma unroll
     for (int j = 0; j < 9; ++j) E[j] = H_(Et[j]);
     r[0] = H_(rt[0]) + Et[3 * a] * q; r[1] = H_(rt[1]) + Et[3 * a + 1] * q; r[2] = H_(rt[2]) + Et[3 * a + 2] * q;
   }
 }
-
+__device__ __forceinline__ void joint_xform(int jt, HDual q, const double* Et, const double* rt, HDual* E, HDual* r) {
+  switch (jt) {
+    case 0: joint_xform_t<0>(q, Et, rt, E, r); break;
+    case 1: joint_xform_t<1>(q, Et, rt, E, r); break;
+    case 2: joint_xform_t<2>(q, Et, rt, E, r); break;
+    case 3: joint_xform_t<3>(q, Et, rt, E, r); break;
+    case 4: joint_xform_t<4>(q, Et, rt, E, r); break;
+    default: joint_xform_t<5>(q, Et, rt, E, r); break;
+  }
+}
 
 
 template <class T>

@@ -9,7 +9,7 @@ capi = importlib.import_module("landing-controller_amd.capi"); rbd = importlib.i
 import test_wb as T
 ap = argparse.ArgumentParser(); ap.add_argument("--members", type=int, default=1024); ap.add_argument("--iters", type=int, default=6); ap.add_argument("--host-loop", action="store_true", help="the round-3 loop: one rollout launch + torch.where merges per step length"); ap.add_argument("--semi", action="store_true"); a = ap.parse_args()
 N, B = 40, a.members
-L = capi.LandingLib(N, 0); R = rbd.Rbd(L)
+L = capi.LandingLib(N, 0, lib_path=os.environ.get("LANDING_LIB")); R = rbd.Rbd(L)
 S = wb.WholeBodySQP(L, R, N, T.DT, T.Q, T.R, T.QN, device="cuda", fused=not a.host_loop, semi_implicit=a.semi)
 nb = min(B, 64)
 x0, u0, xref, f = T._problem(np.random.default_rng(5), nb, N)
