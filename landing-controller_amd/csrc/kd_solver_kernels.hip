@@ -101,7 +101,8 @@ KD_PHASE void kd_member_eval_g(const KdNlpParams& P, const RbdModel& M, int N, c
     for (int j = 0; j < KD_NW; ++j) { const int i = kd_w_index(N, k, j); w[j] = i >= 0 ? x[i] : 0.0; }
     // the rows go straight to the member's g array (a local out[141] is promoted to registers by the unrolled row code: 255 VGPRs + AGPR spills,
     // one workgroup per CU); the last interval writes its 117 rows only
-    kd_stage_rows<double>(P, M, k, k == N - 1, w, g + KD_BND + k * KD_ROWS);
+    KdRowArray<double> rows{g + KD_BND + k * KD_ROWS};
+    kd_stage_rows<double>(P, M, k, k == N - 1, w, rows);
   }
   if (threadIdx.x >= 64 && threadIdx.x < 64 + 48) {      // boundary rows (coordinate picks), by a wave that has no interval to evaluate
     const int i = threadIdx.x - 64, oU = 12 * (N + 1) + 12 * N;

@@ -721,8 +721,11 @@ __device__ __noinline__ void kd_leg_kin_d(const RbdModel& M, int l, const double
 // legmask: bit l set = the rows of leg l that need the leg's kinematics (hip-relative position, leg torques, forward kinematics: the
 // expensive part of the function) are evaluated; a cleared bit writes zeros there.  The value / Jacobian kernels pass 15; the Hessian kernel
 // passes the one leg a pair of directions belongs to (second derivatives of the other legs' rows vanish for that pair).
-template <class T>
-__device__ void kd_stage_rows(const KdNlpParams& P, const RbdModel& M, int k, bool last, const T* w, T* out, int legmask = 15) {
+// `out` is an emitter: out.put(v) receives the rows one after the other.  (Round 4: the callers used to pass an array of KD_ROWS values -- 4.5 KB of
+// hyper-dual numbers per thread in private memory in the Hessian kernel, which only needs lam' out; KdRowArray below is the array form.)
+template <class T> struct KdRowArray { T* p; __device__ __forceinline__ void put(const T& v) { *p++ = v; } };
+template <class T, class OUT>
+__device__ void kd_stage_rows(const KdNlpParams& P, const RbdModel& M, int k, bool last, const T* w, OUT& out, int legmask = 15) {
   typedef typename KdVec<T>::type V;
   const T zero = lit(w[0], 0.0);
   const T* X = w; const T* c = w + 12; const T* f = w + 24; const T* jp = w + 36; const T* Xn = w + 48; const T* cn = w + 60;
@@ -750,12 +753,11 @@ __device__ void kd_stage_rows(const KdNlpParams& P, const RbdModel& M, int k, bo
   // Binv(rpy) (Binv.m:13-17), psi = yaw, theta = pitch
   const T ict = lit(w[0], 1.0) / cp, tt = sp * ict;
   const V ed = mk3((cy * Rw.x + sy * Rw.y) * ict, cy * Rw.y - sy * Rw.x, (cy * Rw.x + sy * Rw.y) * tt + Rw.z);
-  int r = 0;
-  out[r++] = Xn[9] - X[9] - rdd.x * dt; out[r++] = Xn[10] - X[10] - rdd.y * dt; out[r++] = Xn[11] - X[11] - rdd.z * dt;       // :125
-  out[r++] = Xn[6] - X[6] - omd.x * dt; out[r++] = Xn[7] - X[7] - omd.y * dt; out[r++] = Xn[8] - X[8] - omd.z * dt;          // :126
-  out[r++] = Xn[0] - X[0] - v.x * dt; out[r++] = Xn[1] - X[1] - v.y * dt; out[r++] = Xn[2] - X[2] - v.z * dt;                // :127
-  out[r++] = Xn[3] - X[3] - ed.x * dt; out[r++] = Xn[4] - X[4] - ed.y * dt; out[r++] = Xn[5] - X[5] - ed.z * dt;             // :128
-  for (int l = 0; l < 4; ++l) out[r++] = f[3 * l + 2];                                                                       // :131
+  out.put(Xn[9] - X[9] - rdd.x * dt); out.put(Xn[10] - X[10] - rdd.y * dt); out.put(Xn[11] - X[11] - rdd.z * dt);       // :125
+  out.put(Xn[6] - X[6] - omd.x * dt); out.put(Xn[7] - X[7] - omd.y * dt); out.put(Xn[8] - X[8] - omd.z * dt);          // :126
+  out.put(Xn[0] - X[0] - v.x * dt); out.put(Xn[1] - X[1] - v.y * dt); out.put(Xn[2] - X[2] - v.z * dt);                // :127
+  out.put(Xn[3] - X[3] - ed.x * dt); out.put(Xn[4] - X[4] - ed.y * dt); out.put(Xn[5] - X[5] - ed.z * dt);             // :128
+  for (int l = 0; l < 4; ++l) out.put(f[3 * l + 2]);                                                                       // :131
   // world -> base transform of the tree (the six base joints take pos, rpy), for the forward kinematics of :182
   T E0[9], r0[3], Ej[9], rj[3];
   for (int j = 0; j < 9; ++j) E0[j] = lit(w[0], (j % 4 == 0) ? 1.0 : 0.0);
@@ -765,24 +767,24 @@ __device__ void kd_stage_rows(const KdNlpParams& P, const RbdModel& M, int k, bo
   const double l14 = M.l1 + M.l4;
   for (int l = 0; l < 4; ++l) {
     const T cz = c[3 * l + 2], fz = f[3 * l + 2];
-    out[r++] = cz;                                                                                                           // :138
-    out[r++] = fz * cz;                                                                                                      // :139
+    out.put(cz);                                                                                                           // :138
+    out.put(fz * cz);                                                                                                      // :139
     if (!last) {
-      for (int a = 0; a < 3; ++a) out[r++] = fz * (cn[3 * l + a] - c[3 * l + a]);                                              // :142
-      for (int a = 0; a < 3; ++a) out[r++] = fz * (cn[3 * l + a] - c[3 * l + a]);                                              // :143
+      for (int a = 0; a < 3; ++a) out.put(fz * (cn[3 * l + a] - c[3 * l + a]));                                              // :142
+      for (int a = 0; a < 3; ++a) out.put(fz * (cn[3 * l + a] - c[3 * l + a]));                                              // :143
     }
     if (!((legmask >> l) & 1)) {      // rows of this leg's kinematics are not needed by the caller
-      for (int a = 0; a < 7; ++a) out[r++] = zero;
+      for (int a = 0; a < 7; ++a) out.put(zero);
       fkv[3 * l] = c[3 * l]; fkv[3 * l + 1] = c[3 * l + 1]; fkv[3 * l + 2] = c[3 * l + 2];
       continue;
     }
     // hip-relative foot position (4 rows), leg torques (3 rows), foot position of the tree: kd_leg_kin (out of line for T = double)
-    if constexpr (std::is_same<T, double>::value) { kd_leg_kin_d(M, l, w, R, E0, r0, out + r, fkv + 3 * l); r += 7; continue; }
+    if constexpr (std::is_same<T, double>::value) { double o7[7]; kd_leg_kin_d(M, l, w, R, E0, r0, o7, fkv + 3 * l); for (int a = 0; a < 7; ++a) out.put(o7[a]); continue; }
     // (the dual / hyper-dual instantiations of the derivative kernels keep the rows inline: the same code as kd_leg_kin, in place)
     const double hx = l < 2 ? 0.19 : -0.19, hy = (l & 1) ? 0.1 : -0.1;        // params.hipSrbmLocation (get_robot_params.m:90-91)
     const V pr = sub3(mk3(c[3 * l], c[3 * l + 1], c[3 * l + 2]), add3(pos, mk3(R[0] * hx + R[1] * hy, R[3] * hx + R[4] * hy, R[6] * hx + R[7] * hy)));
-    out[r++] = pr.x; out[r++] = pr.y; out[r++] = pr.z;                                                                       // :157-163
-    out[r++] = pr.x * pr.x + pr.y * pr.y + pr.z * pr.z;                                                                      // :164
+    out.put(pr.x); out.put(pr.y); out.put(pr.z);                                                                       // :157-163
+    out.put(pr.x * pr.x + pr.y * pr.y + pr.z * pr.z);                                                                      // :164
     // leg torques J_f'(-R_world_to_body f)  (:167-171, get_foot_jacobians_mc.m:12-24)
     T s1, c1, s2, c2, s3, c3;
     sincos_t(jp[3 * l], s1, c1); sincos_t(jp[3 * l + 1], s2, c2); sincos_t(jp[3 * l + 2], s3, c3);
@@ -792,7 +794,7 @@ __device__ void kd_stage_rows(const KdNlpParams& P, const RbdModel& M, int k, bo
                        {c1 * c23 * M.l3 + c1 * c2 * M.l2 - s1 * (l14 * ss), zero - s1 * s23 * M.l3 - s1 * s2 * M.l2, zero - s1 * s23 * M.l3},
                        {s1 * c23 * M.l3 + c2 * s1 * M.l2 + c1 * (l14 * ss), c1 * s23 * M.l3 + c1 * s2 * M.l2, c1 * s23 * M.l3}};
     const V fb = mulT3(R, mk3(zero - f[3 * l], zero - f[3 * l + 1], zero - f[3 * l + 2]));
-    for (int j = 0; j < 3; ++j) out[r++] = J[0][j] * fb.x + J[1][j] * fb.y + J[2][j] * fb.z;
+    for (int j = 0; j < 3; ++j) out.put(J[0][j] * fb.x + J[1][j] * fb.y + J[2][j] * fb.z);
     // foot position of the tree (get_forward_kin_foot.m)
     T El[9], rl[3];
     for (int j = 0; j < 9; ++j) El[j] = E0[j];
@@ -803,15 +805,15 @@ __device__ void kd_stage_rows(const KdNlpParams& P, const RbdModel& M, int k, bo
     fkv[3 * l] = pf.x; fkv[3 * l + 1] = pf.y; fkv[3 * l + 2] = pf.z;
   }
   const double km = 0.71 * P.mu;
-  for (int l = 0; l < 4; ++l) out[r++] = f[3 * l] - f[3 * l + 2] * km;                                                         // :175
-  for (int l = 0; l < 4; ++l) out[r++] = f[3 * l] + f[3 * l + 2] * km;                                                         // :176
-  for (int l = 0; l < 4; ++l) out[r++] = f[3 * l + 1] - f[3 * l + 2] * km;                                                     // :177
-  for (int l = 0; l < 4; ++l) out[r++] = f[3 * l + 1] + f[3 * l + 2] * km;                                                     // :178
-  out[r++] = X[2];                                                                                                           // :181
-  for (int j = 0; j < 12; ++j) out[r++] = c[j] - fkv[j];                                                                     // :186
-  for (int j = 0; j < 12; ++j) out[r++] = c[j] - fkv[j];                                                                     // :187
-  for (int j = 0; j < 12; ++j) out[r++] = jp[j];                                                                             // :188
-  for (int j = 0; j < 12; ++j) out[r++] = jp[j];                                                                             // :189
+  for (int l = 0; l < 4; ++l) out.put(f[3 * l] - f[3 * l + 2] * km);                                                         // :175
+  for (int l = 0; l < 4; ++l) out.put(f[3 * l] + f[3 * l + 2] * km);                                                         // :176
+  for (int l = 0; l < 4; ++l) out.put(f[3 * l + 1] - f[3 * l + 2] * km);                                                     // :177
+  for (int l = 0; l < 4; ++l) out.put(f[3 * l + 1] + f[3 * l + 2] * km);                                                     // :178
+  out.put(X[2]);                                                                                                           // :181
+  for (int j = 0; j < 12; ++j) out.put(c[j] - fkv[j]);                                                                     // :186
+  for (int j = 0; j < 12; ++j) out.put(c[j] - fkv[j]);                                                                     // :187
+  for (int j = 0; j < 12; ++j) out.put(jp[j]);                                                                             // :188
+  for (int j = 0; j < 12; ++j) out.put(jp[j]);                                                                             // :189
 }
 
 struct KdNlpArgs {
@@ -842,12 +844,12 @@ __global__ void __launch_bounds__(64) landing_kinodyn_nlp_g_kernel(KdNlpArgs a) 
   if (a.skip && a.skip[b]) return;
   const double* x = a.x + a.ox(b);
   double* g = a.g + a.og(b);
-  double w[KD_NW], out[KD_ROWS];
+  double w[KD_NW];
+#pragma unroll
   for (int j = 0; j < KD_NW; ++j) { const int i = kd_w_index(N, k, j); w[j] = i >= 0 ? x[i] : 0.0; }
   const bool last = k == N - 1;
+  KdRowArray<double> out{g + KD_BND + k * KD_ROWS};      // (the last interval emits KD_ROWS_LAST rows)
   kd_stage_rows<double>(a.P, *a.model, k, last, w, out);
-  const int nr = last ? KD_ROWS_LAST : KD_ROWS;
-  for (int r = 0; r < nr; ++r) g[KD_BND + k * KD_ROWS + r] = out[r];
   if (k == 0) {
     for (int i = 0; i < 12; ++i) g[i] = x[i];                                            // q(:,1), qdot(:,1)
     for (int i = 0; i < 12; ++i) g[12 + i] = x[12 * (N + 1) + 12 * N + i];               // c(:,1)
@@ -861,13 +863,13 @@ __global__ void __launch_bounds__(64) landing_kinodyn_nlp_jac_kernel(KdNlpArgs a
   const int col = (int)(idx % KD_NW); const int k = (int)((idx / KD_NW) % a.N); const int b = (int)(idx / ((long long)KD_NW * a.N)), N = a.N;
   if (a.skip && a.skip[b]) return;
   const double* x = a.x + a.ox(b);
-  Dual w[KD_NW], out[KD_ROWS];
+  Dual w[KD_NW];
+#pragma unroll
   for (int j = 0; j < KD_NW; ++j) { const int i = kd_w_index(N, k, j); w[j] = D_(i >= 0 ? x[i] : 0.0, j == col ? 1.0 : 0.0); }
   const bool last = k == N - 1;
+  struct ColOut { double* J; bool zero; __device__ __forceinline__ void put(const Dual& v) { *J = zero ? 0.0 : v.d; J += KD_NW; } };      // row after row of column col
+  ColOut out{a.jac + a.oj(b) + ((size_t)k * KD_ROWS) * KD_NW + col, last && col >= 60};
   kd_stage_rows<Dual>(a.P, *a.model, k, last, w, out);
-  const int nr = last ? KD_ROWS_LAST : KD_ROWS;
-  double* J = a.jac + a.oj(b) + ((size_t)k * KD_ROWS) * KD_NW;
-  for (int r = 0; r < nr; ++r) J[(size_t)r * KD_NW + col] = (last && col >= 60) ? 0.0 : out[r].d;
 }
 
 // Hessian of lam' g restricted to one interval: hess[b][k][i][j] = sum_r lam_r d^2 row_r / dw_i dw_j (72 x 72, symmetric; the 48 boundary rows are
@@ -916,13 +918,14 @@ __global__ void __launch_bounds__(64) landing_kinodyn_nlp_hess_kernel(KdNlpArgs 
   if (last && j >= 60) return;
   const double* x = a.x + a.ox(b);
   const double* lam = a.lam + a.og(b) + KD_BND + (size_t)k * KD_ROWS;
-  HDual w[KD_NW], out[KD_ROWS];
+  HDual w[KD_NW];
+#pragma unroll
   for (int q = 0; q < KD_NW; ++q) { const int ix = kd_w_index(N, k, q); w[q] = H_(ix >= 0 ? x[ix] : 0.0, q == i ? 1.0 : 0.0, q == j ? 1.0 : 0.0, 0.0); }
   const int pl = kd_pair_leg(i, j);
+  struct LamOut { const double* lam; double s; __device__ __forceinline__ void put(const HDual& v) { s += *lam++ * v.ab; } };      // lam' (second-order part), row after row
+  LamOut out{lam, 0.0};
   kd_stage_rows<HDual>(a.P, *a.model, k, last, w, out, pl < 0 ? 15 : (1 << pl));
-  const int nr = last ? KD_ROWS_LAST : KD_ROWS;
-  double s = 0.0;
-  for (int r = 0; r < nr; ++r) s += lam[r] * out[r].ab;
+  const double s = out.s;
   Hk[i * KD_NW + j] = s; Hk[j * KD_NW + i] = s;
 }
 
