@@ -53,6 +53,7 @@ struct KdState {
   int nfilt, it, status, done, need_reg_streak, first_failed, cutstreak, force_step, wd_count, last_mu_it;
   int accepted, armijo_step, fact_ok, skipped_zero, attempt, flag, ls_done, need_corr, fallback, nfact, ntrial, nreset;
   int last_reset_it, ncrawl, clip_k_cur, fresh;
+  int pending;      // the inertia correction of this iteration continues in the next launch (landing_kd_iter_kernel, KD_TRIES_PER_ROUND)
   double prof[8]; long long tp;      // development aid: wall_clock64 ticks (100 MHz) per phase, summed over the iterations: grad | mu | backward | forward | dual | line search | accept
 };
 
@@ -477,7 +478,7 @@ __global__ void __launch_bounds__(KD_THREADS) landing_kd_init_kernel(KdSolveArgs
     K.e_pr = K.e_du = K.e_co = 0.0; K.tau = 0.0; K.a_pr = K.a_du = 0.0; K.th0 = K.ph0 = K.dphi = K.alpha = K.s_corr = K.delta = K.ft = K.fval = 0.0; K.omt = -1.0;
     K.nfilt = 0; K.it = 0; K.status = LANDING_MAX_ITER; K.done = 0; K.need_reg_streak = 0; K.first_failed = 0; K.cutstreak = 0; K.force_step = 0;
     K.wd_count = 0; K.last_mu_it = 0; K.accepted = 0; K.armijo_step = 0; K.fact_ok = 0; K.skipped_zero = 0; K.attempt = 0; K.flag = 0; K.ls_done = 0;
-    K.need_corr = 0; K.fallback = 0; K.nfact = 0; K.ntrial = 0; K.nreset = 0; K.last_reset_it = 0; K.ncrawl = 0; K.clip_k_cur = A.o.clip_k; K.fresh = 0;
+    K.need_corr = 0; K.fallback = 0; K.nfact = 0; K.ntrial = 0; K.nreset = 0; K.last_reset_it = 0; K.ncrawl = 0; K.clip_k_cur = A.o.clip_k; K.fresh = 0; K.pending = 0;
     for (int i = 0; i < 8; ++i) K.prof[i] = 0.0; K.tp = 0;
   }
   __syncthreads();
@@ -503,6 +504,9 @@ __global__ void __launch_bounds__(KD_THREADS) landing_kd_init_kernel(KdSolveArgs
 }
 
 // ---- one interior-point iteration of one member (J and H blocks of the current (x, y) are in the workspace) ---------------------------
+#ifndef KD_TRIES_PER_ROUND
+#define KD_TRIES_PER_ROUND 1
+#endif
 __global__ void __launch_bounds__(KD_THREADS, 2) landing_kd_iter_kernel(KdSolveArgs A) {
   const int m = blockIdx.x;
   if (m >= A.B) return;
@@ -518,90 +522,99 @@ __global__ void __launch_bounds__(KD_THREADS, 2) landing_kd_iter_kernel(KdSolveA
   if (tid == 0) { K = *M.st; K.tp = (long long)wall_clock64(); }
   __syncthreads();
   const int oU = 12 * (N + 1) + 12 * N;
-  // ---------------------------------------------------------------- optimality error (unscaled), stop test
-  kd_grad_lag(M, N, cost);
-  KD_PROF(0);
-  {
-    double du = 0.0;
-    for (int i = tid; i < nx; i += NT) { const bool fixed = i < 12 || (i >= oU && i < oU + 12); if (!fixed) du = fmax(du, fabs(M.gx[i])); }
-    du = block_reduce1(du, RMAX, S.red);
-    KD_BEGIN_SYNCED()
-      const double pr = K.c_pr, co = K.c_co;
-      K.e_pr = pr; K.e_du = du; K.e_co = co;
-      K.flag = 0;
-      if (!(du < 1e300) || !(pr < 1e300) || !(co < 1e300)) { K.status = LANDING_NUMERICAL; K.flag = 1; }
-      else if (fmax(du, fmax(pr, co)) <= o.tol) { K.status = LANDING_CONVERGED; K.flag = 1; }
-      else if (K.it >= o.max_iter) { K.status = LANDING_MAX_ITER; K.flag = 1; }
-      else if (du > o.reset_du && K.nreset >= o.max_resets && o.max_resets > 0) { K.status = LANDING_NUMERICAL; K.flag = 1; }      // jammed again: give up
-      else {
-        // restart rules of the SRBM solver (solver_kernels.hip, landing_nlp.h fresh_restart): a jammed iterate (multipliers blown up), a first
-        // barrier problem that crawls, a later one that has wandered off -> slacks, multipliers, barrier parameter and filter are re-initialised,
-        // at the current x or (after a jam) at the caller's initial guess with the step rule clip_k = 2
-        const int it = K.it, nreset = K.nreset; const double mu = K.mu;
-        const bool jam = du > o.reset_du && nreset < o.max_resets;
-        const bool stalled = o.restart_period > 0 && it - K.last_reset_it >= o.restart_period && mu >= o.mu_init && nreset < o.max_resets && K.ncrawl < ((o.fresh_restart & 4) ? 2 : 1);
-        const bool overreg = o.reset_delta > 0.0 && K.delta_last > o.reset_delta && nreset < o.max_resets;
-        const bool lost = (o.fresh_restart & 8) && o.restart_period > 0 && mu < o.mu_init && pr > 1e-3 && nreset < o.max_resets &&
-                          ((it - K.last_mu_it >= 2 * o.restart_period && it - K.last_reset_it >= o.restart_period) || K.wd_count >= 3);
-        if (jam || stalled || overreg || lost) {
-          K.flag = 2;
-          K.last_reset_it = it;
-          if (stalled) K.ncrawl++;
-          K.nreset = nreset + 1;
-          K.fresh = (((o.fresh_restart & 2) && nreset + 1 == 2) || ((o.fresh_restart & 1) && nreset + 1 == 1 && !stalled && !lost)) ? 1 : 0;
-          if (K.fresh) { if (K.clip_k_cur > 1) K.clip_k_cur = 2; K.th_max = 0.0; }
-          K.mu = o.mu_init; K.nfilt = 0; K.delta_last = 0.0; K.need_reg_streak = 0; K.wd_count = 0; K.cutstreak = 0; K.force_step = 0;
-          K.it = it + 1;
+  // The host loop runs the members in lock step (derivative kernels between the iterations), so a launch lasts as long as its slowest member: one
+  // that needs five regularisation attempts (1.8 ms each) used to hold all others back -- at full batch the launch took 15 ms for 2 x 3.3 ms of work
+  // per slot.  After KD_TRIES_PER_ROUND failed factorisations the member therefore saves its state and RETURNS (pending): the next launch resumes
+  // its inertia correction where it stopped, the derivative kernels skip it meanwhile (A.done[m] = 2: x has not moved).
+  const bool resume = K.pending != 0;
+  if (resume) { KD_BEGIN() K.pending = 0; KD_END(); }
+  else {
+    // ---------------------------------------------------------------- optimality error (unscaled), stop test
+    kd_grad_lag(M, N, cost);
+    KD_PROF(0);
+    {
+      double du = 0.0;
+      for (int i = tid; i < nx; i += NT) { const bool fixed = i < 12 || (i >= oU && i < oU + 12); if (!fixed) du = fmax(du, fabs(M.gx[i])); }
+      du = block_reduce1(du, RMAX, S.red);
+      KD_BEGIN_SYNCED()
+        const double pr = K.c_pr, co = K.c_co;
+        K.e_pr = pr; K.e_du = du; K.e_co = co;
+        K.flag = 0;
+        if (!(du < 1e300) || !(pr < 1e300) || !(co < 1e300)) { K.status = LANDING_NUMERICAL; K.flag = 1; }
+        else if (fmax(du, fmax(pr, co)) <= o.tol) { K.status = LANDING_CONVERGED; K.flag = 1; }
+        else if (K.it >= o.max_iter) { K.status = LANDING_MAX_ITER; K.flag = 1; }
+        else if (du > o.reset_du && K.nreset >= o.max_resets && o.max_resets > 0) { K.status = LANDING_NUMERICAL; K.flag = 1; }      // jammed again: give up
+        else {
+          // restart rules of the SRBM solver (solver_kernels.hip, landing_nlp.h fresh_restart): a jammed iterate (multipliers blown up), a first
+          // barrier problem that crawls, a later one that has wandered off -> slacks, multipliers, barrier parameter and filter are re-initialised,
+          // at the current x or (after a jam) at the caller's initial guess with the step rule clip_k = 2
+          const int it = K.it, nreset = K.nreset; const double mu = K.mu;
+          const bool jam = du > o.reset_du && nreset < o.max_resets;
+          const bool stalled = o.restart_period > 0 && it - K.last_reset_it >= o.restart_period && mu >= o.mu_init && nreset < o.max_resets && K.ncrawl < ((o.fresh_restart & 4) ? 2 : 1);
+          const bool overreg = o.reset_delta > 0.0 && K.delta_last > o.reset_delta && nreset < o.max_resets;
+          const bool lost = (o.fresh_restart & 8) && o.restart_period > 0 && mu < o.mu_init && pr > 1e-3 && nreset < o.max_resets &&
+                            ((it - K.last_mu_it >= 2 * o.restart_period && it - K.last_reset_it >= o.restart_period) || K.wd_count >= 3);
+          if (jam || stalled || overreg || lost) {
+            K.flag = 2;
+            K.last_reset_it = it;
+            if (stalled) K.ncrawl++;
+            K.nreset = nreset + 1;
+            K.fresh = (((o.fresh_restart & 2) && nreset + 1 == 2) || ((o.fresh_restart & 1) && nreset + 1 == 1 && !stalled && !lost)) ? 1 : 0;
+            if (K.fresh) { if (K.clip_k_cur > 1) K.clip_k_cur = 2; K.th_max = 0.0; }
+            K.mu = o.mu_init; K.nfilt = 0; K.delta_last = 0.0; K.need_reg_streak = 0; K.wd_count = 0; K.cutstreak = 0; K.force_step = 0;
+            K.it = it + 1;
+          }
         }
-      }
-    KD_END();
-  }
-  if (K.flag == 1) {
-    if (tid == 0) { K.done = 1; *M.st = K; A.done[m] = 1; }
-    return;
-  }
-  if (K.flag == 2) {      // restart: the next round of launches evaluates the derivatives at the re-initialised point
-    if (K.fresh) {
-      for (int i = tid; i < nx; i += NT) {
-        double v = A.x0[(size_t)m * nx + i];
-        if (i < 12) v = lbm[i]; else if (i >= oU && i < oU + 12) v = lbm[12 + (i - oU)];
-        M.x[i] = v;
-      }
-      __syncthreads();
-      kd_member_eval_g(A.P, *A.model, N, M.x, M.g, M.wbuf);
-      __syncthreads();
+      KD_END();
     }
-    kd_init_slacks(M, ng, lbm, ubm, o);
-    kd_point_pass(M, ng, lbm, ubm, K.mu);
-    if (tid == 0) { *M.st = K; atomicAdd(A.n_active, 1); }
-    return;
-  }
-  // ---------------------------------------------------------------- barrier parameter (monotone)
-  for (;;) {
-    KD_BEGIN()
-      double sd = 1.0, sc = 1.0;
-      if (o.barrier_smax > 0.0) {
-        sd = fmax(o.barrier_smax, (K.c_ys + K.c_zs) / ((double)(ng - 24) + K.c_nz)) / o.barrier_smax;
-        sc = fmax(o.barrier_smax, K.c_zs / K.c_nz) / o.barrier_smax;
+    if (K.flag == 1) {
+      if (tid == 0) { K.done = 1; *M.st = K; A.done[m] = 1; }
+      return;
+    }
+    if (K.flag == 2) {      // restart: the next round of launches evaluates the derivatives at the re-initialised point
+      if (K.fresh) {
+        for (int i = tid; i < nx; i += NT) {
+          double v = A.x0[(size_t)m * nx + i];
+          if (i < 12) v = lbm[i]; else if (i >= oU && i < oU + 12) v = lbm[12 + (i - oU)];
+          M.x[i] = v;
+        }
+        __syncthreads();
+        kd_member_eval_g(A.P, *A.model, N, M.x, M.g, M.wbuf);
+        __syncthreads();
       }
-      const double mu = K.mu;
-      if (fmax(K.e_du / sd, fmax(K.c_pr, K.c_cm / sc)) <= o.kappa_eps * mu && mu > o.tol / 10.0) {
-        K.mu = fmax(o.tol / 10.0, fmin(o.kappa_mu * mu, pow(mu, o.theta_mu)));
-        K.nfilt = 0; K.last_mu_it = K.it; K.wd_count = 0;
-        K.flag = 1;
-      } else { K.flag = 0; K.tau = fmax(o.tau_min, 1.0 - mu); }
+      kd_init_slacks(M, ng, lbm, ubm, o);
+      kd_point_pass(M, ng, lbm, ubm, K.mu);
+      if (tid == 0) { *M.st = K; atomicAdd(A.n_active, 1); }
+      return;
+    }
+    // ---------------------------------------------------------------- barrier parameter (monotone)
+    for (;;) {
+      KD_BEGIN()
+        double sd = 1.0, sc = 1.0;
+        if (o.barrier_smax > 0.0) {
+          sd = fmax(o.barrier_smax, (K.c_ys + K.c_zs) / ((double)(ng - 24) + K.c_nz)) / o.barrier_smax;
+          sc = fmax(o.barrier_smax, K.c_zs / K.c_nz) / o.barrier_smax;
+        }
+        const double mu = K.mu;
+        if (fmax(K.e_du / sd, fmax(K.c_pr, K.c_cm / sc)) <= o.kappa_eps * mu && mu > o.tol / 10.0) {
+          K.mu = fmax(o.tol / 10.0, fmin(o.kappa_mu * mu, pow(mu, o.theta_mu)));
+          K.nfilt = 0; K.last_mu_it = K.it; K.wd_count = 0;
+          K.flag = 1;
+        } else { K.flag = 0; K.tau = fmax(o.tau_min, 1.0 - mu); }
+      KD_END();
+      if (!K.flag) break;
+      kd_point_pass(M, ng, lbm, ubm, K.mu);
+    }
+    KD_PROF(1);
+    // ================================================================ Riccati factorisation with inertia correction (IPOPT's schedule)
+    KD_BEGIN()
+      const double dl = K.delta_last;
+      K.delta = (K.need_reg_streak >= 2 && dl > 0.0) ? fmax(1e-20, dl * o.delta_dec) : 0.0;
+      K.delta = fmax(K.delta, o.delta_floor);      // proximal term (the cost is terminal only: landing_nlp.h delta_floor)
+      K.skipped_zero = K.delta > 0.0; K.fact_ok = 0; K.attempt = 0; K.flag = 1; K.nfact++;
     KD_END();
-    if (!K.flag) break;
-    kd_point_pass(M, ng, lbm, ubm, K.mu);
   }
-  KD_PROF(1);
-  // ================================================================ Riccati factorisation with inertia correction (IPOPT's schedule)
-  KD_BEGIN()
-    const double dl = K.delta_last;
-    K.delta = (K.need_reg_streak >= 2 && dl > 0.0) ? fmax(1e-20, dl * o.delta_dec) : 0.0;
-    K.delta = fmax(K.delta, o.delta_floor);      // proximal term (the cost is terminal only: landing_nlp.h delta_floor)
-    K.skipped_zero = K.delta > 0.0; K.fact_ok = 0; K.attempt = 0; K.flag = 1; K.nfact++;
-  KD_END();
+  int tries = 0;
   for (;;) {
     const bool ok = kd_backward(M, N, cost, K.delta);
     KD_BEGIN()
@@ -617,6 +630,10 @@ __global__ void __launch_bounds__(KD_THREADS, 2) landing_kd_iter_kernel(KdSolveA
       }
     KD_END();
     if (!K.flag) break;
+    if (++tries >= KD_TRIES_PER_ROUND) {
+      if (tid == 0) { K.pending = 1; *M.st = K; A.done[m] = 2; atomicAdd(A.n_active, 1); }
+      return;
+    }
   }
   if (!K.fact_ok) {
     if (tid == 0) { K.status = LANDING_NUMERICAL; K.done = 1; *M.st = K; A.done[m] = 1; }
@@ -806,6 +823,7 @@ __global__ void __launch_bounds__(KD_THREADS, 2) landing_kd_iter_kernel(KdSolveA
       K.it++;
       { const long long n_ = (long long)wall_clock64(); K.prof[6] += (double)(n_ - K.tp); K.tp = n_; }
       *M.st = K;
+      A.done[m] = 0;      // (2 while the member was pending: the next launch of the derivative kernels must see its new x)
       atomicAdd(A.n_active, 1);
     KD_END();
   }

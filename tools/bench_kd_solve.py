@@ -16,7 +16,7 @@ K = importlib.import_module("landing-controller_amd.constants")
 N, B = 20, a.B
 consts = P_.production_constants(a.law)
 P, X0, q, qd = P_.make_batch(B, N, 0.6, seed=a.seed, consts=consts, dt_grid="reference", law=a.law)
-L = capi.LandingLib(N, device=0); R = rbd.Rbd(L)
+L = capi.LandingLib(N, device=0, lib_path=os.environ.get("LANDING_LIB")); R = rbd.Rbd(L)
 t = time.perf_counter(); srbm = L.solve_host(P, X0); t_srbm = time.perf_counter() - t
 mass, Ib, Ibi = K.robot_constants()
 prob = [kd.member_problem(N, q[b], qd[b], srbm["x"][b]) for b in range(B)]
