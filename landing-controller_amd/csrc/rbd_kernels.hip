@@ -724,11 +724,13 @@ __device__ __noinline__ void kd_leg_kin_d(const RbdModel& M, int l, const double
 // `out` is an emitter: out.put(v) receives the rows one after the other.  (Round 4: the callers used to pass an array of KD_ROWS values -- 4.5 KB of
 // hyper-dual numbers per thread in private memory in the Hessian kernel, which only needs lam' out; KdRowArray below is the array form.)
 template <class T> struct KdRowArray { T* p; __device__ __forceinline__ void put(const T& v) { *p++ = v; } };
-template <class T, class OUT>
-__device__ void kd_stage_rows(const KdNlpParams& P, const RbdModel& M, int k, bool last, const T* w, OUT& out, int legmask = 15) {
+// w: the stage's 72 variables -- an array of T, or a view that forms them on access (KdSeedView: the hyper-dual kernel keeps 72 doubles and two seed
+// indices instead of 72 hyper-dual numbers)
+template <class T, class OUT, class WIN>
+__device__ void kd_stage_rows(const KdNlpParams& P, const RbdModel& M, int k, bool last, const WIN& w, OUT& out, int legmask = 15) {
   typedef typename KdVec<T>::type V;
   const T zero = lit(w[0], 0.0);
-  const T* X = w; const T* c = w + 12; const T* f = w + 24; const T* jp = w + 36; const T* Xn = w + 48; const T* cn = w + 60;
+  const auto X = w + 0; const auto c = w + 12; const auto f = w + 24; const auto jp = w + 36; const auto Xn = w + 48; const auto cn = w + 60;
   const double dt = P.dt[k];
   const V pos = mk3(X[0], X[1], X[2]), om = mk3(X[6], X[7], X[8]), v = mk3(X[9], X[10], X[11]);
   T sr, cr, sp, cp, sy, cy;
@@ -918,9 +920,15 @@ __global__ void __launch_bounds__(64) landing_kinodyn_nlp_hess_kernel(KdNlpArgs 
   if (last && j >= 60) return;
   const double* x = a.x + a.ox(b);
   const double* lam = a.lam + a.og(b) + KD_BND + (size_t)k * KD_ROWS;
-  HDual w[KD_NW];
+  double xv[KD_NW];
 #pragma unroll
-  for (int q = 0; q < KD_NW; ++q) { const int ix = kd_w_index(N, k, q); w[q] = H_(ix >= 0 ? x[ix] : 0.0, q == i ? 1.0 : 0.0, q == j ? 1.0 : 0.0, 0.0); }
+  for (int q = 0; q < KD_NW; ++q) { const int ix = kd_w_index(N, k, q); xv[q] = ix >= 0 ? x[ix] : 0.0; }
+  struct KdSeedView {      // w[q] = x_q + eps1 [q == i] + eps2 [q == j], formed on access
+    const double* xv; int i, j, off;
+    __device__ __forceinline__ HDual operator[](int q) const { const int qq = q + off; return H_(xv[qq], qq == i ? 1.0 : 0.0, qq == j ? 1.0 : 0.0, 0.0); }
+    __device__ __forceinline__ KdSeedView operator+(int o) const { return KdSeedView{xv, i, j, off + o}; }
+  };
+  const KdSeedView w{xv, i, j, 0};
   const int pl = kd_pair_leg(i, j);
   struct LamOut { const double* lam; double s; __device__ __forceinline__ void put(const HDual& v) { s += *lam++ * v.ab; } };      // lam' (second-order part), row after row
   LamOut out{lam, 0.0};
