@@ -54,6 +54,7 @@ struct KdState {
   int accepted, armijo_step, fact_ok, skipped_zero, attempt, flag, ls_done, need_corr, fallback, nfact, ntrial, nreset;
   int last_reset_it, ncrawl, clip_k_cur, fresh;
   int pending;      // the inertia correction of this iteration continues in the next launch (landing_kd_iter_kernel, KD_TRIES_PER_ROUND)
+  int stag, full_prev; double e_prev;      // stag_relief (landing_nlp.h): full steps of the last barrier problem that did not halve the error
   double prof[8]; long long tp;      // development aid: wall_clock64 ticks (100 MHz) per phase, summed over the iterations: grad | mu | backward | forward | dual | line search | accept
 };
 
@@ -478,7 +479,7 @@ __global__ void __launch_bounds__(KD_THREADS) landing_kd_init_kernel(KdSolveArgs
     K.e_pr = K.e_du = K.e_co = 0.0; K.tau = 0.0; K.a_pr = K.a_du = 0.0; K.th0 = K.ph0 = K.dphi = K.alpha = K.s_corr = K.delta = K.ft = K.fval = 0.0; K.omt = -1.0;
     K.nfilt = 0; K.it = 0; K.status = LANDING_MAX_ITER; K.done = 0; K.need_reg_streak = 0; K.first_failed = 0; K.cutstreak = 0; K.force_step = 0;
     K.wd_count = 0; K.last_mu_it = 0; K.accepted = 0; K.armijo_step = 0; K.fact_ok = 0; K.skipped_zero = 0; K.attempt = 0; K.flag = 0; K.ls_done = 0;
-    K.need_corr = 0; K.fallback = 0; K.nfact = 0; K.ntrial = 0; K.nreset = 0; K.last_reset_it = 0; K.ncrawl = 0; K.clip_k_cur = A.o.clip_k; K.fresh = 0; K.pending = 0;
+    K.need_corr = 0; K.fallback = 0; K.nfact = 0; K.ntrial = 0; K.nreset = 0; K.last_reset_it = 0; K.ncrawl = 0; K.clip_k_cur = A.o.clip_k; K.fresh = 0; K.pending = 0; K.stag = 0; K.full_prev = 0; K.e_prev = 1e300;
     for (int i = 0; i < 8; ++i) K.prof[i] = 0.0; K.tp = 0;
   }
   __syncthreads();
@@ -539,6 +540,11 @@ __global__ void __launch_bounds__(KD_THREADS, 2) landing_kd_iter_kernel(KdSolveA
       KD_BEGIN_SYNCED()
         const double pr = K.c_pr, co = K.c_co;
         K.e_pr = pr; K.e_du = du; K.e_co = co;
+        if (o.stag_relief > 0) {      // as in landing_ipm_kernel: the proximal term turns the last Newton steps into a linear iteration (one member of the
+          const double E = fmax(pr, du);      // bench batch: 400 full steps from pr 1.5e-5 to 1e-6, a quarter of the batch's wall time)
+          K.stag = (K.mu <= o.tol / 10.0 * 1.0000001 && K.full_prev && E > 0.5 * K.e_prev) ? K.stag + 1 : 0;
+          K.e_prev = E;
+        }
         K.flag = 0;
         if (!(du < 1e300) || !(pr < 1e300) || !(co < 1e300)) { K.status = LANDING_NUMERICAL; K.flag = 1; }
         else if (fmax(du, fmax(pr, co)) <= o.tol) { K.status = LANDING_CONVERGED; K.flag = 1; }
@@ -610,7 +616,9 @@ __global__ void __launch_bounds__(KD_THREADS, 2) landing_kd_iter_kernel(KdSolveA
     KD_BEGIN()
       const double dl = K.delta_last;
       K.delta = (K.need_reg_streak >= 2 && dl > 0.0) ? fmax(1e-20, dl * o.delta_dec) : 0.0;
-      K.delta = fmax(K.delta, o.delta_floor);      // proximal term (the cost is terminal only: landing_nlp.h delta_floor)
+      { double fl = o.delta_floor;                   // proximal term (the cost is terminal only: landing_nlp.h delta_floor)
+        if (o.stag_relief > 0 && K.stag >= o.stag_relief) { for (int e = K.stag - o.stag_relief; e >= 0; --e) fl *= 0.1; if (fl < 1e-12) fl = 0.0; }
+        K.delta = fmax(K.delta, fl); }
       K.skipped_zero = K.delta > 0.0; K.fact_ok = 0; K.attempt = 0; K.flag = 1; K.nfact++;
     KD_END();
   }
@@ -773,6 +781,7 @@ __global__ void __launch_bounds__(KD_THREADS, 2) landing_kd_iter_kernel(KdSolveA
       K.nfilt = nfilt + 1;
     }
     if (o.dual_step_cap > 0.0) K.a_du = fmin(K.a_du, o.dual_step_cap * K.alpha);
+    K.full_prev = (K.accepted && K.alpha == 1.0 && K.a_du == 1.0 && K.attempt <= 1) ? 1 : 0;
   KD_END();
   if (K.fallback) {
     const double alpha = K.alpha;

@@ -1,0 +1,24 @@
+"""dev: the slowest members of the kinodynamic bench batch and the iteration log of the slowest one (LANDING_KD_TRACE)"""
+import importlib, os, sys, subprocess
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)
+P_ = importlib.import_module("landing-controller_amd.problem"); capi = importlib.import_module("landing-controller_amd.capi")
+rbd = importlib.import_module("landing-controller_amd.rbd"); kd = importlib.import_module("landing-controller_amd.kinodyn"); K = importlib.import_module("landing-controller_amd.constants")
+N, B = 20, 1024
+consts = P_.production_constants("main")
+P, X0, q, qd = P_.make_batch(B, N, 0.6, seed=20211, consts=consts, dt_grid="reference", law="main")
+L = capi.LandingLib(N, device=0); R = rbd.Rbd(L)
+srbm = L.solve_host(P, X0)
+mass, Ib, Ibi = K.robot_constants()
+lbs, ubs, costs, x0s = [], [], [], []
+for b in range(B):
+    lb, ub, cost, x0 = kd.member_problem(N, q[b], qd[b], srbm["x"][b], None); lbs.append(lb); ubs.append(ub); costs.append(cost); x0s.append(x0)
+lbs, ubs, costs, x0s = map(np.array, (lbs, ubs, costs, x0s))
+o = R.kinodyn_default_opts()
+if len(sys.argv) > 1:
+    m = int(sys.argv[1]); os.environ["LANDING_KD_TRACE"] = "0"
+    R.kinodyn_solve_host(N, lbs[m:m + 1], ubs[m:m + 1], costs[m:m + 1], x0s[m:m + 1], P_.REFERENCE_DT_GRID, mass, Ib, Ibi, consts.mu, o)
+else:
+    s = R.kinodyn_solve_host(N, lbs, ubs, costs, x0s, P_.REFERENCE_DT_GRID, mass, Ib, Ibi, consts.mu, o)
+    order = np.argsort(-s["iters"]); print("slowest:", [(int(i), int(s["iters"][i]), int(s["status"][i])) for i in order[:12]])
+    print("members above 100 / 150 / 200 iterations:", int((s["iters"] > 100).sum()), int((s["iters"] > 150).sum()), int((s["iters"] > 200).sum()))
