@@ -50,23 +50,31 @@ constexpr int FILT_CAP = 64;
 constexpr int SOLVER_NMAX = 96;   // longest horizon the solver kernel takes: sigma_0..sigma_N of the forward sweep live in the 48 x 49 LDS array, one table row per stage
 constexpr int ES = 26;    // LDS row stride of the elimination side block [gamma_u | I] (24 x 25)
 constexpr int SOLVER_THREADS = 256;
-// condensed stage data (once per iteration): [G targets (table order) | gamma 48 | A^ values] per stage
+// condensed stage data (LDS staging area of the backward sweep): [G targets (table order) | gamma 48 | A^ values] of one stage
 constexpr int COND_GAM = 480, COND_AH = 528, COND_STRIDE = 704;
+constexpr int RCG = 36;   // per stage in the member's workspace: gradient of the running cost w.r.t. (X_k, c_k, f_k) (forms with a running cost)
 // constant Hessian entries of the running cost per stage, stored right behind the Hessian nonzeros so that the
 // condensation tables address them like any other entry of [J | H]: X diagonal (12) | (pos_a, c_leg,a) (12) | c diagonal (12) | f diagonal (12)
 constexpr int RUNC = 48;
 
 // Packed condensation term (8 bytes), stage-local: value = JH[a] * (has_b ? JH[b] : 1) * coeff, coeff = sigma[row] (has_b) /
 // rho[row] (!has_b) for rtype 0, +1 / -1 / 0 for rtype 1 / 2 / 3; summed into the open destination, stored to
-// cond[stage][dst] when `closes`.  a, b = (segment, offset) into the member's [J | H | Hc] array:
+// stg[dst] when `closes`.  a, b = positions in the stage's LDS copy of its nonzeros (segment sa at NZ_*[sa], offset oa inside):
 // segments 0..6 = J X_k | J U_k | J U_{k+1} | H X_k | H U_k | H U_{k+1} | running-cost constants of stage k.
 constexpr int CTAB_MLMAX = 6;
 __host__ __device__ inline unsigned long long cterm_pack(int sa, int oa, int sb, int ob, bool has_b, int rowq, int rtype, int dst, bool closes) {
-  const unsigned lo = (unsigned)oa | ((unsigned)sa << 8) | ((unsigned)ob << 11) | ((unsigned)sb << 19) | ((unsigned)(has_b ? 1 : 0) << 22) | ((unsigned)rowq << 23) | ((unsigned)rtype << 30);
+  const int nz[7] = {NZ_JX, NZ_JU, NZ_JUN, NZ_HX, NZ_HU, NZ_HUN, NZ_TOT};
+  const unsigned pa = (unsigned)(nz[sa] + oa), pb = (unsigned)(nz[sb] + ob);
+  const unsigned lo = pa | (pb << 11) | ((unsigned)(has_b ? 1 : 0) << 22) | ((unsigned)rowq << 23) | ((unsigned)rtype << 30);
   const unsigned hi = (unsigned)dst | ((unsigned)(closes ? 1 : 0) << 10);
   return (unsigned long long)lo | ((unsigned long long)hi << 32);
 }
 __host__ __device__ inline bool cterm_closes(unsigned long long t) { return ((t >> 42) & 1ull) != 0; }
+// Assembly of a stage inside the backward sweep (asm_terms): operands of the condensation terms are positions in the LDS array
+// cx = [nonzeros of the stage (NZ_TOT + RUNC) | sigma (104) | rho (104) | 1, -1, 0]
+constexpr int CX_SR = NZ_TOT + 48, CX_ONE = CX_SR + 208, CX_MONE = CX_ONE + 1, CX_ZERO = CX_ONE + 2, CX_LEN = CX_ONE + 3;
+constexpr int ATAB_TB = 6, ATAB_LTMAX = 6;       // terms per batch; longest per-thread list (a multiple of ATAB_TB): the 1 138..1 234 terms of a stage give 5 per thread
+constexpr int ASM_NSLOT = 512;                   // partial-sum slots of one stage
 
 struct SolverWorkspace {
   double* buf = nullptr; size_t cap = 0;
@@ -74,9 +82,9 @@ struct SolverWorkspace {
   hipEvent_t done = nullptr;     // recorded behind every solve launch: the next launch (any stream) and any re-allocation wait for it
   int* d_tab = nullptr; int* d_stage_tab = nullptr; int n_tab = 0;
   int* d_rterm = nullptr; int rlen = 0;
-  int *d_ctab = nullptr, *d_ctype = nullptr; int c_ml = 0, c_mid = 0;     // packed per-stage-type condensation tables
+  int *d_ctab = nullptr, *d_ctype = nullptr, *d_ccomb = nullptr; int c_ml = 0, c_mid = 0;     // packed per-stage-type assembly tables (aterm_pack): [type][c_ml][256], most frequent type
   static size_t member_stride(const Layout& L) {
-    return (size_t)4 * L.nx + (size_t)14 * L.ng + L.nnz_jac + L.nnz_hess + (size_t)L.N * RUNC + (size_t)(L.N + 1) * RIC_STRIDE + (size_t)L.N * COND_STRIDE;
+    return (size_t)4 * L.nx + (size_t)14 * L.ng + L.nnz_jac + L.nnz_hess + (size_t)L.N * RUNC + (size_t)(L.N + 1) * RIC_STRIDE + (size_t)L.N * RCG;
   }
   int ensure(const Layout& L, int B, hipStream_t stream);
   void release();
@@ -91,9 +99,9 @@ struct SolveArgs {
   const double* p; const double* x0;
   double* x_out; double* f_out; double* lam_out; int* status; int* iters; double* kkt;
   double* ws; size_t ws_stride;
-  const int* tab; const int* stage_tab;
   const unsigned long long* rterm; int rlen;                               // row-product records [rlen][256]
-  const unsigned long long* ctab; const int* ctype; int c_ml, c_mid;      // packed condensation tables [type][c_ml][256], type of every stage
+  const unsigned long long* ctab; const int* ctype; int c_ml, c_mid;      // packed assembly tables [type][c_ml][256] (aterm_pack), type of every stage
+  const unsigned long long* ccomb;                                         // ... and the destinations summed from partial slots [type][256] (acomb_pack)
   const int* edge_map;   // compaction map of the tiled Jacobian write-out (landing_ctx::d_edge_map)
   const int* order;      // dispatch order: workgroup b solves member order[b] (hard-first, see landing_order_kernel); nullptr = identity
 };
@@ -160,7 +168,7 @@ __device__ __forceinline__ MemberMem carve(const Layout& L, double* w) {
   M.zL = w; w += L.ng; M.zU = w; w += L.ng;
   M.y = w; w += L.ng; M.yn = w; w += L.ng;
   M.sig = w; w += L.ng; M.rho = w; w += L.ng;
-  M.J = w; w += L.nnz_jac; M.H = w; w += L.nnz_hess; M.Hc = w; w += (size_t)L.N * RUNC; M.ric = w; w += (size_t)(L.N + 1) * RIC_STRIDE; M.cond = w; w += (size_t)L.N * COND_STRIDE;
+  M.J = w; w += L.nnz_jac; M.H = w; w += L.nnz_hess; M.Hc = w; w += (size_t)L.N * RUNC; M.ric = w; w += (size_t)(L.N + 1) * RIC_STRIDE; M.cond = w; w += (size_t)L.N * RCG;
   M.en = w; w += L.ng; M.ep = w; w += L.ng; M.wn = w; w += L.ng; M.wp = w;
   return M;
 }
@@ -187,9 +195,6 @@ struct IpmState {
 enum { ACT_GO = 0, ACT_STOP = 1, ACT_RESET = 2, ACT_FEAS = 3, ACT_BACK = 4 };
 
 // LDS of one member
-#ifndef LANDING_REC_LDS
-#define LANDING_REC_LDS 0          // 1: stage records leave the CU through an LDS buffer, stored (coalesced) during the NEXT stage's elimination
-#endif
 #ifndef LANDING_PIVOT_BLOCK
 #define LANDING_PIVOT_BLOCK 4      // pivot-block size of the fp64 stage elimination (8: built, measured, slower -- pivot_block_step)
 #endif
@@ -200,34 +205,50 @@ struct Lds {
   double P[24 * PS];
   double A1[2 * XCH];          // Y = P(:,0:12)*A^ (24 x YS = 888) while T^T P T is formed, then the elimination side block
                               // Ex (24 x ES): col 0 = gamma_u -> z, cols 1.. = I -> unit-lower inverse
-  double Ah[12 * YS];
-  double gam[48], pv[24], q[24], bv[12], sig[24], w[48], dinv[24];
+  double Ah[2 * 12 * YS];      // A^ of the stage being eliminated and of the one being assembled (copy k & 1 belongs to stage k)
+  double gam[48], pv[24], q[24], bv[2 * 12], sig[24], w[48], dinv[24];
   double red[(SOLVER_THREADS / 64) * 6];
   double filt_th[FILT_CAP], filt_ph[FILT_CAP];
   double prof[16];
   int flag;
   // member context, written once by every thread with identical values (read back as LDS broadcasts by the
   // __noinline__ phases so that they carry no register state across calls)
-  // condensed data of the next stage, copied in by the elimination of the current one (global latency hidden behind
-  // the block steps) + the scatter codes of the most common stage table, cached once per launch
-  double stg[COND_STRIDE + 12];
-#if LANDING_REC_LDS
-  double recbuf[RIC_STRIDE];      // stage record of the elimination that just finished, on its way to HBM (flush_record)
-#endif
-  int cab[COND_GAM]; int cat[COND_STRIDE - COND_AH]; int c_tab, c_nT, c_nA;
-  // condensation: packed term table of the most frequent stage type (the others are read from L2) and, per stage, the
+  // assembly (asm_issue / asm_copy / asm_terms): term table of the most frequent stage type (the others are read from L2) and, per stage, the
   // bases of the seven [J | H | Hc] segments + the type id (slot 7)
   int segb[SOLVER_NMAX * 8];
+  double carry[ASM_NSLOT];          // partial sums of the destinations that are summed by more than one thread
+  double rcl[RCG];                  // gradient of the running cost of the stage whose G / gamma are assembled
+  double jhl[CX_LEN];               // cx: nonzeros of the stage being assembled, the seven [J | H | Hc] segments side by side (coalesced copy) | sigma | rho of its rows | 1, -1, 0
+  double dump[64];                  // where the stores of terms that close nothing go
+  const unsigned long long* ctab; const unsigned long long* ccomb; int c_ml, c_mid, rc_on;
   // bounds of the rows: lbg/ubg depend on the row's position inside its stage only (boundary rows | rows of a stage |
   // rows of the last stage, which has another layout), so 244 (lb, ub) pairs in LDS replace two ng-long workspace arrays
   // that every row pass used to stream (6 of ~30 array passes per iteration)
   double bnd_lb[36 + 2 * 104], bnd_ub[36 + 2 * 104];
-  MemberMem M; Layout L; const double* p; const int* tab; const int* stage_tab; int prof_on; int fp32;
+  MemberMem M; Layout L; const double* p; int prof_on;
   IpmState ks;
+  unsigned long long atab_mid[ATAB_LTMAX * SOLVER_THREADS];      // (behind everything the tables address: their offsets are 16 bits)
+  unsigned long long acomb_mid[SOLVER_THREADS];
 };
 // One instance per workgroup (= per NLP).  Namespace scope keeps the LDS address space visible to every
 // phase function (ds_* instructions instead of flat_*).
 __shared__ Lds SH;
+// Packed terms of the assembly tables, with every place given as a BYTE OFFSET inside the LDS block (the host builds the tables with
+// offsetof: solver_capi.inc): value = [pa] * [pb] * [pc], summed into the open PIECE of a destination and stored to [d] (+ the
+// distance to the second copy of A^ when `ah` is set and the stage's copy is 1); the sum restarts behind the store unless `keep`
+// (the store of a term that closes nothing goes to a per-lane dump slot).  A piece is a whole destination -- an entry of G (upper
+// triangle), gamma or A^ -- or one of the partial sums that asm_combine adds up in slot order (pieces are cut where the 256 equal
+// chunks of rounds 1-4 were, so every sum keeps its association).
+static_assert(offsetof(Lds, atab_mid) <= 65528, "the assembly tables address G, A^, gamma, cx, the partial sums and the dump slots with 16-bit byte offsets");
+__host__ __device__ inline unsigned long long aterm_pack(int pa, int pb, int pc, int d, bool keep, bool ah) {
+  const unsigned lo = (unsigned)pa | ((unsigned)pb << 16);
+  const unsigned hi = (unsigned)pc | (((unsigned)d | (keep ? 1u : 0u) | (ah ? 2u : 0u)) << 16);
+  return (unsigned long long)lo | ((unsigned long long)hi << 32);
+}
+// destination made of n partial sums (slots at byte offset s0 onwards, added in that order): lo = n | s0 << 16, hi = d | ah << 1; n = 0: nothing
+__host__ __device__ inline unsigned long long acomb_pack(int n, int s0, int d, bool ah) {
+  return (unsigned long long)((unsigned)n | ((unsigned)s0 << 16)) | ((unsigned long long)((unsigned)d | (ah ? 2u : 0u)) << 32);
+}
 
 // fp64 matrix-core tile: D(16x16) = C + A(16 x 4KT) B(4KT x 16) with v_mfma_f64_16x16x4_f64.  Operand layout
 // (cdna_hip_programming.md section 3): lane l supplies A[i = l&15][k = l>>4] and B[k = l>>4][j = l&15]; the accumulator holds
@@ -307,99 +328,132 @@ __device__ __noinline__ void gauss_jordan_wave(const double* G, const double* ga
   if (lane == 0) *flag = ok ? 1 : 0;
 }
 
-// Condensed data of stage k from the LDS staging area into G, gamma, A^ and b (structural nonzeros only; codes from
-// the cached table for the common stage type, from the L2-resident table otherwise).
-__device__ __forceinline__ void stage_scatter(int k) {
-  Lds& S = SH;
-  const int tid = threadIdx.x, NT = blockDim.x;
-  const int off = S.stage_tab[k];
-  const bool cached = (off == S.c_tab);
-  const int* tb = S.tab + off;
-  const int nT = cached ? S.c_nT : tb[0], nA = cached ? S.c_nA : tb[6];
-  const int* ab = S.tab + (cached ? 0 : tb[1]); const int* at = S.tab + (cached ? 0 : tb[7]);
-  for (int e = tid; e < nT; e += NT) {
-    const int c = cached ? S.cab[e] : ab[e], a = c & 255, b = c >> 8;
-    const double v = S.stg[e];
-    S.G[a * GS + b] = v; S.G[b * GS + a] = v;
-  }
-  if (tid < 48) S.gam[tid] = S.stg[COND_GAM + tid];
-  for (int q = tid; q < nA; q += NT) S.Ah[cached ? S.cat[q] : (at[3 * q + 1] * YS + at[3 * q + 2])] = S.stg[COND_AH + q];
-  if (tid < 12) { const int i = tid; S.bv[i < 6 ? i : (i < 9 ? i + 3 : i - 3)] = -S.stg[COND_STRIDE + i]; }
-}
-// The staging copy is split around the block steps of the elimination: loads right after the first step (G and A^ are
-// dead by then), LDS writes after the last one.
-struct StageCopy { double v[3]; double g; };
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Backward sweep, round 5: the ASSEMBLY of stage k - 1 rides on the elimination of stage k.
+// While the four waves eliminate the controls of stage k on the matrix cores, they copy stage k - 1's CCS nonzeros, sigma / rho of its
+// rows and the residual of its dynamics rows from the workspace into LDS (coalesced loads issued behind the first block step), form
+// the condensation terms  G = H + J_d^T Sigma J_d, gamma = J_d^T rho, A^ = -dg_dyn/d(X,c,f)  and store them straight into G, gamma
+// and the NEXT stage's copy of A^ / b between two later block steps.  Rounds 1-4 ran the condensation as a phase of its own over all
+// stages (0.106 ms of the 0.727 ms an iteration took under load) that wrote a 704-double block per stage to the member's workspace,
+// which the sweep read back (473 KB per member and iteration, 12 % of the kernel's HBM traffic) and scattered into G between two
+// barriers at the head of every stage (0.6-0.9 us of the 7 us a stage took).  The arithmetic and its order are unchanged: results are
+// bit-identical to round 4's (tools/dev/emu_ab.py).  Built on the way, measured on the GPU and rejected (profiles/r05_ab_experiments.txt):
+//  * the round-4 term tables (segment / offset pairs, destination codes, carries between threads) decoded inside the block steps, operands
+//    gathered from the workspace: +2.3 us per stage (60 gather instructions of 64 scattered addresses per stage); operands staged through
+//    LDS first: +2.0 us (500 instructions per thread and stage): whatever the four waves execute together is on the chain, so the
+//    per-term work has to be a handful of instructions;
+//  * an ASSEMBLER WAVE: waves 0..2 eliminate (wave 2 carrying the right-hand-side column as a second tile), wave 3 assembles alone: the
+//    elimination itself went from 5.0 to 7.2 us per stage (second tile: 148+ registers, callee-saved spills whose reloads sit in front
+//    of every return) and one wave needs 1.1 us more than that for 1 280 terms.
+//
+// The work is described by packed 8-byte terms (aterm_pack) in stage-LOCAL form: one table per stage type (first / middle /
+// penultimate / last), the middle one resident in LDS.  A thread owns whole destinations (balanced on the host: 5-6 terms per
+// thread).  Rounds 1-4 cut the term list into 256 equal chunks, one per thread, and a destination whose terms straddled chunk borders
+// was finished from per-thread carries in thread order; now a destination is summed by one thread, which restarts the partial sum
+// where those borders were (`bnd`), so every sum keeps its association.
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef const double __attribute__((address_space(1)))* landing_gptr;    // global address space: global_load, not flat_load
 #else                                                                     // (a flat load also ties up the LDS counter)
 typedef const double* landing_gptr;
 #endif
-__device__ __forceinline__ void stage_copy_load(int k, StageCopy& R) {
-  // branch-free: indices clamped instead of guarded (k = -1 reads stage 0 and the copy is never used)
-  const MemberMem& M = SH.M;
-  const int tid = threadIdx.x, kk = k < 0 ? 0 : k;
-  landing_gptr cd = (landing_gptr)(M.cond + (size_t)kk * COND_STRIDE);
-  landing_gptr gg = (landing_gptr)(M.g + SH.L.g_stage(kk));
-  R.v[0] = cd[tid]; R.v[1] = cd[tid + 256];
-  R.v[2] = cd[tid + 512 < COND_STRIDE ? tid + 512 : COND_STRIDE - 1];
-  R.g = gg[tid < 12 ? tid : 0];
+constexpr int ASM_SEG_LEN[7] = {NZ_JU - NZ_JX, NZ_JUN - NZ_JU, NZ_HX - NZ_JUN, NZ_HU - NZ_HX, NZ_HUN - NZ_HU, NZ_TOT - NZ_HUN, RUNC};
+constexpr int ASM_SEG_POS[7] = {NZ_JX, NZ_JU, NZ_JUN, NZ_HX, NZ_HU, NZ_HUN, NZ_TOT};
+static_assert(NZ_JUN - NZ_JU <= SOLVER_THREADS && 2 * 104 <= SOLVER_THREADS, "one load per thread and segment");
+struct AsmRegs { double jh[7], sr, g, rc; };
+// (1) coalesced loads of stage k's nonzeros (one per segment), sigma / rho of its rows, the residual of its dynamics rows; nothing is consumed here
+__device__ __forceinline__ void asm_issue(int k, AsmRegs& R) {
+  const Lds& S = SH;
+  const MemberMem& M = S.M;
+  const int tid = threadIdx.x, ng = S.L.ng;
+  landing_gptr JH = (landing_gptr)M.J;       // [J | H | Hc] are contiguous
+  landing_gptr SR = (landing_gptr)M.sig;     // [sigma | rho] are contiguous
+  const int* sb = S.segb + k * 8;
+  const int g0 = S.L.g_stage(k);
+#pragma unroll
+  for (int sgm = 0; sgm < 7; ++sgm) R.jh[sgm] = JH[sb[sgm] + (tid < ASM_SEG_LEN[sgm] ? tid : 0)];
+  R.sr = SR[tid < 104 ? g0 + tid : (tid < 208 ? ng + g0 + tid - 104 : 0)];      // (the last stage has 80 rows: the tail reads the workspace behind them, never used)
+  R.g = ((landing_gptr)M.g)[g0 + (tid < 12 ? tid : 0)];
+  R.rc = 0.0;
+  if (S.rc_on) R.rc = ((landing_gptr)M.cond)[(size_t)k * RCG + (tid < RCG ? tid : 0)];
 }
-__device__ __forceinline__ void stage_copy_store(const StageCopy& R) {
+// (2) ... into LDS; a barrier follows before asm_terms
+__device__ __forceinline__ void asm_copy(const AsmRegs& R) {
   Lds& S = SH;
   const int tid = threadIdx.x;
-  S.stg[tid] = R.v[0]; S.stg[tid + 256] = R.v[1];
-  if (tid < COND_STRIDE - 512) S.stg[tid + 512] = R.v[2];
-  if (tid < 12) S.stg[COND_STRIDE + tid] = R.g;
+#pragma unroll
+  for (int sgm = 0; sgm < 7; ++sgm) if (tid < ASM_SEG_LEN[sgm]) S.jhl[ASM_SEG_POS[sgm] + tid] = R.jh[sgm];
+  if (tid < 208) S.jhl[CX_SR + tid] = R.sr;
+}
+// (3) products and stores: G and gamma (dead since the tile fetch of the running elimination), A^ / b of copy `nb`.  ATAB_TB terms
+// at a time: codes, then all operands, then the arithmetic and the stores -- three LDS round trips per batch instead of three per term
+__device__ __forceinline__ void asm_terms(int k, int nb, const AsmRegs& R) {
+  Lds& S = SH;
+  const int tid = threadIdx.x, LT = S.c_ml, tp = S.segb[k * 8 + 7];
+  char* const lds0 = reinterpret_cast<char*>(&S);
+  const unsigned ahoff = nb ? (unsigned)(12 * YS * sizeof(double)) : 0u;
+  const bool mid = (tp == S.c_mid);
+  const unsigned long long* gt = S.ctab + (size_t)tp * LT * SOLVER_THREADS;
+  double acc = 0.0;
+  for (int j0 = 0; j0 < LT; j0 += ATAB_TB) {
+    unsigned long long t[ATAB_TB];
+    if (mid) {
+#pragma unroll
+      for (int u = 0; u < ATAB_TB; ++u) t[u] = S.atab_mid[(j0 + u) * SOLVER_THREADS + tid];
+    } else {
+#pragma unroll
+      for (int u = 0; u < ATAB_TB; ++u) t[u] = gt[(j0 + u) * SOLVER_THREADS + tid];
+    }
+    double a[ATAB_TB], b[ATAB_TB], c[ATAB_TB];
+#pragma unroll
+    for (int u = 0; u < ATAB_TB; ++u) {
+      const unsigned lo = (unsigned)t[u], hi = (unsigned)(t[u] >> 32);
+      a[u] = *reinterpret_cast<const double*>(lds0 + (lo & 0xffffu)); b[u] = *reinterpret_cast<const double*>(lds0 + (lo >> 16)); c[u] = *reinterpret_cast<const double*>(lds0 + (hi & 0xffffu));
+    }
+#pragma unroll
+    for (int u = 0; u < ATAB_TB; ++u) {
+      const unsigned dd = (unsigned)(t[u] >> 48);
+      acc += a[u] * b[u] * c[u];
+      *reinterpret_cast<double*>(lds0 + ((dd & 0xfff8u) + ((dd & 2u) ? ahoff : 0u))) = acc;
+      acc = (dd & 1u) ? acc : 0.0;
+    }
+  }
+  if (tid < 12) { const int i = tid; S.bv[nb * 12 + (i < 6 ? i : (i < 9 ? i + 3 : i - 3))] = -R.g; }
+  if (tid < RCG) S.rcl[tid] = R.rc;      // gradient of the running cost (w order X, c, f): added to gamma when its tile is fetched
+}
+// (4) behind the next barrier: the destinations whose terms more than one thread summed
+__device__ __forceinline__ void asm_combine(int k, int nb) {
+  Lds& S = SH;
+  const int tid = threadIdx.x, tp = S.segb[k * 8 + 7];
+  const unsigned long long code = tp == S.c_mid ? S.acomb_mid[tid] : S.ccomb[tp * SOLVER_THREADS + tid];
+  const unsigned lo = (unsigned)code, dd = (unsigned)(code >> 32);
+  const int n = (int)(lo & 7u);
+  if (n > 0) {
+    char* const lds0 = reinterpret_cast<char*>(&S);
+    const double* sl = reinterpret_cast<const double*>(lds0 + (lo >> 16));
+    double tot = 0.0;
+    for (int i = 0; i < n; ++i) tot += sl[i];
+    *reinterpret_cast<double*>(lds0 + ((dd & 0xfff8u) + ((dd & 2u) ? (nb ? (unsigned)(12 * YS * sizeof(double)) : 0u) : 0u))) = tot;
+  }
 }
 
-// Where the elimination of a stage leaves its record, and how the record reaches HBM.  Round 2 stored it from the accumulator
-// tiles straight to the member's workspace at the end of block_eliminate (24 flat_store instructions of scattered 8-byte words per
-// thread): a function return waits for every outstanding memory operation of the wave, so the HBM write latency of those stores sat
-// on the serial chain of EVERY stage (the "epilogue" of DESIGN.md 4.2's stage budget, 0.77 us alone, more under load).  Now the
-// record is assembled in LDS and the next stage's elimination copies it out right after its first block step -- coalesced 8-byte
-// stores in the global address space that drain behind the remaining block steps; only the last record of a sweep is exposed.
-// MEASURED (round 3, tools/dev/ab.sh, same box): no gain -- backward sweep 0.2974 vs 0.2933 ms per iteration alone, 0.3616 vs 0.3611
-// under load, same HBM traffic: the stores are acknowledged by L2 long before the return.  Left in as a switch, off.
-#if LANDING_REC_LDS
-#define REC_DST(rec) (SH.recbuf)
-#else
-#define REC_DST(rec) (rec)
-#endif
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef double __attribute__((address_space(1)))* landing_gptr_w;
 #else
 typedef double* landing_gptr_w;
 #endif
-__device__ __forceinline__ void flush_record(int k) {      // LDS record buffer -> record k of the member (all threads)
-#if LANDING_REC_LDS
-  landing_gptr_w dst = (landing_gptr_w)(SH.M.ric + (size_t)k * RIC_STRIDE);
-  const int tid = threadIdx.x;
-#pragma unroll
-  for (int j = 0; j < (RIC_STRIDE + SOLVER_THREADS - 1) / SOLVER_THREADS; ++j) { const int e = tid + j * SOLVER_THREADS; if (e < RIC_STRIDE) dst[e] = SH.recbuf[e]; }
-#else
-  (void)k;
-#endif
-}
 
-// Elimination of the controls of one stage by the whole workgroup on the matrix cores: blocked Gauss-Jordan with
+// Elimination of the controls of one stage on the matrix cores (waves 0..2): blocked Gauss-Jordan with
 // 4 x 4 pivot blocks on the (NU + 24) x (NU + 25) array  [G_uu G_us gamma_u ; G_su G_ss gamma_s]  (rows/columns: controls
 // first).  After NU/4 block steps the control rows hold [I | K | kappa] and the state rows hold the Schur complement
 // [0 | P_k | p_k] -- gains and cost-to-go in one pass.  The array lives in v_mfma_f64_16x16x4 accumulator tiles: wave w
-// owns column tile w (16 columns x 48 rows = 3 tiles).  One block step = one LDS exchange (the owner of the pivot
+// owns column tile w (16 columns x 48 rows = 3 tiles; with NU = 24 the right-hand side is column 48, the only live column of
+// wave 3's tile).  One block step = one LDS exchange (the owner of the pivot
 // columns publishes them, every wave publishes its slice of the 4 pivot rows), one barrier, the 4 x 4 LDL^T
 // (recomputed by every lane from the broadcast block: no further communication), the normalised pivot rows of the
 // own columns, and ONE rank-4 MFMA per tile:  T -= C R  (C = pivot columns with the pivot rows blanked; the pivot
 // rows are then overwritten by R itself -- forming them as W - (D - I) R would cancel at the scale of W).  The pivots of the 4 x 4 LDL^T are the scalar pivots of the unblocked
-// elimination, so the inertia test (all pivots positive) is unchanged.  Returns false on a non-positive pivot.
-// development sub-timers of the elimination (tools/dev/backprof.py): -DLANDING_ELIM_PROF=n accumulates the time from the start of
-// block_eliminate to point n (1 tile fetch, 2 prologue, 3 block steps, 4 end) into the PH_B_POST slot; off in the product build
-#ifdef LANDING_ELIM_PROF
-#define ELIM_T0() const long long et0_ = SH.prof_on ? (long long)wall_clock64() : 0
-#define ELIM_T(n) do { if ((n) == LANDING_ELIM_PROF && SH.prof_on) { __syncthreads(); if (threadIdx.x == 0) SH.prof[PH_B_POST] += (double)((long long)wall_clock64() - et0_); } } while (0)
-#else
-#define ELIM_T0() do { } while (0)
-#define ELIM_T(n) do { } while (0)
-#endif
+// elimination, so the inertia test (all pivots positive) is unchanged.  Returns false on a non-positive pivot (at the end of the stage).
+//
 // One step of the blocked Gauss-Jordan elimination with a PS x PS pivot block (PS = 4 or 8) at rows / columns [OFF, OFF + PS) of the
 // tile array T (wave ct owns column tile ct, accumulator layout: T[rt][r] = element (row 16 rt + lk + 4 r, column 16 ct + lj)).
 // Exchange through LDS (buffer STEP & 1 of S.A1): every lane publishes the PS pivot-row entries of its column, W[c][PS]; the PS
@@ -466,26 +520,29 @@ __device__ __forceinline__ bool pivot_block_step(f64x4 (&T)[3], int ct, int lj, 
     hm = h > hm ? h : hm;
   }
   const bool ok = hm < (0x7e37e43cu - 0x00100000u);
-  // normalised pivot rows of the own column: D r = w by the two triangular solves (no explicit inverse: a badly conditioned
+  // normalised pivot rows of a column: D r = w by the two triangular solves (no explicit inverse: a badly conditioned
   // pivot block costs no more accuracy than the scalar elimination would); lane group lk keeps r[4 q + lk]
-  double y[PS], r[PS];
+  auto solve = [&](const double (&wv)[PS], double (&R)[NQ]) {
+    double y[PS], r[PS];
 #pragma unroll
-  for (int i = 0; i < PS; ++i) {
-    double acc = w[i];
+    for (int i = 0; i < PS; ++i) {
+      double acc = wv[i];
 #pragma unroll
-    for (int kk = 0; kk < i; ++kk) acc = fma(-l[i][kk], y[kk], acc);
-    y[i] = acc;
-  }
+      for (int kk = 0; kk < i; ++kk) acc = fma(-l[i][kk], y[kk], acc);
+      y[i] = acc;
+    }
 #pragma unroll
-  for (int i = PS - 1; i >= 0; --i) {
-    double acc = y[i] * inv[i];
+    for (int i = PS - 1; i >= 0; --i) {
+      double acc = y[i] * inv[i];
 #pragma unroll
-    for (int kk = i + 1; kk < PS; ++kk) acc = fma(-l[kk][i], r[kk], acc);
-    r[i] = acc;
-  }
+      for (int kk = i + 1; kk < PS; ++kk) acc = fma(-l[kk][i], r[kk], acc);
+      r[i] = acc;
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) R[q] = lk == 0 ? r[4 * q] : (lk == 1 ? r[4 * q + 1] : (lk == 2 ? r[4 * q + 2] : r[4 * q + 3]));
+  };
   double R[NQ];
-#pragma unroll
-  for (int q = 0; q < NQ; ++q) R[q] = lk == 0 ? r[4 * q] : (lk == 1 ? r[4 * q + 1] : (lk == 2 ? r[4 * q + 2] : r[4 * q + 3]));
+  solve(w, R);
   if (16 * ct + 16 > OFF) {                              // tiles whose columns are all eliminated already stay as they are
 #pragma unroll
     for (int q = 0; q < NQ; ++q)
@@ -497,6 +554,7 @@ __device__ __forceinline__ bool pivot_block_step(f64x4 (&T)[3], int ct, int lj, 
   return ok;                                             // identical in every lane of the workgroup (tested after the update so
 }                                                        // that the operand fetches are not held behind it)
 
+// (`k` = stage, its copy of A^ / b is k & 1; the assembly of stage k - 1 rides along)
 template <int NU, int PB>
 __device__ __noinline__ bool block_eliminate(double* __restrict__ rec, double delta, int k) {
   Lds& S = SH;
@@ -505,22 +563,34 @@ __device__ __noinline__ bool block_eliminate(double* __restrict__ rec, double de
   const int c = 16 * ct + lj;
   const bool isg = (c == NR), live = (c <= NR);
   const int bcol = c < NU ? 24 + c : (c < NR ? c - NU : 0);        // position of the own column in the (sigma, f, c+) order of G
-  ELIM_T0();
+  const int cb = k & 1;
+  const double* Ah = S.Ah + cb * (12 * YS);
+  const double* bv = S.bv + cb * 12;
   f64x4 T[3];
-  {   // tile fetch: every lane walks its own column (base, stride) of the condensed G / of gamma; delta_w on the diagonal
-    const double* src = isg ? S.gam : S.G + bcol;
-    const int stride = isg ? 1 : GS;
+  {   // tile fetch: every lane walks its own column of the condensed G (the assembly fills the upper triangle only) / of gamma; delta_w on the diagonal
+    const double* const lds0 = reinterpret_cast<const double*>(&S);      // one branch-free load per element: offsets (doubles) from the start of the LDS block
+    const int oG = (int)(offsetof(Lds, G) / sizeof(double)), oGam = (int)(offsetof(Lds, gam) / sizeof(double));
 #pragma unroll
     for (int rt = 0; rt < 3; ++rt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int rho = 16 * rt + lk + 4 * r;
         const int a = rho < NU ? 24 + rho : (rho < NR ? rho - NU : 0);
-        const double v = src[a * stride] + (rho == c ? delta : 0.0);
+        const double v = lds0[isg ? oGam + a : oG + (a < bcol ? a * GS + bcol : bcol * GS + a)] + (rho == c ? delta : 0.0);
         T[rt][r] = (live && rho < NR) ? v : 0.0;
       }
+    if (S.rc_on) {      // (uniform) + gradient of the running cost of the stage's variables (X, c, f) in the column of gamma
+#pragma unroll
+      for (int rt = 0; rt < 3; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int rho = 16 * rt + lk + 4 * r;
+          const int a = rho < NU ? 24 + rho : (rho < NR ? rho - NU : 0);
+          const double g = S.rcl[a < RCG ? a : 0];
+          T[rt][r] += (isg && rho < NR && a < RCG) ? g : 0.0;
+        }
+    }
   }
-  ELIM_T(1);
   {   // + T^T P T and T^T (P b + p) of the next stage's cost-to-go, formed where it is consumed.  With
       // A_ext = [A^ | b] (12 rows) the own column of Y = P(:,0:12) A_ext comes out of the matrix cores in accumulator
       // layout, which IS the B-operand layout of the next product (row 4kt+k of k-step kt sits in lane group k):
@@ -529,7 +599,7 @@ __device__ __noinline__ bool block_eliminate(double* __restrict__ rec, double de
     double be[3];
 #pragma unroll
     for (int kt = 0; kt < 3; ++kt) {
-      const double va = S.Ah[(4 * kt + lk) * YS + (bcol < 36 ? bcol : 0)], vb = S.bv[4 * kt + lk];
+      const double va = Ah[(4 * kt + lk) * YS + (bcol < 36 ? bcol : 0)], vb = bv[4 * kt + lk];
       be[kt] = isg ? vb : ((live && bcol < 36) ? va : 0.0);
     }
     f64x4 Y1 = {0.0, 0.0, 0.0, 0.0};
@@ -547,7 +617,7 @@ __device__ __noinline__ bool block_eliminate(double* __restrict__ rec, double de
       const int a = rho < NU ? 24 + rho : (rho < NR ? rho - NU : 99);
 #pragma unroll
       for (int kt = 0; kt < 3; ++kt) {
-        const double av = S.Ah[(4 * kt + lk) * YS + (a < 36 ? a : 0)];
+        const double av = Ah[(4 * kt + lk) * YS + (a < 36 ? a : 0)];
         T[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a < 36 ? av : 0.0, Y1[kt], T[rt], 0, 0, 0);
       }
     }
@@ -567,37 +637,48 @@ __device__ __noinline__ bool block_eliminate(double* __restrict__ rec, double de
       T[0][3] += Y2[0]; T[1][0] += Y2[1]; T[1][1] += Y2[2];
     }
   }
-  ELIM_T(2);
-  StageCopy nxt;
+  // assembly of stage k - 1 (asm_issue / asm_copy / asm_terms / asm_combine): loads behind the first block step (every wave is past
+  // the tile fetch: G and gamma are free), LDS copy before block step SC, whose barrier publishes it, products and stores behind
+  // that step, sums of several threads behind the next one.
+  // A non-positive pivot does not end the stage early: the sweep is abandoned by the caller, a few block steps later
+  constexpr int NSTEP = (NU + PB - 1) / PB, SC = NSTEP >= 5 ? 3 : 1;
+  static_assert(NSTEP >= 3 && NSTEP <= 6 && SC + 2 <= NSTEP, "3..6 block steps per stage");
+  AsmRegs nxt;
+  const bool more = k > 0;                               // (uniform)
+#ifndef LANDING_DEV_ASM_LEVEL      // development probe (tools/dev/stage_time.py): 0 = no assembly, 1 = loads and LDS copy, 2 = + products, 3 = everything (results are garbage below 3)
+#define LANDING_DEV_ASM_LEVEL 3
+#endif
+#define ASM_HOOK(step) do { if constexpr (SC == (step) && LANDING_DEV_ASM_LEVEL >= 1) { if (more) asm_copy(nxt); } if constexpr (SC + 1 == (step) && LANDING_DEV_ASM_LEVEL >= 2) { if (more) asm_terms(k - 1, cb ^ 1, nxt); } if constexpr (SC + 2 == (step) && LANDING_DEV_ASM_LEVEL >= 3) { if (more) asm_combine(k - 1, cb ^ 1); } } while (0)
   bool ok = pivot_block_step<NU, (PB > NU ? NU : PB), 0, 0>(T, ct, lj, lk, c);
-  stage_copy_load(k - 1, nxt);                           // every wave is past the prologue: the staging area is free, and
-                                                         // the loads have the remaining block steps to arrive
-  if (NU == 24) flush_record(k + 1);                     // the record the previous elimination left in LDS (none before the last stage's)
-  ELIM_T(5);
-  if (!ok) return false;
-  if constexpr (NU > PB) { if (!pivot_block_step<NU, (NU - PB >= PB ? PB : NU - PB), PB, 1>(T, ct, lj, lk, c)) return false; }
-  if constexpr (NU > 2 * PB) { if (!pivot_block_step<NU, (NU - 2 * PB >= PB ? PB : NU - 2 * PB), 2 * PB, 2>(T, ct, lj, lk, c)) return false; }
-  if constexpr (NU > 3 * PB) { if (!pivot_block_step<NU, (NU - 3 * PB >= PB ? PB : NU - 3 * PB), 3 * PB, 3>(T, ct, lj, lk, c)) return false; }
-  if constexpr (NU > 4 * PB) { if (!pivot_block_step<NU, (NU - 4 * PB >= PB ? PB : NU - 4 * PB), 4 * PB, 4>(T, ct, lj, lk, c)) return false; }
-  if constexpr (NU > 5 * PB) { if (!pivot_block_step<NU, (NU - 5 * PB >= PB ? PB : NU - 5 * PB), 5 * PB, 5>(T, ct, lj, lk, c)) return false; }
-  ELIM_T(3);
-  stage_copy_store(nxt);                                 // before the record stores below (in-order memory counter)
-  ELIM_T(6);
+  if (more && LANDING_DEV_ASM_LEVEL >= 1) asm_issue(k - 1, nxt);
+  ASM_HOOK(1);
+  if constexpr (NU > PB) ok &= pivot_block_step<NU, (NU - PB >= PB ? PB : NU - PB), PB, 1>(T, ct, lj, lk, c);
+  ASM_HOOK(2);
+  if constexpr (NU > 2 * PB) ok &= pivot_block_step<NU, (NU - 2 * PB >= PB ? PB : NU - 2 * PB), 2 * PB, 2>(T, ct, lj, lk, c);
+  ASM_HOOK(3);
+  if constexpr (NU > 3 * PB) ok &= pivot_block_step<NU, (NU - 3 * PB >= PB ? PB : NU - 3 * PB), 3 * PB, 3>(T, ct, lj, lk, c);
+  ASM_HOOK(4);
+  if constexpr (NU > 4 * PB) ok &= pivot_block_step<NU, (NU - 4 * PB >= PB ? PB : NU - 4 * PB), 4 * PB, 4>(T, ct, lj, lk, c);
+  ASM_HOOK(5);
+  if constexpr (NU > 5 * PB) ok &= pivot_block_step<NU, (NU - 5 * PB >= PB ? PB : NU - 5 * PB), 5 * PB, 5>(T, ct, lj, lk, c);
+  ASM_HOOK(6);
+#undef ASM_HOOK
+  if (!ok) return false;                                 // (identical in every lane)
   {   // closed-loop state map for the forward sweep: X+ = A^_sigma sigma + A^_f f + b with f = -(K_f sigma + kappa_f), i.e.
       // Mt = A^_sigma - A^_f K_f, mv = b - A^_f kappa_f.  K_f / kappa_f are rows 0..11 of the first row tile, already in
       // B-operand layout (k-step kt = accumulator kt).
     f64x4 Mq = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int kt = 0; kt < 3; ++kt) {
-      const double af = S.Ah[(lj < 12 ? lj : 0) * YS + 24 + 4 * kt + lk];
+      const double af = Ah[(lj < 12 ? lj : 0) * YS + 24 + 4 * kt + lk];
       Mq = __builtin_amdgcn_mfma_f64_16x16x4f64(lj < 12 ? af : 0.0, T[0][kt], Mq, 0, 0, 0);
     }
     if (c >= NU && c <= NR) {
 #pragma unroll
       for (int r = 0; r < 3; ++r) {
         const int i = lk + 4 * r;
-        if (c < NR) REC_DST(rec)[RIC_MT + i * 24 + (c - NU)] = S.Ah[i * YS + (c - NU)] - Mq[r];
-        else REC_DST(rec)[RIC_MV + i] = S.bv[i] - Mq[r];
+        if (c < NR) rec[RIC_MT + i * 24 + (c - NU)] = Ah[i * YS + (c - NU)] - Mq[r];
+        else rec[RIC_MV + i] = bv[i] - Mq[r];
       }
     }
   }
@@ -611,288 +692,24 @@ __device__ __noinline__ bool block_eliminate(double* __restrict__ rec, double de
         const int rho = 16 * rt + lk + 4 * r;
         const double v = T[rt][r];
         if (rho < NU) {
-          if (c < NR) REC_DST(rec)[RIC_K + rho * 24 + sj] = v; else REC_DST(rec)[RIC_KAP + rho] = v;
+          if (c < NR) rec[RIC_K + rho * 24 + sj] = v; else rec[RIC_KAP + rho] = v;
         } else if (rho < NR) {
           const int i = rho - NU;
-          if (c < NR) { S.P[i * PS + sj] = v; if (i < 12) REC_DST(rec)[RIC_PX + i * 24 + sj] = v; }
-          else { S.pv[i] = v; if (i < 12) REC_DST(rec)[RIC_PV + i] = v; }
-        }
-      }
-  }
-  ELIM_T(4);
-  return true;
-}
-
-// The same elimination in SINGLE precision on v_mfma_f32_16x16x4_f32 (BASELINE configs[4] / SURVEY 8f row N3: "fp32 MFMA KKT
-// factor"; landing_solver_opts::factor_fp32).  G, gamma, A^, b and the cost-to-go are rounded to float as they are fetched from
-// LDS, T^T P T, the 4 x 4 LDL^T, the triangular solves and the rank-4 updates run in float, the gains / cost-to-go / closed-loop
-// map go back to the (double) stage record and LDS arrays.  Nothing else changes precision: the residuals, the right-hand sides,
-// the forward sweep and the line search stay fp64, so the factor only makes the Newton step inexact (relative error ~1e-6) and the
-// outer interior-point iteration is the refinement loop -- the KKT residual that decides convergence is the fp64 one.
-// The f32 accumulator layout differs from the f64 one (row = 4 (l>>4) + r instead of (l>>4) + 4 r, cdna_hip_programming.md
-// section 3): lane group lk holds FOUR CONSECUTIVE rows, so the four pivot rows of a block step sit in the registers of ONE lane
-// group (lk = b & 3) and the contraction index of the products that consume an accumulator as B operand is (k-step kt, lane
-// group lk) <-> row 4 lk + kt.
-typedef float f32x4 __attribute__((vector_size(16)));
-template <int NU>
-__device__ __noinline__ bool block_eliminate_f32(double* __restrict__ rec, double delta, int k) {
-  Lds& S = SH;
-  constexpr int NR = NU + 24;
-  const int tid = threadIdx.x, ct = tid >> 6, l = tid & 63, lj = l & 15, lk = l >> 4;
-  const int c = 16 * ct + lj;
-  const bool isg = (c == NR), live = (c <= NR);
-  const int bcol = c < NU ? 24 + c : (c < NR ? c - NU : 0);
-  f32x4 T[3];
-  {
-    const double* src = isg ? S.gam : S.G + bcol;
-    const int stride = isg ? 1 : GS;
-#pragma unroll
-    for (int rt = 0; rt < 3; ++rt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int rho = 16 * rt + 4 * lk + r;
-        const int a = rho < NU ? 24 + rho : (rho < NR ? rho - NU : 0);
-        const double v = src[a * stride] + (rho == c ? delta : 0.0);
-        T[rt][r] = (live && rho < NR) ? (float)v : 0.0f;
-      }
-  }
-  {
-    const bool cplus = live && !isg && bcol >= 36;
-    const int pcol = cplus ? 12 + bcol - 36 : 0;
-    float be[3];
-#pragma unroll
-    for (int kt = 0; kt < 3; ++kt) {
-      const double va = S.Ah[(4 * kt + lk) * YS + (bcol < 36 ? bcol : 0)], vb = S.bv[4 * kt + lk];
-      be[kt] = isg ? (float)vb : ((live && bcol < 36) ? (float)va : 0.0f);
-    }
-    f32x4 Y1 = {0.0f, 0.0f, 0.0f, 0.0f};              // rows 0..15 of P(:,0:12) [A^ | b] (+ P(:,c+), p): lane group lk, register r <-> row 4 lk + r
-#pragma unroll
-    for (int kt = 0; kt < 3; ++kt) Y1 = __builtin_amdgcn_mfma_f32_16x16x4f32((float)S.P[lj * PS + 4 * kt + lk], be[kt], Y1, 0, 0, 0);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = 4 * lk + r;                    // (rows 12..15 are never consumed)
-      const double dp = S.P[row * PS + pcol], dv = S.pv[row];
-      Y1[r] += cplus ? (float)dp : (isg ? (float)dv : 0.0f);
-    }
-#pragma unroll
-    for (int rt = 0; rt < 3; ++rt) {
-      const int rho = 16 * rt + lj;
-      const int a = rho < NU ? 24 + rho : (rho < NR ? rho - NU : 99);
-#pragma unroll
-      for (int kt = 0; kt < 4; ++kt) {               // contraction row 4 lk + kt (< 12: lane group 3 supplies zeros)
-        const double av = S.Ah[(lk < 3 ? 4 * lk + kt : 0) * YS + (a < 36 ? a : 0)];
-        T[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32((a < 36 && lk < 3) ? (float)av : 0.0f, Y1[kt], T[rt], 0, 0, 0);
-      }
-    }
-    if (NU == 24) {   // rows of c+ (control rows 12..23 = tile 0 rows 12..15, tile 1 rows 0..7): + rows 12..23 of P T, accumulated in place
-#pragma unroll
-      for (int kt = 0; kt < 3; ++kt) {
-        const double p0 = S.P[(lj >= 12 ? lj : 12) * PS + 4 * kt + lk], p1 = S.P[(lj < 8 ? 16 + lj : 16) * PS + 4 * kt + lk];
-        T[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(lj >= 12 ? (float)p0 : 0.0f, be[kt], T[0], 0, 0, 0);
-        T[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(lj < 8 ? (float)p1 : 0.0f, be[kt], T[1], 0, 0, 0);
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int r0 = 12 + r, r1 = 16 + 4 * (lk < 2 ? lk : 0) + r;
-        const double d0 = cplus ? S.P[r0 * PS + pcol] : (isg ? S.pv[r0] : 0.0);
-        const double d1 = cplus ? S.P[r1 * PS + pcol] : (isg ? S.pv[r1] : 0.0);
-        if (lk == 3) T[0][r] += (float)d0;
-        if (lk < 2) T[1][r] += (float)d1;
-      }
-    }
-  }
-  StageCopy nxt;
-  float* XB = reinterpret_cast<float*>(S.A1);
-#pragma unroll
-  for (int b = 0; b < NU / 4; ++b) {
-    const int rtb = b >> 2, lb = b & 3;
-    float* W = XB + (b & 1) * XCH;
-    float* C = W + 256;
-    if (lk == lb) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) W[c * 4 + r] = T[rtb][r];
-    }
-    if (ct == rtb && (lj >> 2) == lb) {
-#pragma unroll
-      for (int rt = 0; rt < 3; ++rt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) C[(16 * rt + 4 * lk + r) * 4 + (lj & 3)] = T[rt][r];
-    }
-    __syncthreads();
-    if (b == 0) { stage_copy_load(k - 1, nxt); if (NU == 24) flush_record(k + 1); }
-    const float* Dp = C + 16 * b;
-    const float a00 = Dp[0], a10 = Dp[4], a11 = Dp[5], a20 = Dp[8], a21 = Dp[9], a22 = Dp[10], a30 = Dp[12], a31 = Dp[13], a32 = Dp[14], a33 = Dp[15];
-    const float w0 = W[c * 4 + 0], w1 = W[c * 4 + 1], w2 = W[c * 4 + 2], w3 = W[c * 4 + 3];
-    float am[3];
-#pragma unroll
-    for (int rt = 0; rt < 3; ++rt) { const float cv = C[(16 * rt + lj) * 4 + lk]; am[rt] = ((16 * rt + lj) >> 2 == b) ? 0.0f : cv; }
-    const float d0 = a00, i0 = __builtin_amdgcn_rcpf(d0);
-    const float l10 = a10 * i0, l20 = a20 * i0, l30 = a30 * i0;
-    const float d1 = fmaf(-l10, a10, a11), i1 = __builtin_amdgcn_rcpf(d1);
-    const float t21 = fmaf(-l20, a10, a21), t31 = fmaf(-l30, a10, a31);
-    const float l21 = t21 * i1, l31 = t31 * i1;
-    const float d2 = fmaf(-l21, t21, fmaf(-l20, a20, a22)), i2 = __builtin_amdgcn_rcpf(d2);
-    const float t32 = fmaf(-l31, t21, fmaf(-l30, a20, a32));
-    const float l32 = t32 * i2;
-    const float d3 = fmaf(-l32, t32, fmaf(-l31, t31, fmaf(-l30, a30, a33))), i3 = __builtin_amdgcn_rcpf(d3);
-    const float dmin = fminf(fminf(d0, d1), fminf(d2, d3)), dmax = fmaxf(fmaxf(d0, d1), fmaxf(d2, d3));
-    const bool ok = (dmin > 1e-30f) && (dmax < 1e30f) && (d0 == d0) && (d1 == d1) && (d2 == d2) && (d3 == d3);
-    const float y1 = fmaf(-l10, w0, w1);
-    const float y2 = fmaf(-l21, y1, fmaf(-l20, w0, w2));
-    const float y3 = fmaf(-l32, y2, fmaf(-l31, y1, fmaf(-l30, w0, w3)));
-    const float r3 = y3 * i3;
-    const float r2 = fmaf(-l32, r3, y2 * i2);
-    const float r1 = fmaf(-l31, r3, fmaf(-l21, r2, y1 * i1));
-    const float r0 = fmaf(-l30, r3, fmaf(-l20, r2, fmaf(-l10, r1, w0 * i0)));
-    const float R = lk == 0 ? r0 : (lk == 1 ? r1 : (lk == 2 ? r2 : r3));
-    if (16 * ct + 16 > 4 * b) {
-#pragma unroll
-      for (int rt = 0; rt < 3; ++rt) T[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(am[rt], -R, T[rt], 0, 0, 0);
-      if (lk == lb) { T[rtb][0] = r0; T[rtb][1] = r1; T[rtb][2] = r2; T[rtb][3] = r3; }
-    }
-    if (!ok) return false;
-  }
-  stage_copy_store(nxt);
-  {
-    f32x4 Mq = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-    for (int kt = 0; kt < 4; ++kt) {
-      const double af = S.Ah[(lj < 12 ? lj : 0) * YS + 24 + (lk < 3 ? 4 * lk + kt : 0)];
-      Mq = __builtin_amdgcn_mfma_f32_16x16x4f32((lj < 12 && lk < 3) ? (float)af : 0.0f, T[0][kt], Mq, 0, 0, 0);
-    }
-    if (c >= NU && c <= NR && lk < 3) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int i = 4 * lk + r;
-        if (c < NR) REC_DST(rec)[RIC_MT + i * 24 + (c - NU)] = S.Ah[i * YS + (c - NU)] - (double)Mq[r];
-        else REC_DST(rec)[RIC_MV + i] = S.bv[i] - (double)Mq[r];
-      }
-    }
-  }
-  if (c >= NU && c <= NR) {
-    const int sj = c - NU;
-#pragma unroll
-    for (int rt = 0; rt < 3; ++rt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int rho = 16 * rt + 4 * lk + r;
-        const double v = (double)T[rt][r];
-        if (rho < NU) {
-          if (c < NR) REC_DST(rec)[RIC_K + rho * 24 + sj] = v; else REC_DST(rec)[RIC_KAP + rho] = v;
-        } else if (rho < NR) {
-          const int i = rho - NU;
-          if (c < NR) { S.P[i * PS + sj] = v; if (i < 12) REC_DST(rec)[RIC_PX + i * 24 + sj] = v; }
-          else { S.pv[i] = v; if (i < 12) REC_DST(rec)[RIC_PV + i] = v; }
+          if (c < NR) { S.P[i * PS + sj] = v; if (i < 12) rec[RIC_PX + i * 24 + sj] = v; }
+          else { S.pv[i] = v; if (i < 12) rec[RIC_PV + i] = v; }
         }
       }
   }
   return true;
 }
 
-// Everything of one backward Riccati step that follows the assembly of G, gamma (templated on the control
-// dimension: 24 = (f_k, c_{k+1}), 12 = last stage).  Writes P_k, p_k into S and the stage record.
+// One backward Riccati step (templated on the control dimension: 24 = (f_k, c_{k+1}), 12 = last stage): elimination of the
+// controls of stage k (G + T^T P T; P_k, p_k -> LDS, gains -> record k) with the assembly of stage k - 1 riding along.
 template <int NU>
 __device__ __forceinline__ bool riccati_step(double* rec, double delta, int k) {
-  Lds& S = SH;
-  const bool ok = S.fp32 ? block_eliminate_f32<NU>(rec, delta, k) : block_eliminate<NU, LANDING_PIVOT_BLOCK>(rec, delta, k);
-  if (!ok) { __syncthreads(); return false; }
+  const bool ok = block_eliminate<NU, LANDING_PIVOT_BLOCK>(rec, delta, k);
   __syncthreads();
-  return true;
-}
-
-// Condensation (once per iteration): G targets = H + J_d^T Sigma J_d, gamma = J_d^T rho, A^ = -dg_dyn/d(X,c,f) of
-// every stage, straight from the CCS nonzeros.  The work is described by packed 8-byte terms (cterm_pack) in
-// stage-LOCAL form: one table per stage type (first / middle / penultimate / last), the middle one cached in LDS -- the
-// round-1 version streamed a member-global list of 16-byte records (720 KB per member and iteration, four times the
-// J and H nonzeros themselves) from L2/HBM.  Thread t owns the terms [t*c_ml, (t+1)*c_ml) of every stage's list: perfectly
-// balanced (5 terms per thread and stage at N = 40).  A destination whose terms straddle chunk borders is finished by the
-// thread holding its closing term, which adds the carries of its `nprev` predecessors from LDS in thread order --
-// deterministic.  Two stages per batch: their gathers are issued together, one barrier per batch.
-__device__ LANDING_INL_COND void condense(const unsigned long long* __restrict__ ctab, int ML, int mid) {
-  Lds& S = SH;
-  const MemberMem& M = S.M;
-  const int ng = S.L.ng, N = S.L.N, tid = threadIdx.x;
-  // scratch of this phase lives in the Riccati arrays, which are dead here: the term table of the most frequent stage type in
-  // S.G (12 KB of 18.8, re-loaded from L2 on every call: 12 KB against the 720 KB the round-1 list streamed), the carries of
-  // even batches behind it, those of odd batches in S.A1
-  static_assert(CTAB_MLMAX * SOLVER_THREADS + 2 * SOLVER_THREADS <= 48 * GS && 2 * SOLVER_THREADS <= 2 * XCH, "condensation scratch fits");
-  unsigned long long* ctab_mid = reinterpret_cast<unsigned long long*>(S.G);
-  double* carry_even = S.G + CTAB_MLMAX * SOLVER_THREADS;
-  double* carry_odd = S.A1;
-  {
-    const unsigned long long* src = ctab + (size_t)mid * ML * SOLVER_THREADS;
-    for (int e = tid; e < ML * SOLVER_THREADS; e += SOLVER_THREADS) ctab_mid[e] = src[e];
-  }
-  __syncthreads();
-  const double* __restrict__ JH = M.J;       // [J | H | Hc] are contiguous
-  const double* __restrict__ SR = M.sig;     // [sigma | rho] are contiguous
-  double* __restrict__ cond = M.cond;
-  constexpr int SB = 2;
-  const unsigned long long PAD = cterm_pack(0, 0, 0, 0, false, 0, 3, 0, false);
-  int batch = 0;
-  for (int k0 = 0; k0 < N; k0 += SB, ++batch) {
-    unsigned long long t[SB][CTAB_MLMAX];
-    double a[SB][CTAB_MLMAX], b[SB][CTAB_MLMAX], c[SB][CTAB_MLMAX];
-#pragma unroll
-    for (int s = 0; s < SB; ++s) {
-      const int k = k0 + s < N ? k0 + s : N - 1;
-      const int tp = S.segb[k * 8 + 7];
-      const unsigned long long* gt = ctab + (size_t)tp * ML * SOLVER_THREADS;
-#pragma unroll
-      for (int j = 0; j < CTAB_MLMAX; ++j) t[s][j] = j < ML ? (tp == mid ? ctab_mid[j * SOLVER_THREADS + tid] : gt[j * SOLVER_THREADS + tid]) : PAD;
-    }
-#pragma unroll
-    for (int s = 0; s < SB; ++s) {
-      const int k = k0 + s < N ? k0 + s : N - 1;
-      const int* sb = S.segb + k * 8;
-      const int g0 = S.L.g_stage(k);
-#pragma unroll
-      for (int j = 0; j < CTAB_MLMAX; ++j) {
-        const unsigned lo = (unsigned)t[s][j];
-        const int ia = sb[(lo >> 8) & 7] + (int)(lo & 255u), ib = sb[(lo >> 19) & 7] + (int)((lo >> 11) & 255u);
-        const bool has_b = (lo >> 22) & 1u;
-        const int rt = (int)(lo >> 30), row = g0 + (int)((lo >> 23) & 127u);
-        a[s][j] = JH[ia];
-        b[s][j] = JH[has_b ? ib : ia];
-        c[s][j] = SR[rt == 0 ? row + (has_b ? 0 : ng) : 0];
-      }
-    }
-    double pend_acc[SB]; int pend_dst[SB], pend_n[SB];
-    double* carry = (batch & 1) ? carry_odd : carry_even;
-#pragma unroll
-    for (int s = 0; s < SB; ++s) {
-      pend_acc[s] = 0.0; pend_dst[s] = 0; pend_n[s] = 0;
-      double* cd = cond + (size_t)(k0 + s < N ? k0 + s : N - 1) * COND_STRIDE;
-      const bool live = k0 + s < N;
-      double acc = 0.0;
-#pragma unroll
-      for (int j = 0; j < CTAB_MLMAX; ++j) {
-        const unsigned lo = (unsigned)t[s][j], hi = (unsigned)(t[s][j] >> 32);
-        const bool has_b = (lo >> 22) & 1u;
-        const int rt = (int)(lo >> 30);
-        const double cc = rt == 0 ? c[s][j] : (rt == 1 ? 1.0 : (rt == 2 ? -1.0 : 0.0));
-        acc += a[s][j] * (has_b ? b[s][j] : 1.0) * cc;
-        if ((hi >> 10) & 1u) {
-          const int np = (int)((hi >> 11) & 7u);
-          if (np > 0) { pend_acc[s] = acc; pend_dst[s] = (int)(hi & 1023u); pend_n[s] = np; }
-          else if (live) cd[hi & 1023u] = acc;
-          acc = 0.0;
-        }
-      }
-      carry[s * SOLVER_THREADS + tid] = acc;       // what the chunk contributes to a destination that closes in a later thread
-    }
-    __syncthreads();
-#pragma unroll
-    for (int s = 0; s < SB; ++s) {
-      if (pend_n[s] > 0 && k0 + s < N) {
-        double tot = 0.0;
-        for (int i = pend_n[s]; i >= 1; --i) tot += carry[s * SOLVER_THREADS + tid - i];
-        cond[(size_t)(k0 + s) * COND_STRIDE + pend_dst[s]] = tot + pend_acc[s];
-      }
-    }
-    // (the next batch writes the other half of S.carry; the barrier of that batch orders it against these reads)
-  }
-  __syncthreads();
+  return ok;
 }
 
 // One backward Riccati sweep with regularisation delta (terminal cost-to-go, stages N-1..0, free feet of
@@ -921,29 +738,29 @@ __device__ LANDING_INL_BACK bool riccati_backward(double delta) {
   // background of the condensed stage data: the scatter below writes the structural nonzeros only (the patterns
   // of the stages nest along the sweep unless the tables say otherwise), nothing else writes G / A^ any more
   for (int e = lane; e < 48 * GS; e += NT) S.G[e] = 0.0;
-  for (int e = lane; e < 12 * YS; e += NT) S.Ah[e] = 0.0;
+  for (int e = lane; e < 2 * 12 * YS; e += NT) S.Ah[e] = 0.0;
   if (lane < 24) S.pv[lane] = (lane < 12) ? S.pv[lane] : 0.0;
-  {   // condensed data of the last stage -> staging area (the only exposed copy of the sweep)
-    StageCopy first;
-    stage_copy_load(N - 1, first);
-    stage_copy_store(first);
+  __syncthreads();
+  {   // the only exposed assembly of the sweep
+    AsmRegs first;
+    asm_issue(N - 1, first);
+    asm_copy(first);
+    __syncthreads();
+    asm_terms(N - 1, (N - 1) & 1, first);
+    __syncthreads();
+    asm_combine(N - 1, (N - 1) & 1);
   }
   __syncthreads();
   for (int k = N - 1; k >= 0 && ok; --k) {
     const bool last = (k == N - 1);
     long long tb_ = S.prof_on ? (long long)wall_clock64() : 0;
-    // ---- condensed stage data (copied into LDS during the previous stage's elimination) -> G, gamma, A^, b
-    stage_scatter(k);
-    __syncthreads();
-    PROF_ADD(PH_B_ASM, tb_);
-    // ---- G + T^T P T, elimination of the controls: P_k, p_k, gains -> record k; stages the data of stage k-1
+    // ---- G + T^T P T, elimination of the controls: P_k, p_k, gains -> record k; the assembly of stage k - 1 rides along
     double* rec = M.ric + (size_t)k * RIC_STRIDE;
     ok = last ? riccati_step<12>(rec, delta, k) : riccati_step<24>(rec, delta, k);
     if (lane == 0) { S.prof[PH_NSTAGE] += 1.0; if (ok) S.prof[PH_NSTAGE_OK] += 1.0; }
     PROF_ADD(PH_B_ELIM, tb_);
   }
   if (ok) {
-    flush_record(0);      // (the riccati_step of stage 0 ended with a barrier: the record is complete in LDS)
     // ---- stage 0: X_0 fixed, feet c_0 free: P_cc dc0 = -(p_c + P_cx dX0), same elimination on a 12x12 block
     if (lane < 12) {
       const int i = lane;
@@ -983,9 +800,9 @@ __device__ LANDING_INL_FWD void forward_pass() {
   const MemberMem& M = S.M;
   const int N = L.N, tid = threadIdx.x, NT = blockDim.x;
   double* sg = S.G;                    // sigma_k, k = 0..N  at sg[24 k]           (N <= SOLVER_NMAX = 96: 2328 of the 2352 doubles of G)
-  double* buf = S.stg;                 // two stage slots of RIC_FWDN doubles: the staging area of the backward sweep (free here) and A1
+  double* buf = S.jhl;                 // two stage slots of RIC_FWDN doubles: the assembler's copy of a stage's nonzeros (free here) and A1
   double* buf1 = S.A1;
-  static_assert(24 * (SOLVER_NMAX + 1) <= 48 * GS && RIC_FWDN <= COND_STRIDE + 12 && RIC_FWDN <= XCH * 2, "forward scratch fits");
+  static_assert(24 * (SOLVER_NMAX + 1) <= 48 * GS && RIC_FWDN <= NZ_TOT + RUNC && RIC_FWDN <= XCH * 2, "forward scratch fits");
   auto slot = [&](int k) { return (k & 1) ? buf1 : buf; };
   auto fetch = [&](int k, double (&r)[3]) {
     landing_gptr rec = (landing_gptr)(M.ric + (size_t)(k < N ? k : N - 1) * RIC_STRIDE + RIC_FWD0);   // global_load: a flat load would also tie up the LDS counter
@@ -1114,16 +931,16 @@ __device__ __noinline__ void rc_add_grad() {     // objective gradient of the st
   const Layout& L = SH.L; const MemberMem& M = SH.M;
   for (int k = threadIdx.x; k < L.N; k += blockDim.x) { double* gU = M.gx + L.x_U(k); (void)run_cost_stage(L, M.x, SH.p, k, M.gx + L.x_X(k), gU, gU + 12); }
 }
-__device__ __noinline__ void rc_add_gamma() {    // ... and into the stage right-hand sides gamma_k (w order X, c, f)
+__device__ __noinline__ void rc_add_gamma() {    // ... and, per stage, for the right-hand sides gamma_k (w order X, c, f): added when the tile of gamma is fetched (block_eliminate)
   const Layout& L = SH.L; const MemberMem& M = SH.M;
   for (int k = threadIdx.x; k < L.N; k += blockDim.x) {
     double gr[36];
 #pragma unroll
     for (int a = 0; a < 36; ++a) gr[a] = 0.0;
     (void)run_cost_stage(L, M.x, SH.p, k, gr, gr + 12, gr + 24);
-    double* gm = M.cond + (size_t)k * COND_STRIDE + COND_GAM;
+    double* gm = M.cond + (size_t)k * RCG;
 #pragma unroll
-    for (int a = 0; a < 36; ++a) gm[a] += gr[a];
+    for (int a = 0; a < 36; ++a) gm[a] = gr[a];
   }
 }
 __device__ __noinline__ void rc_f_dphi(double& f0, double& dphi) {     // running cost at x and its directional derivative along dx (per-thread partial sums)
@@ -1230,17 +1047,13 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
   double* __restrict__ r_g = M.g; double* __restrict__ r_gt = M.gt; double* __restrict__ r_s = M.s; double* __restrict__ r_ds = M.ds;
   double* __restrict__ r_zL = M.zL; double* __restrict__ r_zU = M.zU;
   double* __restrict__ r_y = M.y; double* __restrict__ r_yn = M.yn; double* __restrict__ r_sig = M.sig; double* __restrict__ r_rho = M.rho;
-  S.M = M; S.L = L; S.p = p; S.tab = A.tab; S.stage_tab = A.stage_tab; S.prof_on = A.prof != nullptr; S.fp32 = o.factor_fp32;
+  S.M = M; S.L = L; S.p = p; S.prof_on = A.prof != nullptr;
+  S.ctab = A.ctab; S.ccomb = A.ccomb; S.c_ml = A.c_ml; S.c_mid = A.c_mid; S.rc_on = 0;
+  if (lane < SOLVER_THREADS) S.acomb_mid[lane] = A.ccomb[A.c_mid * SOLVER_THREADS + lane];
+  for (int e = lane; e < 64; e += NT) S.dump[e] = 0.0;
+  for (int e = lane; e < A.c_ml * SOLVER_THREADS; e += NT) S.atab_mid[e] = A.ctab[(size_t)A.c_mid * A.c_ml * SOLVER_THREADS + e];      // term table of the most frequent stage type
+  if (lane == 0) { S.jhl[CX_ONE] = 1.0; S.jhl[CX_MONE] = -1.0; S.jhl[CX_ZERO] = 0.0; }
   if (lane < 16) S.prof[lane] = 0.0;
-  {   // scatter codes of the table shared by the middle stages
-    const int off = A.stage_tab[N / 2];
-    const int* tb = A.tab + off;
-    const int nT = tb[0], nA = tb[6];
-    const int* ab = A.tab + tb[1]; const int* at = A.tab + tb[7];
-    for (int e = lane; e < nT; e += NT) S.cab[e] = ab[e];
-    for (int q = lane; q < nA; q += NT) S.cat[q] = at[3 * q + 1] * YS + at[3 * q + 2];
-    if (lane == 0) { S.c_tab = off; S.c_nT = nT; S.c_nA = nA; }
-  }
   {   // condensation: segment bases of every stage, packed term table of the most frequent stage type
     const int nj = L.nnz_jac, nh = L.nnz_hess;
     for (int k = lane; k < N; k += NT) {
@@ -1557,8 +1370,8 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
     }
     PROF_ADD(PH_ERR, K.tp);
 
-    condense(A.ctab, A.c_ml, A.c_mid);
-    if (L.run_cost && !K.feas) { rc_add_gamma(); __syncthreads(); }   // ... and in the stage right-hand sides gamma_k (w order X, c, f)
+    // (the condensation G_k = H_k + J_d^T Sigma J_d, gamma_k, A^_k is part of the backward sweep: cond_issue / cond_finish)
+    { const int rc = (L.run_cost && !K.feas) ? 1 : 0; if (lane == 0) S.rc_on = rc; if (rc) rc_add_gamma(); __syncthreads(); }   // gradient of the running cost for the stage right-hand sides
     PROF_ADD(PH_SIGRHO, K.tp);
     // ================================================================ Riccati factorisation with inertia correction
     // IPOPT's inertia-correction schedule (delta_w = 0 first, then max(1e-20, delta_last/3), then x8 / x100),
