@@ -222,16 +222,15 @@ typedef struct {
                             of the round (lab): mean 53.5 -> 48.5 iterations but 1 member in 1000 wandered off at mu = 1e-4; with the
                             watchdog, the slack correction and the later-barrier-problem restart in place it is safe: CPU port on two
                             batches mean 53.2 -> 50.3, median 52 -> 49, slowest 107 -> 95 (numbers at scale in DESIGN.md).  0 = unscaled */
-  int factor_fp32;       /* 1: the stage eliminations of the Riccati factorisation (T^T P T, blocked LDL^T, gains, cost-to-go) run in
-                            single precision on v_mfma_f32_16x16x4_f32 -- BASELINE configs[4]'s "fp32 MFMA KKT factor".  Residuals,
-                            right-hand sides, forward sweep, line search and the convergence test stay fp64: the step becomes an
-                            inexact Newton step and the interior-point iteration itself is the refinement loop (KKT <= tol is the
-                            fp64 residual, as always).  Default 0, also in landing_solver_opts_warm(): measured on MI355X (round 2) the
-                            variant converges like the fp64 one from a cold start (1024 / 1024 members, mean 53.0 vs 53.3 iterations)
-                            and needs 9.3 instead of 8.1 iterations per warm-started tick, but a stage elimination is 11 % SLOWER
-                            (0.325 vs 0.292 ms of backward sweep per iteration with a CU to itself): the operands are still staged in
-                            the fp64 LDS arrays and converted at fetch, and the sweep is latency-bound, not matrix-core-bound
-                                                                                                                    */
+  int factor_fp32;       /* RETIRED in round 5 -- must be 0; landing_solve_batch rejects any other value (LANDING_E_ARG).  Rounds 2-4 had a
+                            variant of the stage elimination in single precision on v_mfma_f32_16x16x4_f32 (BASELINE configs[4]'s "fp32
+                            MFMA KKT factor"; everything outside the factor fp64).  It reached the same fp64 KKT tolerance but never
+                            paid: a stage elimination was 11 % SLOWER than the fp64 one (0.325 vs 0.292 ms of backward sweep per
+                            iteration), a warm-started tick needed 9.3 instead of 8.1 iterations, median tick 4.2 vs 4.0 ms and
+                            98 % instead of 100 % of the ticks inside the 10 ms budget at batch 256 (profiles/r03_mpc_fp32.json): the
+                            sweep is bound by latency and instruction issue, not by the matrix cores, and the 4 x 4 pivot blocks are
+                            factored redundantly in registers either way.  configs[4] runs the fp64 factor.  The field
+                            stays so that the struct layout of rounds 2-4 callers is unchanged                                       */
   int feas_phase;        /* feasibility (restoration) phase, default 1 (0 in landing_solver_opts_warm).  The reference configures IPOPT, whose
                             answer to a jammed iterate is its restoration phase; here a solve that would end as LANDING_NUMERICAL or
                             LANDING_MAX_ITER continues, once, on the ELASTIC problem: every inequality row may be violated by n, q >= 0 at the

@@ -621,22 +621,33 @@ __device__ LANDING_INL_EVAL_G void member_eval_g(const Layout& L, const double* 
 }
 // out-of-line copy for the rare call sites of the solver (initial point, restart from the initial guess, line-search fall-back)
 __device__ __noinline__ void member_eval_g_rare(const Layout& L, const double* x, const double* p, double* g) { member_eval_g(L, x, p, g); }
-__device__ LANDING_INL_TASK void eval_task_jac(const Layout& L, const srbm::StageVars& z, const srbm::StageParams& P, int k,
-                                           const double* fz_prev, double* J) {
-  SeqStoreJ ex{J + L.jx(k)}, eu{J + L.ju(k)};
-  srbm::stage_jac(z, P, k == 0, k == L.N - 1, fz_prev, ex, eu);
+// The derivative tasks of one stage.  Each loads the stage's variables itself: handing them over as `const StageVars&` made the caller
+// write the two structs to its stack frame (77 private-memory stores per lane and call) and every task read them back from there.
+struct StageIn { srbm::StageVars z; srbm::StageParams P; double fz_prev[4]; };
+__device__ __forceinline__ void load_stage_in(const Layout& L, const double* x, const double* p, int k, StageIn& I) {
+  load_stage(L, x, p, k, I.z, I.P);
+  for (int l = 0; l < 4; ++l) I.fz_prev[l] = 0.0;
+  if (k > 0) { const double* Up = x + L.x_U(k - 1); for (int l = 0; l < 4; ++l) I.fz_prev[l] = Up[12 + 3 * l + 2]; }
 }
-__device__ LANDING_INL_TASK void eval_task_jty(const Layout& L, const srbm::StageVars& z, const srbm::StageParams& P, int k,
-                                           const double* fz_prev, const double* y, double* gx) {
+__device__ LANDING_INL_TASK void eval_task_jac(const Layout& L, const double* x, const double* p, int k, double* J) {
+  StageIn I; load_stage_in(L, x, p, k, I);
+  SeqStoreJ ex{J + L.jx(k)}, eu{J + L.ju(k)};
+  srbm::stage_jac(I.z, I.P, k == 0, k == L.N - 1, I.fz_prev, ex, eu);
+}
+__device__ LANDING_INL_TASK void eval_task_jty(const Layout& L, const double* x, const double* p, int k, const double* y, double* gx) {
+  StageIn I; load_stage_in(L, x, p, k, I);
   const bool first = (k == 0);
   const double* lprev = first ? y : y + L.g_stage(k - 1);
   DotLam ex{y + L.g_stage(k), lprev, first, gx + L.x_X(k), 0.0, false};
   DotLam eu{y + L.g_stage(k), lprev, first, gx + L.x_U(k), 0.0, false};
-  srbm::stage_jac(z, P, first, k == L.N - 1, fz_prev, ex, eu);
+  srbm::stage_jac(I.z, I.P, first, k == L.N - 1, I.fz_prev, ex, eu);
   ex.finish(); eu.finish();
 }
-__device__ LANDING_INL_TASK void eval_task_hess(const Layout& L, const srbm::StageVars& z, const srbm::StageParams& P, int k,
-                                            const double* y, double* H) {
+// Hessian values of stage k: PART 0 = both column groups, 1 = the X_k columns (29 values), 2 = the U_k columns (148 / 160).  The solver
+// runs 1 and 2 on two waves (round 5; the fourth wave used to idle through the derivative phase)
+template <int PART>
+__device__ LANDING_INL_TASK void eval_task_hess(const Layout& L, const double* x, const double* p, int k, const double* y, double* H) {
+  StageIn I; load_stage_in(L, x, p, k, I);
   const bool first = (k == 0);
   double lps[12];
   for (int i = 0; i < 12; ++i) lps[i] = 0.0;
@@ -645,8 +656,9 @@ __device__ LANDING_INL_TASK void eval_task_hess(const Layout& L, const srbm::Sta
     for (int l = 0; l < 4; ++l) for (int i = 0; i < 3; ++i) lps[3 * l + i] = lp[16 + 12 * l + 2 + i] + lp[16 + 12 * l + 5 + i];
   }
   LamStage lam{y + L.g_stage(k)};
-  SeqStoreH hx{H + L.hx(k)}, hu{H + L.hu(k)};
-  srbm::stage_hess(z, P, first, k == L.N - 1, lam, lps, hx, hu);
+  if (PART == 0) { SeqStoreH hx{H + L.hx(k)}, hu{H + L.hu(k)}; srbm::stage_hess(I.z, I.P, first, k == L.N - 1, lam, lps, hx, hu); }
+  else if (PART == 1) { SeqStoreH hx{H + L.hx(k)}; NullEmit hu; srbm::stage_hess(I.z, I.P, first, k == L.N - 1, lam, lps, hx, hu); }
+  else { NullEmit hx; SeqStoreH hu{H + L.hu(k)}; srbm::stage_hess(I.z, I.P, first, k == L.N - 1, lam, lps, hx, hu); }
 }
 
 // Jacobian / Hessian nonzeros (CCS order) and gx = grad f + J^T y of one member.
@@ -661,28 +673,19 @@ __device__ LANDING_INL_EVAL_JH void member_eval_jh(const Layout& L, const double
     v += (i < 6) ? y[12 + i] + y[18 + i] : y[24 + i - 6] + y[30 + i - 6];
     gx[12 * N + i] = v;
   }
-  // (stage, task) pairs over the threads: task 0 = Jacobian values, 1 = J^T y (column dot products), 2 = Hessian
-  // one wavefront per task (no divergent calls): wave 0 -> Jacobian, wave 1 -> J^T y, wave 2 -> Hessian; with fewer
-  // than 3 waves the tasks are looped
+  // (stage, task) pairs over the threads: task 0 = Jacobian values, 1 = J^T y (column dot products), 2 = Hessian X_k columns, 3 = Hessian U_k columns
+  // one wavefront per task (no divergent calls); with fewer than 4 waves the tasks are looped
   const int nwave = (blockDim.x + 63) >> 6, wave = threadIdx.x >> 6;
   (void)tiles; (void)edge_map;      // (round 2's tiled write-out of the Jacobian task inside the solver: measured slower, removed)
-  for (int task = wave; task < 3; task += nwave)
+  for (int task = wave; task < 4; task += nwave)
   for (int k = threadIdx.x & 63; k < N; k += 64) {
-    const bool first = (k == 0);
-    srbm::StageVars z; srbm::StageParams P;
-    load_stage(L, x, p, k, z, P);
-    double fz_prev[4] = {0, 0, 0, 0};
-    if (!first) { const double* Up = x + L.x_U(k - 1); for (int l = 0; l < 4; ++l) fz_prev[l] = Up[12 + 3 * l + 2]; }
-#ifdef LANDING_DEV_SKIP_TASK
+#ifdef LANDING_DEV_SKIP_TASK          // development probe (tools/dev): which task bounds the derivative phase
     if (task == LANDING_DEV_SKIP_TASK) continue;
 #endif
-    if (task == 0) eval_task_jac(L, z, P, k, fz_prev, J);
-    else if (task == 1) eval_task_jty(L, z, P, k, fz_prev, y, gx);
-#ifdef LANDING_DEV_SKIP_TASK          // development probe (tools/dev): which task bounds the derivative phase
-    else if (LANDING_DEV_SKIP_TASK != 2) eval_task_hess(L, z, P, k, y, H);
-#else
-    else eval_task_hess(L, z, P, k, y, H);
-#endif
+    if (task == 0) eval_task_jac(L, x, p, k, J);
+    else if (task == 1) eval_task_jty(L, x, p, k, y, gx);
+    else if (task == 2) eval_task_hess<1>(L, x, p, k, y, H);
+    else eval_task_hess<2>(L, x, p, k, y, H);
   }
 }
 

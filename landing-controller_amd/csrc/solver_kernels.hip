@@ -1212,7 +1212,7 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
     // tiles in the dead G array -- and is slower: 0.049 vs 0.039 ms alone, 0.094 vs 0.085 under load; every lane then runs the
     // full middle-stage stream and the wave serialises on 24 tile flushes, while the scattered stores of this version drain
     // asynchronously behind the arithmetic of the other two waves)
-    if (lane < 192 && (lane & 63) < nst) member_eval_jh(L, M.x, p, M.y, M.J, M.H, M.gx, nullptr, nullptr, K.feas ? 0.0 : 1.0);
+    if ((lane & 63) < nst) member_eval_jh(L, M.x, p, M.y, M.J, M.H, M.gx, nullptr, nullptr, K.feas ? 0.0 : 1.0);
     __syncthreads();
     if (L.run_cost && !K.feas) { rc_add_grad(); __syncthreads(); }   // objective gradient of the stage variables (the terminal part is in member_eval_jh)
     PROF_ADD(PH_EVAL, K.tp);

@@ -320,28 +320,6 @@ def test_n20_production_problem_full_batch(libs, oracle_mod, law, min_conv):
 
 
 @pytest.mark.gpu
-def test_solver_fp32_factor_reaches_fp64_kkt(oracle_mod):
-    """BASELINE configs[4] names an fp32 matrix-core KKT factor: with landing_solver_opts::factor_fp32 the stage eliminations run on
-    v_mfma_f32_16x16x4_f32; everything outside the factor is fp64, so the solve must still end at KKT <= 1e-6 under the oracle's
-    (reference-equivalent) functions -- cold start, configs[4]'s batch of 256, and the iteration count must stay close to the fp64 one"""
-    N, B = 40, 256
-    O = oracle_mod.Oracle(N)
-    P, X0, _, _ = lc("problem").make_batch(B, N, 0.6, seed=515)
-    L = lc("capi").LandingLib(N, device=0)
-    o = L.default_opts(); o.max_iter = 300
-    a = L.solve_host(P, X0, o)
-    o.factor_fp32 = 1
-    b = L.solve_host(P, X0, o)
-    assert (a["status"] == 0).sum() >= B - 1 and (b["status"] == 0).sum() >= B - 1
-    assert b["iters"].mean() <= 1.15 * a["iters"].mean()
-    assert np.abs(a["x"] - b["x"]).max() > 0.0                       # the option does change the arithmetic
-    for m in range(0, B, 16):
-        if b["status"][m] == 0:
-            assert O.kkt(b["x"][m], P[m], b["lam_g"][m]).max() <= 1e-6 * 1.0001
-    L.close()
-
-
-@pytest.mark.gpu
 def test_soak_failures_are_rescued(oracle_mod):
     """members found by tools/soak.py (65 536 fresh drop states) that hit max_iter with IPOPT's independent dual step length and
     restarts in place only -- ordinary drop states, each solvable from the same initial guess with another step rule: they converge

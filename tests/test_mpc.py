@@ -72,10 +72,9 @@ def test_receding_horizon_closed_loop(oracle_mod):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("fp32", [0, 1])
-def test_receding_horizon_configs4_full_size(oracle_mod, fp32):
-    """BASELINE configs[4] at its stated size: closed loop at batch 256 (one NLP per CU), N = 40, 100 Hz budget, with the fp64 and the
-    fp32 matrix-core KKT factor.  Asserted: every tick's converged members are KKT points (<= 1e-6, kernel report = oracle on a
+def test_receding_horizon_configs4_full_size(oracle_mod):
+    """BASELINE configs[4] at its stated size: closed loop at batch 256 (one NLP per CU), N = 40, 100 Hz budget, fp64 matrix-core KKT
+    factor (the fp32 variant the config names was built in rounds 2-4, measured slower and retired: include/landing_nlp.h).  Asserted: every tick's converged members are KKT points (<= 1e-6, kernel report = oracle on a
     sample), >= 90 % of the members converge per tick on average, the tick-time percentiles against the 10 ms budget (wall clock
     around shift + solve, synchronised), and that the loop really is warm (iterations per tick << cold)."""
     import time
@@ -85,7 +84,7 @@ def test_receding_horizon_configs4_full_size(oracle_mod, fp32):
     L = capi.LandingLib(N, device=0)
     O = oracle_mod.Oracle(N)
     P, X0, _, _ = Pm.make_batch(B, N, 0.6, seed=515)
-    ow = L.warm_opts(); ow.factor_fp32 = fp32; ow.max_iter = 10       # real-time iteration: at most 10 interior-point iterations per tick
+    ow = L.warm_opts(); ow.max_iter = 10       # real-time iteration: at most 10 interior-point iterations per tick
     ctl = mpc.RecedingHorizon(L, P, X0, opts_warm=ow)
     torch.cuda.synchronize()
     cold_it = ctl.iters.cpu().numpy().astype(float).mean()
@@ -109,10 +108,10 @@ def test_receding_horizon_configs4_full_size(oracle_mod, fp32):
             xh, ph = ctl.x.cpu().numpy(), ctl.p.cpu().numpy()
             assert np.array_equal(xh[:, :12], state.cpu().numpy())
     lat = np.array(lat[2:])                     # the first ticks load code objects
-    print("configs[4] B=256 fp32=%d: tick ms p50 %.2f p90 %.2f max %.2f, iterations/tick %.1f (cold %.1f), converged/tick %.3f" %
-          (fp32, np.median(lat), np.percentile(lat, 90), lat.max(), np.mean(its), cold_it, np.mean(conv)), "status-2 members per tick:", n2)
-    assert np.mean(conv) >= (0.9 if not fp32 else 0.8), conv      # measured: 0.97 (fp64), 0.86 (fp32 factor: 9.2 iterations per tick against the cap of 10; the others continue at the next tick)
+    print("configs[4] B=256: tick ms p50 %.2f p90 %.2f max %.2f, iterations/tick %.1f (cold %.1f), converged/tick %.3f" %
+          (np.median(lat), np.percentile(lat, 90), lat.max(), np.mean(its), cold_it, np.mean(conv)), "status-2 members per tick:", n2)
+    assert np.mean(conv) >= 0.9, conv      # measured: 0.97
     assert np.mean(its) < 0.3 * cold_it
-    # 100 Hz budget: measured round 2 (max_iter 10): fp64 100 % of the ticks inside 10 ms; fp32 factor slower per iteration
-    assert np.median(lat) <= 10.0 and np.percentile(lat, 90) <= (10.0 if not fp32 else 14.0), (np.median(lat), np.percentile(lat, 90))
+    # 100 Hz budget: measured (max_iter 10): 100 % of the ticks inside 10 ms
+    assert np.median(lat) <= 10.0 and np.percentile(lat, 90) <= 10.0 and lat.max() <= 10.0, (np.median(lat), np.percentile(lat, 90), lat.max())
     L.close()

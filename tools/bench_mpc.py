@@ -1,7 +1,7 @@
 """BASELINE configs[4]: receding-horizon landing MPC, warm-started re-solves at the controller rate, batch 256 (one
 workgroup per CU).  Reports the per-tick latency distribution against the 10 ms budget of a 100 Hz loop, iterations per
-tick and the fraction of ticks whose every member reached KKT <= 1e-6.  fp64 by default; --warm factor_fp32=1 runs the stage eliminations on the
-fp32 matrix cores (configs[4]'s variant; measured slower).    python tools/bench_mpc.py [--batch 256] [--ticks 50]"""
+tick and the fraction of ticks whose every member reached KKT <= 1e-6.  fp64 factor (the fp32 variant configs[4] names was retired in round 5:
+measured slower, include/landing_nlp.h).    python tools/bench_mpc.py [--batch 256] [--ticks 50]"""
 import argparse, importlib, json, os, sys, time
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
