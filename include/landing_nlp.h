@@ -268,6 +268,22 @@ typedef struct {
                             factorisation accepted) in the last barrier problem have not halved max(pr, du) (default 3; 0 = never): against a
                             curvature of ~1e-5 the proximal term turns Newton's method into a linear iteration of rate delta / (sigma + delta)
                             -- one member of the bench batch needed 45 full steps from pr 1e-5 to 1e-6.  Any other step resets it.      */
+  int feas_jam;          /* (round 5) the feasibility phase starts EARLY, at most once per solve, when the line search has been jammed:
+                            a leaky count of iterations whose accepted step length is below 1e-2 (+1 per such iteration, -2 per other
+                            iteration) reaches this number while the primal infeasibility is above 1e-3.  Default 8; 0 = the phase starts
+                            only where the solve would end as NUMERICAL / MAX_ITER (rounds 3-4); 0 in landing_solver_opts_warm.  IPOPT
+                            enters its restoration phase when the step length falls below alpha_min; rounds 3-4 let such a member run
+                            into the iteration limit first -- on the reference's production problem (N = 20, non-uniform grid) the
+                            locally infeasible drop states (1.8 % of the data-generation law) took 300 iterations to reach the phase and
+                            the slowest member of every batch 600, against 42 for a converging member.  No member of the bench family
+                            (N = 40, uniform grid) meets the rule (same iterates, 131 072 drop states)                                  */
+  int feas_stat;         /* (round 5) the feasibility phase ends when the 1-norm violation of the inequality rows has stayed within 5 % of a
+                            reference value for this many iterations in a row, mu <= 1e-4 and the equality rows (dynamics, slack
+                            definitions) hold to 1e-3 (default 25; 0 = off): with a violation
+                            above feas_cert the member is reported LANDING_INFEASIBLE (the violation is stationary: what is left of the
+                            elastic problem's optimality error is the polishing of its last barrier problems, which took 200+ iterations
+                            of wandering full steps for such members), otherwise the solve restarts from the point like after an
+                            elastic KKT point.  kkt[0] is the violation in both cases                                                  */
 } landing_solver_opts;
 
 /* status codes written per batch member by landing_solve_batch */
@@ -275,7 +291,9 @@ typedef struct {
 #define LANDING_MAX_ITER 1
 #define LANDING_NUMERICAL 2     /* NaN/Inf or regularisation blow-up; other members unaffected */
 #define LANDING_INFEASIBLE 3    /* the feasibility phase (landing_solver_opts::feas_phase) ended at a KKT point of the elastic problem with positive
-                                   violation: a certificate of LOCAL infeasibility (what IPOPT reports as "converged to a point of local
+                                   violation, or with a violation that has been stationary for feas_stat iterations at mu <= 1e-4 (equality
+                                   rows within 1e-3 there): a
+                                   certificate of LOCAL infeasibility (what IPOPT reports as "converged to a point of local
                                    infeasibility"); x is that point, kkt[0] its largest violation                                            */
 
 void landing_form_default(landing_form* f);

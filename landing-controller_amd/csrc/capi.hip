@@ -91,7 +91,7 @@ void landing_solver_opts_default(landing_solver_opts* o) {
   o->kappa_eps = 0.0 /* auto: 120 for the terminal-cost form, 10 for forms with a running cost (landing_nlp.h) */; o->kappa_mu = 0.2; o->theta_mu = 0.0 /* auto: 1.8 / IPOPT's 1.5 */; o->max_soc = 0; o->max_resets = 8; o->reset_du = 1e9;
   o->delta_init = 1e-4; o->delta_inc_first = 10.0; o->delta_inc = 4.0; o->delta_dec = 0.5; o->tau_min = 0.9; o->alpha_fallback = 1e-2;
   o->stage_local_reg = 0; o->sticky_delta = 0; o->restart_period = 75; o->reset_delta = 1e5; o->dispatch_order = 1;
-  o->clip_k = 4; o->clip_until = 0.03; o->theta_floor = 30.0; o->fresh_restart = 9; o->dual_step_cap = 1.0; o->slack_corr = 0.9; o->watchdog = 3; o->barrier_smax = 1.0; o->factor_fp32 = 0; o->jam_clip = 2; o->stag_relief = 3;
+  o->clip_k = 4; o->clip_until = 0.03; o->theta_floor = 30.0; o->fresh_restart = 9; o->dual_step_cap = 1.0; o->slack_corr = 0.9; o->watchdog = 3; o->barrier_smax = 1.0; o->factor_fp32 = 0; o->jam_clip = 2; o->stag_relief = 3; o->feas_jam = 8; o->feas_stat = 25;
   o->feas_phase = 1; o->feas_rho = 1000.0; o->feas_cert = 1e-4;
   o->delta_floor = 3e-4;
 }
@@ -102,7 +102,7 @@ void landing_solver_opts_warm(landing_solver_opts* o) {
   o->clip_k = 0;                 // a shifted plan starts next to the boundary of many rows: classic rule
   o->fresh_restart = 0;          // the initial guess of a tick IS the previous plan
   o->restart_period = 0;         // the crawl detector is tied to mu_init; a warm start is not expected to crawl
-  o->jam_clip = 0; o->stag_relief = 0;      // cold-start rules
+  o->jam_clip = 0; o->stag_relief = 0; o->feas_jam = 0;      // cold-start rules
   o->feas_phase = 0;             // a tick that hits its iteration cap continues at the next tick; no restoration inside a tick
   o->max_iter = 14;              // real-time iteration cap: a tick never runs longer than ~14 x 0.56 ms at one NLP per CU; a member
                                  // that needs more keeps its improved iterate and continues at the next tick (status 1)

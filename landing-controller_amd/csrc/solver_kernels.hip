@@ -190,6 +190,7 @@ struct IpmState {
   int action, flag, fresh, ls_done, need_corr, fallback;
   // feasibility (restoration) phase, landing_nlp.h: 1 while the elastic problem is being solved; lim = iteration limit in force
   int feas, feas_used, lim, fact_failed;
+  int fjam, fstat; double v1_ref;      // feas_jam / feas_stat (landing_nlp.h): leaky count of iterations with a tiny accepted step; iterations with a stationary violation, its reference value
   double c_rn, f_vmax, f_v1;      // |z + w - rho|_inf of the elastic rows; max-norm and 1-norm violation of the inequality rows at x
 };
 enum { ACT_GO = 0, ACT_STOP = 1, ACT_RESET = 2, ACT_FEAS = 3, ACT_BACK = 4 };
@@ -1198,7 +1199,7 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
     K.last_reset_it = 0; K.ncrawl = 0; K.clip_k_cur = o.clip_k; K.last_mu_it = 0; K.cutstreak = 0; K.wd_count = 0; K.force_step = 0;
     K.e_pr = 0; K.e_du = 0; K.e_co = 0;
     K.jamrun = 0; K.stag = 0; K.full_prev = 0; K.e_prev = 1e300;
-    K.feas = 0; K.feas_used = 0; K.fact_failed = 0; K.lim = o.max_iter; K.c_rn = 0.0; K.f_vmax = 0.0; K.f_v1 = 0.0;
+    K.feas = 0; K.feas_used = 0; K.fact_failed = 0; K.lim = o.max_iter; K.fjam = 0; K.fstat = 0; K.v1_ref = 0.0; K.c_rn = 0.0; K.f_vmax = 0.0; K.f_v1 = 0.0;
   }
   __syncthreads();
   // the lane = stage phases are called by the lanes that have work only: the callee-saved registers an out-of-line function touches
@@ -1242,7 +1243,12 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
           else if (K.f_vmax <= 1e-9 && pr <= o.tol) act = ACT_BACK;
           else if (conv && K.f_v1 > o.feas_cert) { K.status = LANDING_INFEASIBLE; act = ACT_STOP; }
           else if (conv) act = ACT_BACK;
-          else if (it >= K.lim) act = ACT_STOP;
+          else if (o.feas_stat > 0) {      // stationary violation (landing_nlp.h)
+            const double v1 = K.f_v1;
+            if (K.fstat < 0 || !(fabs(v1 - K.v1_ref) <= 0.05 * K.v1_ref)) { K.v1_ref = v1; K.fstat = 0; } else K.fstat++;
+            if (K.fstat >= o.feas_stat && mu <= 1e-4 && pr <= 1e-3) { if (v1 > o.feas_cert) { K.status = LANDING_INFEASIBLE; act = ACT_STOP; } else act = ACT_BACK; }
+          }
+          if (act == ACT_GO && it >= K.lim) act = ACT_STOP;
           if (act == ACT_BACK) {
             K.feas = 0; K.lim = it + (o.max_iter > 1 ? o.max_iter : 1); K.status = LANDING_MAX_ITER;
             K.mu = o.mu_init; K.nfilt = 0; K.delta_last = 0.0; K.need_reg_streak = 0; K.wd_count = 0; K.th_max = 0.0; K.nreset = 0; K.last_reset_it = it; K.ncrawl = 0;
@@ -1255,6 +1261,7 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
         else if (fmax(du, fmax(pr, co)) <= o.tol) { K.status = LANDING_CONVERGED; act = ACT_STOP; }
         else if (it >= K.lim) give_up = true;      // (>=: K.it runs ahead of a limit set from a max_iter < 1)
         else if (du > o.reset_du && nreset >= o.max_resets && o.max_resets > 0) { K.status = LANDING_NUMERICAL; give_up = true; }   // jammed again: give up
+        else if (o.feas_jam > 0 && K.fjam >= o.feas_jam && pr > 1e-3 && !K.feas_used && o.feas_phase) give_up = true;      // jammed line search: the feasibility phase starts now (landing_nlp.h)
         else {
           // crawling: still in the first barrier problem (mu never decreased) restart_period iterations after the last (re)start
           const bool stalled = o.restart_period > 0 && it - K.last_reset_it >= o.restart_period && mu >= o.mu_init && nreset < o.max_resets && K.ncrawl < ((o.fresh_restart & 4) ? 2 : 1);
@@ -1282,7 +1289,7 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
           // the solve would end here as NUMERICAL / MAX_ITER: enter the feasibility phase once (landing_solver_opts::feas_phase)
           if (o.feas_phase && !K.feas_used && o.max_iter > 0) {      // (max_iter < 1: the caller asked for no iteration at all, the phase would get none either)
             act = ACT_FEAS;
-            K.feas = 1; K.feas_used = 1; K.status = LANDING_MAX_ITER; K.lim = it + o.max_iter;
+            K.feas = 1; K.feas_used = 1; K.status = LANDING_MAX_ITER; K.lim = it + o.max_iter; K.fstat = -1;
             K.mu = o.mu_init; K.nfilt = 0; K.th_max = 0.0; K.delta_last = 0.0; K.need_reg_streak = 0; K.cutstreak = 0; K.force_step = 0; K.wd_count = 0;
             K.it = it + 1;
           } else act = ACT_STOP;
@@ -1633,6 +1640,7 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
       }
       if (o.dual_step_cap > 0.0) K.a_du = fmin(K.a_du, o.dual_step_cap * K.alpha);      // the multipliers do not run ahead of a blocked primal step (landing_nlp.h)
       if (o.jam_clip > 0) K.jamrun = (!K.clip_now && K.a_pr < 0.02) ? K.jamrun + 1 : 0;
+      if (o.feas_jam > 0) K.fjam = (!K.feas && K.alpha < 1e-2) ? K.fjam + 1 : (K.fjam > 2 ? K.fjam - 2 : 0);
       K.full_prev = (K.accepted && K.alpha == 1.0 && K.a_du == 1.0 && K.attempt <= 1) ? 1 : 0;
     KS_END();
     if (K.fallback) {

@@ -45,6 +45,7 @@ typedef struct {
   double feas_cert;      /* l1 violation above which the elastic KKT point counts as a certificate                                           */
   double delta_floor;    /* first regularisation tried in an iteration of the terminal-cost form (include/landing_nlp.h)                     */
   int jam_clip, stag_relief;      /* include/landing_nlp.h */
+  int feas_jam, feas_stat;        /* include/landing_nlp.h (round 5) */
 } lo_solver_opts;
 
 void lo_solver_opts_default(lo_solver_opts* o) {
@@ -53,7 +54,7 @@ void lo_solver_opts_default(lo_solver_opts* o) {
   o->delta_init = 1e-4; o->delta_inc_first = 10.0; o->delta_inc = 4.0; o->delta_dec = 0.5; o->tau_min = 0.9; o->alpha_fallback = 1e-2; o->restart_period = 75; o->reset_delta = 1e5;
   o->barrier_smax = 1.0; o->watchdog = 3; o->slack_corr = 0.9; o->dual_step_cap = 1.0; o->fresh_restart = 9; o->theta_floor = 30.0; o->clip_k = 4; o->clip_until = 0.03;
   o->feas_phase = 1; o->feas_rho = 1000.0; o->feas_cert = 1e-4;
-  o->delta_floor = 3e-4; o->jam_clip = 2; o->stag_relief = 3;
+  o->delta_floor = 3e-4; o->jam_clip = 2; o->stag_relief = 3; o->feas_jam = 8; o->feas_stat = 25;
 }
 
 #define NW 48
@@ -225,6 +226,7 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
   init_slacks(W, op);
   int stag = 0, full_prev = 0; double e_prev = 1e300; const int stag_k = op->stag_relief;      /* jam_clip / stag_relief: include/landing_nlp.h */
   int jamrun = 0; const int jam_k = op->jam_clip; const double jam_a = 0.02;
+  int fjam = 0, fstat = 0; double v1_ref = 0.0;      /* feas_jam / feas_stat: include/landing_nlp.h */
   for (it = 0; it <= lim; ++it) {
     double du = 0, pr = 0, co = 0, tau, delta;
     int fact_ok = 0, attempt, clip_now; double use_reset = 0.0;
@@ -288,6 +290,10 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
       if (!(du < 1e300) || !(pr < 1e300) || !(co < 1e300)) { status = 2; break; }
       if (vmax <= 1e-9 && pr <= op->tol) back = 1;                       /* a feasible point: back to the interior-point solve from here */
       else if (fmax(du, fmax(pr, co)) <= op->tol) { if (v1 > op->feas_cert) { status = 3; break; } back = 1; }
+      else if (op->feas_stat > 0) {      /* stationary violation (include/landing_nlp.h) */
+        if (fstat < 0 || !(fabs(v1 - v1_ref) <= 0.05 * v1_ref)) { v1_ref = v1; fstat = 0; } else fstat++;
+        if (fstat >= op->feas_stat && mu <= 1e-4 && pr <= 1e-3) { if (v1 > op->feas_cert) { status = 3; break; } back = 1; }
+      }
       if (back) {
         feas = 0; W->feas = 0; lim = it + (op->max_iter > 1 ? op->max_iter : 1);
         init_slacks(W, op); mu = op->mu_init; nfilt = 0; delta_last = 0.0; streak = 0; wd_count = 0; th_max = 0.0; nreset = 0; last_reset_it = it; ncrawl = 0; cutstreak = 0; force_step = 0;
@@ -304,9 +310,11 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
       else if (fmax(du, fmax(pr, co)) <= op->tol) { status = 0; break; }
       else if (it >= lim) give_up = 1;
       else if (du > op->reset_du && nreset >= op->max_resets && op->max_resets > 0) { status = 2; give_up = 1; }
+      else if (op->feas_jam > 0 && fjam >= op->feas_jam && pr > 1e-3 && !feas_used && op->feas_phase) { give_up = 1; if (getenv("LO_TRACE")) fprintf(stderr, "   jammed line search -> feasibility phase at it %d\n", it); }
       if (give_up) {
         if (!op->feas_phase || feas_used || op->max_iter < 1) break;
         /* feasibility phase: from the current point (from the caller's initial guess when the iterate is not finite) */
+        fstat = -1;
         feas = 1; W->feas = 1; feas_used = 1; status = 1; nfilt = 0; th_max = 0.0; delta_last = 0.0; streak = 0; lim = it + op->max_iter; cutstreak = 0; force_step = 0; wd_count = 0;
         { int bad = 0; for (i = 0; i < nx; ++i) if (!(fabs(W->x[i]) < 1e6)) bad = 1;
           if (bad) { memcpy(W->x, x0, sizeof(double) * nx); for (i = 0; i < 6; ++i) { W->x[i] = p[o.q_init + i]; W->x[6 + i] = p[o.qd_init + i]; } }
@@ -585,6 +593,7 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
     if (getenv("LO_TRACE")) fprintf(stderr, "      alpha %9.2e a_pr %9.2e a_du %9.2e delta %8.1e acc %d armijo %d th0 %9.2e dphi %9.2e clip %d\n", alpha, a_pr, a_du, delta, accepted, armijo, th0, dphi, clip_now);
     if (op->dual_step_cap > 0.0) a_du = fmin(a_du, op->dual_step_cap * alpha);      /* the multipliers do not run ahead of a blocked primal step */
     if (jam_k > 0) { if (!clip_now && a_pr < jam_a) jamrun++; else jamrun = 0; }
+    if (op->feas_jam > 0) { if (!feas && alpha < 1e-2) fjam++; else fjam = fjam > 2 ? fjam - 2 : 0; }
     full_prev = accepted && alpha == 1.0 && a_du == 1.0 && attempt <= 1;
     memcpy(W->x, W->xt, sizeof(double) * nx);
     for (r = 0; r < ng; ++r) {

@@ -209,6 +209,41 @@ def test_feasibility_phase_rescues_or_certifies(oracle_mod):
     L.close()
 
 
+def test_feas_jam_and_stat_cut_the_production_tail(emu_lib, oracle_mod):
+    """landing_solver_opts::feas_jam / feas_stat (round 5) on the reference's production problem (N = 20, non-uniform grid, data-generation
+    law): the feasibility phase starts when the line search jams instead of at the iteration limit, and ends when the violation is
+    stationary.  CPU port on 256 drop states: the slowest member needs far fewer iterations, nobody who converged without the phase changes
+    a bit, the members left undecided do not become more; and the emulated kernel follows the port through both rules on a member that
+    ends with a certificate of local infeasibility after 130 instead of ~500 iterations."""
+    N = 20
+    Pm = lc("problem")
+    O = oracle_mod.Oracle(N)
+    P, X0, _, _ = Pm.make_batch(1024, N, 0.6, seed=100000, consts=Pm.production_constants("datagen"), dt_grid="reference", law="datagen")
+    P, X0 = P[:256], X0[:256]
+    new = oracle_mod.cpu_solve_batch(O, P, X0, threads=8, max_iter=300)
+    old = oracle_mod.cpu_solve_batch(O, P, X0, threads=8, max_iter=300, feas_jam=0, feas_stat=0)
+    print("iterations max %d -> %d, mean %.1f -> %.1f; converged %d -> %d, certified %d -> %d, undecided %d -> %d" % (
+        old["iters"].max(), new["iters"].max(), old["iters"].mean(), new["iters"].mean(), (old["status"] == 0).sum(), (new["status"] == 0).sum(),
+        (old["status"] == 3).sum(), (new["status"] == 3).sum(), np.isin(old["status"], (1, 2)).sum(), np.isin(new["status"], (1, 2)).sum()))
+    assert new["iters"].max() <= 0.8 * old["iters"].max() and new["iters"].sum() < old["iters"].sum()
+    assert np.isin(new["status"], (1, 2)).sum() <= np.isin(old["status"], (1, 2)).sum()
+    assert (new["status"] == 0).sum() >= (old["status"] == 0).sum() - 3
+    quick = (old["status"] == 0) & (old["iters"] < 100) & (new["iters"] == old["iters"])      # never near either rule
+    assert quick.sum() >= 230 and np.array_equal(new["x"][quick], old["x"][quick])
+    for b in np.nonzero(new["status"] == 3)[0]:
+        g = O.g(new["x"][b], P[b]); lb, ub = O.bounds(P[b]); eq = lb == ub
+        viol = np.maximum(np.maximum(lb - g, g - ub), 0.0)
+        assert np.abs(g[eq] - lb[eq]).max() <= 1e-3 * 1.0001 and abs(viol.max() - new["kkt"][b, 0]) <= 1e-9 and viol.sum() > 1e-4
+    m = int(np.nonzero((new["status"] == 3) & (new["iters"] < 200) & (old["iters"] > 300))[0][0])      # certified early by the new rules
+    L = lc("capi").LandingLib(N, lib_path=emu_lib)
+    o = L.default_opts(); o.max_iter = 300
+    assert (o.feas_jam, o.feas_stat) == (8, 25)
+    g = L.solve_host(P[m:m + 1], X0[m:m + 1], o)
+    assert g["status"][0] == 3 and g["iters"][0] == new["iters"][m]
+    assert np.abs(g["x"][0] - new["x"][m]).max() <= 1e-5 and abs(g["kkt"][0, 0] - new["kkt"][m, 0]) <= 1e-7
+    L.close()
+
+
 def test_stag_relief_shortens_the_known_slow_member(oracle_mod):
     """landing_solver_opts::stag_relief (round 4): member 304 of the bench batch (seed 20211) reaches pr ~ 1e-5 after 36 iterations and then takes 45 FULL
     Newton steps to 1e-6 -- the proximal term delta_floor against a curvature of ~1e-5.  With the rule (default 3) the floor shrinks once three such steps have
