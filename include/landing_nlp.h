@@ -503,7 +503,11 @@ int landing_kinodyn_nlp_hess(landing_ctx* ctx, int B, int N, const double* d_x, 
  * landing_solve_batch on this NLP's stage structure (state (X_k, c_k), controls (f_k, jpos_k, c_k+1): the joint angles are stage-local and are
  * eliminated inside the stage), exact first and second derivatives from landing_kinodyn_nlp_eval / _hess, B members per call.
  *   landing_kinodyn_form     the literals of the script's constraint set (:139-189)
- *   landing_kinodyn_bounds   lbg / ubg [ng x B] from the script's arguments (host arrays, trailing batch axis; Opti's canonicalisation)
+ *   landing_kinodyn_bounds   lbg / ubg [ng x B] from the script's arguments (host arrays, trailing batch axis; Opti's canonicalisation, with ONE
+ *                            caveat: the 8 friction rows of an interval, `f_xy >= -0.71 mu f_z` (:176,178), are emitted as g = f_xy + km f_z in [0, inf);
+ *                            neither side of that inequality is parametric, so a CasADi-built Opti may hold them as -km f_z - f_xy in (-inf, 0] --
+ *                            not checkable here (libcasadi is an absent blob): g, the jac_g rows and lam_g of those rows would then differ in SIGN from
+ *                            a CasADi-built nlpsol; the feasible set and the solver are unaffected)
  *   landing_kinodyn_solve_batch   device pointers: d_lbg, d_ubg [B][ng]; d_cost [B][24] = QN (12) | Xref(:, end) (12) (terminal cost :83-86);
  *                            d_x0 [B][nx]; dt, mass, Ib, Ib_inv, mu shared by the batch (prm).  Outputs as landing_solve_batch: d_x [B][nx],
  *                            d_f [B], d_lam_g [B][ng] (CasADi sign), d_status [B] (LANDING_*), d_iters [B], d_kkt [B][3] (pr, du, compl unscaled)
@@ -520,7 +524,9 @@ typedef struct {
   double kin_box_z_lo, kin_box_z_hi;  /* :153-154  -0.4, -0.075 */
   double tau_max[3];              /* model.tauMax = gr .* motorTauMax (get_robot_model.m:236-240): 18, 18, 27.99 */
 } landing_kinodyn_form;
-void landing_kinodyn_form_default(landing_kinodyn_form* f);
+void landing_kinodyn_form_default(landing_kinodyn_form* f);       /* the literals of main_scripts/landing_optimization.m (kin_box_y = 0.10 + kin_box(2), :150) */
+void landing_kinodyn_form_knitro(landing_kinodyn_form* f);        /* ... of generate_solver/generate_landingCtrller_KNITRO.m (kin_box_y = 0.125 + kin_box(2), :154): what
+                                                                      landing_solve_kinodyn_24[_on] use when no form is passed -- they stand for the function that script builds */
 void landing_kinodyn_solver_opts_default(landing_solver_opts* o);
 int landing_kinodyn_bounds(int N, int B, const landing_kinodyn_form* form, const double* q_init, const double* qd_init, const double* c_init,
                            const double* q_min, const double* q_term_min, const double* q_term_max, const double* qd_term_min, const double* qd_term_max,
@@ -535,7 +541,7 @@ int landing_kinodyn_solve_batch_host(landing_ctx* ctx, int B, int N, const landi
                                      const double* cost, const double* x0, const landing_solver_opts* opts,
                                      double* x, double* f, double* lam_g, int* status, int* iters, double* kkt);
 
-int landing_solve_kinodyn_24(landing_ctx* ctx, int N, int B, const landing_kinodyn_form* form /* NULL = the script's literals */,
+int landing_solve_kinodyn_24(landing_ctx* ctx, int N, int B, const landing_kinodyn_form* form /* NULL = landing_kinodyn_form_knitro */,
                              const double* Xref, const double* Uref, const double* dt, const double* q_min, const double* q_max, const double* qd_min,
                              const double* qd_max, const double* q_init, const double* qd_init, const double* c_init, const double* q_term_min,
                              const double* q_term_max, const double* qd_term_min, const double* qd_term_max, const double* QN, const double* x0,
@@ -551,6 +557,13 @@ int landing_solve_kinodyn_24_on(int device, int N, int B, const double* Xref, co
                                 const double* x0, const double* jpos_min, const double* jpos_max, const double* kin_box, const double* mu, const double* l_leg_max,
                                 const double* mass, const double* Ib, const double* Ib_inv, const landing_solver_opts* opts,
                                 double* x_star, double* f_star, double* lam_g, int* status, int* iters, double* kkt);
+/* ... with a constraint-set form (NULL = landing_kinodyn_form_knitro): the same call, `form` in front of the 24 arguments */
+int landing_solve_kinodyn_24_on_form(int device, int N, int B, const landing_kinodyn_form* form, const double* Xref, const double* Uref, const double* dt,
+                                     const double* q_min, const double* q_max, const double* qd_min, const double* qd_max, const double* q_init, const double* qd_init,
+                                     const double* c_init, const double* q_term_min, const double* q_term_max, const double* qd_term_min, const double* qd_term_max,
+                                     const double* QN, const double* x0, const double* jpos_min, const double* jpos_max, const double* kin_box, const double* mu,
+                                     const double* l_leg_max, const double* mass, const double* Ib, const double* Ib_inv, const landing_solver_opts* opts,
+                                     double* x_star, double* f_star, double* lam_g, int* status, int* iters, double* kkt);
 /* CCS patterns of this NLP in CasADi's compressed form, which = 0: jac_g_x (ng x nx), 1: upper triangle of hess_gamma_x_x; colind [nx + 1],
  * row [*nnz] (pass row = NULL to get the count first).  Derived from the derivative kernels themselves (device needed). */
 int landing_kinodyn_pattern(landing_ctx* ctx, int N, int which, long long* colind, long long* row, long long* nnz);

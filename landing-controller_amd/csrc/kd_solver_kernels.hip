@@ -191,6 +191,83 @@ KD_PHASE void kd_condense_stage(const KdMem& M, int N, int k, double delta) {
   __syncthreads();
 }
 
+// One step of the blocked Gauss-Jordan elimination of the stage array (64 x 64 in accumulator tiles: T[rt][r] = element (row 16 rt + lk + 4 r,
+// column 16 ct + lj), wave ct owns column tile ct) with the 4 x 4 pivot block at rows / columns [OFF, OFF + 4).  Exchange through LDS (buffer
+// STEP & 1 in KSH.Jc, free during the elimination): every lane publishes the 4 pivot-row entries of its column, W[c][4]; the lanes that hold
+// the pivot columns publish them, C[row][4]; one barrier; then every lane factors the pivot block D = L diag(d) L^T redundantly, solves
+// D r = w for its own column and the wave applies T -= C R with one matrix-core instruction per row tile; the pivot rows become R itself.
+// The scalar pivots d are those of the unblocked elimination (inertia test unchanged).  Same scheme as pivot_block_step of solver_kernels.hip;
+// here the state columns 0..23 are never pivots, so only the tile of columns 32..47 may be skipped once it is eliminated.
+template <int OFF, int STEP>
+__device__ __forceinline__ bool kd_pivot_block_step(f64x4 (&T)[4], int ct, int lj, int lk, int c) {
+  static_assert((OFF & 3) == 0 && OFF >= KD_NSIG && OFF + 4 <= KD_NV, "pivot blocks of the controls");
+  KdLds& S = KSH;
+  constexpr int RTB = OFF >> 4, R0 = (OFF & 15) >> 2;
+  static_assert(2 * (64 * 4 + 64 * 4) <= KD_JC_ROWS * KD_JC_S, "exchange buffers fit the chunk buffer");
+  double* W = S.Jc + (STEP & 1) * 512;
+  double* C = W + 256;
+  W[c * 4 + lk] = T[RTB][R0];
+  if (ct == RTB && lj >= (OFF & 15) && lj < (OFF & 15) + 4) {
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) C[(16 * rt + lk + 4 * r) * 4 + (lj - (OFF & 15))] = T[rt][r];
+  }
+  __syncthreads();
+  double a[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j <= i; ++j) a[i][j] = C[(OFF + i) * 4 + j];
+  double w[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) w[i] = W[c * 4 + i];
+  double am[4];
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt) { const int row = 16 * rt + lj; const double cv = C[row * 4 + lk]; am[rt] = (row >= OFF && row < OFF + 4) ? 0.0 : cv; }   // pivot rows: no update
+  auto recip = [](double d) { double i = __builtin_amdgcn_rcp(d); i = fma(i, fma(-d, i, 1.0), i); return fma(i, fma(-d, i, 1.0), i); };
+  double l[4][4], t[4][4], inv[4];
+  unsigned hm = 0u;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+#pragma unroll
+    for (int i = j; i < 4; ++i) {
+      double acc = a[i][j];
+#pragma unroll
+      for (int kk = 0; kk < j; ++kk) acc = fma(-l[i][kk], t[j][kk], acc);
+      t[i][j] = acc;
+    }
+    inv[j] = recip(t[j][j]);
+#pragma unroll
+    for (int i = j + 1; i < 4; ++i) l[i][j] = t[i][j] * inv[j];
+    const unsigned h = (unsigned)__double2hiint(t[j][j]) - 0x00100000u;      // pivot in (2^-1022, ~1e300): one unsigned range test on the high word
+    hm = h > hm ? h : hm;
+  }
+  const bool ok = hm < (0x7e37e43cu - 0x00100000u);
+  double y[4], r[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    double acc = w[i];
+#pragma unroll
+    for (int kk = 0; kk < i; ++kk) acc = fma(-l[i][kk], y[kk], acc);
+    y[i] = acc;
+  }
+#pragma unroll
+  for (int i = 3; i >= 0; --i) {
+    double acc = y[i] * inv[i];
+#pragma unroll
+    for (int kk = i + 1; kk < 4; ++kk) acc = fma(-l[kk][i], r[kk], acc);
+    r[i] = acc;
+  }
+  const double R = lk == 0 ? r[0] : (lk == 1 ? r[1] : (lk == 2 ? r[2] : r[3]));
+  if (!(ct == 2 && OFF >= 48)) {      // (the tile of columns 32..47 holds eliminated controls only from then on)
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) T[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(am[rt], -R, T[rt], 0, 0, 0);
+    T[RTB][R0] = R;      // the pivot rows become the normalised rows, exactly
+  }
+  return ok;
+}
+
 // ---- one backward step: adds T' P+ T, T'(P+ t0 + p+) of the next stage's cost-to-go, eliminates the controls (Gauss-Jordan, scalar pivots),
 // leaves gains / cost-to-go in the record and in KSH.Pm, KSH.pv.  ns_next = 24 (12 for the last interval: sigma_N = X_N).  false = a pivot
 // was not positive (wrong inertia).
@@ -223,43 +300,34 @@ KD_PHASE bool kd_riccati_stage(const KdMem& M, int N, int k) {
     if (tid < 12) S.Ms[(48 + tid) * KD_MS + 60] += S.Y[(12 + tid) * KD_AS + 36];
   }
   __syncthreads();
-  // Gauss-Jordan on the control rows / columns 24 .. nv-1 of [M | m], the array held in REGISTERS: thread t owns column t & 63 (61 in use) of
-  // the rows (t >> 6) + 4 q, q = 0..14.  One pivot step = the owners of the pivot row and of the pivot column publish them (double-buffered
-  // LDS slots), ONE barrier, 15 fused multiply-adds per thread.  (First version: the array in LDS, every step a read-modify-write pass over
-  // 3720 words with two barriers -- 105 us per stage, 2.1 ms per factorisation, measured on the MI355X.)
+  // Gauss-Jordan on the control rows / columns 24 .. nv-1 of [M | m] on the fp64 matrix cores (round 5): the 64 x 64 array lives in
+  // v_mfma_f64_16x16x4 accumulator tiles (wave w owns column tile w, four row tiles), pivot blocks of 4 x 4 -- kd_pivot_block_step, the
+  // scheme of the SRBM solver's block_eliminate (solver_kernels.hip): 9 exchange + barrier rounds per stage instead of 36.  (Round 4: scalar
+  // pivots with the array in registers, one barrier per pivot: 1.1 ms per factorisation.)
   bool ok = true;
   {
-    const int c = tid & 63, rg = tid >> 6;
-    double m[15];
+    const int ct = tid >> 6, l = tid & 63, lj = l & 15, lk = l >> 4, c = 16 * ct + lj;
+    f64x4 T[4];
 #pragma unroll
-    for (int q = 0; q < 15; ++q) m[q] = c < KD_MS ? S.Ms[(rg + 4 * q) * KD_MS + c] : 0.0;
-    double* prow = S.Jc;                     // 2 x 64   (the chunk buffer of the condensation is free here)
-    double* pcol = S.Jc + 128;               // 2 x 64
+    for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
-    for (int p = KD_NSIG; p < KD_NV; ++p) {
-      if (p < nv) {                          // (uniform)
-        const int buf = p & 1, pq = p >> 2, prg = p & 3;
-        if (rg == prg) prow[buf * 64 + c] = m[pq];
-        if (c == p) {
-#pragma unroll
-          for (int q = 0; q < 15; ++q) pcol[buf * 64 + rg + 4 * q] = m[q];
-        }
-        __syncthreads();
-        const double d = prow[buf * 64 + p];
-        if (!(d > 0.0) || !(d < 1e300)) ok = false;      // uniform; the remaining steps run on (their results are discarded)
-        const double pr = prow[buf * 64 + c] * (1.0 / d);
-#pragma unroll
-        for (int q = 0; q < 15; ++q) {
-          const int r = rg + 4 * q;
-          m[q] = (r == p) ? pr : m[q] - pcol[buf * 64 + r] * pr;
-        }
-      }
+      for (int r = 0; r < 4; ++r) { const int row = 16 * rt + lk + 4 * r; T[rt][r] = (row < KD_NV && c < KD_MS) ? S.Ms[row * KD_MS + c] : 0.0; }
+    ok &= kd_pivot_block_step<24, 0>(T, ct, lj, lk, c);
+    ok &= kd_pivot_block_step<28, 1>(T, ct, lj, lk, c);
+    ok &= kd_pivot_block_step<32, 2>(T, ct, lj, lk, c);
+    ok &= kd_pivot_block_step<36, 3>(T, ct, lj, lk, c);
+    ok &= kd_pivot_block_step<40, 4>(T, ct, lj, lk, c);
+    ok &= kd_pivot_block_step<44, 5>(T, ct, lj, lk, c);
+    if (!last) {      // (uniform)
+      ok &= kd_pivot_block_step<48, 6>(T, ct, lj, lk, c);
+      ok &= kd_pivot_block_step<52, 7>(T, ct, lj, lk, c);
+      ok &= kd_pivot_block_step<56, 8>(T, ct, lj, lk, c);
     }
     __syncthreads();
-    if (c < KD_MS) {
 #pragma unroll
-      for (int q = 0; q < 15; ++q) S.Ms[(rg + 4 * q) * KD_MS + c] = m[q];
-    }
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { const int row = 16 * rt + lk + 4 * r; if (row < KD_NV && c < KD_MS) S.Ms[row * KD_MS + c] = T[rt][r]; }
     __syncthreads();
   }
   if (!ok) { __syncthreads(); return false; }
@@ -617,7 +685,7 @@ __global__ void __launch_bounds__(KD_THREADS, 2) landing_kd_iter_kernel(KdSolveA
       const double dl = K.delta_last;
       K.delta = (K.need_reg_streak >= 2 && dl > 0.0) ? fmax(1e-20, dl * o.delta_dec) : 0.0;
       { double fl = o.delta_floor;                   // proximal term (the cost is terminal only: landing_nlp.h delta_floor)
-        if (o.stag_relief > 0 && K.stag >= o.stag_relief) { for (int e = K.stag - o.stag_relief; e >= 0; --e) fl *= 0.1; if (fl < 1e-12) fl = 0.0; }
+        if (o.stag_relief > 0 && K.stag >= o.stag_relief) { for (int e = K.stag - o.stag_relief; e >= 0 && fl >= 1e-12; --e) fl *= 0.1; if (fl < 1e-12) fl = 0.0; }
         K.delta = fmax(K.delta, fl); }
       K.skipped_zero = K.delta > 0.0; K.fact_ok = 0; K.attempt = 0; K.flag = 1; K.nfact++;
     KD_END();

@@ -1391,7 +1391,7 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
       if (!L.run_cost && !K.feas) {      // proximal term of the terminal-cost form (landing_nlp.h)
         double fl = o.delta_floor;
         if (o.stag_relief > 0 && K.stag >= o.stag_relief) {      // ... a tenth of it per stagnating iteration
-          for (int e = K.stag - o.stag_relief; e >= 0; --e) fl *= 0.1;
+          for (int e = K.stag - o.stag_relief; e >= 0 && fl >= 1e-12; --e) fl *= 0.1;
           if (fl < 1e-12) fl = 0.0;
         }
         K.delta = fmax(K.delta, fl);

@@ -26,7 +26,7 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
   const double* a[24]; double* tmp[24]; size_t per[24]; int i, b, N, B, device;
   long long nx, ng;
   char msg[256];
-  landing_solver_opts o;
+  landing_solver_opts o; landing_kinodyn_form form; int own_opts = 0;
   const mxArray* os = nrhs == 25 ? prhs[24] : NULL;
   if (nrhs != 24 && nrhs != 25) mexErrMsgTxt("landing_refine_mex: 24 inputs (generate_landingCtrller_KNITRO.m:373-377) and an optional options struct");
   if (nlhs > 6) mexErrMsgTxt("landing_refine_mex: at most 6 outputs [X, F, STATUS, ITERS, KKT, LAM_G]");
@@ -65,6 +65,15 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
   OPT_D(reset_delta); OPT_I(clip_k); OPT_D(clip_until); OPT_D(theta_floor); OPT_I(fresh_restart); OPT_D(dual_step_cap); OPT_D(slack_corr); OPT_I(watchdog);
   OPT_D(barrier_smax); OPT_D(delta_floor); OPT_I(jam_clip); OPT_I(stag_relief);
   device = (int)opt_scalar(os, "device", 0.0);
+  {      /* the library's defaults (incl. its retry ladder for the members the first pass leaves undecided) unless the caller set a solver option */
+    static const char* solver_fields[] = {"tol", "max_iter", "mu_init", "bound_push", "bound_frac", "kappa_eps", "kappa_mu", "theta_mu", "max_resets", "reset_du",
+      "restart_period", "delta_init", "delta_inc_first", "delta_inc", "delta_dec", "tau_min", "alpha_fallback", "reset_delta", "clip_k", "clip_until", "theta_floor",
+      "fresh_restart", "dual_step_cap", "slack_corr", "watchdog", "barrier_smax", "delta_floor", "jam_clip", "stag_relief"};
+    size_t q;
+    for (q = 0; q < sizeof(solver_fields) / sizeof(solver_fields[0]); ++q) if (os && mxGetField(os, 0, solver_fields[q])) own_opts = 1;
+  }
+  landing_kinodyn_form_knitro(&form);      /* literals of generate_landingCtrller_KNITRO.m; options.kin_box_y0 (0.10: landing_optimization.m) / kin_box_x0 override them */
+  form.kin_box_y0 = opt_scalar(os, "kin_box_y0", form.kin_box_y0); form.kin_box_x0 = opt_scalar(os, "kin_box_x0", form.kin_box_x0);
   {
     mxArray* f = nlhs > 1 ? mxCreateDoubleMatrix(1, B, mxREAL) : NULL;
     mxArray* st = nlhs > 2 ? mxCreateNumericMatrix(1, B, mxINT32_CLASS, mxREAL) : NULL;
@@ -73,8 +82,8 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     mxArray* lg = nlhs > 5 ? mxCreateDoubleMatrix((mwSize)ng, B, mxREAL) : NULL;
     int rc;
     plhs[0] = mxCreateDoubleMatrix((mwSize)nx, B, mxREAL);
-    rc = landing_solve_kinodyn_24_on(device, N, B, a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[8], a[9], a[10], a[11], a[12], a[13], a[14], a[15], a[16], a[17],
-                                     a[18], a[19], a[20], a[21], a[22], a[23], &o, mxGetPr(plhs[0]), f ? mxGetPr(f) : NULL, lg ? mxGetPr(lg) : NULL,
+    rc = landing_solve_kinodyn_24_on_form(device, N, B, &form, a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[8], a[9], a[10], a[11], a[12], a[13], a[14], a[15], a[16], a[17],
+                                     a[18], a[19], a[20], a[21], a[22], a[23], own_opts ? &o : NULL, mxGetPr(plhs[0]), f ? mxGetPr(f) : NULL, lg ? mxGetPr(lg) : NULL,
                                      st ? (int*)mxGetData(st) : NULL, it ? (int*)mxGetData(it) : NULL, kk ? mxGetPr(kk) : NULL);
     for (i = 0; i < 24; ++i) if (tmp[i]) mxFree(tmp[i]);
     if (rc) mexErrMsgTxt(landing_last_error());
