@@ -62,11 +62,12 @@ struct KdMem {
   double *x, *xt, *dx, *gx;
   double *g, *gt, *s, *ds, *zL, *zU, *y, *yn, *sig, *rho;
   double *J, *H, *rec, *wbuf;      // wbuf [N][72]: gathered stage variables of the in-kernel row evaluation
+  double* jty;                     // [N][72]: J_k' y_k per interval and block column, written by the Jacobian kernel (rbd_kernels.hip, KdNlpArgs::jty)
   KdState* st;
 };
 __host__ __device__ inline size_t kd_ws_stride(int N) {
   const size_t nx = (size_t)kd_nx(N), ng = (size_t)kd_ng(N);
-  return 4 * nx + 10 * ng + (size_t)N * KD_ROWS * KD_NW + (size_t)N * KD_NW * KD_NW + (size_t)(N + 1) * KD_REC + (size_t)N * KD_NW + (sizeof(KdState) + 7) / 8 + 8;
+  return 4 * nx + 10 * ng + (size_t)N * KD_ROWS * KD_NW + (size_t)N * KD_NW * KD_NW + (size_t)(N + 1) * KD_REC + 2 * (size_t)N * KD_NW + (sizeof(KdState) + 7) / 8 + 8;
 }
 __device__ __forceinline__ KdMem kd_carve(int N, double* w) {
   const size_t nx = (size_t)kd_nx(N), ng = (size_t)kd_ng(N);
@@ -76,6 +77,7 @@ __device__ __forceinline__ KdMem kd_carve(int N, double* w) {
   M.y = w; w += ng; M.yn = w; w += ng; M.sig = w; w += ng; M.rho = w; w += ng;
   M.J = w; w += (size_t)N * KD_ROWS * KD_NW; M.H = w; w += (size_t)N * KD_NW * KD_NW; M.rec = w; w += (size_t)(N + 1) * KD_REC;
   M.wbuf = w; w += (size_t)N * KD_NW;
+  M.jty = w; w += (size_t)N * KD_NW;
   M.st = reinterpret_cast<KdState*>(w);
   return M;
 }
@@ -445,7 +447,8 @@ KD_PHASE void kd_forward(const KdMem& M, int N, const double* lbm) {
   __syncthreads();
 }
 
-// gx = grad f + J' y over the free rows (rows 24 .. ng-1): one thread per variable, the (at most two) block columns that hold it
+// gx = grad f + J' y over the free rows (rows 24 .. ng-1): one thread per variable, the (at most two) block columns that hold it.  The column
+// products J_k' y_k are a by-product of the Jacobian kernel (M.jty; round 4 re-read every J block here: 1.5 MB and 0.49 ms per member-iteration)
 KD_PHASE void kd_grad_lag(const KdMem& M, int N, const double* cost) {
   const int tid = threadIdx.x, NT = blockDim.x, nx = kd_nx(N);
   const int oJ = 12 * (N + 1), oU = oJ + 12 * N;
@@ -455,16 +458,8 @@ KD_PHASE void kd_grad_lag(const KdMem& M, int N, const double* cost) {
     else if (i < oU) { k = (i - oJ) / 12; j0 = 36 + (i - oJ) % 12; }
     else { k = (i - oU) / 24; const int q = (i - oU) % 24; j0 = 12 + q; if (q < 12) j1 = 60 + q; }
     double a = 0.0;
-    if (k < N) {
-      const double* Jk = M.J + (size_t)k * KD_ROWS * KD_NW; const double* yk = M.y + KD_BND + k * KD_ROWS;
-      const int nr = k == N - 1 ? KD_ROWS_LAST : KD_ROWS;
-      for (int r = 0; r < nr; ++r) a += Jk[r * KD_NW + j0] * yk[r];
-    }
-    if (j1 >= 0 && k >= 1) {
-      const double* Jp = M.J + (size_t)(k - 1) * KD_ROWS * KD_NW; const double* yp = M.y + KD_BND + (k - 1) * KD_ROWS;
-      const int nrp = (k - 1 == N - 1) ? KD_ROWS_LAST : KD_ROWS;      // (X_N sits in the last interval's block)
-      for (int r = 0; r < nrp; ++r) a += Jp[r * KD_NW + j1] * yp[r];
-    }
+    if (k < N) a += M.jty[(size_t)k * KD_NW + j0];
+    if (j1 >= 0 && k >= 1) a += M.jty[(size_t)(k - 1) * KD_NW + j1];
     if (i >= 12 * N && i < 12 * N + 12) {      // X_N: terminal cost and the four terminal row groups
       const int q = i - 12 * N;
       a += 2.0 * cost[q] * (M.x[i] - cost[12 + q]);
@@ -574,7 +569,7 @@ __global__ void __launch_bounds__(KD_THREADS) landing_kd_init_kernel(KdSolveArgs
 
 // ---- one interior-point iteration of one member (J and H blocks of the current (x, y) are in the workspace) ---------------------------
 #ifndef KD_TRIES_PER_ROUND
-#define KD_TRIES_PER_ROUND 1
+#define KD_TRIES_PER_ROUND 3      // (round 5: 3 with the matrix-core elimination, 0.7 instead of 1.8 ms per attempt -- 1.23 -> 1.07 s per batch of 1024; round 4: 1)
 #endif
 __global__ void __launch_bounds__(KD_THREADS, 2) landing_kd_iter_kernel(KdSolveArgs A) {
   const int m = blockIdx.x;

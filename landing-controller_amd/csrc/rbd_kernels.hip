@@ -823,6 +823,7 @@ struct KdNlpArgs {
   // member strides in doubles (0 = dense arrays [B][nx], [B][ng], [B][N][141][72], [B][N][72][72]) and an optional per-member skip flag: the
   // interior-point solver (kd_solver_kernels.hip) evaluates straight into its per-member workspace and skips members that have finished
   long long sx, sg, sj, sh; const int* skip;
+  double* jty = nullptr;      // optional [member stride sj][N][72]: J_k' lam_k per interval and column, a by-product of the Jacobian kernel (the solver's grad f + J' y)
   __host__ __device__ size_t ox(int b) const { return (size_t)b * (sx ? (size_t)sx : (size_t)(12 * (N + 1) + 36 * N)); }
   __host__ __device__ size_t og(int b) const { return (size_t)b * (sg ? (size_t)sg : (size_t)(48 + (N - 1) * 141 + 117)); }
   __host__ __device__ size_t oj(int b) const { return (size_t)b * (sj ? (size_t)sj : (size_t)N * 141 * 72); }
@@ -869,9 +870,12 @@ __global__ void __launch_bounds__(64) landing_kinodyn_nlp_jac_kernel(KdNlpArgs a
 #pragma unroll
   for (int j = 0; j < KD_NW; ++j) { const int i = kd_w_index(N, k, j); w[j] = D_(i >= 0 ? x[i] : 0.0, j == col ? 1.0 : 0.0); }
   const bool last = k == N - 1;
-  struct ColOut { double* J; bool zero; __device__ __forceinline__ void put(const Dual& v) { *J = zero ? 0.0 : v.d; J += KD_NW; } };      // row after row of column col
-  ColOut out{a.jac + a.oj(b) + ((size_t)k * KD_ROWS) * KD_NW + col, last && col >= 60};
+  // row after row of column col; with lam given the column's product with the multipliers of the interval's rows comes along (rows in order)
+  struct ColOut { double* J; bool zero; const double* y; double acc;
+                  __device__ __forceinline__ void put(const Dual& v) { const double d = zero ? 0.0 : v.d; *J = d; J += KD_NW; if (y) { acc += d * *y; ++y; } } };
+  ColOut out{a.jac + a.oj(b) + ((size_t)k * KD_ROWS) * KD_NW + col, last && col >= 60, (a.jty && a.lam) ? a.lam + a.og(b) + KD_BND + (size_t)k * KD_ROWS : nullptr, 0.0};
   kd_stage_rows<Dual>(a.P, *a.model, k, last, w, out);
+  if (a.jty && a.lam) a.jty[a.oj(b) + (size_t)k * KD_NW + col] = out.acc;
 }
 
 // Hessian of lam' g restricted to one interval: hess[b][k][i][j] = sum_r lam_r d^2 row_r / dw_i dw_j (72 x 72, symmetric; the 48 boundary rows are

@@ -46,14 +46,16 @@ def kin_box_of(rpy0, v_world0):
 
 def bounds(N, q_init, qd_init, c_init, kin_box, q_term_min=(-10, -10, 0.15, -0.1, -0.1, -10), q_term_max=(10, 10, 5, 0.1, 0.1, 10),
            qd_term_min=(-10, -10, -10, -.5, -.5, -.5), qd_term_max=(10, 10, 10, .5, .5, .5), z_min=0.075, l_leg_max=0.4,
-           jpos_min=JPOS_MIN, jpos_max=JPOS_MAX, tau_max=TAU_MAX, comp_eps=1e-3, slip_eps=1e-3, fk_band=0.01):
-    """lbg, ubg [ng] in the row order of landing_kinodyn_nlp_eval; defaults = the script's values (:208-258)"""
+           jpos_min=JPOS_MIN, jpos_max=JPOS_MAX, tau_max=TAU_MAX, comp_eps=1e-3, slip_eps=1e-3, fk_band=0.01, kin_box_y0=0.10):
+    """lbg, ubg [ng] in the row order of landing_kinodyn_nlp_eval; defaults = the script's values (:208-258).  kin_box_y0: 0.10 in
+    landing_optimization.m:150 (landing_kinodyn_form_default), 0.125 in generate_landingCtrller_KNITRO.m:154 (landing_kinodyn_form_knitro --
+    what the 24-argument solver function uses)"""
     ng = dims(N)[1]
     lb, ub = np.zeros(ng), np.zeros(ng)
     lb[0:6] = ub[0:6] = q_init; lb[6:12] = ub[6:12] = qd_init; lb[12:24] = ub[12:24] = c_init
     lb[24:30] = q_term_min; ub[24:30] = INF; lb[30:36] = -INF; ub[30:36] = q_term_max
     lb[36:42] = qd_term_min; ub[36:42] = INF; lb[42:48] = -INF; ub[42:48] = qd_term_max
-    kbx, kby = 0.125 + kin_box[0], 0.10 + kin_box[1]
+    kbx, kby = 0.125 + kin_box[0], kin_box_y0 + kin_box[1]
     for k in range(N):
         last = k == N - 1
         o = 48 + 141 * k

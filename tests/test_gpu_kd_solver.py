@@ -59,7 +59,7 @@ def test_refinement_of_1024_srbm_solutions_every_member_decided_and_certified(ct
     ok, cert = s["status"] == 0, s["status"] == 3
     assert (ok | cert).mean() >= 0.995, np.bincount(s["status"], minlength=4)
     assert ok.sum() >= 0.75 * B
-    prob = [kd.member_problem(N, q[b], qd[b], srbm["x"][b]) for b in range(B)]
+    prob = [kd.member_problem(N, q[b], qd[b], srbm["x"][b], kin_box_y0=0.125) for b in range(B)]      # the 24-argument function = generate_landingCtrller_KNITRO.m's: kin_box_y = 0.125 + kin_box(2) (:154)
     lb, ub, cost = (np.array([p[i] for p in prob]) for i in range(3))
     # every converged member: the oracle's KKT residual, and it is what the kernel reported
     k = _certify(s["x"][ok], s["lam_g"][ok], lb[ok], ub[ok], cost[ok], dt, consts.mu)
@@ -98,7 +98,7 @@ def test_stored_drop_known_answer(ctx):
     args["x0"][12 * (N + 1) + 12 * N:12 * (N + 1) + 12 * N + 12, 0] = U[:12, 0]
     s = R.kinodyn_solve_24(N, args)
     assert s["status"][0] == 0 and s["f"][0] <= 2e-5, (s["status"], s["f"], s["kkt"])
-    lb, ub = kd.bounds(N, q, qd, U[:12, 0], kd.kin_box_of(q[3:6], qd[3:6]))
+    lb, ub = kd.bounds(N, q, qd, U[:12, 0], kd.kin_box_of(q[3:6], qd[3:6]), kin_box_y0=0.125)      # (the 24-argument function's form: landing_kinodyn_form_knitro)
     cost = np.concatenate([kd.QN_DEFAULT, kd.Q_TERM_REF, np.zeros(6)])
     k = _certify(s["x"], s["lam_g"], lb[None], ub[None], cost[None], dt, consts.mu)
     assert k.max() <= KKT_TOL * 1.0001, k

@@ -161,3 +161,44 @@ def test_c_model_builder_equals_python_model_and_gateway_compiles(tmp_path):
     subprocess.run(["gcc", "-O1", "-std=c99", "-D_POSIX_C_SOURCE=200809L", "-fPIC", "-shared", "-Wall", "-Werror", "-Wno-unused-function", "-I", os.path.join(ROOT, "tests", "stubs"),
                     "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "matlab", "landing_refine_mex.c"), "-o", so, "-L", PKG, "-llanding_mi355x", "-Wl,-rpath," + PKG], check=True)
     assert "mexFunction" in subprocess.run(["nm", "-D", so], capture_output=True, text=True).stdout
+
+
+def test_kinodyn_bounds_forms_match_the_two_reference_scripts():
+    """landing_solve_kinodyn_24[_on] stand for the function generate_landingCtrller_KNITRO.m builds, whose lateral kinematic box is
+    kin_box_y = 0.125 + kin_box(2) (:154); main_scripts/landing_optimization.m:150 has 0.10.  landing_kinodyn_form_knitro / _default are those two
+    literal sets; landing_kinodyn_bounds (pure host code) with either equals the numpy restatement of the rows (kinodyn.bounds), and the two
+    forms differ in the eight lateral-box bounds of every interval only."""
+    import ctypes as C
+    capi, kd = lc("capi"), lc("kinodyn")
+    lib = capi.load()
+    N, B = 20, 2
+
+    class Form(C.Structure):
+        _fields_ = [("comp_eps", C.c_double), ("slip_eps", C.c_double), ("fk_band", C.c_double), ("kin_box_x0", C.c_double), ("kin_box_y0", C.c_double),
+                    ("kin_box_y_in", C.c_double), ("kin_box_z_lo", C.c_double), ("kin_box_z_hi", C.c_double), ("tau_max", C.c_double * 3)]
+    fd, fk = Form(), Form()
+    lib.landing_kinodyn_form_default(C.byref(fd)); lib.landing_kinodyn_form_knitro(C.byref(fk))
+    assert (fd.kin_box_x0, fd.kin_box_y0, fk.kin_box_x0, fk.kin_box_y0) == (0.125, 0.10, 0.125, 0.125)
+    for f in ("comp_eps", "slip_eps", "fk_band", "kin_box_y_in", "kin_box_z_lo", "kin_box_z_hi"):
+        assert getattr(fd, f) == getattr(fk, f)
+    rng = np.random.default_rng(3)
+    q = np.column_stack([np.zeros((B, 2)), 0.5 + 0.1 * rng.random(B), 0.2 * rng.normal(size=(B, 3))]); qd = rng.normal(size=(B, 6))
+    nx, ng = kd.dims(N)
+    dp = C.POINTER(C.c_double)
+    arr = lambda v: np.ascontiguousarray(v, float)
+    ci = arr([kd.c_init_of(q[b]) for b in range(B)]); kb = arr([kd.kin_box_of(q[b, 3:6], qd[b, 3:6]) for b in range(B)])
+    rep = lambda v: arr(np.tile(np.asarray(v, float), (B, 1)))
+    ins = [arr(q), arr(qd), ci, rep([-10, -10, 0.075, -10, -10, -10]), rep([-10, -10, 0.15, -0.1, -0.1, -10]), rep([10, 10, 5, 0.1, 0.1, 10]),
+           rep([-10, -10, -10, -.5, -.5, -.5]), rep([10, 10, 10, .5, .5, .5]), rep(kd.JPOS_MIN), rep(kd.JPOS_MAX), kb, arr(np.full((B, 1), 0.4))]
+    out = {}
+    for name, form, y0 in (("default", fd, 0.10), ("knitro", fk, 0.125)):
+        lb = np.zeros((B, ng)); ub = np.zeros((B, ng))
+        rc = lib.landing_kinodyn_bounds(C.c_int(N), C.c_int(B), C.byref(form), *[a.ctypes.data_as(dp) for a in ins], lb.ctypes.data_as(dp), ub.ctypes.data_as(dp))
+        assert rc == 0
+        for b in range(B):
+            l2, u2 = kd.bounds(N, q[b], qd[b], ci[b], kb[b], kin_box_y0=y0)
+            assert np.array_equal(lb[b], l2) and np.array_equal(ub[b], u2), name
+        out[name] = (lb, ub)
+    diff = (out["default"][0] != out["knitro"][0]) | (out["default"][1] != out["knitro"][1])
+    d = lambda i: np.abs(np.where(diff, out["default"][i], 0.0) - np.where(diff, out["knitro"][i], 0.0))
+    assert diff.sum() == B * N * 4 and np.allclose((d(0) + d(1))[diff], 0.025)

@@ -8,6 +8,7 @@ sys.path.insert(0, ROOT)
 ap = argparse.ArgumentParser()
 ap.add_argument("--B", type=int, default=1024); ap.add_argument("--seed", type=int, default=20211); ap.add_argument("--law", default="main")
 ap.add_argument("--reps", type=int, default=3); ap.add_argument("--max-iter", type=int, default=500)
+ap.add_argument("--ik", type=int, default=0, help="1: joint-angle guess = inverse kinematics of the SRBM feet (Rbd.kinodynamic_screen) instead of the data-generation caller's constant guess")
 a = ap.parse_args()
 import torch
 P_ = importlib.import_module("landing-controller_amd.problem"); capi = importlib.import_module("landing-controller_amd.capi")
@@ -19,7 +20,14 @@ P, X0, q, qd = P_.make_batch(B, N, 0.6, seed=a.seed, consts=consts, dt_grid="ref
 L = capi.LandingLib(N, device=0, lib_path=os.environ.get("LANDING_LIB")); R = rbd.Rbd(L)
 t = time.perf_counter(); srbm = L.solve_host(P, X0); t_srbm = time.perf_counter() - t
 mass, Ib, Ibi = K.robot_constants()
-prob = [kd.member_problem(N, q[b], qd[b], srbm["x"][b]) for b in range(B)]
+jp_guess = [None] * B
+t_ik = 0.0
+if a.ik:
+    torch.cuda.synchronize(); t = time.perf_counter()
+    scr = R.kinodynamic_screen(N, torch.tensor(srbm["x"], device="cuda"))
+    jp_guess = scr["jpos"].cpu().numpy().transpose(0, 2, 1)      # [B, 12, N]
+    t_ik = time.perf_counter() - t
+prob = [kd.member_problem(N, q[b], qd[b], srbm["x"][b], jp_guess[b]) for b in range(B)]
 lb, ub, cost, x0 = (np.array([p[i] for p in prob]) for i in range(4))
 T = lambda v: torch.tensor(v, device="cuda")
 dl, du, dc, dx0 = T(lb), T(ub), T(cost), T(x0)
@@ -36,7 +44,7 @@ for _ in range(a.reps):
 s, i, k = st.cpu().numpy(), it.cpu().numpy(), kk.cpu().numpy()
 ok = s == 0
 print(json.dumps({"what": "kinodynamic refinement of %d SRBM solutions (N = 20, production grid, law %s, seed %d)" % (B, a.law, a.seed), "batch": B,
-                  "srbm_solve_s": t_srbm, "srbm_converged": int((srbm["status"] == 0).sum()), "refinement_s": times, "refinement_s_best": min(times),
+                  "srbm_solve_s": t_srbm, "jpos_guess": "inverse kinematics of the SRBM feet (%.4f s)" % t_ik if a.ik else "constant (generate_training_data_automated.m:143)", "srbm_converged": int((srbm["status"] == 0).sum()), "refinement_s": times, "refinement_s_best": min(times),
                   "status_counts": np.bincount(s, minlength=4).tolist(), "converged": int(ok.sum()), "certified_infeasible": int((s == 3).sum()),
                   "iters_mean_converged": float(i[ok].mean()), "iters_p99_converged": float(np.percentile(i[ok], 99)), "iters_max": int(i.max()),
                   "kkt_max_converged": k[ok].max(axis=0).tolist(), "refined_per_s": float(ok.sum() / min(times)), "rounds": int(i.max()) + 1}))
