@@ -46,7 +46,7 @@ FP64_PEAK_TFLOPS = 78.6      # MI355X fp64 vector = matrix peak (AMD datasheet; 
 HBM_PEAK_GBPS = 8000.0       # MI355X_MICROARCH.md
 SURVEY_8D_KKT_FLOPS = 4.4e6  # block-tridiagonal factor+solve per interior-point iteration at N=40
 SURVEY_8D_CALLBACK_FLOPS = 0.14e6
-PMC_FILE = os.path.join(ROOT, "profiles", "r04_pmc_ipm.json")      # default of --pmc-file
+PMC_FILE = os.path.join(ROOT, "profiles", "r05_pmc_ipm.json")      # default of --pmc-file
 
 
 def kernel_source_sha():
