@@ -31,7 +31,7 @@ constexpr int KD_NSIG = 24, KD_NV = 60;          // state; stage variables v = (
 constexpr int KD_MS = 62;                        // LDS row stride of the stage array [M | m] (column 60 = right-hand side)
 constexpr int KD_PS = 25;                        // LDS row stride of the cost-to-go P (24 x 24)
 constexpr int KD_AS = 37;                        // LDS row stride of [A^ | b] (12 x 37)
-constexpr int KD_JC_ROWS = 32, KD_JC_S = 65;     // rows per chunk of the staged Jacobian, LDS row stride (64 columns + pad)
+constexpr int KD_JC_ROWS = 36, KD_JC_S = 65;     // rows per chunk of the staged Jacobian (the 129 inequality rows of an interval = 4 chunks), LDS row stride (64 columns + pad)
 // per-interval record of the backward sweep (doubles): gains K (36 x 24) | kappa (36) | [A^ | b] (12 x 37) | state rows of the cost-to-go
 // P_k (12 x 24) | p_k (12)
 constexpr int KD_REC_K = 0, KD_REC_KAP = 864, KD_REC_AH = 900, KD_REC_PX = 1344, KD_REC_PV = 1632, KD_REC = 1648;
@@ -168,13 +168,26 @@ KD_PHASE void kd_condense_stage(const KdMem& M, int N, int k, double delta) {
   f64x4 acc[4];
   for (int t = 0; t < 4; ++t) acc[t] = f64x4{0.0, 0.0, 0.0, 0.0};
   double macc = 0.0;
-  for (int r0 = 12; r0 < nr; r0 += KD_JC_ROWS) {
-    for (int e = tid; e < KD_JC_ROWS * 64; e += NT) {
-      const int rr = e >> 6, c = e & 63, r = r0 + rr;
-      S.Jc[rr * KD_JC_S + c] = (r < nr && c < nv) ? Jk[r * KD_NW + kd_v2w(c)] : 0.0;
+  // (round 5: the loads of the next chunk are in flight while the matrix cores work on this one -- they used to be exposed, 5 x ~2 us per stage)
+  constexpr int NE = (KD_JC_ROWS * 64 + KD_THREADS - 1) / KD_THREADS;
+  double pre[NE], pre_sg = 0.0, pre_rh = 0.0;
+  auto fetch = [&](int r0) {
+#pragma unroll
+    for (int q = 0; q < NE; ++q) {
+      const int e = tid + q * KD_THREADS, rr = e >> 6, c = e & 63, r = r0 + rr;
+      const bool in = rr < KD_JC_ROWS && r < nr && c < nv;
+      const double v = Jk[(in ? r : 12) * KD_NW + kd_v2w(in ? c : 0)];      // unconditional load (clamped): all NE loads are issued together
+      pre[q] = in ? v : 0.0;
     }
-    if (tid < KD_JC_ROWS) { const int r = r0 + tid; S.sgc[tid] = r < nr ? M.sig[g0 + r] : 0.0; S.rhc[tid] = r < nr ? M.rho[g0 + r] : 0.0; }
+    { const int r = r0 + tid; const bool in = tid < KD_JC_ROWS && r < nr; const double a = M.sig[g0 + (in ? r : 12)], b = M.rho[g0 + (in ? r : 12)]; pre_sg = in ? a : 0.0; pre_rh = in ? b : 0.0; }
+  };
+  fetch(12);
+  for (int r0 = 12; r0 < nr; r0 += KD_JC_ROWS) {
+#pragma unroll
+    for (int q = 0; q < NE; ++q) { const int e = tid + q * KD_THREADS, rr = e >> 6, c = e & 63; if (rr < KD_JC_ROWS) S.Jc[rr * KD_JC_S + c] = pre[q]; }
+    if (tid < KD_JC_ROWS) { S.sgc[tid] = pre_sg; S.rhc[tid] = pre_rh; }
     __syncthreads();
+    if (r0 + KD_JC_ROWS < nr) fetch(r0 + KD_JC_ROWS);      // (uniform)
     for (int t = 0; t < 4; ++t)
       acc[t] = mfma_tile<KD_JC_ROWS / 4>(acc[t], [&](int i, int kk) { return S.Jc[kk * KD_JC_S + 16 * wave + i] * S.sgc[kk]; },
                                          [&](int kk, int j) { return S.Jc[kk * KD_JC_S + 16 * t + j]; });
@@ -385,10 +398,27 @@ KD_PHASE void kd_forward(const KdMem& M, int N, const double* lbm) {
   // sigma_0 is fixed by the initial conditions (rows 0..23: lb = ub = q_init, qd_init, c_init)
   if (tid < 24) { const int xi = tid < 12 ? tid : oU + (tid - 12); S.dsg[tid] = lbm[tid] - M.x[xi]; }
   __syncthreads();
+  // the records (gains K 36 x 24, kappa, [A^ | b]: the first KD_REC_PX doubles) travel one stage ahead through registers into a double
+  // buffer in the stage array (free here): round 4 read them from the workspace inside the serial chain, two exposed round trips per stage
+  constexpr int NREC = KD_REC_PX, NQ = (NREC + KD_THREADS - 1) / KD_THREADS;
+  static_assert(2 * NREC <= KD_NV * KD_MS, "two records fit the stage array");
+  double nxt[NQ];
+  auto fetch = [&](int k) {
+    const double* rec = M.rec + (size_t)(k < N ? k : N - 1) * KD_REC;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) { const int e = tid + q * KD_THREADS; nxt[q] = rec[e < NREC ? e : NREC - 1]; }
+  };
+  auto stash = [&](int k) {
+    double* b = S.Ms + (k & 1) * NREC;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) { const int e = tid + q * KD_THREADS; if (e < NREC) b[e] = nxt[q]; }
+  };
+  fetch(0); stash(0); fetch(1);
+  __syncthreads();
   for (int k = 0; k < N; ++k) {
     const bool last = k == N - 1;
     const int nu = last ? 24 : 36;
-    const double* rec = M.rec + (size_t)k * KD_REC;
+    const double* rec = S.Ms + (k & 1) * NREC;
     const double* sk = S.dsg + 24 * k;
     // du = -(K dsigma + kappa)
     if (tid < nu) {
@@ -396,6 +426,7 @@ KD_PHASE void kd_forward(const KdMem& M, int N, const double* lbm) {
       for (int t = 0; t < 24; ++t) a += rec[KD_REC_K + tid * 24 + t] * sk[t];
       S.dxw[24 + tid] = -a;      // dxw[24..] = (df, djpos, dc+)
     }
+    stash(k + 1); fetch(k + 2);      // (the other buffer: nobody reads it during this stage)
     __syncthreads();
     if (tid < 12) {              // dX+ = A^ (dsigma, df) + b
       double a = rec[KD_REC_AH + tid * KD_AS + 36];
@@ -424,22 +455,53 @@ KD_PHASE void kd_forward(const KdMem& M, int N, const double* lbm) {
     M.yn[KD_BND + k * KD_ROWS + r] = -a;
   }
   __syncthreads();
-  // ds = J_I dx + (g - s): one wave per row, lanes over the 72 columns of the interval's block
+  // ds = J_I dx + (g - s): one wave per row, lanes over the 72 columns of the interval's block, four rows of a wave in flight at a time.
+  // The steps of all intervals' block variables are gathered first (into the stage array, free here), so that no barrier separates the
+  // intervals and the loads of the J blocks (74 KB per interval) stream (round 4: one row after the other, a barrier pair per interval)
   const int wave = tid >> 6, l = tid & 63;
-  for (int k = 0; k < N; ++k) {
-    const int nr = k == N - 1 ? KD_ROWS_LAST : KD_ROWS, g0 = KD_BND + k * KD_ROWS;
-    if (tid < KD_NW) { const int i = kd_w_index(N, k, tid); S.dxw[tid] = i >= 0 ? M.dx[i] : 0.0; }
-    __syncthreads();
-    const double* Jk = M.J + (size_t)k * KD_ROWS * KD_NW;
-    for (int r = 12 + wave; r < nr; r += 4) {
-      double a = Jk[r * KD_NW + l] * S.dxw[l];
-      if (l < KD_NW - 64) a += Jk[r * KD_NW + 64 + l] * S.dxw[64 + l];
+  static_assert(64 * KD_NW <= KD_NV * KD_MS + KD_NSIG * KD_PS + KD_NSIG + 12 * KD_AS + KD_NSIG * KD_AS, "the gathered steps of N <= 64 intervals fit the arrays in front of Jc");
+  double* dxa = S.Ms;      // [N][72]  (runs on into Pm, pv, Ah, Y for long horizons: all free during the forward sweep)
+  for (int e = tid; e < N * KD_NW; e += NT) { const int k = e / KD_NW, i = kd_w_index(N, k, e % KD_NW); dxa[e] = i >= 0 ? M.dx[i] : 0.0; }
+  __syncthreads();
+  {
+    const int nrows = (N - 1) * (KD_ROWS - 12) + (KD_ROWS_LAST - 12);      // inequality rows of all intervals, interval-major
+    // software pipeline: the loads of the next four rows are issued before the shuffle chains of the current four
+    double j0[4], j1[4], gs[4] = {0.0, 0.0, 0.0, 0.0}; int kk[4], gr[4];
+    auto issue = [&](int q0) {
 #pragma unroll
-      for (int mask = 32; mask >= 1; mask >>= 1) a += __shfl_xor(a, mask);
-      if (l == 0) M.ds[g0 + r] = a + (M.g[g0 + r] - M.s[g0 + r]);
+      for (int u = 0; u < 4; ++u) {
+        const int q = q0 + u < nrows ? q0 + u : nrows - 1;
+        const int k = q / (KD_ROWS - 12), r = 12 + q % (KD_ROWS - 12);
+        const double* Jr = M.J + ((size_t)k * KD_ROWS + r) * KD_NW;
+        j0[u] = Jr[l]; j1[u] = Jr[64 + (l < KD_NW - 64 ? l : 0)];
+        kk[u] = k; gr[u] = KD_BND + k * KD_ROWS + r;
+      }
+      if (l < 4) { const int g = l == 0 ? gr[0] : (l == 1 ? gr[1] : (l == 2 ? gr[2] : gr[3])); gs[0] = M.g[g] - M.s[g]; }
+    };
+    issue(4 * wave);
+    for (int q0 = 4 * wave; q0 < nrows; q0 += 16) {
+      double a[4]; int gc[4]; const double gsc = gs[0];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const double* dk = dxa + kk[u] * KD_NW;
+        a[u] = j0[u] * dk[l];
+        if (l < KD_NW - 64) a[u] += j1[u] * dk[64 + l];
+        gc[u] = gr[u];
+      }
+      if (q0 + 16 < nrows) issue(q0 + 16);      // (uniform per wave)
+#pragma unroll
+      for (int mask = 32; mask >= 1; mask >>= 1) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) a[u] += __shfl_xor(a[u], mask);
+      }
+      if (l < 4 && q0 + l < nrows) {
+        const double v = l == 0 ? a[0] : (l == 1 ? a[1] : (l == 2 ? a[2] : a[3]));
+        const int g = l == 0 ? gc[0] : (l == 1 ? gc[1] : (l == 2 ? gc[2] : gc[3]));
+        M.ds[g] = v + gsc;
+      }
     }
-    __syncthreads();
   }
+  __syncthreads();
   if (tid < 24) {      // terminal rows: copies of X_N
     const int r = 24 + tid, xi = tid < 12 ? (tid % 6) : 6 + (tid % 6);
     M.ds[r] = M.dx[12 * N + xi] + (M.g[r] - M.s[r]);
