@@ -33,6 +33,6 @@ lat = np.array(lat)
 print(json.dumps({"workload": "receding-horizon SRBM landing MPC, N=40, dt=15 ms, batch=%d, warm-started (shifted plan, bound_push=bound_frac=mu_init=1e-4)" % B,
                   "ticks": a.ticks, "tick_ms_p50": float(np.median(lat)), "tick_ms_p90": float(np.percentile(lat, 90)), "tick_ms_max": float(lat.max()),
                   "rate_hz_p50": 1e3 / float(np.median(lat)), "ticks_within_10ms": float((lat <= 10.0).mean()),
-                  "iters_per_tick_mean": float(np.mean(its)), "max_iter_per_tick": int(ctl.opts_warm.max_iter), "factor_fp32": int(ctl.opts_warm.factor_fp32), "warm_overrides": a.warm, "members_converged_mean": float(np.mean(ok)), "batch": B,
+                  "iters_per_tick_mean": float(np.mean(its)), "max_iter_per_tick": int(ctl.opts_warm.max_iter), "factor": "fp64", "warm_overrides": a.warm, "members_converged_mean": float(np.mean(ok)), "batch": B,
                   "cold_solve_ms": 1e3 * t_cold, "cold_iters_mean": cold_iters, "cold_converged": cold_ok,
                   "trajectory_solves_per_s": B / (float(np.median(lat)) * 1e-3)}))
