@@ -1,8 +1,9 @@
 """Streaming batches through one GPU with several of them in flight (the data-generation use case of
 generate_data/generate_training_data_automated.m:38: thousands of independent drop states).
 
-The time of ONE batch of 1024 NLPs is set by its slowest member (2.5-4x the mean iteration count) while most CUs idle;
-a second batch in flight fills them: 8.6 k instead of 5.7 k NLPs/s on one MI355X.  One solver
+The time of ONE batch of 1024 NLPs is set by its slowest member and by the granularity of two members per resident slot
+(DESIGN.md 4.2); a second batch in flight fills the CUs that idle in its tail: 24.4 k instead of 18.7 k NLPs/s on one MI355X
+(round 5, profiles/r05_bench.json `two_batches_in_flight`).  One solver
 context (workspace, tables) and one HIP stream per lane; a lane is reused as soon as its previous batch has been read.
 
     pipe = BatchPipeline(N=40, depth=2)
