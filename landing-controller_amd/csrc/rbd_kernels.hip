@@ -913,10 +913,11 @@ __host__ __device__ inline int kd_pair_list(unsigned char* pi, unsigned char* pj
   return n;
 }
 constexpr int KD_NPAIR = 561;
-__global__ void __launch_bounds__(64) landing_kinodyn_nlp_hess_kernel(KdNlpArgs a, const unsigned char* __restrict__ pair_i, const unsigned char* __restrict__ pair_j) {
+// (npair pairs per block: the KD_NPAIR candidates of kd_pair_list, or the subset of them whose entry is not structurally zero -- solver_capi.inc, kd_ensure_pairs)
+__global__ void __launch_bounds__(64) landing_kinodyn_nlp_hess_kernel(KdNlpArgs a, const unsigned char* __restrict__ pair_i, const unsigned char* __restrict__ pair_j, int npair) {
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (long long)a.B * a.N * KD_NPAIR) return;
-  const int pr = (int)(idx % KD_NPAIR); const int k = (int)((idx / KD_NPAIR) % a.N); const int b = (int)(idx / ((long long)KD_NPAIR * a.N)), N = a.N;
+  if (idx >= (long long)a.B * a.N * npair) return;
+  const int pr = (int)(idx % npair); const int k = (int)((idx / npair) % a.N); const int b = (int)(idx / ((long long)npair * a.N)), N = a.N;
   const int i = pair_i[pr], j = pair_j[pr];
   if (a.skip && a.skip[b]) return;
   double* Hk = a.hess + a.oh(b) + ((size_t)k * KD_NW) * KD_NW;
