@@ -55,6 +55,9 @@ struct KdState {
   int last_reset_it, ncrawl, clip_k_cur, fresh;
   int pending;      // the inertia correction of this iteration continues in the next launch (landing_kd_iter_kernel, KD_TRIES_PER_ROUND)
   int stag, full_prev; double e_prev;      // stag_relief (landing_nlp.h): full steps of the last barrier problem that did not halve the error
+  // feasibility (restoration) phase, round 5 -- the scheme of landing_ipm_kernel (solver_kernels.hip, landing_nlp.h feas_phase / feas_jam / feas_stat):
+  // feas = 1 while the elastic problem is being solved, lim = iteration limit in force, fjam / fstat / v1_ref = the two rules' counters
+  int feas, feas_used, lim, fjam, fstat; double v1_ref, c_rn, f_vmax, f_v1;
   double prof[8]; long long tp;      // development aid: wall_clock64 ticks (100 MHz) per phase, summed over the iterations: grad | mu | backward | forward | dual | line search | accept
 };
 
@@ -63,11 +66,12 @@ struct KdMem {
   double *g, *gt, *s, *ds, *zL, *zU, *y, *yn, *sig, *rho;
   double *J, *H, *rec, *wbuf;      // wbuf [N][72]: gathered stage variables of the in-kernel row evaluation
   double* jty;                     // [N][72]: J_k' y_k per interval and block column, written by the Jacobian kernel (rbd_kernels.hip, KdNlpArgs::jty)
+  double *en, *ep, *wn, *wp;       // feasibility phase: violation variables of the lower / upper side of every inequality row and their multipliers
   KdState* st;
 };
 __host__ __device__ inline size_t kd_ws_stride(int N) {
   const size_t nx = (size_t)kd_nx(N), ng = (size_t)kd_ng(N);
-  return 4 * nx + 10 * ng + (size_t)N * KD_ROWS * KD_NW + (size_t)N * KD_NW * KD_NW + (size_t)(N + 1) * KD_REC + 2 * (size_t)N * KD_NW + (sizeof(KdState) + 7) / 8 + 8;
+  return 4 * nx + 10 * ng + (size_t)N * KD_ROWS * KD_NW + (size_t)N * KD_NW * KD_NW + (size_t)(N + 1) * KD_REC + 2 * (size_t)N * KD_NW + 4 * ng + (sizeof(KdState) + 7) / 8 + 8;
 }
 __device__ __forceinline__ KdMem kd_carve(int N, double* w) {
   const size_t nx = (size_t)kd_nx(N), ng = (size_t)kd_ng(N);
@@ -78,6 +82,7 @@ __device__ __forceinline__ KdMem kd_carve(int N, double* w) {
   M.J = w; w += (size_t)N * KD_ROWS * KD_NW; M.H = w; w += (size_t)N * KD_NW * KD_NW; M.rec = w; w += (size_t)(N + 1) * KD_REC;
   M.wbuf = w; w += (size_t)N * KD_NW;
   M.jty = w; w += (size_t)N * KD_NW;
+  M.en = w; w += ng; M.ep = w; w += ng; M.wn = w; w += ng; M.wp = w; w += ng;
   M.st = reinterpret_cast<KdState*>(w);
   return M;
 }
@@ -370,7 +375,7 @@ __device__ __forceinline__ void kd_terminal(const KdMem& M, int N, const double*
   __syncthreads();
   if (tid < 12) {
     const int i = tid, ra = i < 6 ? 24 + i : 36 + (i - 6), rb = i < 6 ? 30 + i : 42 + (i - 6);
-    const double qn2 = 2.0 * cost[i];
+    const double qn2 = S.ks.feas ? 0.0 : 2.0 * cost[i];      // (the feasibility phase has no objective)
     const double pd = qn2 + M.sig[ra] + M.sig[rb] + delta, pg = qn2 * (M.x[12 * N + i] - cost[12 + i]) + M.rho[ra] + M.rho[rb];
     S.Pm[i * KD_PS + i] = pd; S.pv[i] = pg;
     double* rec = M.rec + (size_t)N * KD_REC;
@@ -511,7 +516,7 @@ KD_PHASE void kd_forward(const KdMem& M, int N, const double* lbm) {
 
 // gx = grad f + J' y over the free rows (rows 24 .. ng-1): one thread per variable, the (at most two) block columns that hold it.  The column
 // products J_k' y_k are a by-product of the Jacobian kernel (M.jty; round 4 re-read every J block here: 1.5 MB and 0.49 ms per member-iteration)
-KD_PHASE void kd_grad_lag(const KdMem& M, int N, const double* cost) {
+KD_PHASE void kd_grad_lag(const KdMem& M, int N, const double* cost, double obj) {      // obj: 1, or 0 in the feasibility phase
   const int tid = threadIdx.x, NT = blockDim.x, nx = kd_nx(N);
   const int oJ = 12 * (N + 1), oU = oJ + 12 * N;
   for (int i = tid; i < nx; i += NT) {
@@ -524,7 +529,7 @@ KD_PHASE void kd_grad_lag(const KdMem& M, int N, const double* cost) {
     if (j1 >= 0 && k >= 1) a += M.jty[(size_t)(k - 1) * KD_NW + j1];
     if (i >= 12 * N && i < 12 * N + 12) {      // X_N: terminal cost and the four terminal row groups
       const int q = i - 12 * N;
-      a += 2.0 * cost[q] * (M.x[i] - cost[12 + q]);
+      a += obj * 2.0 * cost[q] * (M.x[i] - cost[12 + q]);
       a += q < 6 ? M.y[24 + q] + M.y[30 + q] : M.y[36 + (q - 6)] + M.y[42 + (q - 6)];
     }
     M.gx[i] = a;
@@ -558,6 +563,48 @@ KD_PHASE void kd_point_pass(const KdMem& M, int ng, const double* lbm, const dou
   double v[6] = {pr, co, cm, ys, zs, nz}; const int op[6] = {RMAX, RMAX, RMAX, RSUM, RSUM, RSUM};
   block_reduce<6>(v, op, S.red);
   KD_BEGIN_SYNCED() S.ks.c_pr = v[0]; S.ks.c_co = v[1]; S.ks.c_cm = v[2]; S.ks.c_ys = v[3]; S.ks.c_zs = v[4]; S.ks.c_nz = fmax(v[5], 1.0); KD_END();
+}
+
+// the same for the elastic problem of the feasibility phase (solver_kernels.hip, el_step): every inequality row lb <= s <= ub becomes
+// a = s - lb + n >= 0, n >= 0 (b = ub + q - s >= 0, q >= 0) at the price rho_pen (n + q); the row enters the condensed system with sigma = z / D.
+// Also leaves the violation of the inequality rows at x (max norm, 1-norm) and |z + w - rho_pen|_inf in K
+KD_PHASE void kd_feas_point_pass(const KdMem& M, int ng, const double* lbm, const double* ubm, double mu_, double frho) {
+  KdLds& S = KSH;
+  const int tid = threadIdx.x, NT = blockDim.x;
+  const double INF = INFINITY;
+  double pr = 0.0, co = 0.0, cm = 0.0, rn = 0.0, ys = 0.0, zs = 0.0, nz = 0.0, vmax = 0.0, v1 = 0.0;
+  for (int r = tid; r < ng; r += NT) {
+    const double lb = lbm[r], ub = ubm[r];
+    double sg = 0.0, rh = 0.0;
+    if (r >= 24) {
+      const double g = M.g[r];
+      ys += fabs(M.y[r]);
+      if (lb == ub) pr = fmax(pr, fabs(g - lb));
+      else {
+        const double s = M.s[r], v = fmax(fmax(lb - g, g - ub), 0.0);
+        pr = fmax(pr, fabs(g - s)); vmax = fmax(vmax, v); v1 += v;
+        if (lb > -INF) {
+          const double n = M.en[r], a = s - lb + n, z = M.zL[r], w = M.wn[r], D = a + z * n / w;
+          const double c = (mu_ - a * z - z * (mu_ - n * w + n * (z + w - frho)) / w) / D;
+          co = fmax(co, fmax(a * z, n * w)); cm = fmax(cm, fmax(fabs(a * z - mu_), fabs(n * w - mu_))); rn = fmax(rn, fabs(z + w - frho));
+          sg += z / D; rh -= z + c; zs += z; nz += 1.0;
+        }
+        if (ub < INF) {
+          const double q = M.ep[r], b = ub + q - s, z = M.zU[r], w = M.wp[r], D = b + z * q / w;
+          const double c = (mu_ - b * z - z * (mu_ - q * w + q * (z + w - frho)) / w) / D;
+          co = fmax(co, fmax(b * z, q * w)); cm = fmax(cm, fmax(fabs(b * z - mu_), fabs(q * w - mu_))); rn = fmax(rn, fabs(z + w - frho));
+          sg += z / D; rh += z + c; zs += z; nz += 1.0;
+        }
+        rh += sg * (g - s);
+      }
+    }
+    M.sig[r] = sg; M.rho[r] = rh;
+  }
+  double v[6] = {pr, co, cm, ys, zs, nz}; const int op[6] = {RMAX, RMAX, RMAX, RSUM, RSUM, RSUM};
+  block_reduce<6>(v, op, S.red);
+  double u[3] = {rn, vmax, v1}; const int op3[3] = {RMAX, RMAX, RSUM};
+  block_reduce<3>(u, op3, S.red);
+  KD_BEGIN_SYNCED() S.ks.c_pr = v[0]; S.ks.c_co = v[1]; S.ks.c_cm = v[2]; S.ks.c_ys = v[3]; S.ks.c_zs = v[4]; S.ks.c_nz = fmax(v[5], 1.0); S.ks.c_rn = u[0]; S.ks.f_vmax = u[1]; S.ks.f_v1 = u[2]; KD_END();
 }
 
 KD_PHASE void kd_init_slacks(const KdMem& M, int ng, const double* lbm, const double* ubm, const landing_solver_opts& o) {
@@ -605,6 +652,7 @@ __global__ void __launch_bounds__(KD_THREADS) landing_kd_init_kernel(KdSolveArgs
     K.nfilt = 0; K.it = 0; K.status = LANDING_MAX_ITER; K.done = 0; K.need_reg_streak = 0; K.first_failed = 0; K.cutstreak = 0; K.force_step = 0;
     K.wd_count = 0; K.last_mu_it = 0; K.accepted = 0; K.armijo_step = 0; K.fact_ok = 0; K.skipped_zero = 0; K.attempt = 0; K.flag = 0; K.ls_done = 0;
     K.need_corr = 0; K.fallback = 0; K.nfact = 0; K.ntrial = 0; K.nreset = 0; K.last_reset_it = 0; K.ncrawl = 0; K.clip_k_cur = A.o.clip_k; K.fresh = 0; K.pending = 0; K.stag = 0; K.full_prev = 0; K.e_prev = 1e300;
+    K.feas = 0; K.feas_used = 0; K.lim = A.o.max_iter; K.fjam = 0; K.fstat = 0; K.v1_ref = 0.0; K.c_rn = 0.0; K.f_vmax = 0.0; K.f_v1 = 0.0;
     for (int i = 0; i < 8; ++i) K.prof[i] = 0.0; K.tp = 0;
   }
   __syncthreads();
@@ -656,7 +704,7 @@ __global__ void __launch_bounds__(KD_THREADS, 2) landing_kd_iter_kernel(KdSolveA
   if (resume) { KD_BEGIN() K.pending = 0; KD_END(); }
   else {
     // ---------------------------------------------------------------- optimality error (unscaled), stop test
-    kd_grad_lag(M, N, cost);
+    kd_grad_lag(M, N, cost, K.feas ? 0.0 : 1.0);
     KD_PROF(0);
     {
       double du = 0.0;
@@ -664,17 +712,42 @@ __global__ void __launch_bounds__(KD_THREADS, 2) landing_kd_iter_kernel(KdSolveA
       du = block_reduce1(du, RMAX, S.red);
       KD_BEGIN_SYNCED()
         const double pr = K.c_pr, co = K.c_co;
+        if (K.feas) du = fmax(du, K.c_rn);      // the elastic problem has the extra stationarity rows rho_pen - z - w = 0
         K.e_pr = pr; K.e_du = du; K.e_co = co;
         if (o.stag_relief > 0) {      // as in landing_ipm_kernel: the proximal term turns the last Newton steps into a linear iteration (one member of the
           const double E = fmax(pr, du);      // bench batch: 400 full steps from pr 1.5e-5 to 1e-6, a quarter of the batch's wall time)
-          K.stag = (K.mu <= o.tol / 10.0 * 1.0000001 && K.full_prev && E > 0.5 * K.e_prev) ? K.stag + 1 : 0;
+          K.stag = (!K.feas && K.mu <= o.tol / 10.0 * 1.0000001 && K.full_prev && E > 0.5 * K.e_prev) ? K.stag + 1 : 0;
           K.e_prev = E;
         }
-        K.flag = 0;
-        if (!(du < 1e300) || !(pr < 1e300) || !(co < 1e300)) { K.status = LANDING_NUMERICAL; K.flag = 1; }
+        K.flag = 0;      // 0: iterate, 1: stop, 2: restart, 3: back from the feasibility phase, 4: into the feasibility phase
+        bool give_up = false;
+        if (K.feas) {
+          // feasibility phase (landing_nlp.h): a feasible point (or an elastic KKT point with negligible violation) restarts the solve from here, an elastic
+          // KKT point with positive violation -- or a violation that has been stationary for feas_stat iterations with the equality rows at 1e-3 -- is the
+          // certificate of local infeasibility
+          const bool conv = fmax(du, fmax(pr, co)) <= o.tol;
+          if (!(du < 1e300) || !(pr < 1e300) || !(co < 1e300)) { K.status = LANDING_NUMERICAL; K.flag = 1; }
+          else if (K.f_vmax <= 1e-9 && pr <= o.tol) K.flag = 3;
+          else if (conv && K.f_v1 > o.feas_cert) { K.status = LANDING_INFEASIBLE; K.flag = 1; }
+          else if (conv) K.flag = 3;
+          else if (o.feas_stat > 0) {
+            const double v1 = K.f_v1;
+            if (K.fstat < 0 || !(fabs(v1 - K.v1_ref) <= 0.05 * K.v1_ref)) { K.v1_ref = v1; K.fstat = 0; } else K.fstat++;
+            if (K.fstat >= o.feas_stat && K.mu <= 1e-4 && pr <= 1e-3) { if (v1 > o.feas_cert) { K.status = LANDING_INFEASIBLE; K.flag = 1; } else K.flag = 3; }
+          }
+          if (K.flag == 0 && K.it >= K.lim) { K.status = LANDING_MAX_ITER; K.flag = 1; }
+          if (K.flag == 3) {
+            K.feas = 0; K.lim = K.it + (o.max_iter > 1 ? o.max_iter : 1); K.status = LANDING_MAX_ITER;
+            K.mu = o.mu_init; K.nfilt = 0; K.delta_last = 0.0; K.need_reg_streak = 0; K.wd_count = 0; K.th_max = 0.0; K.nreset = 0; K.last_reset_it = K.it; K.ncrawl = 0;
+            K.cutstreak = 0; K.force_step = 0;
+            K.it = K.it + 1;
+          }
+        }
+        else if (!(du < 1e300) || !(pr < 1e300) || !(co < 1e300)) { K.status = LANDING_NUMERICAL; give_up = true; }
         else if (fmax(du, fmax(pr, co)) <= o.tol) { K.status = LANDING_CONVERGED; K.flag = 1; }
-        else if (K.it >= o.max_iter) { K.status = LANDING_MAX_ITER; K.flag = 1; }
-        else if (du > o.reset_du && K.nreset >= o.max_resets && o.max_resets > 0) { K.status = LANDING_NUMERICAL; K.flag = 1; }      // jammed again: give up
+        else if (K.it >= K.lim) { K.status = LANDING_MAX_ITER; give_up = true; }
+        else if (du > o.reset_du && K.nreset >= o.max_resets && o.max_resets > 0) { K.status = LANDING_NUMERICAL; give_up = true; }      // jammed again: give up
+        else if (o.feas_jam > 0 && K.fjam >= o.feas_jam && pr > 1e-3 && !K.feas_used && o.feas_phase) { K.status = LANDING_MAX_ITER; give_up = true; }      // jammed line search (landing_nlp.h)
         else {
           // restart rules of the SRBM solver (solver_kernels.hip, landing_nlp.h fresh_restart): a jammed iterate (multipliers blown up), a first
           // barrier problem that crawls, a later one that has wandered off -> slacks, multipliers, barrier parameter and filter are re-initialised,
@@ -695,6 +768,14 @@ __global__ void __launch_bounds__(KD_THREADS, 2) landing_kd_iter_kernel(KdSolveA
             K.mu = o.mu_init; K.nfilt = 0; K.delta_last = 0.0; K.need_reg_streak = 0; K.wd_count = 0; K.cutstreak = 0; K.force_step = 0;
             K.it = it + 1;
           }
+        }
+        if (give_up) {      // the solve would end here as NUMERICAL / MAX_ITER: enter the feasibility phase once
+          if (o.feas_phase && !K.feas_used && o.max_iter > 0) {
+            K.flag = 4;
+            K.feas = 1; K.feas_used = 1; K.status = LANDING_MAX_ITER; K.lim = K.it + o.max_iter; K.fstat = -1;
+            K.mu = o.mu_init; K.nfilt = 0; K.th_max = 0.0; K.delta_last = 0.0; K.need_reg_streak = 0; K.cutstreak = 0; K.force_step = 0; K.wd_count = 0;
+            K.it = K.it + 1;
+          } else K.flag = 1;
         }
       KD_END();
     }
@@ -718,6 +799,45 @@ __global__ void __launch_bounds__(KD_THREADS, 2) landing_kd_iter_kernel(KdSolveA
       if (tid == 0) { *M.st = K; atomicAdd(A.n_active, 1); }
       return;
     }
+    if (K.flag == 3) {      // a feasible point (or negligible violation): the interior-point solve restarts from it; derivatives at the new multipliers next round
+      for (int r = tid + 24; r < ng; r += NT) if (lbm[r] == ubm[r]) M.y[r] = 0.0;
+      __syncthreads();
+      kd_init_slacks(M, ng, lbm, ubm, o);
+      kd_point_pass(M, ng, lbm, ubm, K.mu);
+      if (tid == 0) { *M.st = K; A.done[m] = 0; atomicAdd(A.n_active, 1); }
+      return;
+    }
+    if (K.flag == 4) {      // into the feasibility phase from the current point (from the caller's initial guess when the iterate is not finite)
+      double big = 0.0;
+      for (int i = tid; i < nx; i += NT) { const double v = fabs(M.x[i]); big = fmax(big, v < 1e6 ? v : 1e300); }
+      big = block_reduce1(big, RMAX, S.red);
+      if (!(big < 1e6)) {
+        for (int i = tid; i < nx; i += NT) {
+          double v = A.x0[(size_t)m * nx + i];
+          if (i < 12) v = lbm[i]; else if (i >= oU && i < oU + 12) v = lbm[12 + (i - oU)];
+          M.x[i] = v;
+        }
+      }
+      __syncthreads();
+      kd_member_eval_g(A.P, *A.model, N, M.x, M.g, M.wbuf);
+      __syncthreads();
+      {
+        const double frho = o.feas_rho, mu0 = o.mu_init;
+        for (int r = tid + 24; r < ng; r += NT) {
+          const double lb = lbm[r], ub = ubm[r], g = M.g[r];
+          if (lb == ub) { M.y[r] = 0.0; continue; }
+          // slack on the row value; violation variables sized so that both distances start at a comfortable value
+          double zl = 0.0, zu = 0.0, n0 = 0.0, q0 = 0.0, wl = 0.0, wu = 0.0;
+          if (lb > -INF) { const double v = lb - g; n0 = fmax(v, 0.0) + fmax(1e-2, 0.1 * fabs(v)); zl = fmin(mu0 / (g - lb + n0), 0.5 * frho); wl = frho - zl; }
+          if (ub < INF) { const double v = g - ub; q0 = fmax(v, 0.0) + fmax(1e-2, 0.1 * fabs(v)); zu = fmin(mu0 / (ub + q0 - g), 0.5 * frho); wu = frho - zu; }
+          M.s[r] = g; M.en[r] = n0; M.ep[r] = q0; M.zL[r] = zl; M.zU[r] = zu; M.wn[r] = wl; M.wp[r] = wu; M.y[r] = zu - zl;
+        }
+      }
+      __syncthreads();
+      kd_feas_point_pass(M, ng, lbm, ubm, K.mu, o.feas_rho);
+      if (tid == 0) { *M.st = K; A.done[m] = 0; atomicAdd(A.n_active, 1); }
+      return;
+    }
     // ---------------------------------------------------------------- barrier parameter (monotone)
     for (;;) {
       KD_BEGIN()
@@ -734,14 +854,14 @@ __global__ void __launch_bounds__(KD_THREADS, 2) landing_kd_iter_kernel(KdSolveA
         } else { K.flag = 0; K.tau = fmax(o.tau_min, 1.0 - mu); }
       KD_END();
       if (!K.flag) break;
-      kd_point_pass(M, ng, lbm, ubm, K.mu);
+      if (K.feas) kd_feas_point_pass(M, ng, lbm, ubm, K.mu, o.feas_rho); else kd_point_pass(M, ng, lbm, ubm, K.mu);
     }
     KD_PROF(1);
     // ================================================================ Riccati factorisation with inertia correction (IPOPT's schedule)
     KD_BEGIN()
       const double dl = K.delta_last;
       K.delta = (K.need_reg_streak >= 2 && dl > 0.0) ? fmax(1e-20, dl * o.delta_dec) : 0.0;
-      { double fl = o.delta_floor;                   // proximal term (the cost is terminal only: landing_nlp.h delta_floor)
+      { double fl = K.feas ? 0.0 : o.delta_floor;    // proximal term (the cost is terminal only: landing_nlp.h delta_floor; off in the feasibility phase)
         if (o.stag_relief > 0 && K.stag >= o.stag_relief) { for (int e = K.stag - o.stag_relief; e >= 0 && fl >= 1e-12; --e) fl *= 0.1; if (fl < 1e-12) fl = 0.0; }
         K.delta = fmax(K.delta, fl); }
       K.skipped_zero = K.delta > 0.0; K.fact_ok = 0; K.attempt = 0; K.flag = 1; K.nfact++;
@@ -768,12 +888,17 @@ __global__ void __launch_bounds__(KD_THREADS, 2) landing_kd_iter_kernel(KdSolveA
       return;
     }
   }
-  if (!K.fact_ok) {
+  if (!K.fact_ok) {      // no regularisation made the step computable: give up (status NUMERICAL) or -- once -- continue in the feasibility phase: the next
+    // round's stop test sees a non-finite error and takes that path (the point itself is kept)
+    if (o.feas_phase && !K.feas_used && !K.feas && o.max_iter > 0) {
+      if (tid == 0) { K.c_pr = INFINITY; *M.st = K; A.done[m] = 0; atomicAdd(A.n_active, 1); }
+      return;
+    }
     if (tid == 0) { K.status = LANDING_NUMERICAL; K.done = 1; *M.st = K; A.done[m] = 1; }
     return;
   }
   KD_BEGIN()
-    if (K.delta > o.delta_floor) { K.delta_last = K.delta; K.need_reg_streak++; } else K.need_reg_streak = 0;
+    if (K.delta > (K.feas ? 0.0 : o.delta_floor)) { K.delta_last = K.delta; K.need_reg_streak++; } else K.need_reg_streak = 0;
     if (K.need_reg_streak > 8) K.need_reg_streak = 0;
   KD_END();
   KD_PROF(2);
@@ -785,9 +910,31 @@ __global__ void __launch_bounds__(KD_THREADS, 2) landing_kd_iter_kernel(KdSolveA
     // clip_k rule (landing_nlp.h): while the point is far from feasible the step length comes from the clip_k-th largest ratio |ds| / distance;
     // the slacks with a larger one stop at (1 - tau) of their distance (omt > 0 in the passes below).  Without it ONE slack after the other
     // cuts the step by 1 - tau per iteration from the callers' guess (measured on the first GPU batch: a_pr 2e-1, 3e-2, 3e-3 ... 3e-15)
-    const bool clip_now = K.clip_k_cur > 1 && K.c_pr > o.clip_until;
+    const bool feas = K.feas != 0;
+    const bool clip_now = !feas && K.clip_k_cur > 1 && K.c_pr > o.clip_until;
     double top[4] = {0.0, 0.0, 0.0, 0.0};
     double m_pr = 0.0, m_du = 0.0, th0 = 0.0, bar = 0.0, dphi = 0.0, f0 = 0.0;
+    if (feas) {      // elastic rows: steps of the eliminated variables, step bounds (a, n, b, q and their multipliers stay positive), merit data
+      const double frho = o.feas_rho;
+      for (int r = tid + 24; r < ng; r += NT) {
+        const double lb = lbm[r], ub = ubm[r], g = M.g[r];
+        if (lb == ub) { th0 += fabs(g - lb); continue; }
+        const double s = M.s[r], ds = M.ds[r];
+        th0 += fabs(g - s);
+        if (lb > -INF) {
+          const double n = M.en[r], a = s - lb + n, z = M.zL[r], w = M.wn[r];
+          const ElStep e = el_step(1.0, a, n, z, w, mu, frho, ds);
+          m_pr = fmax(m_pr, fmax(-e.da / a, -e.dn / n)); m_du = fmax(m_du, fmax(-e.dz / z, -e.dw / w));
+          bar -= log(a * n); dphi += frho * e.dn - mu * (e.da / a + e.dn / n); f0 += frho * n;
+        }
+        if (ub < INF) {
+          const double q = M.ep[r], b = ub + q - s, z = M.zU[r], w = M.wp[r];
+          const ElStep e = el_step(-1.0, b, q, z, w, mu, frho, ds);
+          m_pr = fmax(m_pr, fmax(-e.da / b, -e.dn / q)); m_du = fmax(m_du, fmax(-e.dz / z, -e.dw / w));
+          bar -= log(b * q); dphi += frho * e.dn - mu * (e.da / b + e.dn / q); f0 += frho * q;
+        }
+      }
+    } else
     for (int r = tid + 24; r < ng; r += NT) {
       const double lb = lbm[r], ub = ubm[r], g = M.g[r];
       if (lb == ub) { th0 += fabs(g - lb); continue; }
@@ -808,7 +955,7 @@ __global__ void __launch_bounds__(KD_THREADS, 2) landing_kd_iter_kernel(KdSolveA
       }
       bar -= log(dprod);
     }
-    if (tid < 12) { const double d = M.x[12 * N + tid] - cost[12 + tid], qn = cost[tid]; f0 = qn * d * d; dphi += 2.0 * qn * d * M.dx[12 * N + tid]; }
+    if (tid < 12 && !feas) { const double d = M.x[12 * N + tid] - cost[12 + tid], qn = cost[tid]; f0 = qn * d * d; dphi += 2.0 * qn * d * M.dx[12 * N + tid]; }
     double v[6] = {m_pr, m_du, th0, bar, dphi, f0}; const int op[6] = {RMAX, RMAX, RSUM, RSUM, RSUM, RSUM};
     block_reduce<6>(v, op, S.red);
     if (clip_now) block_top4(top, S.red);         // (uniform: clip_now comes from K)
@@ -832,6 +979,18 @@ __global__ void __launch_bounds__(KD_THREADS, 2) landing_kd_iter_kernel(KdSolveA
     kd_member_eval_g(A.P, *A.model, N, M.xt, M.gt, M.wbuf);
     __syncthreads();
     double tht = 0.0, bt = 0.0, ft = 0.0;
+    const bool feas = K.feas != 0;
+    if (feas) {      // elastic rows at the trial step length: theta over all rows, merit = rho_pen (n + q) - mu sum of logs (mu applied below)
+      const double frho = o.feas_rho;
+      for (int r = tid + 24; r < ng; r += NT) {
+        const double lb = lbm[r], ub = ubm[r], g = M.gt[r];
+        if (lb == ub) { tht += fabs(g - lb); continue; }
+        const double s0 = M.s[r], ds = M.ds[r], s = s0 + alpha * ds;
+        tht += fabs(g - s);
+        if (lb > -INF) { const double n0 = M.en[r]; const ElStep e = el_step(1.0, s0 - lb + n0, n0, M.zL[r], M.wn[r], mu, frho, ds); const double n = n0 + alpha * e.dn; bt -= log((s - lb + n) * n); ft += frho * n; }
+        if (ub < INF) { const double q0 = M.ep[r]; const ElStep e = el_step(-1.0, ub + q0 - s0, q0, M.zU[r], M.wp[r], mu, frho, ds); const double q = q0 + alpha * e.dn; bt -= log((ub + q - s) * q); ft += frho * q; }
+      }
+    } else
     for (int r = tid + 24; r < ng; r += NT) {
       const double lb = lbm[r], ub = ubm[r], g = M.gt[r];
       if (lb == ub) { tht += fabs(g - lb); continue; }
@@ -840,7 +999,7 @@ __global__ void __launch_bounds__(KD_THREADS, 2) landing_kd_iter_kernel(KdSolveA
       tht += fabs(g - s);
       bt -= log((lb > -INF ? s - lb : 1.0) * (ub < INF ? ub - s : 1.0));
     }
-    if (tid < 12) { const double d = M.xt[12 * N + tid] - cost[12 + tid]; ft = cost[tid] * d * d; }
+    if (tid < 12 && !feas) { const double d = M.xt[12 * N + tid] - cost[12 + tid]; ft = cost[tid] * d * d; }
     { double v[3] = {tht, bt, ft}; const int op[3] = {RSUM, RSUM, RSUM}; block_reduce<3>(v, op, S.red); tht = v[0]; bt = v[1]; ft = v[2]; }
     KD_BEGIN_SYNCED()
       K.ntrial++;
@@ -860,7 +1019,7 @@ __global__ void __launch_bounds__(KD_THREADS, 2) landing_kd_iter_kernel(KdSolveA
       if (accepted) done = true;
       K.need_corr = 0;
       if (!done) {
-        if (o.slack_corr > 0.0 && alpha == K.a_pr && tht >= th0) { K.need_corr = 1; K.ft = ft; }
+        if (o.slack_corr > 0.0 && !K.feas && alpha == K.a_pr && tht >= th0) { K.need_corr = 1; K.ft = ft; }
         else { K.alpha = alpha * 0.5; if (!(K.alpha > 1e-10)) done = true; }
       }
       K.accepted = accepted ? 1 : 0; K.ls_done = done ? 1 : 0;
@@ -893,7 +1052,7 @@ __global__ void __launch_bounds__(KD_THREADS, 2) landing_kd_iter_kernel(KdSolveA
   KD_BEGIN()
     const double a_pr = K.a_pr;
     K.force_step = 0;
-    if (o.watchdog > 0) {
+    if (o.watchdog > 0 && !K.feas) {
       if (K.accepted && K.alpha <= 0.0625 * a_pr) { if (++K.cutstreak >= o.watchdog) { K.force_step = 1; K.cutstreak = 0; K.wd_count++; } }
       else K.cutstreak = 0;
     }
@@ -907,6 +1066,7 @@ __global__ void __launch_bounds__(KD_THREADS, 2) landing_kd_iter_kernel(KdSolveA
     }
     if (o.dual_step_cap > 0.0) K.a_du = fmin(K.a_du, o.dual_step_cap * K.alpha);
     K.full_prev = (K.accepted && K.alpha == 1.0 && K.a_du == 1.0 && K.attempt <= 1) ? 1 : 0;
+    if (o.feas_jam > 0) K.fjam = (!K.feas && K.alpha < 1e-2) ? K.fjam + 1 : (K.fjam > 2 ? K.fjam - 2 : 0);
   KD_END();
   if (K.fallback) {
     const double alpha = K.alpha;
@@ -918,7 +1078,41 @@ __global__ void __launch_bounds__(KD_THREADS, 2) landing_kd_iter_kernel(KdSolveA
   KD_PROF(5);
   // ================================================================ accept the trial point; errors, Sigma, rho of the new iterate
   for (int i = tid; i < nx; i += NT) M.x[i] = M.xt[i];
-  {
+  if (K.feas) {      // elastic rows: primal variables with alpha, multipliers with a_du (kept inside the kappa_Sigma band), then the quantities of the new point
+    const double alpha = K.alpha, a_du = K.a_du, mu = K.mu, frho = o.feas_rho;
+    for (int r = tid; r < ng; r += NT) {
+      const double lb = lbm[r], ub = ubm[r];
+      M.g[r] = M.gt[r];
+      if (r < 24) continue;
+      if (lb == ub) { M.y[r] = M.y[r] + alpha * (M.yn[r] - M.y[r]); continue; }
+      const double s0 = M.s[r], ds = M.ds[r], s = s0 + alpha * ds;
+      double zl = 0.0, zu = 0.0;
+      if (lb > -INF) {
+        const double n0 = M.en[r], z0 = M.zL[r], w0 = M.wn[r];
+        const ElStep e = el_step(1.0, s0 - lb + n0, n0, z0, w0, mu, frho, ds);
+        const double n = n0 + alpha * e.dn, a = s - lb + n;
+        zl = fmin(fmax(z0 + a_du * e.dz, 1e-10 * mu / a), 1e10 * mu / a);
+        M.wn[r] = fmin(fmax(w0 + a_du * e.dw, 1e-10 * mu / n), 1e10 * mu / n); M.en[r] = n;
+      }
+      if (ub < INF) {
+        const double q0 = M.ep[r], z0 = M.zU[r], w0 = M.wp[r];
+        const ElStep e = el_step(-1.0, ub + q0 - s0, q0, z0, w0, mu, frho, ds);
+        const double q = q0 + alpha * e.dn, b = ub + q - s;
+        zu = fmin(fmax(z0 + a_du * e.dz, 1e-10 * mu / b), 1e10 * mu / b);
+        M.wp[r] = fmin(fmax(w0 + a_du * e.dw, 1e-10 * mu / q), 1e10 * mu / q); M.ep[r] = q;
+      }
+      M.s[r] = s; M.zL[r] = zl; M.zU[r] = zu; M.y[r] = zu - zl;
+    }
+    __syncthreads();
+    kd_feas_point_pass(M, ng, lbm, ubm, mu, frho);
+    KD_BEGIN()
+      K.it++;
+      { const long long n_ = (long long)wall_clock64(); K.prof[6] += (double)(n_ - K.tp); K.tp = n_; }
+      *M.st = K;
+      A.done[m] = 0;
+      atomicAdd(A.n_active, 1);
+    KD_END();
+  } else {
     const double alpha = K.alpha, a_du = K.a_du, mu = K.mu, s_corr = K.s_corr, omt = K.omt;
     double npr = 0.0, nco = 0.0, ncm = 0.0, nys = 0.0, nzs = 0.0, nnz = 0.0;
     for (int r = tid; r < ng; r += NT) {
@@ -974,7 +1168,7 @@ __global__ void __launch_bounds__(KD_THREADS) landing_kd_finish_kernel(KdSolveAr
   const double INF = INFINITY;
   KdLds& S = KSH;
   const int oU = 12 * (N + 1) + 12 * N;
-  kd_grad_lag(M, N, cost);
+  kd_grad_lag(M, N, cost, 1.0);
   // multipliers of the fixed rows from stationarity of X(:,1), c(:,1): lam = -(grad f + J' y)
   if (tid < 24) M.y[tid] = -M.gx[tid < 12 ? tid : oU + (tid - 12)];
   double du = 0.0, fo = 0.0;
