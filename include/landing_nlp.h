@@ -515,7 +515,12 @@ int landing_kinodyn_nlp_hess(landing_ctx* ctx, int B, int N, const double* d_x, 
  *                            (Xref 12 x (N+1) x B, Uref 24 x N x B (inactive, may be NULL), dt 1 x N x B, 6-vectors 6 x B, c_init 12 x B, QN 12 x B,
  *                            x0 nx x B, jpos_min / jpos_max 12 x B, kin_box 2 x B, mu / l_leg_max / mass 1 x B, Ib / Ib_inv 3 x B); dt, mu, mass, Ib,
  *                            Ib_inv must be the same for every member of one call (they are constants of every caller in the reference).
- * Needs landing_rbd_set_model.  N = number of intervals (the script's N - 1 = 20), N <= 64.                                                 */
+ * Needs landing_rbd_set_model.  N = number of intervals (the script's N - 1 = 20), N <= 64.
+ * Options: landing_kinodyn_solver_opts_default = landing_solver_opts_default with max_iter 500, bound_push = bound_frac = 0.01, mu_init 0.1, theta_mu 1.5
+ * and feas_jam 0.  The feasibility (restoration) phase of landing_solve_batch exists here too (round 5; feas_phase, feas_rho, feas_cert, feas_stat): a member
+ * that would end as NUMERICAL / MAX_ITER continues on the elastic problem and ends as a KKT point of the original NLP, with a certificate of local
+ * infeasibility (status 3), or undecided.  The host-array entry points re-solve the few members a first pass leaves undecided with two other slack / barrier
+ * initialisations when the caller passes no options (retry ladder).                                                                              */
 typedef struct {
   double comp_eps, slip_eps;      /* :139  f_z c_z <= 1e-3;  :142-143  |f_z (c+ - c)| <= 1e-3 */
   double fk_band;                 /* :186-187  |c - FK(q, jpos)| <= 0.01 */
