@@ -241,8 +241,10 @@ landing_ctx* landing_create(int N, int device, const landing_form* form) {
   landing_ctx* c = new landing_ctx();
   c->L = landing::make_layout(N);
   c->device = device;
+#ifdef LANDING_DEV_SWITCHES      // development builds only (tools/dev): environment switches of the measurements recorded in profiles/r0*_ab_experiments.txt
   { const char* e = getenv("LANDING_SWEEP_SERIAL"); c->sweep_concurrent = !(e && e[0] == '1'); }
   { const char* e = getenv("LANDING_SWEEP_SPLIT"); if (e && e[0] >= '0' && e[0] <= '3') c->sweep_split = e[0] - '0'; }
+#endif
   {  // positions of the U_k Jacobian entries of stages 0 / N-1 inside the uniform (middle-stage) emission sequence
     struct RecCodes { std::vector<int>* v; void col() {} void end() {} void put(int r, double) { v->push_back(r); } };
     std::vector<int> cx, cu;
