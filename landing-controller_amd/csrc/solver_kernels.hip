@@ -568,17 +568,23 @@ __device__ __noinline__ bool block_eliminate(double* __restrict__ rec, double de
   const double* Ah = S.Ah + cb * (12 * YS);
   const double* bv = S.bv + cb * 12;
   f64x4 T[3];
+  // Every operand of the prologue is ONE unconditional LDS load: where a lane has no operand (dead column, row outside the array, structural zero)
+  // the index points at a slot that holds 0.0 (cx's constant).  Written as `cond ? S.Ah[i] : 0.0` the compiler turned each of the ~40 operand fetches
+  // into a branch around a load with a wait behind it -- a chain of LDS round trips, 1.4 us of the 7 us a stage takes (round 5).
+  const double* const lds0 = reinterpret_cast<const double*>(&S);
+  const int oG = (int)(offsetof(Lds, G) / sizeof(double)), oGam = (int)(offsetof(Lds, gam) / sizeof(double)), oP = (int)(offsetof(Lds, P) / sizeof(double)),
+            oPv = (int)(offsetof(Lds, pv) / sizeof(double)), oAh = (int)(offsetof(Lds, Ah) / sizeof(double)) + cb * (12 * YS), oBv = (int)(offsetof(Lds, bv) / sizeof(double)) + cb * 12,
+            oZ = (int)(offsetof(Lds, jhl) / sizeof(double)) + CX_ZERO;
   {   // tile fetch: every lane walks its own column of the condensed G (the assembly fills the upper triangle only) / of gamma; delta_w on the diagonal
-    const double* const lds0 = reinterpret_cast<const double*>(&S);      // one branch-free load per element: offsets (doubles) from the start of the LDS block
-    const int oG = (int)(offsetof(Lds, G) / sizeof(double)), oGam = (int)(offsetof(Lds, gam) / sizeof(double));
 #pragma unroll
     for (int rt = 0; rt < 3; ++rt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int rho = 16 * rt + lk + 4 * r;
         const int a = rho < NU ? 24 + rho : (rho < NR ? rho - NU : 0);
-        const double v = lds0[isg ? oGam + a : oG + (a < bcol ? a * GS + bcol : bcol * GS + a)] + (rho == c ? delta : 0.0);
-        T[rt][r] = (live && rho < NR) ? v : 0.0;
+        const bool in = live && rho < NR;
+        const double v = lds0[in ? (isg ? oGam + a : oG + (a < bcol ? a * GS + bcol : bcol * GS + a)) : oZ] + (rho == c ? delta : 0.0);
+        T[rt][r] = in ? v : 0.0;
       }
     if (S.rc_on) {      // (uniform) + gradient of the running cost of the stage's variables (X, c, f) in the column of gamma
 #pragma unroll
@@ -599,42 +605,42 @@ __device__ __noinline__ bool block_eliminate(double* __restrict__ rec, double de
     const bool cplus = live && !isg && bcol >= 36;
     double be[3];
 #pragma unroll
-    for (int kt = 0; kt < 3; ++kt) {
-      const double va = Ah[(4 * kt + lk) * YS + (bcol < 36 ? bcol : 0)], vb = bv[4 * kt + lk];
-      be[kt] = isg ? vb : ((live && bcol < 36) ? va : 0.0);
-    }
-    f64x4 Y1 = {0.0, 0.0, 0.0, 0.0};
+    for (int kt = 0; kt < 3; ++kt) be[kt] = lds0[isg ? oBv + 4 * kt + lk : ((live && bcol < 36) ? oAh + (4 * kt + lk) * YS + bcol : oZ)];
+    double pa1[3], add1[3];
 #pragma unroll
-    for (int kt = 0; kt < 3; ++kt) Y1 = __builtin_amdgcn_mfma_f64_16x16x4f64(S.P[lj * PS + 4 * kt + lk], be[kt], Y1, 0, 0, 0);
+    for (int kt = 0; kt < 3; ++kt) pa1[kt] = lds0[oP + lj * PS + 4 * kt + lk];
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      const int row = lk + 4 * r;
-      const double dp = S.P[row * PS + (cplus ? 12 + bcol - 36 : 0)], dv = S.pv[row];
-      Y1[r] += cplus ? dp : (isg ? dv : 0.0);
-    }
+    for (int r = 0; r < 3; ++r) { const int row = lk + 4 * r; add1[r] = lds0[cplus ? oP + row * PS + 12 + bcol - 36 : (isg ? oPv + row : oZ)]; }
+    double av[3][3];
 #pragma unroll
     for (int rt = 0; rt < 3; ++rt) {
       const int rho = 16 * rt + lj;
       const int a = rho < NU ? 24 + rho : (rho < NR ? rho - NU : 99);
 #pragma unroll
-      for (int kt = 0; kt < 3; ++kt) {
-        const double av = Ah[(4 * kt + lk) * YS + (a < 36 ? a : 0)];
-        T[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a < 36 ? av : 0.0, Y1[kt], T[rt], 0, 0, 0);
-      }
+      for (int kt = 0; kt < 3; ++kt) av[rt][kt] = lds0[a < 36 ? oAh + (4 * kt + lk) * YS + a : oZ];
     }
+    double pa2[3], add2[3];
+    if (NU == 24) {
+#pragma unroll
+      for (int kt = 0; kt < 3; ++kt) pa2[kt] = lds0[lj < 12 ? oP + (12 + lj) * PS + 4 * kt + lk : oZ];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) { const int row = 12 + lk + 4 * r; add2[r] = lds0[cplus ? oP + row * PS + 12 + bcol - 36 : (isg ? oPv + row : oZ)]; }
+    }
+    f64x4 Y1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kt = 0; kt < 3; ++kt) Y1 = __builtin_amdgcn_mfma_f64_16x16x4f64(pa1[kt], be[kt], Y1, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 3; ++r) Y1[r] += add1[r];
+#pragma unroll
+    for (int rt = 0; rt < 3; ++rt)
+#pragma unroll
+      for (int kt = 0; kt < 3; ++kt) T[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[rt][kt], Y1[kt], T[rt], 0, 0, 0);
     if (NU == 24) {   // rows of c+ (control rows 12..23): + rows 12..23 of P T
       f64x4 Y2 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-      for (int kt = 0; kt < 3; ++kt) {
-        const double pa = S.P[(lj < 12 ? 12 + lj : 0) * PS + 4 * kt + lk];
-        Y2 = __builtin_amdgcn_mfma_f64_16x16x4f64(lj < 12 ? pa : 0.0, be[kt], Y2, 0, 0, 0);
-      }
+      for (int kt = 0; kt < 3; ++kt) Y2 = __builtin_amdgcn_mfma_f64_16x16x4f64(pa2[kt], be[kt], Y2, 0, 0, 0);
 #pragma unroll
-      for (int r = 0; r < 3; ++r) {
-        const int row = 12 + lk + 4 * r;
-        const double dp = S.P[row * PS + (cplus ? 12 + bcol - 36 : 0)], dv = S.pv[row];
-        Y2[r] += cplus ? dp : (isg ? dv : 0.0);
-      }
+      for (int r = 0; r < 3; ++r) Y2[r] += add2[r];
       T[0][3] += Y2[0]; T[1][0] += Y2[1]; T[1][1] += Y2[2];
     }
   }
@@ -671,8 +677,8 @@ __device__ __noinline__ bool block_eliminate(double* __restrict__ rec, double de
     f64x4 Mq = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int kt = 0; kt < 3; ++kt) {
-      const double af = Ah[(lj < 12 ? lj : 0) * YS + 24 + 4 * kt + lk];
-      Mq = __builtin_amdgcn_mfma_f64_16x16x4f64(lj < 12 ? af : 0.0, T[0][kt], Mq, 0, 0, 0);
+      const double af = lds0[lj < 12 ? oAh + lj * YS + 24 + 4 * kt + lk : oZ];
+      Mq = __builtin_amdgcn_mfma_f64_16x16x4f64(af, T[0][kt], Mq, 0, 0, 0);
     }
     if (c >= NU && c <= NR) {
 #pragma unroll
