@@ -91,7 +91,12 @@ struct SolverWorkspace {
 };
 
 // optional per-member phase timers (wall_clock64 ticks, 100 MHz) -- enabled when SolveArgs.prof != nullptr
-enum { PH_EVAL = 0, PH_ERR, PH_SIGRHO, PH_BACK, PH_FWD, PH_DUAL, PH_LS, PH_ACCEPT, PH_NFACT, PH_NTRIAL, PH_NITER, PH_NSTAGE_OK, PH_B_ASM, PH_NSTAGE, PH_B_ELIM, PH_B_POST, PH_COUNT = 16 };   // 11 / 13: stage eliminations that succeeded / were attempted (stage-0 foot block included)
+enum { PH_EVAL = 0, PH_ERR, PH_SIGRHO, PH_BACK, PH_FWD, PH_DUAL, PH_LS, PH_ACCEPT, PH_NFACT, PH_NTRIAL, PH_NITER, PH_NSTAGE_OK, PH_B_ASM, PH_NSTAGE, PH_B_ELIM, PH_B_POST,
+#ifdef LANDING_STAGE_PROF      // development build (tools/dev/stage_prof.py): time of wave 0 between marks inside block_eliminate, slots 16..
+       PH_COUNT = 32 };
+#else
+       PH_COUNT = 16 };
+#endif   // 11 / 13: stage eliminations that succeeded / were attempted (stage-0 foot block included)
 #define PROF_ADD(slot, tstart) do { if (SH.prof_on) { const long long n_ = (long long)wall_clock64(); if (threadIdx.x == 0) { SH.prof[slot] += (double)(n_ - (tstart)); (tstart) = n_; } } } while (0)
 
 struct SolveArgs {
@@ -196,6 +201,9 @@ struct IpmState {
 enum { ACT_GO = 0, ACT_STOP = 1, ACT_RESET = 2, ACT_FEAS = 3, ACT_BACK = 4 };
 
 // LDS of one member
+#ifndef LANDING_PIVOT_2X2
+#define LANDING_PIVOT_2X2 1        // the 4 x 4 pivot block through its 2 x 2 partition (pivot_block_step; 0: LDL^T + two triangular solves, rounds 2-4)
+#endif
 #ifndef LANDING_PIVOT_BLOCK
 #define LANDING_PIVOT_BLOCK 4      // pivot-block size of the fp64 stage elimination (8: built, measured, slower -- pivot_block_step)
 #endif
@@ -210,7 +218,7 @@ struct Lds {
   double gam[48], pv[24], q[24], bv[2 * 12], sig[24], w[48], dinv[24];
   double red[(SOLVER_THREADS / 64) * 6];
   double filt_th[FILT_CAP], filt_ph[FILT_CAP];
-  double prof[16];
+  double prof[32];
   int flag;
   // member context, written once by every thread with identical values (read back as LDS broadcasts by the
   // __noinline__ phases so that they carry no register state across calls)
@@ -500,6 +508,31 @@ __device__ __forceinline__ bool pivot_block_step(f64x4 (&T)[3], int ct, int lj, 
 #pragma unroll
     for (int rt = 0; rt < 3; ++rt) { const int row = 16 * rt + lj; const double cv = C[row * PS + 4 * q + lk]; am[q][rt] = (row >= OFF && row < OFF + PS) ? 0.0 : cv; }   // pivot rows: no update
   auto recip = [](double d) { double i = __builtin_amdgcn_rcp(d); i = fma(i, fma(-d, i, 1.0), i); return fma(i, fma(-d, i, 1.0), i); };
+#if LANDING_PIVOT_2X2
+  static_assert(PS == 4, "2 x 2 partitioned pivot block");
+  // The 4 x 4 pivot block through its 2 x 2 partition  D = [A B^T; B C]:  A^-1 from its determinant, E = B A^-1, Schur complement S = C - E B^T, S^-1 from its
+  // determinant, then  r_2 = S^-1 (w_2 - E w_1),  r_1 = A^-1 w_1 - E^T r_2.  Two reciprocals on the serial chain instead of four and ~24 dependent operations
+  // instead of ~64 of the LDL^T + two triangular solves (every lane computes this between the barrier and its matrix-core update: it is latency, not
+  // throughput).  Inertia: the four leading principal minors a00, det A, det A * s00, det A * det S are positive exactly when the four pivots of the
+  // unblocked elimination are (Sylvester), so the test -- a00, det A, s00, det S in (2^-1022, ~1e300) -- accepts the same matrices up to rounding.
+  const double a00 = a[0][0], a10 = a[1][0], a11 = a[1][1], a20 = a[2][0], a21 = a[2][1], a22 = a[2][2], a30 = a[3][0], a31 = a[3][1], a32 = a[3][2], a33 = a[3][3];
+  const double detA = fma(a00, a11, -a10 * a10), iA = recip(detA);
+  const double e00 = fma(a20, a11, -a21 * a10) * iA, e01 = fma(a21, a00, -a20 * a10) * iA, e10 = fma(a30, a11, -a31 * a10) * iA, e11 = fma(a31, a00, -a30 * a10) * iA;
+  const double s00 = fma(-e01, a21, fma(-e00, a20, a22)), s10 = fma(-e11, a21, fma(-e10, a20, a32)), s11 = fma(-e11, a31, fma(-e10, a30, a33));
+  const double detS = fma(s00, s11, -s10 * s10), iS = recip(detS);
+  unsigned hm = 0u;
+  { const double piv[4] = {a00, detA, s00, detS};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const unsigned h = (unsigned)__double2hiint(piv[j]) - 0x00100000u; hm = h > hm ? h : hm; } }
+  const bool ok = hm < (0x7e37e43cu - 0x00100000u);
+  auto solve = [&](const double (&wv)[PS], double (&R)[NQ]) {
+    const double t2 = fma(-e01, wv[1], fma(-e00, wv[0], wv[2])), t3 = fma(-e11, wv[1], fma(-e10, wv[0], wv[3]));
+    const double r2 = fma(s11, t2, -s10 * t3) * iS, r3 = fma(s00, t3, -s10 * t2) * iS;
+    const double q0 = fma(a11, wv[0], -a10 * wv[1]) * iA, q1 = fma(a00, wv[1], -a10 * wv[0]) * iA;
+    const double r0 = fma(-e10, r3, fma(-e00, r2, q0)), r1 = fma(-e11, r3, fma(-e01, r2, q1));
+    R[0] = lk == 0 ? r0 : (lk == 1 ? r1 : (lk == 2 ? r2 : r3));
+  };
+#else
   // D = L diag(d) L^T: t[i][j] = l[i][j] d[j] = a[i][j] - sum_{k<j} l[i][k] t[j][k]
   double l[PS][PS], t[PS][PS], inv[PS];
   unsigned hm = 0u;
@@ -542,6 +575,7 @@ __device__ __forceinline__ bool pivot_block_step(f64x4 (&T)[3], int ct, int lj, 
 #pragma unroll
     for (int q = 0; q < NQ; ++q) R[q] = lk == 0 ? r[4 * q] : (lk == 1 ? r[4 * q + 1] : (lk == 2 ? r[4 * q + 2] : r[4 * q + 3]));
   };
+#endif
   double R[NQ];
   solve(w, R);
   if (16 * ct + 16 > OFF) {                              // tiles whose columns are all eliminated already stay as they are
@@ -567,6 +601,12 @@ __device__ __noinline__ bool block_eliminate(double* __restrict__ rec, double de
   const int cb = k & 1;
   const double* Ah = S.Ah + cb * (12 * YS);
   const double* bv = S.bv + cb * 12;
+#ifdef LANDING_STAGE_PROF
+  long long stg_t_ = SH.prof_on ? (long long)wall_clock64() : 0;
+#define STG_T(i) do { if (SH.prof_on && threadIdx.x == 0) { const long long n_ = (long long)wall_clock64(); SH.prof[16 + (i)] += (double)(n_ - stg_t_); stg_t_ = n_; } } while (0)
+#else
+#define STG_T(i) do { } while (0)
+#endif
   f64x4 T[3];
   // Every operand of the prologue is ONE unconditional LDS load: where a lane has no operand (dead column, row outside the array, structural zero)
   // the index points at a slot that holds 0.0 (cx's constant).  Written as `cond ? S.Ah[i] : 0.0` the compiler turned each of the ~40 operand fetches
@@ -656,18 +696,28 @@ __device__ __noinline__ bool block_eliminate(double* __restrict__ rec, double de
 #define LANDING_DEV_ASM_LEVEL 3
 #endif
 #define ASM_HOOK(step) do { if constexpr (SC == (step) && LANDING_DEV_ASM_LEVEL >= 1) { if (more) asm_copy(nxt); } if constexpr (SC + 1 == (step) && LANDING_DEV_ASM_LEVEL >= 2) { if (more) asm_terms(k - 1, cb ^ 1, nxt); } if constexpr (SC + 2 == (step) && LANDING_DEV_ASM_LEVEL >= 3) { if (more) asm_combine(k - 1, cb ^ 1); } } while (0)
+  STG_T(0);      // prologue
   bool ok = pivot_block_step<NU, (PB > NU ? NU : PB), 0, 0>(T, ct, lj, lk, c);
+  STG_T(1);      // block step 0
   if (more && LANDING_DEV_ASM_LEVEL >= 1) asm_issue(k - 1, nxt);
+  STG_T(2);      // asm_issue
   ASM_HOOK(1);
   if constexpr (NU > PB) ok &= pivot_block_step<NU, (NU - PB >= PB ? PB : NU - PB), PB, 1>(T, ct, lj, lk, c);
   ASM_HOOK(2);
   if constexpr (NU > 2 * PB) ok &= pivot_block_step<NU, (NU - 2 * PB >= PB ? PB : NU - 2 * PB), 2 * PB, 2>(T, ct, lj, lk, c);
+  STG_T(3);      // block steps 1, 2
   ASM_HOOK(3);
+  STG_T(4);      // asm_copy (NU = 24)
   if constexpr (NU > 3 * PB) ok &= pivot_block_step<NU, (NU - 3 * PB >= PB ? PB : NU - 3 * PB), 3 * PB, 3>(T, ct, lj, lk, c);
+  STG_T(5);      // block step 3
   ASM_HOOK(4);
+  STG_T(6);      // asm_terms
   if constexpr (NU > 4 * PB) ok &= pivot_block_step<NU, (NU - 4 * PB >= PB ? PB : NU - 4 * PB), 4 * PB, 4>(T, ct, lj, lk, c);
+  STG_T(7);      // block step 4
   ASM_HOOK(5);
+  STG_T(8);      // asm_combine
   if constexpr (NU > 5 * PB) ok &= pivot_block_step<NU, (NU - 5 * PB >= PB ? PB : NU - 5 * PB), 5 * PB, 5>(T, ct, lj, lk, c);
+  STG_T(9);      // block step 5
   ASM_HOOK(6);
 #undef ASM_HOOK
   if (!ok) return false;                                 // (identical in every lane)
@@ -707,6 +757,7 @@ __device__ __noinline__ bool block_eliminate(double* __restrict__ rec, double de
         }
       }
   }
+  STG_T(10);     // epilogue
   return true;
 }
 
@@ -1060,7 +1111,7 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
   for (int e = lane; e < 64; e += NT) S.dump[e] = 0.0;
   for (int e = lane; e < A.c_ml * SOLVER_THREADS; e += NT) S.atab_mid[e] = A.ctab[(size_t)A.c_mid * A.c_ml * SOLVER_THREADS + e];      // term table of the most frequent stage type
   if (lane == 0) { S.jhl[CX_ONE] = 1.0; S.jhl[CX_MONE] = -1.0; S.jhl[CX_ZERO] = 0.0; }
-  if (lane < 16) S.prof[lane] = 0.0;
+  if (lane < 32) S.prof[lane] = 0.0;
   {   // condensation: segment bases of every stage, packed term table of the most frequent stage type
     const int nj = L.nnz_jac, nh = L.nnz_hess;
     for (int k = lane; k < N; k += NT) {
