@@ -165,7 +165,10 @@ typedef struct {
                             time cuts every step to 1..10 % for 3-4 iterations until its multiplier has grown (round-2 traces,
                             DESIGN.md 4.2); letting the few worst jam together instead of one after the other: mean 63 -> 53
                             iterations, slowest member of eight seeded batches 160..246 -> 100..133, inertia-failure retries
-                            1.28 -> 1.15 sweeps per iteration (tests/dev/ipm_lab.py).  0 / 1 = the classic rule (IPOPT)             */
+                            1.28 -> 1.15 sweeps per iteration (tests/dev/ipm_lab.py).  0 / 1 = the classic rule (IPOPT).
+                            landing_kinodyn_solve_batch also takes values above 4 (default there 16, round 5): the step length that
+                            leaves at most clip_k - 1 slacks blocked, from a histogram of the ratios over half-octaves (never below
+                            the 4-slack rule's); landing_solve_batch treats values above 4 as 4                                    */
   double clip_until;     /* ... applied only while the primal infeasibility (max norm, slack rows included) is above this value
                             (default 0.03): close to feasibility the classic rule is kept -- without the switch 1 member in 1000
                             parks at pr ~ 2e-2 with diverging multipliers                                                     */
@@ -284,6 +287,20 @@ typedef struct {
                             elastic problem's optimality error is the polishing of its last barrier problems, which took 200+ iterations
                             of wandering full steps for such members), otherwise the solve restarts from the point like after an
                             elastic KKT point.  kkt[0] is the violation in both cases                                                  */
+  int kd_clone_after;    /* (round 5, landing_kinodyn_solve_batch only; landing_solve_batch ignores the three kd_ fields) PORTFOLIO of the
+                            kinodynamic refinement: after this many rounds of the lock-step loop every member that is still iterating
+                            is posed AGAIN, from the callers' initial guess, in three clone slots under three other option sets (the step
+                            rule with 16 clipped slacks | the same with bound_push = bound_frac = 0.1 | mu_init = 1); a second wave
+                            follows after twice as many rounds for members that had no slot in the first.  The first member of such
+                            a family (the original included) that converges ends the others and is reported under the original's
+                            index (x, lam_g, kkt, iters = that member's own count).  0 = off.  Why: which member of a batch is
+                            slow depends on the path, not on the problem -- of 5 bench batches of 1024 (law "main") three hold a
+                            member that needs 400 .. 1000 iterations (batch 1.1 .. 2.0 s instead of 0.72 s: the loop runs as long
+                            as its slowest member), and each of these members converges in 28 .. 73 iterations under at least one
+                            of the three sets (profiles/r05_ab_experiments.txt).  Default of landing_kinodyn_solver_opts_default:
+                            see there; 0 in landing_solver_opts_default                                                              */
+  int kd_clone_max;      /* families per wave (workspace: 2 waves x 3 variants x kd_clone_max member blocks behind the batch)          */
+  int kd_clone_iter;     /* iteration limit of a clone (its feasibility phase included in the usual way: limit + limit); 0 = 200      */
 } landing_solver_opts;
 
 /* status codes written per batch member by landing_solve_batch */

@@ -92,6 +92,7 @@ void landing_solver_opts_default(landing_solver_opts* o) {
   o->delta_init = 1e-4; o->delta_inc_first = 10.0; o->delta_inc = 4.0; o->delta_dec = 0.5; o->tau_min = 0.9; o->alpha_fallback = 1e-2;
   o->stage_local_reg = 0; o->sticky_delta = 0; o->restart_period = 75; o->reset_delta = 1e5; o->dispatch_order = 1;
   o->clip_k = 4; o->clip_until = 0.03; o->theta_floor = 30.0; o->fresh_restart = 9; o->dual_step_cap = 1.0; o->slack_corr = 0.9; o->watchdog = 3; o->barrier_smax = 1.0; o->factor_fp32 = 0; o->jam_clip = 2; o->stag_relief = 3; o->feas_jam = 8; o->feas_stat = 25;
+  o->kd_clone_after = 0; o->kd_clone_max = 0; o->kd_clone_iter = 0;
   o->feas_phase = 1; o->feas_rho = 1000.0; o->feas_cert = 1e-4;
   o->delta_floor = 3e-4;
 }

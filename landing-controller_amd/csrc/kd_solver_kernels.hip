@@ -52,7 +52,7 @@ struct KdState {
   double filt_th[KD_FILT], filt_ph[KD_FILT];
   int nfilt, it, status, done, need_reg_streak, first_failed, cutstreak, force_step, wd_count, last_mu_it;
   int accepted, armijo_step, fact_ok, skipped_zero, attempt, flag, ls_done, need_corr, fallback, nfact, ntrial, nreset;
-  int last_reset_it, ncrawl, clip_k_cur, fresh;
+  int last_reset_it, ncrawl, clip_k_cur, fresh, reg_it;
   int pending;      // the inertia correction of this iteration continues in the next launch (landing_kd_iter_kernel, KD_TRIES_PER_ROUND)
   int stag, full_prev; double e_prev;      // stag_relief (landing_nlp.h): full steps of the last barrier problem that did not halve the error
   // feasibility (restoration) phase, round 5 -- the scheme of landing_ipm_kernel (solver_kernels.hip, landing_nlp.h feas_phase / feas_jam / feas_stat):
@@ -96,7 +96,21 @@ struct KdSolveArgs {
   double* x_out; double* f_out; double* lam_out; int* status; int* iters; double* kkt;
   int* n_active;           // number of members still iterating (written by the iteration kernel)
   int* done;               // [B] 1 = the member has finished (read by the function-layer kernels: finished members are skipped)
+  // Portfolio (round 5, landing_nlp.h kd_clone_after): members B0 .. B-1 are CLONE slots -- workspace blocks without a problem of their own.  After
+  // kd_clone_after rounds the members still iterating are posed again in KD_NVAR clone slots each, from the callers' guess under another option set
+  // (ov[v]); the first member of such a family that converges ends the others, the finish kernel reports it under the original's index.
+  int B0, F, m_lo;         // clone slot of (wave w, variant v, family i) = B0 + ((w * KD_NVAR + v) * F + i); m_lo: first member of an init launch
+  int* src;                // [B - B0] the original of a clone slot, -1 = unused
+  int* win;                // [B0] first member of the family of original a that converged (-1: none yet)
+  int* cloned;             // [B0] 1 = the original has clones
+  landing_solver_opts ov[3];
 };
+#ifndef KD_NVAR_DEF
+#define KD_NVAR_DEF 3
+#endif
+constexpr int KD_NVAR = KD_NVAR_DEF, KD_NWAVE = 2;
+__device__ __forceinline__ int kd_problem_of(const KdSolveArgs& A, int m) { return m < A.B0 ? m : A.src[m - A.B0]; }
+__device__ __forceinline__ const landing_solver_opts& kd_opts_of(const KdSolveArgs& A, int m) { return m < A.B0 ? A.o : A.ov[((m - A.B0) / A.F) % KD_NVAR]; }
 
 // variable j of v = (X_k, c_k, f_k, jpos_k, c_k+1) -> column of the interval's block over w = (X_k, c_k, f_k, jpos_k, X_k+1, c_k+1)
 __host__ __device__ inline int kd_v2w(int j) { return j < 48 ? j : j + 12; }
@@ -135,6 +149,7 @@ struct KdLds {
   double dsg[KD_NSIG * 65];            // d sigma_k of every knot (N <= 64)
   double dxw[KD_NW];
   double red[(KD_THREADS / 64) * 6];
+  int hist[64];                        // clip_k > 4: histogram of the blocking slacks over half-octaves of |ds| / distance
   int flag;
   KdState ks;
 };
@@ -629,14 +644,17 @@ KD_PHASE void kd_init_slacks(const KdMem& M, int ng, const double* lbm, const do
 
 // ---- start of a solve: initial point, slacks, multipliers, iteration state ------------------------------------------------------
 __global__ void __launch_bounds__(KD_THREADS) landing_kd_init_kernel(KdSolveArgs A) {
-  const int m = blockIdx.x;
+  const int m = blockIdx.x + A.m_lo;
   if (m >= A.B) return;
+  const int pm = kd_problem_of(A, m);      // (clone slots: the original's problem data, the variant's options)
+  if (pm < 0) return;
+  const landing_solver_opts& o = kd_opts_of(A, m);
   const int N = A.N, nx = kd_nx(N), ng = kd_ng(N), tid = threadIdx.x, NT = blockDim.x;
   const KdMem M = kd_carve(N, A.ws + (size_t)m * A.ws_stride);
-  const double* lbm = A.lb + (size_t)m * ng; const double* ubm = A.ub + (size_t)m * ng;
+  const double* lbm = A.lb + (size_t)pm * ng; const double* ubm = A.ub + (size_t)pm * ng;
   const int oU = 12 * (N + 1) + 12 * N;
   for (int i = tid; i < nx; i += NT) {
-    double v = A.x0[(size_t)m * nx + i];
+    double v = A.x0[(size_t)pm * nx + i];
     if (i < 12) v = lbm[i];                                  // X(:,1) and c(:,1) are fixed (:89-91)
     else if (i >= oU && i < oU + 12) v = lbm[12 + (i - oU)];
     M.x[i] = v;
@@ -644,15 +662,15 @@ __global__ void __launch_bounds__(KD_THREADS) landing_kd_init_kernel(KdSolveArgs
   __syncthreads();
   kd_member_eval_g(A.P, *A.model, N, M.x, M.g, M.wbuf);
   __syncthreads();
-  kd_init_slacks(M, ng, lbm, ubm, A.o);
+  kd_init_slacks(M, ng, lbm, ubm, o);
   KdState& K = KSH.ks;
   if (tid == 0) {
-    K.mu = A.o.mu_init; K.delta_last = 0.0; K.th_max = 0.0; K.c_pr = K.c_co = K.c_cm = K.c_ys = K.c_zs = 0.0; K.c_nz = 1.0;
+    K.mu = o.mu_init; K.delta_last = 0.0; K.th_max = 0.0; K.c_pr = K.c_co = K.c_cm = K.c_ys = K.c_zs = 0.0; K.c_nz = 1.0;
     K.e_pr = K.e_du = K.e_co = 0.0; K.tau = 0.0; K.a_pr = K.a_du = 0.0; K.th0 = K.ph0 = K.dphi = K.alpha = K.s_corr = K.delta = K.ft = K.fval = 0.0; K.omt = -1.0;
     K.nfilt = 0; K.it = 0; K.status = LANDING_MAX_ITER; K.done = 0; K.need_reg_streak = 0; K.first_failed = 0; K.cutstreak = 0; K.force_step = 0;
     K.wd_count = 0; K.last_mu_it = 0; K.accepted = 0; K.armijo_step = 0; K.fact_ok = 0; K.skipped_zero = 0; K.attempt = 0; K.flag = 0; K.ls_done = 0;
-    K.need_corr = 0; K.fallback = 0; K.nfact = 0; K.ntrial = 0; K.nreset = 0; K.last_reset_it = 0; K.ncrawl = 0; K.clip_k_cur = A.o.clip_k; K.fresh = 0; K.pending = 0; K.stag = 0; K.full_prev = 0; K.e_prev = 1e300;
-    K.feas = 0; K.feas_used = 0; K.lim = A.o.max_iter; K.fjam = 0; K.fstat = 0; K.v1_ref = 0.0; K.c_rn = 0.0; K.f_vmax = 0.0; K.f_v1 = 0.0;
+    K.need_corr = 0; K.fallback = 0; K.nfact = 0; K.ntrial = 0; K.nreset = 0; K.last_reset_it = 0; K.ncrawl = 0; K.clip_k_cur = o.clip_k; K.fresh = 0; K.reg_it = -1000; K.pending = 0; K.stag = 0; K.full_prev = 0; K.e_prev = 1e300;
+    K.feas = 0; K.feas_used = 0; K.lim = o.max_iter; K.fjam = 0; K.fstat = 0; K.v1_ref = 0.0; K.c_rn = 0.0; K.f_vmax = 0.0; K.f_v1 = 0.0;
     for (int i = 0; i < 8; ++i) K.prof[i] = 0.0; K.tp = 0;
   }
   __syncthreads();
@@ -671,13 +689,16 @@ __global__ void __launch_bounds__(KD_THREADS) landing_kd_init_kernel(KdSolveArgs
   }
   viol = block_reduce1(viol, RMAX, KSH.red);
   if (tid == 0) {
-    if (viol > A.o.tol) { K.status = LANDING_INFEASIBLE; K.done = 1; K.e_pr = viol; }
+    if (viol > o.tol) { K.status = LANDING_INFEASIBLE; K.done = 1; K.e_pr = viol; }
     *M.st = K;
     A.done[m] = K.done;
   }
 }
 
 // ---- one interior-point iteration of one member (J and H blocks of the current (x, y) are in the workspace) ---------------------------
+#ifndef KD_DELTA_JUMP
+#define KD_DELTA_JUMP 12     // (round 5; 0 = off: rounds 3-4)
+#endif
 #ifndef KD_TRIES_PER_ROUND
 #define KD_TRIES_PER_ROUND 3      // (round 5: 3 with the matrix-core elimination, 0.7 instead of 1.8 ms per attempt -- 1.23 -> 1.07 s per batch of 1024; round 4: 1)
 #endif
@@ -686,10 +707,16 @@ __global__ void __launch_bounds__(KD_THREADS, 2) landing_kd_iter_kernel(KdSolveA
   if (m >= A.B) return;
   const int N = A.N, nx = kd_nx(N), ng = kd_ng(N), tid = threadIdx.x, NT = blockDim.x;
   const KdMem M = kd_carve(N, A.ws + (size_t)m * A.ws_stride);
+  const int pm = kd_problem_of(A, m);
+  if (pm < 0) return;                                       // unused clone slot
   if (M.st->done) return;                                   // (uniform: one global word per member)
-  const landing_solver_opts& o = A.o;
-  const double* lbm = A.lb + (size_t)m * ng; const double* ubm = A.ub + (size_t)m * ng;
-  const double* cost = A.cost + (size_t)m * 24;
+  if (A.win) {      // portfolio: a relative of this member has converged -- the family's result is there
+    const int w = A.win[pm];
+    if (w >= 0 && w != m) { if (threadIdx.x == 0) { M.st->done = 1; A.done[m] = 1; } return; }
+  }
+  const landing_solver_opts& o = kd_opts_of(A, m);
+  const double* lbm = A.lb + (size_t)pm * ng; const double* ubm = A.ub + (size_t)pm * ng;
+  const double* cost = A.cost + (size_t)pm * 24;
   const double INF = INFINITY;
   KdLds& S = KSH;
   KdState& K = S.ks;
@@ -780,13 +807,16 @@ __global__ void __launch_bounds__(KD_THREADS, 2) landing_kd_iter_kernel(KdSolveA
       KD_END();
     }
     if (K.flag == 1) {
-      if (tid == 0) { K.done = 1; *M.st = K; A.done[m] = 1; }
+      if (tid == 0) {
+        K.done = 1; *M.st = K; A.done[m] = 1;
+        if (A.win && K.status == LANDING_CONVERGED) atomicCAS(&A.win[pm], -1, m);
+      }
       return;
     }
     if (K.flag == 2) {      // restart: the next round of launches evaluates the derivatives at the re-initialised point
       if (K.fresh) {
         for (int i = tid; i < nx; i += NT) {
-          double v = A.x0[(size_t)m * nx + i];
+          double v = A.x0[(size_t)pm * nx + i];
           if (i < 12) v = lbm[i]; else if (i >= oU && i < oU + 12) v = lbm[12 + (i - oU)];
           M.x[i] = v;
         }
@@ -813,7 +843,7 @@ __global__ void __launch_bounds__(KD_THREADS, 2) landing_kd_iter_kernel(KdSolveA
       big = block_reduce1(big, RMAX, S.red);
       if (!(big < 1e6)) {
         for (int i = tid; i < nx; i += NT) {
-          double v = A.x0[(size_t)m * nx + i];
+          double v = A.x0[(size_t)pm * nx + i];
           if (i < 12) v = lbm[i]; else if (i >= oU && i < oU + 12) v = lbm[12 + (i - oU)];
           M.x[i] = v;
         }
@@ -878,6 +908,12 @@ __global__ void __launch_bounds__(KD_THREADS, 2) landing_kd_iter_kernel(KdSolveA
       if (!ok && K.attempt < 60) {
         double d = K.delta; const double dl = K.delta_last;
         if (d == 0.0) d = (dl == 0.0) ? o.delta_init : fmax(1e-20, dl * o.delta_dec);
+#if KD_DELTA_JUMP > 0
+        // the first failure at the proximal floor is IPOPT's failure at delta = 0: continue from the last successful regularisation (if that was at
+        // most KD_DELTA_JUMP iterations ago), not fourfold from the floor -- a member that needs delta ~ 1e2 .. 1e4 in its first barrier problem
+        // re-probes the floor every ninth iteration (need_reg_streak) and spent up to eight attempts = three rounds of the lock-step loop on the way back
+        else if (K.attempt == 1 && dl * o.delta_dec > d * o.delta_inc && K.it - K.reg_it <= KD_DELTA_JUMP) d = dl * o.delta_dec;
+#endif
         else d *= (dl == 0.0 ? o.delta_inc_first : o.delta_inc);
         if (!(d > 1e40)) { K.delta = d; K.flag = 1; K.nfact++; }
       }
@@ -898,7 +934,7 @@ __global__ void __launch_bounds__(KD_THREADS, 2) landing_kd_iter_kernel(KdSolveA
     return;
   }
   KD_BEGIN()
-    if (K.delta > (K.feas ? 0.0 : o.delta_floor)) { K.delta_last = K.delta; K.need_reg_streak++; } else K.need_reg_streak = 0;
+    if (K.delta > (K.feas ? 0.0 : o.delta_floor)) { K.delta_last = K.delta; K.reg_it = K.it; K.need_reg_streak++; } else K.need_reg_streak = 0;
     if (K.need_reg_streak > 8) K.need_reg_streak = 0;
   KD_END();
   KD_PROF(2);
@@ -914,6 +950,11 @@ __global__ void __launch_bounds__(KD_THREADS, 2) landing_kd_iter_kernel(KdSolveA
     const bool clip_now = !feas && K.clip_k_cur > 1 && K.c_pr > o.clip_until;
     double top[4] = {0.0, 0.0, 0.0, 0.0};
     double m_pr = 0.0, m_du = 0.0, th0 = 0.0, bar = 0.0, dphi = 0.0, f0 = 0.0;
+    // clip_k > 4: the step length that leaves at most clip_k - 1 slacks blocked comes from a histogram (half-octave buckets of ratio / tau)
+    const bool clip_hist = clip_now && K.clip_k_cur > 4;
+    const double rtau = 1.0 / K.tau;
+    if (clip_hist) { if (tid < 64) S.hist[tid] = 0; __syncthreads(); }
+    auto hist_push = [&](double rt) { if (clip_hist && rt * rtau > 1.0) { int b = (int)ceil(2.0 * log2(rt * rtau)); atomicAdd(&S.hist[b < 1 ? 1 : b > 63 ? 63 : b], 1); } };
     if (feas) {      // elastic rows: steps of the eliminated variables, step bounds (a, n, b, q and their multipliers stay positive), merit data
       const double frho = o.feas_rho;
       for (int r = tid + 24; r < ng; r += NT) {
@@ -944,13 +985,13 @@ __global__ void __launch_bounds__(KD_THREADS, 2) landing_kd_iter_kernel(KdSolveA
       if (lb > -INF) {
         const double d = s - lb, rd = 1.0 / d, zl = M.zL[r];
         const double dz = -zl * rd * ds + (mu * rd - zl);
-        m_pr = fmax(m_pr, -ds * rd); top4_push(top, -ds * rd); m_du = fmax(m_du, -dz / zl);
+        m_pr = fmax(m_pr, -ds * rd); top4_push(top, -ds * rd); hist_push(-ds * rd); m_du = fmax(m_du, -dz / zl);
         dprod = d; dphi -= mu * ds * rd;
       }
       if (ub < INF) {
         const double d = ub - s, rd = 1.0 / d, zu = M.zU[r];
         const double dz = zu * rd * ds + (mu * rd - zu);
-        m_pr = fmax(m_pr, ds * rd); top4_push(top, ds * rd); m_du = fmax(m_du, -dz / zu);
+        m_pr = fmax(m_pr, ds * rd); top4_push(top, ds * rd); hist_push(ds * rd); m_du = fmax(m_du, -dz / zu);
         dprod *= d; dphi += mu * ds * rd;
       }
       bar -= log(dprod);
@@ -963,12 +1004,28 @@ __global__ void __launch_bounds__(KD_THREADS, 2) landing_kd_iter_kernel(KdSolveA
       const double tau = K.tau;
       K.a_pr = (v[0] > tau) ? tau / v[0] : 1.0;
       if (clip_now) { const double rk = top[(K.clip_k_cur > 4 ? 4 : K.clip_k_cur) - 1]; K.a_pr = (rk > tau) ? tau / rk : 1.0; }
+      if (clip_hist) {
+        int cum = 0, b = 63;
+        for (; b >= 1; --b) { if (cum + S.hist[b] > K.clip_k_cur - 1) break; cum += S.hist[b]; }
+        K.a_pr = b >= 1 ? fmax(K.a_pr, exp2(-0.5 * (double)b)) : 1.0;      // (never below the 4th-ratio rule: the top bucket is open-ended)
+      }
       K.omt = clip_now ? 1.0 - tau : -1.0;
       K.a_du = (v[1] > tau) ? tau / v[1] : 1.0;
       K.th0 = v[2]; K.dphi = v[4]; K.ph0 = v[5] + mu * v[3]; K.fval = v[5];
       if (K.th_max == 0.0) K.th_max = 1e4 * fmax(1.0, v[2]);
       K.alpha = K.a_pr; K.s_corr = 0.0; K.accepted = 0; K.armijo_step = 0; K.ls_done = K.a_pr > 1e-10 ? 0 : 1;
     KD_END();
+#ifdef LANDING_KD_BLOCKERS      // development aid: the rows whose slack sets the primal step length of this iteration
+    if (!feas) {
+      const double apr = K.a_pr;
+      for (int r = tid + 24; r < ng; r += NT) {
+        const double lb = lbm[r], ub = ubm[r]; if (lb == ub) continue;
+        const double s = M.s[r], ds = M.ds[r];
+        const double rl = lb > -INF ? -ds / (s - lb) : 0.0, ru = ub < INF ? ds / (ub - s) : 0.0;
+        if (fmax(rl, ru) * apr >= 0.25) printf("  blk it %d a_pr %.2e row %d k %d j %d %s ratio %.2e dist %.2e ds %.2e g %.3e s %.3e z %.2e\n", K.it, apr, r, r < 48 ? -1 : (r - 48) / 141, r < 48 ? r : (r - 48) % 141, rl > ru ? "L" : "U", fmax(rl, ru), rl > ru ? s - lb : ub - s, ds, M.g[r], s, rl > ru ? M.zL[r] : M.zU[r]);
+      }
+    }
+#endif
   }
   KD_PROF(4);
   // ================================================================ filter line search
@@ -1157,12 +1214,32 @@ __global__ void __launch_bounds__(KD_THREADS, 2) landing_kd_iter_kernel(KdSolveA
   }
 }
 
+// ---- portfolio: the originals still iterating get their clone slots (one launch, one thread; wave w uses its own slot range) -----------
+__global__ void __launch_bounds__(KD_THREADS) landing_kd_clone_kernel(KdSolveArgs A, int wave) {
+  if (blockIdx.x != 0) return;
+  __shared__ int cnt[KD_THREADS];
+  const int tid = threadIdx.x, per = (A.B0 + KD_THREADS - 1) / KD_THREADS, a0 = tid * per, a1 = (a0 + per < A.B0) ? a0 + per : A.B0;
+  int n = 0;
+  for (int a = a0; a < a1; ++a) n += (A.done[a] != 1 && !A.cloned[a]) ? 1 : 0;
+  cnt[tid] = n;
+  __syncthreads();
+  int nf = 0;
+  for (int t = 0; t < tid; ++t) nf += cnt[t];
+  for (int a = a0; a < a1 && nf < A.F; ++a) {
+    if (A.done[a] == 1 || A.cloned[a]) continue;
+    A.cloned[a] = 1;
+    for (int v = 0; v < KD_NVAR; ++v) A.src[(wave * KD_NVAR + v) * A.F + nf] = a;
+    ++nf;
+  }
+}
+
 // ---- end of a solve: outputs (the J blocks of the final (x, y) are in the workspace) ------------------------------------------------
 __global__ void __launch_bounds__(KD_THREADS) landing_kd_finish_kernel(KdSolveArgs A) {
   const int m = blockIdx.x;
-  if (m >= A.B) return;
+  if (m >= A.B0) return;
   const int N = A.N, nx = kd_nx(N), ng = kd_ng(N), tid = threadIdx.x, NT = blockDim.x;
-  const KdMem M = kd_carve(N, A.ws + (size_t)m * A.ws_stride);
+  const int wm = (A.win && A.win[m] >= 0) ? A.win[m] : m;      // portfolio: the member of the family that converged first (else the original)
+  const KdMem M = kd_carve(N, A.ws + (size_t)wm * A.ws_stride);
   const double* lbm = A.lb + (size_t)m * ng; const double* ubm = A.ub + (size_t)m * ng;
   const double* cost = A.cost + (size_t)m * 24;
   const double INF = INFINITY;

@@ -152,7 +152,8 @@ def test_solver_opts_mirror_matches_the_header():
     want = dict(tol=1e-6, max_iter=3000, mu_init=0.0, bound_push=0.0, bound_frac=0.1, kappa_eps=0.0, kappa_mu=0.2, theta_mu=0.0, max_soc=0, max_resets=8,
                 reset_du=1e9, stage_local_reg=0, sticky_delta=0, restart_period=75, dispatch_order=1, delta_init=1e-4, delta_inc_first=10.0, delta_inc=4.0,
                 delta_dec=0.5, tau_min=0.9, alpha_fallback=1e-2, reset_delta=1e5, clip_k=4, clip_until=0.03, theta_floor=30.0, fresh_restart=9,
-                dual_step_cap=1.0, slack_corr=0.9, watchdog=3, barrier_smax=1.0, factor_fp32=0, feas_phase=1, feas_rho=1000.0, feas_cert=1e-4, delta_floor=3e-4, jam_clip=2, stag_relief=3, feas_jam=8, feas_stat=25)
+                dual_step_cap=1.0, slack_corr=0.9, watchdog=3, barrier_smax=1.0, factor_fp32=0, feas_phase=1, feas_rho=1000.0, feas_cert=1e-4, delta_floor=3e-4, jam_clip=2, stag_relief=3, feas_jam=8, feas_stat=25,
+                kd_clone_after=0, kd_clone_max=0, kd_clone_iter=0)
     assert {n: getattr(o, n) for n, _ in capi.SolverOpts._fields_} == want
     w = capi.SolverOpts(); lib.landing_solver_opts_warm(C.byref(w))
     assert (w.bound_push, w.bound_frac, w.mu_init, w.restart_period, w.max_iter, w.clip_k, w.fresh_restart, w.factor_fp32) == (1e-4, 1e-4, 1e-4, 0, 14, 0, 0, 0)

@@ -178,6 +178,7 @@ def test_feasibility_phase_decides_the_hard_law_in_one_pass(ctx):
     lb, ub, cost, x0 = (np.array([p[i] for p in prob]) for i in range(4))
     o = R.kinodyn_default_opts()
     assert (o.feas_phase, o.feas_jam, o.feas_stat) == (1, 0, 25)
+    assert (o.clip_k, o.restart_period, o.kd_clone_after, o.kd_clone_max, o.kd_clone_iter) == (16, 30, 56, 96, 200)      # round 5: portfolio (landing_nlp.h)
     s = R.kinodyn_solve_host(N, lb, ub, cost, x0, dt, mass, Ib, Ibi, consts.mu, o)
     ok, cert = s["status"] == 0, s["status"] == 3
     print("law datagen, one pass: %d converged + %d certified + %d undecided; iterations max %d" % (ok.sum(), cert.sum(), (~ok & ~cert).sum(), s["iters"].max()))

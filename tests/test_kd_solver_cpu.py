@@ -113,6 +113,36 @@ def test_emulated_kernels_solve_a_short_horizon_member(emu):
     Ls.close()
 
 
+def test_portfolio_reports_the_first_member_of_a_family_that_converges():
+    """landing_solver_opts::kd_clone_after (round 5): the member still iterating after 4 rounds is posed again in three clone slots under other option
+    sets; whichever member of the family converges first is reported under the original's index -- a KKT point <= 1e-6 under the oracle like any other.
+    A clone time the solve never reaches leaves every bit of the result alone."""
+    from oracle import kinodyn_oracle as ko
+    kd, P = lc("kinodyn"), lc("problem")
+    mass, Ib, Ibi, _ = _consts()
+    Ns, dtv = 6, np.full(6, 0.05)
+    Ls = lc("capi").LandingLib(Ns, lib_path=os.path.join(ROOT, "tests", "emu", "liblanding_emu.so")); Rs = lc("rbd").Rbd(Ls)
+    q = np.array([0, 0, 0.0, 0.05, 0.15, -0.05]); qd = np.array([0.1, -0.1, 0.05, 0.2, -0.1, -1.0])
+    q[2] = 0.35 + abs(min((kd.rot_xyz(q[3:6]) @ np.array([sx * 0.19, sy * 0.1, 0.0]))[2] for sx in (1, -1) for sy in (1, -1))) + abs(dtv[0] * qd[5])
+    _, x0s, _, _ = P.make_member(Ns, 0.3, q, qd, P.production_constants("main"), dtv)
+    lb, ub, cost, x0 = kd.member_problem(Ns, q, qd, x0s)
+    res = {}
+    for name, after, lim in (("off", 0, 6), ("never", 400, 6), ("early", 4, 80)):      # (the first two stop at the iteration limit: the emulation is slow)
+        o = Rs.kinodyn_default_opts(); o.max_iter = lim; o.feas_phase = 0; o.kd_clone_after = after; o.kd_clone_max = 1; o.kd_clone_iter = 80
+        res[name] = Rs.kinodyn_solve_host(Ns, lb, ub, cost, x0, dtv, mass, Ib, Ibi, 0.75, o)
+    for k in ("x", "lam_g", "kkt", "status", "iters"):
+        assert np.array_equal(res["off"][k], res["never"][k]), k
+    s = res["early"]
+    assert s["status"][0] == 0 and s["iters"][0] <= 60, (s["status"], s["iters"])
+    gf = kd.terminal_cost(s["x"][0], Ns, cost[12:], cost[:12])[1]
+    k = ko.kkt_batch(s["x"], s["lam_g"], Ns, dtv, mass, Ib, Ibi, 0.75, lb[None], ub[None], gf[None])
+    assert k.max() <= 1e-6 * 1.0001, k
+    assert np.allclose(k[0], s["kkt"][0], rtol=1e-4, atol=1e-10)
+    assert np.array_equal(s["x"][0][:12], np.concatenate([q, qd]))
+    assert res["off"]["status"][0] == 1 and res["off"]["iters"][0] == 6
+    Ls.close()
+
+
 def test_presolve_certificate_and_patterns(emu):
     L, R = emu
     kd, P = lc("kinodyn"), lc("problem")

@@ -8,6 +8,8 @@ sys.path.insert(0, ROOT)
 ap = argparse.ArgumentParser()
 ap.add_argument("--B", type=int, default=1024); ap.add_argument("--seed", type=int, default=20211); ap.add_argument("--law", default="main")
 ap.add_argument("--reps", type=int, default=3); ap.add_argument("--max-iter", type=int, default=500)
+ap.add_argument("--opt", action="append", default=[], help="solver option override k=v (repeatable)")
+ap.add_argument("--dump", default="", help="write the per-member status / iteration arrays there (.npz)")
 ap.add_argument("--ik", type=int, default=0, help="1: joint-angle guess = inverse kinematics of the SRBM feet (Rbd.kinodynamic_screen) instead of the data-generation caller's constant guess")
 a = ap.parse_args()
 import torch
@@ -35,6 +37,8 @@ nx, ng = kd.dims(N)
 x = torch.empty(B, nx, device="cuda", dtype=torch.float64); kk = torch.empty(B, 3, device="cuda", dtype=torch.float64)
 st = torch.empty(B, device="cuda", dtype=torch.int32); it = torch.empty(B, device="cuda", dtype=torch.int32)
 o = R.kinodyn_default_opts(); o.max_iter = a.max_iter
+for kv in a.opt:
+    k_, v_ = kv.split("="); setattr(o, k_, type(getattr(o, k_))(float(v_)))
 times = []
 for _ in range(a.reps):
     torch.cuda.synchronize(); t = time.perf_counter()
@@ -43,7 +47,9 @@ for _ in range(a.reps):
     torch.cuda.synchronize(); times.append(time.perf_counter() - t)
 s, i, k = st.cpu().numpy(), it.cpu().numpy(), kk.cpu().numpy()
 ok = s == 0
-print(json.dumps({"what": "kinodynamic refinement of %d SRBM solutions (N = 20, production grid, law %s, seed %d)" % (B, a.law, a.seed), "batch": B,
+if a.dump:
+    np.savez(a.dump, status=s, iters=i, kkt=k)
+print(json.dumps({"opts": a.opt, "what": "kinodynamic refinement of %d SRBM solutions (N = 20, production grid, law %s, seed %d)" % (B, a.law, a.seed), "batch": B,
                   "srbm_solve_s": t_srbm, "jpos_guess": "inverse kinematics of the SRBM feet (%.4f s)" % t_ik if a.ik else "constant (generate_training_data_automated.m:143)", "srbm_converged": int((srbm["status"] == 0).sum()), "refinement_s": times, "refinement_s_best": min(times),
                   "status_counts": np.bincount(s, minlength=4).tolist(), "converged": int(ok.sum()), "certified_infeasible": int((s == 3).sum()),
                   "iters_mean_converged": float(i[ok].mean()), "iters_p99_converged": float(np.percentile(i[ok], 99)), "iters_max": int(i.max()),

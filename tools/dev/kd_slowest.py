@@ -7,7 +7,7 @@ rbd = importlib.import_module("landing-controller_amd.rbd"); kd = importlib.impo
 N, B = 20, 1024
 consts = P_.production_constants("main")
 P, X0, q, qd = P_.make_batch(B, N, 0.6, seed=20211, consts=consts, dt_grid="reference", law="main")
-L = capi.LandingLib(N, device=0); R = rbd.Rbd(L)
+L = capi.LandingLib(N, device=0, lib_path=os.environ.get("LANDING_LIB")); R = rbd.Rbd(L)
 srbm = L.solve_host(P, X0)
 mass, Ib, Ibi = K.robot_constants()
 lbs, ubs, costs, x0s = [], [], [], []
@@ -16,7 +16,7 @@ for b in range(B):
 lbs, ubs, costs, x0s = map(np.array, (lbs, ubs, costs, x0s))
 o = R.kinodyn_default_opts()
 if len(sys.argv) > 1:
-    m = int(sys.argv[1]); os.environ["LANDING_KD_TRACE"] = "0"
+    m = int(sys.argv[1]); os.environ["LANDING_KD_TRACE"] = "0"; o.max_iter = 500
     R.kinodyn_solve_host(N, lbs[m:m + 1], ubs[m:m + 1], costs[m:m + 1], x0s[m:m + 1], P_.REFERENCE_DT_GRID, mass, Ib, Ibi, consts.mu, o)
 else:
     s = R.kinodyn_solve_host(N, lbs, ubs, costs, x0s, P_.REFERENCE_DT_GRID, mass, Ib, Ibi, consts.mu, o)
