@@ -289,16 +289,18 @@ typedef struct {
                             elastic KKT point.  kkt[0] is the violation in both cases                                                  */
   int kd_clone_after;    /* (round 5, landing_kinodyn_solve_batch only; landing_solve_batch ignores the three kd_ fields) PORTFOLIO of the
                             kinodynamic refinement: after this many rounds of the lock-step loop every member that is still iterating
-                            is posed AGAIN, from the callers' initial guess, in three clone slots under three other option sets (the step
-                            rule with 16 clipped slacks | the same with bound_push = bound_frac = 0.1 | mu_init = 1); a second wave
+                            is posed AGAIN, from the callers' initial guess, in three clone slots under three other option sets (the other
+                            step rule: clip_k 4 if the caller's is above 4, else 16 | clip_k 16 with bound_push = bound_frac = 0.1 |
+                            mu_init = 1; everything else as the caller set it, iteration limit kd_clone_iter); a second wave
                             follows after twice as many rounds for members that had no slot in the first.  The first member of such
                             a family (the original included) that converges ends the others and is reported under the original's
                             index (x, lam_g, kkt, iters = that member's own count).  0 = off.  Why: which member of a batch is
                             slow depends on the path, not on the problem -- of 5 bench batches of 1024 (law "main") three hold a
                             member that needs 400 .. 1000 iterations (batch 1.1 .. 2.0 s instead of 0.72 s: the loop runs as long
                             as its slowest member), and each of these members converges in 28 .. 73 iterations under at least one
-                            of the three sets (profiles/r05_ab_experiments.txt).  Default of landing_kinodyn_solver_opts_default:
-                            see there; 0 in landing_solver_opts_default                                                              */
+                            of the three sets (profiles/r05_ab_experiments.txt).  landing_kinodyn_solver_opts_default: 56 / 96 / 200
+                            (with clip_k 16 and restart_period 30: 0.51 .. 0.59 s per batch on eight seeds, every member decided);
+                            0 in landing_solver_opts_default                                                              */
   int kd_clone_max;      /* families per wave (workspace: 2 waves x 3 variants x kd_clone_max member blocks behind the batch)          */
   int kd_clone_iter;     /* iteration limit of a clone (its feasibility phase included in the usual way: limit + limit); 0 = 200      */
 } landing_solver_opts;
@@ -534,7 +536,8 @@ int landing_kinodyn_nlp_hess(landing_ctx* ctx, int B, int N, const double* d_x, 
  *                            Ib_inv must be the same for every member of one call (they are constants of every caller in the reference).
  * Needs landing_rbd_set_model.  N = number of intervals (the script's N - 1 = 20), N <= 64.
  * Options: landing_kinodyn_solver_opts_default = landing_solver_opts_default with max_iter 500, bound_push = bound_frac = 0.01, mu_init 0.1, theta_mu 1.5
- * and feas_jam 0.  The feasibility (restoration) phase of landing_solve_batch exists here too (round 5; feas_phase, feas_rho, feas_cert, feas_stat): a member
+ * and feas_jam 0; round 5 (late): clip_k 16, restart_period 30 and the portfolio kd_clone_after 56 / kd_clone_max 96 / kd_clone_iter 200 (see those fields: the
+ * members still iterating after 56 rounds race three clones of themselves; d_iters of such a member is the winner's own count).  The feasibility (restoration) phase of landing_solve_batch exists here too (round 5; feas_phase, feas_rho, feas_cert, feas_stat): a member
  * that would end as NUMERICAL / MAX_ITER continues on the elastic problem and ends as a KKT point of the original NLP, with a certificate of local
  * infeasibility (status 3), or undecided.  The host-array entry points re-solve the few members a first pass leaves undecided with two other slack / barrier
  * initialisations when the caller passes no options (retry ladder).                                                                              */
