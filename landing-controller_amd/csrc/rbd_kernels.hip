@@ -860,15 +860,30 @@ __global__ void __launch_bounds__(64) landing_kinodyn_nlp_g_kernel(KdNlpArgs a) 
   }
 }
 // Jacobian blocks: jac[b][k][row][col], col over w (72), one thread per (member, interval, column)
-__global__ void __launch_bounds__(64) landing_kinodyn_nlp_jac_kernel(KdNlpArgs a) {
-  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (long long)a.B * a.N * KD_NW) return;
-  const int col = (int)(idx % KD_NW); const int k = (int)((idx / KD_NW) % a.N); const int b = (int)(idx / ((long long)KD_NW * a.N)), N = a.N;
+// One block = KD_JAC_STAGES intervals of ONE member x 72 columns (4 intervals = 4.5 wavefronts: 0.435 s per batch; 8 = 9 full wavefronts but 168 VGPRs: 0.443; 2: 0.453); the stage variables of those intervals live in LDS and the seeded
+// dual numbers are formed on access (as in the Hessian kernel below) instead of 72 dual numbers = 144 VGPRs per lane.  Grid = B * ceil(N / KD_JAC_STAGES).
+#ifndef KD_JAC_STAGES_DEF
+#define KD_JAC_STAGES_DEF 4
+#endif
+constexpr int KD_JAC_STAGES = KD_JAC_STAGES_DEF, KD_JAC_THREADS = KD_JAC_STAGES * KD_NW;      // 576
+__host__ __device__ inline long long kd_jac_blocks(long long B, int N) { return B * ((N + KD_JAC_STAGES - 1) / KD_JAC_STAGES); }
+__global__ void __launch_bounds__(KD_JAC_THREADS) landing_kinodyn_nlp_jac_kernel(KdNlpArgs a) {
+  const int N = a.N, nblk = (N + KD_JAC_STAGES - 1) / KD_JAC_STAGES;
+  const int b = (int)(blockIdx.x / nblk), k0 = (int)(blockIdx.x % nblk) * KD_JAC_STAGES;
+  if (b >= a.B) return;
   if (a.skip && a.skip[b]) return;
+  __shared__ double xs[KD_JAC_STAGES][KD_NW];
   const double* x = a.x + a.ox(b);
-  Dual w[KD_NW];
-#pragma unroll
-  for (int j = 0; j < KD_NW; ++j) { const int i = kd_w_index(N, k, j); w[j] = D_(i >= 0 ? x[i] : 0.0, j == col ? 1.0 : 0.0); }
+  const int ks = (int)threadIdx.x / KD_NW, col = (int)threadIdx.x % KD_NW, k = k0 + ks;
+  if (k < N) { const int i = kd_w_index(N, k, col); xs[ks][col] = i >= 0 ? x[i] : 0.0; }
+  __syncthreads();
+  if (k >= N) return;
+  struct DualSeedView {      // w[q] = x_q + eps [q == col], formed on access
+    const double* xv; int col, off;
+    __device__ __forceinline__ Dual operator[](int q) const { const int qq = q + off; return D_(xv[qq], qq == col ? 1.0 : 0.0); }
+    __device__ __forceinline__ DualSeedView operator+(int o) const { return DualSeedView{xv, col, off + o}; }
+  };
+  const DualSeedView w{xs[ks], col, 0};
   const bool last = k == N - 1;
   // row after row of column col; with lam given the column's product with the multipliers of the interval's rows comes along (rows in order)
   struct ColOut { double* J; bool zero; const double* y; double acc;
@@ -914,20 +929,29 @@ __host__ __device__ inline int kd_pair_list(unsigned char* pi, unsigned char* pj
 }
 constexpr int KD_NPAIR = 561;
 // (npair pairs per block: the KD_NPAIR candidates of kd_pair_list, or the subset of them whose entry is not structurally zero -- solver_capi.inc, kd_ensure_pairs)
-__global__ void __launch_bounds__(64) landing_kinodyn_nlp_hess_kernel(KdNlpArgs a, const unsigned char* __restrict__ pair_i, const unsigned char* __restrict__ pair_j, int npair) {
-  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (long long)a.B * a.N * npair) return;
-  const int pr = (int)(idx % npair); const int k = (int)((idx / npair) % a.N); const int b = (int)(idx / ((long long)npair * a.N)), N = a.N;
-  const int i = pair_i[pr], j = pair_j[pr];
+// One block (one wave) = 64 pairs of ONE (member, interval): the 72 stage variables are common to the block and live in LDS (read on access, one broadcast
+// ds_read each) instead of 144 VGPRs per lane -- the kernel ran at 256 VGPRs + 256 AGPRs + 1.6 KB of scratch per lane with them.  Grid = B * N * ceil(npair / 64).
+__host__ __device__ inline long long kd_hess_blocks(long long B, int N, int npair) { return B * N * ((npair + 63) / 64); }
+#ifndef KD_HESS_WAVES
+#define KD_HESS_WAVES 1
+#endif
+__global__ void __launch_bounds__(64, KD_HESS_WAVES) landing_kinodyn_nlp_hess_kernel(KdNlpArgs a, const unsigned char* __restrict__ pair_i, const unsigned char* __restrict__ pair_j, int npair) {
+  const int nch = (npair + 63) / 64, N = a.N;
+  const long long blk = blockIdx.x;
+  const int ch = (int)(blk % nch); const int k = (int)((blk / nch) % N); const int b = (int)(blk / ((long long)nch * N));
+  if (b >= a.B) return;
   if (a.skip && a.skip[b]) return;
+  __shared__ double xv[KD_NW];
+  const double* x = a.x + a.ox(b);
+  for (int q = threadIdx.x; q < KD_NW; q += 64) { const int ix = kd_w_index(N, k, q); xv[q] = ix >= 0 ? x[ix] : 0.0; }
+  __syncthreads();
+  const int pr = ch * 64 + (int)threadIdx.x;
+  if (pr >= npair) return;
+  const int i = pair_i[pr], j = pair_j[pr];
   double* Hk = a.hess + a.oh(b) + ((size_t)k * KD_NW) * KD_NW;
   const bool last = k == N - 1;
   if (last && j >= 60) return;
-  const double* x = a.x + a.ox(b);
   const double* lam = a.lam + a.og(b) + KD_BND + (size_t)k * KD_ROWS;
-  double xv[KD_NW];
-#pragma unroll
-  for (int q = 0; q < KD_NW; ++q) { const int ix = kd_w_index(N, k, q); xv[q] = ix >= 0 ? x[ix] : 0.0; }
   struct KdSeedView {      // w[q] = x_q + eps1 [q == i] + eps2 [q == j], formed on access
     const double* xv; int i, j, off;
     __device__ __forceinline__ HDual operator[](int q) const { const int qq = q + off; return H_(xv[qq], qq == i ? 1.0 : 0.0, qq == j ? 1.0 : 0.0, 0.0); }
