@@ -931,22 +931,34 @@ constexpr int KD_NPAIR = 561;
 // (npair pairs per block: the KD_NPAIR candidates of kd_pair_list, or the subset of them whose entry is not structurally zero -- solver_capi.inc, kd_ensure_pairs)
 // One block (one wave) = 64 pairs of ONE (member, interval): the 72 stage variables are common to the block and live in LDS (read on access, one broadcast
 // ds_read each) instead of 144 VGPRs per lane -- the kernel ran at 256 VGPRs + 256 AGPRs + 1.6 KB of scratch per lane with them.  Grid = B * N * ceil(npair / 64).
-__host__ __device__ inline long long kd_hess_blocks(long long B, int N, int npair) { return B * N * ((npair + 63) / 64); }
+// (The pairs of KD_HESS_G = 2 consecutive intervals are numbered through: 2 x 286 = 572 pairs fill 9 wavefronts but for 4 lanes; interval by interval the fifth
+// wavefront of each had 30 of 64 lanes at work.)
+#ifndef KD_HESS_G_DEF
+#define KD_HESS_G_DEF 2
+#endif
+constexpr int KD_HESS_G = KD_HESS_G_DEF;
+__host__ __device__ inline long long kd_hess_blocks(long long B, int N, int npair) { return B * ((N + KD_HESS_G - 1) / KD_HESS_G) * ((KD_HESS_G * npair + 63) / 64); }
 #ifndef KD_HESS_WAVES
 #define KD_HESS_WAVES 1
 #endif
 __global__ void __launch_bounds__(64, KD_HESS_WAVES) landing_kinodyn_nlp_hess_kernel(KdNlpArgs a, const unsigned char* __restrict__ pair_i, const unsigned char* __restrict__ pair_j, int npair) {
-  const int nch = (npair + 63) / 64, N = a.N;
+  const int nch = (KD_HESS_G * npair + 63) / 64, N = a.N, ngr = (N + KD_HESS_G - 1) / KD_HESS_G;
   const long long blk = blockIdx.x;
-  const int ch = (int)(blk % nch); const int k = (int)((blk / nch) % N); const int b = (int)(blk / ((long long)nch * N));
+  const int ch = (int)(blk % nch); const int gr = (int)((blk / nch) % ngr); const int b = (int)(blk / ((long long)nch * ngr));
   if (b >= a.B) return;
   if (a.skip && a.skip[b]) return;
-  __shared__ double xv[KD_NW];
+  __shared__ double xs[KD_HESS_G][KD_NW];
   const double* x = a.x + a.ox(b);
-  for (int q = threadIdx.x; q < KD_NW; q += 64) { const int ix = kd_w_index(N, k, q); xv[q] = ix >= 0 ? x[ix] : 0.0; }
+  for (int t = threadIdx.x; t < KD_HESS_G * KD_NW; t += 64) {
+    const int kk = gr * KD_HESS_G + t / KD_NW, q = t % KD_NW;
+    const int ix = kk < N ? kd_w_index(N, kk, q) : -1;
+    xs[t / KD_NW][q] = ix >= 0 ? x[ix] : 0.0;
+  }
   __syncthreads();
-  const int pr = ch * 64 + (int)threadIdx.x;
-  if (pr >= npair) return;
+  const int p = ch * 64 + (int)threadIdx.x;
+  const int ks = p / npair, pr = p - ks * npair, k = gr * KD_HESS_G + ks;
+  if (ks >= KD_HESS_G || k >= N) return;
+  const double* xv = xs[ks];
   const int i = pair_i[pr], j = pair_j[pr];
   double* Hk = a.hess + a.oh(b) + ((size_t)k * KD_NW) * KD_NW;
   const bool last = k == N - 1;
