@@ -291,8 +291,8 @@ typedef struct {
                             kinodynamic refinement: after this many rounds of the lock-step loop every member that is still iterating
                             is posed AGAIN, from the callers' initial guess, in three clone slots under three other option sets (the other
                             step rule: clip_k 4 if the caller's is above 4, else 16 | clip_k 16 with bound_push = bound_frac = 0.1 |
-                            mu_init = 1; everything else as the caller set it, iteration limit kd_clone_iter); a second wave
-                            follows after twice as many rounds for members that had no slot in the first.  The first member of such
+                            mu_init = 1; everything else as the caller set it, iteration limit kd_clone_iter); three more waves
+                            follow after 2, 3 and 4 times as many rounds for members that had no slot before.  The first member of such
                             a family (the original included) that converges ends the others and is reported under the original's
                             index (x, lam_g, kkt, iters = that member's own count).  0 = off.  Why: which member of a batch is
                             slow depends on the path, not on the problem -- of 5 bench batches of 1024 (law "main") three hold a
@@ -301,7 +301,7 @@ typedef struct {
                             of the three sets (profiles/r05_ab_experiments.txt).  landing_kinodyn_solver_opts_default: 56 / 96 / 200
                             (with clip_k 16 and restart_period 30: 0.51 .. 0.59 s per batch on eight seeds, every member decided);
                             0 in landing_solver_opts_default                                                              */
-  int kd_clone_max;      /* families per wave (workspace: 2 waves x 3 variants x kd_clone_max member blocks behind the batch)          */
+  int kd_clone_max;      /* families per wave (workspace: 4 waves x 3 variants x kd_clone_max member blocks behind the batch)          */
   int kd_clone_iter;     /* iteration limit of a clone (its feasibility phase included in the usual way: limit + limit); 0 = 200      */
 } landing_solver_opts;
 

@@ -108,7 +108,10 @@ struct KdSolveArgs {
 #ifndef KD_NVAR_DEF
 #define KD_NVAR_DEF 3
 #endif
-constexpr int KD_NVAR = KD_NVAR_DEF, KD_NWAVE = 2;
+#ifndef KD_NWAVE_DEF
+#define KD_NWAVE_DEF 4
+#endif
+constexpr int KD_NVAR = KD_NVAR_DEF, KD_NWAVE = KD_NWAVE_DEF;
 __device__ __forceinline__ int kd_problem_of(const KdSolveArgs& A, int m) { return m < A.B0 ? m : A.src[m - A.B0]; }
 __device__ __forceinline__ const landing_solver_opts& kd_opts_of(const KdSolveArgs& A, int m) { return m < A.B0 ? A.o : A.ov[((m - A.B0) / A.F) % KD_NVAR]; }
 
