@@ -198,3 +198,38 @@ def test_feasibility_phase_decides_the_hard_law_in_one_pass(ctx):
     o.feas_phase = 0      # ... and without the phase those members end undecided
     s0 = R.kinodyn_solve_host(N, lb, ub, cost, x0, dt, mass, Ib, Ibi, consts.mu, o)
     assert (s0["status"][phase] != 0).all() and np.isin(s0["status"], (1, 2)).sum() > (~ok & ~cert).sum()
+
+
+def test_portfolio_takes_the_outlier_out_of_the_batch(ctx):
+    """landing_solver_opts::kd_clone_after (round 5): 1024 drop states of law "main", seed 10 -- without the portfolio (clip_k 16 as in the defaults) one member needs 670 iterations
+    and the lock-step loop waits for it (1.54 s for the batch through the host entry point); with it (the defaults) that member's family converges after
+    105 (0.52 s), nobody needs more than 250 iterations of its own, nobody is undecided, every member that converged without the portfolio still converges, and every converged member -- the
+    clones' winners included -- is a KKT point <= 1e-6 under the oracle.  Members that never met the clone time keep every bit."""
+    import time
+    L, R = ctx
+    P, kd = lc("problem"), lc("kinodyn")
+    B = 1024
+    consts = P.production_constants("main")
+    Pp, X0, q, qd = P.make_batch(B, N, 0.6, seed=10, consts=consts, dt_grid="reference", law="main")
+    srbm = L.solve_host(Pp, X0)
+    mass, Ib, Ibi, dt = _consts()
+    prob = [kd.member_problem(N, q[b], qd[b], srbm["x"][b]) for b in range(B)]
+    lb, ub, cost, x0 = (np.array([p[i] for p in prob]) for i in range(4))
+    on = R.kinodyn_default_opts()
+    off = R.kinodyn_default_opts(); off.kd_clone_after = 0
+    res, secs = {}, {}
+    for name, o in (("off", off), ("on", on)):
+        t = time.perf_counter(); res[name] = R.kinodyn_solve_host(N, lb, ub, cost, x0, dt, mass, Ib, Ibi, consts.mu, o); secs[name] = time.perf_counter() - t
+    a, s = res["off"], res["on"]
+    und = lambda r: int(np.isin(r["status"], (1, 2)).sum())
+    print("portfolio off: %d undecided, slowest member %d iterations, %.2f s; on: %d undecided, slowest %d, %.2f s (host entry point, copies included)" % (
+        und(a), a["iters"].max(), secs["off"], und(s), s["iters"].max(), secs["on"]))
+    assert a["iters"].max() >= 400                                   # the outlier is there ...
+    assert und(s) == 0 and s["iters"].max() <= 250                    # ... and gone
+    assert np.all(s["status"][a["status"] == 0] == 0) and (s["status"] == 0).sum() >= (a["status"] == 0).sum()
+    early = a["iters"] < 50                                           # finished before the clone time (56 rounds): untouched
+    assert early.sum() >= 0.7 * B and np.array_equal(a["x"][early], s["x"][early]) and np.array_equal(a["iters"][early], s["iters"][early])
+    ok = s["status"] == 0
+    kk = _certify(s["x"][ok], s["lam_g"][ok], lb[ok], ub[ok], cost[ok], dt, consts.mu)
+    assert kk.max() <= KKT_TOL * 1.0001, kk.max()
+    assert np.allclose(kk, s["kkt"][ok], rtol=1e-3, atol=1e-9)
