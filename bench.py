@@ -27,6 +27,8 @@ sharding, gather, per-rank timing, reductions, JSON) on CPU with the solve repla
                      N=40) / HIP-event duration
   cpu_baseline     = oracle/landing_solver_cpu.c (scalar fp64 port of the same algorithm, OpenMP over
                      members) on a bounded sample of the same workload, on this box's host cores (rank 0, N=1 only)
+  next_rows        = SURVEY 8(f) rows measured beside the headline, behind the timed region, never part of `value` (N=1 only):
+                     kinodyn_refinement = row N1, one batch of 1024 through landing_kinodyn_solve_batch (tools/bench_kd_solve.py)
 """
 import argparse
 import importlib
@@ -390,10 +392,49 @@ def main():
             out.update(measure_details(a, lib, np, torch, dev, mk, B, N, P, X0, dP, dX0, st, it, kkt, kernel_ms, solve, world, stream, ev0, ev1, dev_batches, sweep_timing))
             out["pcie_inclusive"] = pcie
             out["two_batches_in_flight"] = piped
+            if world == 1 and not a.no_extras:
+                out["next_rows"] = {"kinodyn_refinement": measure_kinodyn(np, torch, local)}
         print(json.dumps(out), flush=True)
     if multi:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def measure_kinodyn(np, torch, local, B=1024, N=20, seed=20211, reps=2):
+    """SURVEY 8f row N1 beside the headline (rank 0, behind the timed region, never part of `value`): the production callers' pipeline on one batch --
+    SRBM solve (N = 20, production grid, law "main") -> kinodynamic refinement of the same drop states through the device-pointer entry point.  The same
+    measurement as tools/bench_kd_solve.py (profiles/r05_kd_bench.json).  Any failure is reported as a string: this leg must not take the headline down."""
+    try:
+        P_ = importlib.import_module("landing-controller_amd.problem"); capi = importlib.import_module("landing-controller_amd.capi")
+        rbd = importlib.import_module("landing-controller_amd.rbd"); kd = importlib.import_module("landing-controller_amd.kinodyn")
+        K = importlib.import_module("landing-controller_amd.constants")
+        consts = P_.production_constants("main")
+        P, X0, q, qd = P_.make_batch(B, N, 0.6, seed=seed, consts=consts, dt_grid="reference", law="main")
+        L = capi.LandingLib(N, device=local); R = rbd.Rbd(L)
+        srbm = L.solve_host(P, X0)
+        mass, Ib, Ibi = K.robot_constants()
+        prob = [kd.member_problem(N, q[b], qd[b], srbm["x"][b], None) for b in range(B)]
+        lb, ub, cost, x0 = (np.array([p[i] for p in prob]) for i in range(4))
+        T = lambda v: torch.tensor(v, device="cuda:%d" % local)
+        dl, du, dc, dx0 = T(lb), T(ub), T(cost), T(x0)
+        nx, ng = kd.dims(N)
+        x = torch.empty(B, nx, device=dl.device, dtype=torch.float64); st = torch.empty(B, device=dl.device, dtype=torch.int32); it = torch.empty_like(st)
+        o = R.kinodyn_default_opts()
+        times = []
+        for _ in range(reps + 1):      # (the first call builds the context's tables and workspace)
+            torch.cuda.synchronize(); t = time.perf_counter()
+            R.kinodyn_solve_device(B, N, dl.data_ptr(), du.data_ptr(), dc.data_ptr(), dx0.data_ptr(), P_.REFERENCE_DT_GRID, mass, Ib, Ibi, consts.mu, o, x.data_ptr(),
+                                   d_status=st.data_ptr(), d_iters=it.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize(); times.append(time.perf_counter() - t)
+        s, i = st.cpu().numpy(), it.cpu().numpy()
+        L.close()
+        ok = s == 0
+        return {"what": "kinodynamic refinement (row N1) of %d SRBM solutions, N = 20, production grid, law main, seed %d; library defaults (portfolio of clone slots, DESIGN 4.8)" % (B, seed),
+                "refinement_s": min(times[1:]), "members_per_s": B / min(times[1:]), "converged_per_s": float(ok.sum() / min(times[1:])),
+                "status_counts": np.bincount(s, minlength=4).tolist(), "undecided": int(np.isin(s, (1, 2)).sum()), "iters_mean_converged": float(i[ok].mean()), "iters_max": int(i.max()),
+                "srbm_converged": int((srbm["status"] == 0).sum())}
+    except Exception as e:      # noqa: BLE001
+        return {"error": "%s: %s" % (type(e).__name__, e)}
 
 
 def measure_sweep(lib, torch, dev, mk, B, dX0, dP, stream, ev0, ev1):
