@@ -101,7 +101,7 @@ struct KdSolveArgs {
   // (ov[v]); the first member of such a family that converges ends the others, the finish kernel reports it under the original's index.
   int B0, F, m_lo;         // clone slot of (wave w, variant v, family i) = B0 + ((w * KD_NVAR + v) * F + i); m_lo: first member of an init launch
   int* src;                // [B - B0] the original of a clone slot, -1 = unused
-  int* win;                // [B0] first member of the family of original a that converged (-1: none yet)
+  int* win;                // [B0] the member of the family of original a that converged first (KD_NOWIN: none yet; of several in one round the lowest index: atomicMin)
   int* cloned;             // [B0] 1 = the original has clones
   landing_solver_opts ov[3];
 };
@@ -112,6 +112,7 @@ struct KdSolveArgs {
 #define KD_NWAVE_DEF 4
 #endif
 constexpr int KD_NVAR = KD_NVAR_DEF, KD_NWAVE = KD_NWAVE_DEF;
+constexpr int KD_NOWIN = 0x7f7f7f7f;      // (a byte pattern: the host sets it with one memset)
 __device__ __forceinline__ int kd_problem_of(const KdSolveArgs& A, int m) { return m < A.B0 ? m : A.src[m - A.B0]; }
 __device__ __forceinline__ const landing_solver_opts& kd_opts_of(const KdSolveArgs& A, int m) { return m < A.B0 ? A.o : A.ov[((m - A.B0) / A.F) % KD_NVAR]; }
 
@@ -163,6 +164,9 @@ __shared__ KdLds KSH;
 #define KD_END() } __syncthreads()
 #define KD_PROF(slot) do { if (threadIdx.x == 0) { const long long n_ = (long long)wall_clock64(); KSH.ks.prof[slot] += (double)(n_ - KSH.ks.tp); KSH.ks.tp = n_; } } while (0)
 
+#ifndef KD_EARLY_FETCH
+#define KD_EARLY_FETCH 1      // (same-box A/B: 0.4478 -> 0.4446 s per batch)
+#endif
 // ---- condensation of interval k into KSH.Ms (nv x nv + rhs), KSH.Ah ------------------------------------------------------------
 KD_PHASE void kd_condense_stage(const KdMem& M, int N, int k, double delta) {
   KdLds& S = KSH;
@@ -172,6 +176,41 @@ KD_PHASE void kd_condense_stage(const KdMem& M, int N, int k, double delta) {
   const double* __restrict__ Jk = M.J + (size_t)k * KD_ROWS * KD_NW;
   const double* __restrict__ Hk = M.H + (size_t)k * KD_NW * KD_NW;
   const int g0 = KD_BND + k * KD_ROWS;
+#if KD_EARLY_FETCH
+  // + J_I' Sigma J_I and m = J_I' rho over the inequality rows 12 .. nr-1, in chunks of KD_JC_ROWS rows staged in LDS; the product runs on
+  // the fp64 matrix cores: wave w owns row tile w of M (16 rows), four column tiles
+  const int wave = tid >> 6, l = tid & 63, lj = l & 15, lk = l >> 4;
+  f64x4 acc[4];
+  for (int t = 0; t < 4; ++t) acc[t] = f64x4{0.0, 0.0, 0.0, 0.0};
+  double macc = 0.0;
+  // (round 5: the loads of the next chunk are in flight while the matrix cores work on this one -- they used to be exposed, 5 x ~2 us per stage)
+  constexpr int NE = (KD_JC_ROWS * 64 + KD_THREADS - 1) / KD_THREADS;
+  double pre[NE], pre_sg = 0.0, pre_rh = 0.0;
+  auto fetch = [&](int r0) {
+#pragma unroll
+    for (int q = 0; q < NE; ++q) {
+      const int e = tid + q * KD_THREADS, rr = e >> 6, c = e & 63, r = r0 + rr;
+      const bool in = rr < KD_JC_ROWS && r < nr && c < nv;
+      const double v = Jk[(in ? r : 12) * KD_NW + kd_v2w(in ? c : 0)];      // unconditional load (clamped): all NE loads are issued together
+      pre[q] = in ? v : 0.0;
+    }
+    { const int r = r0 + tid; const bool in = tid < KD_JC_ROWS && r < nr; const double a = M.sig[g0 + (in ? r : 12)], b = M.rho[g0 + (in ? r : 12)]; pre_sg = in ? a : 0.0; pre_rh = in ? b : 0.0; }
+  };
+  fetch(12);      // (round 5, late: the first chunk's loads are in flight behind the Hessian block's)
+  // Hessian block of lam' g over v, delta_w on the diagonal, right-hand side cleared
+  for (int e = tid; e < KD_NV * KD_MS; e += NT) {
+    const int a = e / KD_MS, b = e % KD_MS;
+    double v = 0.0;
+    if (a < nv && b < nv) v = Hk[kd_v2w(a) * KD_NW + kd_v2w(b)] + (a == b ? delta : 0.0);
+    S.Ms[e] = v;
+  }
+  // [A^ | b] from the defect rows: X_k+1 = A^ (sigma_k, f_k) + b in step form  (rows in the order of X)
+  for (int e = tid; e < 12 * KD_AS; e += NT) {
+    const int r = e / KD_AS, c = e % KD_AS;
+    S.Ah[KD_ROW2X[r] * KD_AS + c] = c < 36 ? -Jk[r * KD_NW + c] : -M.g[g0 + r];
+  }
+  __syncthreads();
+#else
   // Hessian block of lam' g over v, delta_w on the diagonal, right-hand side cleared
   for (int e = tid; e < KD_NV * KD_MS; e += NT) {
     const int a = e / KD_MS, b = e % KD_MS;
@@ -205,6 +244,7 @@ KD_PHASE void kd_condense_stage(const KdMem& M, int N, int k, double delta) {
     { const int r = r0 + tid; const bool in = tid < KD_JC_ROWS && r < nr; const double a = M.sig[g0 + (in ? r : 12)], b = M.rho[g0 + (in ? r : 12)]; pre_sg = in ? a : 0.0; pre_rh = in ? b : 0.0; }
   };
   fetch(12);
+#endif
   for (int r0 = 12; r0 < nr; r0 += KD_JC_ROWS) {
 #pragma unroll
     for (int q = 0; q < NE; ++q) { const int e = tid + q * KD_THREADS, rr = e >> 6, c = e & 63; if (rr < KD_JC_ROWS) S.Jc[rr * KD_JC_S + c] = pre[q]; }
@@ -715,7 +755,7 @@ __global__ void __launch_bounds__(KD_THREADS, 2) landing_kd_iter_kernel(KdSolveA
   if (M.st->done) return;                                   // (uniform: one global word per member)
   if (A.win) {      // portfolio: a relative of this member has converged -- the family's result is there
     const int w = A.win[pm];
-    if (w >= 0 && w != m) { if (threadIdx.x == 0) { M.st->done = 1; A.done[m] = 1; } return; }
+    if (w != KD_NOWIN && w != m) { if (threadIdx.x == 0) { M.st->done = 1; A.done[m] = 1; } return; }
   }
   const landing_solver_opts& o = kd_opts_of(A, m);
   const double* lbm = A.lb + (size_t)pm * ng; const double* ubm = A.ub + (size_t)pm * ng;
@@ -812,7 +852,7 @@ __global__ void __launch_bounds__(KD_THREADS, 2) landing_kd_iter_kernel(KdSolveA
     if (K.flag == 1) {
       if (tid == 0) {
         K.done = 1; *M.st = K; A.done[m] = 1;
-        if (A.win && K.status == LANDING_CONVERGED) atomicCAS(&A.win[pm], -1, m);
+        if (A.win && K.status == LANDING_CONVERGED) atomicMin(&A.win[pm], m);      // (relatives that converge in the same round: the lowest index, whatever the order)
       }
       return;
     }
@@ -1241,7 +1281,7 @@ __global__ void __launch_bounds__(KD_THREADS) landing_kd_finish_kernel(KdSolveAr
   const int m = blockIdx.x;
   if (m >= A.B0) return;
   const int N = A.N, nx = kd_nx(N), ng = kd_ng(N), tid = threadIdx.x, NT = blockDim.x;
-  const int wm = (A.win && A.win[m] >= 0) ? A.win[m] : m;      // portfolio: the member of the family that converged first (else the original)
+  const int wm = (A.win && A.win[m] != KD_NOWIN) ? A.win[m] : m;      // portfolio: the member of the family that converged first (else the original)
   const KdMem M = kd_carve(N, A.ws + (size_t)wm * A.ws_stride);
   const double* lbm = A.lb + (size_t)m * ng; const double* ubm = A.ub + (size_t)m * ng;
   const double* cost = A.cost + (size_t)m * 24;

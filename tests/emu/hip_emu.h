@@ -137,6 +137,7 @@ inline hip_emu_f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, hip_
 }
 inline int atomicAdd(int* p, int v) { const int o = *p; *p += v; return o; }      // (one block at a time, fibers never preempt)
 inline int atomicCAS(int* p, int cmp, int v) { const int o = *p; if (o == cmp) *p = v; return o; }
+inline int atomicMin(int* p, int v) { const int o = *p; if (v < o) *p = v; return o; }
 inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
 inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
 inline double __builtin_amdgcn_rcp(double x) { return 1.0 / x; }

@@ -221,6 +221,8 @@ def test_portfolio_takes_the_outlier_out_of_the_batch(ctx):
     for name, o in (("off", off), ("on", on)):
         t = time.perf_counter(); res[name] = R.kinodyn_solve_host(N, lb, ub, cost, x0, dt, mass, Ib, Ibi, consts.mu, o); secs[name] = time.perf_counter() - t
     a, s = res["off"], res["on"]
+    again = R.kinodyn_solve_host(N, lb, ub, cost, x0, dt, mass, Ib, Ibi, consts.mu, on)      # relatives that converge in one round: the lowest index wins, whatever the timing
+    assert np.array_equal(again["x"], s["x"]) and np.array_equal(again["iters"], s["iters"]) and np.array_equal(again["status"], s["status"])
     und = lambda r: int(np.isin(r["status"], (1, 2)).sum())
     print("portfolio off: %d undecided, slowest member %d iterations, %.2f s; on: %d undecided, slowest %d, %.2f s (host entry point, copies included)" % (
         und(a), a["iters"].max(), secs["off"], und(s), s["iters"].max(), secs["on"]))
