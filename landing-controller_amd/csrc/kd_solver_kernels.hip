@@ -197,17 +197,34 @@ KD_PHASE void kd_condense_stage(const KdMem& M, int N, int k, double delta) {
     { const int r = r0 + tid; const bool in = tid < KD_JC_ROWS && r < nr; const double a = M.sig[g0 + (in ? r : 12)], b = M.rho[g0 + (in ? r : 12)]; pre_sg = in ? a : 0.0; pre_rh = in ? b : 0.0; }
   };
   fetch(12);      // (round 5, late: the first chunk's loads are in flight behind the Hessian block's)
-  // Hessian block of lam' g over v, delta_w on the diagonal, right-hand side cleared
-  for (int e = tid; e < KD_NV * KD_MS; e += NT) {
-    const int a = e / KD_MS, b = e % KD_MS;
-    double v = 0.0;
-    if (a < nv && b < nv) v = Hk[kd_v2w(a) * KD_NW + kd_v2w(b)] + (a == b ? delta : 0.0);
-    S.Ms[e] = v;
-  }
-  // [A^ | b] from the defect rows: X_k+1 = A^ (sigma_k, f_k) + b in step form  (rows in the order of X)
-  for (int e = tid; e < 12 * KD_AS; e += NT) {
-    const int r = e / KD_AS, c = e % KD_AS;
-    S.Ah[KD_ROW2X[r] * KD_AS + c] = c < 36 ? -Jk[r * KD_NW + c] : -M.g[g0 + r];
+  // Hessian block of lam' g over v, delta_w on the diagonal, right-hand side cleared; [A^ | b] from the defect rows: X_k+1 = A^ (sigma_k, f_k) + b in
+  // step form (rows in the order of X).  All loads of a thread are issued together, unconditionally (clamped addresses), and only then stored: with the load under
+  // the bounds test each of the 15 rounds waited for its own load -- 13.8 of the 26 us a stage's condensation took under load (development timers)
+  {
+    constexpr int NH = (KD_NV * KD_MS + KD_THREADS - 1) / KD_THREADS, NA = (12 * KD_AS + KD_THREADS - 1) / KD_THREADS;
+    double hv[NH], av[NA];
+#pragma unroll
+    for (int q = 0; q < NH; ++q) {
+      const int e = tid + q * KD_THREADS, a = e / KD_MS, b = e % KD_MS;
+      const bool in = a < nv && b < nv;
+      hv[q] = Hk[kd_v2w(in ? a : 0) * KD_NW + kd_v2w(in ? b : 0)];
+    }
+#pragma unroll
+    for (int q = 0; q < NA; ++q) {
+      const int e = tid + q * KD_THREADS, ee = e < 12 * KD_AS ? e : 0, r = ee / KD_AS, c = ee % KD_AS;
+      const double vj = Jk[r * KD_NW + (c < 36 ? c : 0)], vg = M.g[g0 + r];
+      av[q] = c < 36 ? -vj : -vg;
+    }
+#pragma unroll
+    for (int q = 0; q < NH; ++q) {
+      const int e = tid + q * KD_THREADS, a = e / KD_MS, b = e % KD_MS;
+      if (e < KD_NV * KD_MS) S.Ms[e] = (a < nv && b < nv) ? hv[q] + (a == b ? delta : 0.0) : 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < NA; ++q) {
+      const int e = tid + q * KD_THREADS, ee = e < 12 * KD_AS ? e : 0, r = ee / KD_AS, c = ee % KD_AS;
+      if (e < 12 * KD_AS) S.Ah[KD_ROW2X[r] * KD_AS + c] = av[q];
+    }
   }
   __syncthreads();
 #else
