@@ -173,8 +173,11 @@ KD_PHASE void kd_condense_stage(const KdMem& M, int N, int k, double delta) {
   const int tid = threadIdx.x, NT = blockDim.x;
   const bool last = k == N - 1;
   const int nv = last ? 48 : KD_NV, nr = last ? KD_ROWS_LAST : KD_ROWS;
-  const double* __restrict__ Jk = M.J + (size_t)k * KD_ROWS * KD_NW;
-  const double* __restrict__ Hk = M.H + (size_t)k * KD_NW * KD_NW;
+  // (global address space: global_load, not flat_load -- a flat load also counts on the LDS counter, so every wait for an LDS read would wait for the
+  // prefetched rows as well: solver_kernels.hip landing_gptr)
+  const landing_gptr Jk = (landing_gptr)(M.J + (size_t)k * KD_ROWS * KD_NW);
+  const landing_gptr Hk = (landing_gptr)(M.H + (size_t)k * KD_NW * KD_NW);
+  const landing_gptr Gsig = (landing_gptr)M.sig, Grho = (landing_gptr)M.rho, Gg = (landing_gptr)M.g;
   const int g0 = KD_BND + k * KD_ROWS;
 #if KD_EARLY_FETCH
   // + J_I' Sigma J_I and m = J_I' rho over the inequality rows 12 .. nr-1, in chunks of KD_JC_ROWS rows staged in LDS; the product runs on
@@ -194,7 +197,7 @@ KD_PHASE void kd_condense_stage(const KdMem& M, int N, int k, double delta) {
       const double v = Jk[(in ? r : 12) * KD_NW + kd_v2w(in ? c : 0)];      // unconditional load (clamped): all NE loads are issued together
       pre[q] = in ? v : 0.0;
     }
-    { const int r = r0 + tid; const bool in = tid < KD_JC_ROWS && r < nr; const double a = M.sig[g0 + (in ? r : 12)], b = M.rho[g0 + (in ? r : 12)]; pre_sg = in ? a : 0.0; pre_rh = in ? b : 0.0; }
+    { const int r = r0 + tid; const bool in = tid < KD_JC_ROWS && r < nr; const double a = Gsig[g0 + (in ? r : 12)], b = Grho[g0 + (in ? r : 12)]; pre_sg = in ? a : 0.0; pre_rh = in ? b : 0.0; }
   };
   fetch(12);      // (round 5, late: the first chunk's loads are in flight behind the Hessian block's)
   // Hessian block of lam' g over v, delta_w on the diagonal, right-hand side cleared; [A^ | b] from the defect rows: X_k+1 = A^ (sigma_k, f_k) + b in
@@ -212,7 +215,7 @@ KD_PHASE void kd_condense_stage(const KdMem& M, int N, int k, double delta) {
 #pragma unroll
     for (int q = 0; q < NA; ++q) {
       const int e = tid + q * KD_THREADS, ee = e < 12 * KD_AS ? e : 0, r = ee / KD_AS, c = ee % KD_AS;
-      const double vj = Jk[r * KD_NW + (c < 36 ? c : 0)], vg = M.g[g0 + r];
+      const double vj = Jk[r * KD_NW + (c < 36 ? c : 0)], vg = Gg[g0 + r];
       av[q] = c < 36 ? -vj : -vg;
     }
 #pragma unroll
@@ -238,7 +241,7 @@ KD_PHASE void kd_condense_stage(const KdMem& M, int N, int k, double delta) {
   // [A^ | b] from the defect rows: X_k+1 = A^ (sigma_k, f_k) + b in step form  (rows in the order of X)
   for (int e = tid; e < 12 * KD_AS; e += NT) {
     const int r = e / KD_AS, c = e % KD_AS;
-    S.Ah[KD_ROW2X[r] * KD_AS + c] = c < 36 ? -Jk[r * KD_NW + c] : -M.g[g0 + r];
+    S.Ah[KD_ROW2X[r] * KD_AS + c] = c < 36 ? -Jk[r * KD_NW + c] : -Gg[g0 + r];
   }
   __syncthreads();
   // + J_I' Sigma J_I and m = J_I' rho over the inequality rows 12 .. nr-1, in chunks of KD_JC_ROWS rows staged in LDS; the product runs on
@@ -258,7 +261,7 @@ KD_PHASE void kd_condense_stage(const KdMem& M, int N, int k, double delta) {
       const double v = Jk[(in ? r : 12) * KD_NW + kd_v2w(in ? c : 0)];      // unconditional load (clamped): all NE loads are issued together
       pre[q] = in ? v : 0.0;
     }
-    { const int r = r0 + tid; const bool in = tid < KD_JC_ROWS && r < nr; const double a = M.sig[g0 + (in ? r : 12)], b = M.rho[g0 + (in ? r : 12)]; pre_sg = in ? a : 0.0; pre_rh = in ? b : 0.0; }
+    { const int r = r0 + tid; const bool in = tid < KD_JC_ROWS && r < nr; const double a = Gsig[g0 + (in ? r : 12)], b = Grho[g0 + (in ? r : 12)]; pre_sg = in ? a : 0.0; pre_rh = in ? b : 0.0; }
   };
   fetch(12);
 #endif
@@ -484,7 +487,7 @@ KD_PHASE void kd_forward(const KdMem& M, int N, const double* lbm) {
   static_assert(2 * NREC <= KD_NV * KD_MS, "two records fit the stage array");
   double nxt[NQ];
   auto fetch = [&](int k) {
-    const double* rec = M.rec + (size_t)(k < N ? k : N - 1) * KD_REC;
+    const landing_gptr rec = (landing_gptr)(M.rec + (size_t)(k < N ? k : N - 1) * KD_REC);      // (global_load: see kd_condense_stage)
 #pragma unroll
     for (int q = 0; q < NQ; ++q) { const int e = tid + q * KD_THREADS; nxt[q] = rec[e < NREC ? e : NREC - 1]; }
   };
@@ -528,7 +531,7 @@ KD_PHASE void kd_forward(const KdMem& M, int N, const double* lbm) {
   // multipliers of the defect rows of interval k: y = -(P_k+1 dsigma_k+1 + p_k+1)_X in the row order of the defects
   for (int e = tid; e < 12 * N; e += NT) {
     const int k = e / 12, r = e % 12, i = KD_ROW2X[r];
-    const double* recn = M.rec + (size_t)(k + 1) * KD_REC;
+    const landing_gptr recn = (landing_gptr)(M.rec + (size_t)(k + 1) * KD_REC);
     const double* sn = S.dsg + 24 * (k + 1);
     double a = recn[KD_REC_PV + i];
     for (int t = 0; t < 24; ++t) a += recn[KD_REC_PX + i * 24 + t] * sn[t];
@@ -552,11 +555,11 @@ KD_PHASE void kd_forward(const KdMem& M, int N, const double* lbm) {
       for (int u = 0; u < 4; ++u) {
         const int q = q0 + u < nrows ? q0 + u : nrows - 1;
         const int k = q / (KD_ROWS - 12), r = 12 + q % (KD_ROWS - 12);
-        const double* Jr = M.J + ((size_t)k * KD_ROWS + r) * KD_NW;
+        const landing_gptr Jr = (landing_gptr)(M.J + ((size_t)k * KD_ROWS + r) * KD_NW);      // (global_load: the dk reads below wait on the LDS counter only)
         j0[u] = Jr[l]; j1[u] = Jr[64 + (l < KD_NW - 64 ? l : 0)];
         kk[u] = k; gr[u] = KD_BND + k * KD_ROWS + r;
       }
-      if (l < 4) { const int g = l == 0 ? gr[0] : (l == 1 ? gr[1] : (l == 2 ? gr[2] : gr[3])); gs[0] = M.g[g] - M.s[g]; }
+      if (l < 4) { const int g = l == 0 ? gr[0] : (l == 1 ? gr[1] : (l == 2 ? gr[2] : gr[3])); gs[0] = ((landing_gptr)M.g)[g] - ((landing_gptr)M.s)[g]; }
     };
     issue(4 * wave);
     for (int q0 = 4 * wave; q0 < nrows; q0 += 16) {
