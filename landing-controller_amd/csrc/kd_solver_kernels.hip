@@ -1040,19 +1040,19 @@ __global__ void __launch_bounds__(KD_THREADS, 2) landing_kd_iter_kernel(KdSolveA
       }
     } else
     for (int r = tid + 24; r < ng; r += NT) {
-      const double lb = lbm[r], ub = ubm[r], g = M.g[r];
+      // (every array of the row is loaded before the first test: under the tests each load waited for its own round trip -- 3 per row instead of 1)
+      const double lb = lbm[r], ub = ubm[r], g = M.g[r], s = M.s[r], ds = M.ds[r], zl_ = M.zL[r], zu_ = M.zU[r];
       if (lb == ub) { th0 += fabs(g - lb); continue; }
-      const double s = M.s[r], ds = M.ds[r];
       th0 += fabs(g - s);
       double dprod = 1.0;
       if (lb > -INF) {
-        const double d = s - lb, rd = 1.0 / d, zl = M.zL[r];
+        const double d = s - lb, rd = 1.0 / d, zl = zl_;
         const double dz = -zl * rd * ds + (mu * rd - zl);
         m_pr = fmax(m_pr, -ds * rd); top4_push(top, -ds * rd); hist_push(-ds * rd); m_du = fmax(m_du, -dz / zl);
         dprod = d; dphi -= mu * ds * rd;
       }
       if (ub < INF) {
-        const double d = ub - s, rd = 1.0 / d, zu = M.zU[r];
+        const double d = ub - s, rd = 1.0 / d, zu = zu_;
         const double dz = zu * rd * ds + (mu * rd - zu);
         m_pr = fmax(m_pr, ds * rd); top4_push(top, ds * rd); hist_push(ds * rd); m_du = fmax(m_du, -dz / zu);
         dprod *= d; dphi += mu * ds * rd;
@@ -1112,10 +1112,10 @@ __global__ void __launch_bounds__(KD_THREADS, 2) landing_kd_iter_kernel(KdSolveA
       }
     } else
     for (int r = tid + 24; r < ng; r += NT) {
-      const double lb = lbm[r], ub = ubm[r], g = M.gt[r];
+      const double lb = lbm[r], ub = ubm[r], g = M.gt[r], so = M.s[r], dso = M.ds[r];      // (loads before the tests: see the step-bound pass)
       if (lb == ub) { tht += fabs(g - lb); continue; }
-      double s = M.s[r] + alpha * M.ds[r];
-      if (omt > 0.0) { const double so = M.s[r]; if (lb > -INF) s = fmax(s, lb + omt * (so - lb)); if (ub < INF) s = fmin(s, ub - omt * (ub - so)); }
+      double s = so + alpha * dso;
+      if (omt > 0.0) { if (lb > -INF) s = fmax(s, lb + omt * (so - lb)); if (ub < INF) s = fmin(s, ub - omt * (ub - so)); }
       tht += fabs(g - s);
       bt -= log((lb > -INF ? s - lb : 1.0) * (ub < INF ? ub - s : 1.0));
     }
@@ -1237,23 +1237,23 @@ __global__ void __launch_bounds__(KD_THREADS, 2) landing_kd_iter_kernel(KdSolveA
     double npr = 0.0, nco = 0.0, ncm = 0.0, nys = 0.0, nzs = 0.0, nnz = 0.0;
     for (int r = tid; r < ng; r += NT) {
       const double lb = lbm[r], ub = ubm[r], g = M.gt[r];
+      const double y_ = M.y[r], yn0_ = M.yn[r], so = M.s[r], ds = M.ds[r], zlo_ = M.zL[r], zuo_ = M.zU[r];      // (loads before the tests: see the step-bound pass)
       M.g[r] = g;
       double sg = 0.0, rh = 0.0;
       if (r >= 24) {
-        if (lb == ub) { const double yn_ = M.y[r] + alpha * (M.yn[r] - M.y[r]); M.y[r] = yn_; nys += fabs(yn_); npr = fmax(npr, fabs(g - lb)); }
+        if (lb == ub) { const double yn_ = y_ + alpha * (yn0_ - y_); M.y[r] = yn_; nys += fabs(yn_); npr = fmax(npr, fabs(g - lb)); }
         else {
-          const double so = M.s[r], ds = M.ds[r];
           double s = so + alpha * ds;
           if (omt > 0.0) { if (lb > -INF) s = fmax(s, lb + omt * (so - lb)); if (ub < INF) s = fmin(s, ub - omt * (ub - so)); }
           if (s_corr > 0.0) { const double lo = lb > -INF ? lb + s_corr * (s - lb) : -INF, hi = ub < INF ? ub - s_corr * (ub - s) : INF; s = fmin(fmax(g, lo), hi); }
           double zl = 0.0, zu = 0.0;
           if (lb > -INF) {
-            const double dold = so - lb, zo = M.zL[r], dz = -zo / dold * ds + (mu / dold - zo), d = s - lb;
+            const double dold = so - lb, zo = zlo_, dz = -zo / dold * ds + (mu / dold - zo), d = s - lb;
             zl = fmin(fmax(zo + a_du * dz, 1e-10 * mu / d), 1e10 * mu / d);
             nco = fmax(nco, d * zl); ncm = fmax(ncm, fabs(d * zl - mu)); sg += zl / d; rh -= mu / d; nzs += zl; nnz += 1.0;
           }
           if (ub < INF) {
-            const double dold = ub - so, zo = M.zU[r], dz = zo / dold * ds + (mu / dold - zo), d = ub - s;
+            const double dold = ub - so, zo = zuo_, dz = zo / dold * ds + (mu / dold - zo), d = ub - s;
             zu = fmin(fmax(zo + a_du * dz, 1e-10 * mu / d), 1e10 * mu / d);
             nco = fmax(nco, d * zu); ncm = fmax(ncm, fabs(d * zu - mu)); sg += zu / d; rh += mu / d; nzs += zu; nnz += 1.0;
           }
