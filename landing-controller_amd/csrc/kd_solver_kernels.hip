@@ -763,7 +763,8 @@ __global__ void __launch_bounds__(KD_THREADS) landing_kd_init_kernel(KdSolveArgs
 #define KD_DELTA_JUMP 12     // (round 5; 0 = off: rounds 3-4)
 #endif
 #ifndef KD_TRIES_PER_ROUND
-#define KD_TRIES_PER_ROUND 3      // (round 5: 3 with the matrix-core elimination, 0.7 instead of 1.8 ms per attempt -- 1.23 -> 1.07 s per batch of 1024; round 4: 1)
+#define KD_TRIES_PER_ROUND 2      // (round 5: 3 with the matrix-core elimination, 0.7 instead of 1.8 ms per attempt -- 1.23 -> 1.07 s per batch of 1024; round 4: 1.  With the
+                                  // portfolio and the delta_w continuation 2: the tail rounds wait for their slowest member's attempts -- 0.408 -> 0.394 s, 1 attempt 0.411)
 #endif
 __global__ void __launch_bounds__(KD_THREADS, 2) landing_kd_iter_kernel(KdSolveArgs A) {
   const int m = blockIdx.x;
