@@ -960,6 +960,7 @@ __global__ void __launch_bounds__(64, KD_HESS_WAVES) landing_kinodyn_nlp_hess_ke
   if (ks >= KD_HESS_G || k >= N) return;
   const double* xv = xs[ks];
   const int i = pair_i[pr], j = pair_j[pr];
+  if (i == 255) return;      // padding of the wavefront-pure order (solver_capi.inc kd_ensure_pairs)
   double* Hk = a.hess + a.oh(b) + ((size_t)k * KD_NW) * KD_NW;
   const bool last = k == N - 1;
   if (last && j >= 60) return;
