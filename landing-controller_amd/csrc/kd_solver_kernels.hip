@@ -474,6 +474,9 @@ KD_PHASE bool kd_backward(const KdMem& M, int N, const double* cost, double delt
 }
 
 // forward sweep: dx of every variable, multipliers of the defect rows (yn), ds of every inequality row
+#ifndef KD_DS_U
+#define KD_DS_U 16
+#endif
 KD_PHASE void kd_forward(const KdMem& M, int N, const double* lbm) {
   KdLds& S = KSH;
   const int tid = threadIdx.x, NT = blockDim.x;
@@ -548,38 +551,43 @@ KD_PHASE void kd_forward(const KdMem& M, int N, const double* lbm) {
   __syncthreads();
   {
     const int nrows = (N - 1) * (KD_ROWS - 12) + (KD_ROWS_LAST - 12);      // inequality rows of all intervals, interval-major
-    // software pipeline: the loads of the next four rows are issued before the shuffle chains of the current four
-    double j0[4], j1[4], gs[4] = {0.0, 0.0, 0.0, 0.0}; int kk[4], gr[4];
+    // software pipeline: the loads of the next KD_DS_U rows of this wave are issued before the shuffle chains of the current ones (round 5: 4 rows; late round 5: 16 -- same box 0.378 -> 0.370 s per batch, 8 rows 0.372 --
+    // 160 steps of a wave each waited about one load latency: the pass was most of the forward sweep's 0.37 ms)
+    constexpr int U = KD_DS_U;
+    double j0[U], j1[U], gs = 0.0; int kk[U], gr[U];
     auto issue = [&](int q0) {
+      int gl = KD_BND + 12;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < U; ++u) {
         const int q = q0 + u < nrows ? q0 + u : nrows - 1;
         const int k = q / (KD_ROWS - 12), r = 12 + q % (KD_ROWS - 12);
         const landing_gptr Jr = (landing_gptr)(M.J + ((size_t)k * KD_ROWS + r) * KD_NW);      // (global_load: the dk reads below wait on the LDS counter only)
         j0[u] = Jr[l]; j1[u] = Jr[64 + (l < KD_NW - 64 ? l : 0)];
         kk[u] = k; gr[u] = KD_BND + k * KD_ROWS + r;
+        gl = l == u ? gr[u] : gl;
       }
-      if (l < 4) { const int g = l == 0 ? gr[0] : (l == 1 ? gr[1] : (l == 2 ? gr[2] : gr[3])); gs[0] = ((landing_gptr)M.g)[g] - ((landing_gptr)M.s)[g]; }
+      if (l < U) gs = ((landing_gptr)M.g)[gl] - ((landing_gptr)M.s)[gl];
     };
-    issue(4 * wave);
-    for (int q0 = 4 * wave; q0 < nrows; q0 += 16) {
-      double a[4]; int gc[4]; const double gsc = gs[0];
+    issue(U * wave);
+    for (int q0 = U * wave; q0 < nrows; q0 += 4 * U) {
+      double a[U]; int gc[U]; const double gsc = gs;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < U; ++u) {
         const double* dk = dxa + kk[u] * KD_NW;
         a[u] = j0[u] * dk[l];
         if (l < KD_NW - 64) a[u] += j1[u] * dk[64 + l];
         gc[u] = gr[u];
       }
-      if (q0 + 16 < nrows) issue(q0 + 16);      // (uniform per wave)
+      if (q0 + 4 * U < nrows) issue(q0 + 4 * U);      // (uniform per wave)
 #pragma unroll
       for (int mask = 32; mask >= 1; mask >>= 1) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) a[u] += __shfl_xor(a[u], mask);
+        for (int u = 0; u < U; ++u) a[u] += __shfl_xor(a[u], mask);
       }
-      if (l < 4 && q0 + l < nrows) {
-        const double v = l == 0 ? a[0] : (l == 1 ? a[1] : (l == 2 ? a[2] : a[3]));
-        const int g = l == 0 ? gc[0] : (l == 1 ? gc[1] : (l == 2 ? gc[2] : gc[3]));
+      if (l < U && q0 + l < nrows) {
+        double v = a[0]; int g = gc[0];
+#pragma unroll
+        for (int u = 1; u < U; ++u) { v = l == u ? a[u] : v; g = l == u ? gc[u] : g; }
         M.ds[g] = v + gsc;
       }
     }
