@@ -119,28 +119,6 @@ __device__ __forceinline__ const landing_solver_opts& kd_opts_of(const KdSolveAr
 // variable j of v = (X_k, c_k, f_k, jpos_k, c_k+1) -> column of the interval's block over w = (X_k, c_k, f_k, jpos_k, X_k+1, c_k+1)
 __host__ __device__ inline int kd_v2w(int j) { return j < 48 ? j : j + 12; }
 
-// g at x for one member: one lane per interval (callers pass every thread of the block; lanes >= N only write boundary rows / idle)
-KD_PHASE void kd_member_eval_g(const KdNlpParams& P, const RbdModel& M, int N, const double* x, double* g, double* wbuf) {
-  for (int k = threadIdx.x; k < N; k += blockDim.x) {
-    // the 72 stage variables are gathered into the member's workspace and read from there where they are used: as a local array they are
-    // promoted to 144 VGPRs and, with the rows' temporaries, put the phase at 253 VGPRs + 32 AGPRs of spill (one workgroup per CU)
-    double* w = wbuf + (size_t)k * KD_NW;
-    for (int j = 0; j < KD_NW; ++j) { const int i = kd_w_index(N, k, j); w[j] = i >= 0 ? x[i] : 0.0; }
-    // the rows go straight to the member's g array (a local out[141] is promoted to registers by the unrolled row code: 255 VGPRs + AGPR spills,
-    // one workgroup per CU); the last interval writes its 117 rows only
-    KdRowArray<double> rows{g + KD_BND + k * KD_ROWS};
-    kd_stage_rows<double>(P, M, k, k == N - 1, w, rows);
-  }
-  if (threadIdx.x >= 64 && threadIdx.x < 64 + 48) {      // boundary rows (coordinate picks), by a wave that has no interval to evaluate
-    const int i = threadIdx.x - 64, oU = 12 * (N + 1) + 12 * N;
-    double v;
-    if (i < 12) v = x[i];
-    else if (i < 24) v = x[oU + (i - 12)];
-    else { const int j = i - 24; v = j < 12 ? x[12 * N + (j % 6)] : x[12 * N + 6 + (j % 6)]; }
-    g[i] = v;
-  }
-}
-
 // LDS of one member's workgroup
 struct KdLds {
   double Ms[KD_NV * KD_MS];            // stage array [M | m]
@@ -158,6 +136,42 @@ struct KdLds {
   KdState ks;
 };
 __shared__ KdLds KSH;
+
+// g at x for one member: one lane per interval (callers pass every thread of the block, in uniform control flow; lanes >= N only write boundary rows / idle).
+// The 72 stage variables of every interval are gathered by the WHOLE block into LDS (the arrays of the sweeps, free wherever g is evaluated) with all loads of a
+// thread in flight, and read from there where the rows use them.  (Round 4-5: each interval's lane gathered its own 72 into the member's workspace, load after store
+// after load -- 72 exposed round trips, most of the line search's 0.11 ms; as a local array they are promoted to 144 VGPRs and put the phase at 253 VGPRs + spills.)
+KD_PHASE void kd_member_eval_g(const KdNlpParams& P, const RbdModel& M, int N, const double* x, double* g, double* wbuf) {
+  (void)wbuf;
+  static_assert(64 * KD_NW <= KD_NV * KD_MS + KD_NSIG * KD_PS + KD_NSIG + 12 * KD_AS + KD_NSIG * KD_AS, "the gathered variables of N <= 64 intervals fit the arrays in front of Jc");
+  double* ws = KSH.Ms;
+  const int tid = threadIdx.x, NT = blockDim.x, tot = N * KD_NW;
+  constexpr int NB = 6;
+  for (int e0 = 0; e0 < tot; e0 += NB * NT) {
+    double t[NB]; int ix[NB];
+#pragma unroll
+    for (int q = 0; q < NB; ++q) { const int e = e0 + tid + q * NT, ee = e < tot ? e : 0; ix[q] = kd_w_index(N, ee / KD_NW, ee % KD_NW); t[q] = x[ix[q] >= 0 ? ix[q] : 0]; }
+#pragma unroll
+    for (int q = 0; q < NB; ++q) { const int e = e0 + tid + q * NT; if (e < tot) ws[e] = ix[q] >= 0 ? t[q] : 0.0; }
+  }
+  __syncthreads();
+  for (int k = tid; k < N; k += NT) {
+    const double* w = ws + (size_t)k * KD_NW;
+    // the rows go straight to the member's g array (a local out[141] is promoted to registers by the unrolled row code: 255 VGPRs + AGPR spills,
+    // one workgroup per CU); the last interval writes its 117 rows only
+    KdRowArray<double> rows{g + KD_BND + k * KD_ROWS};
+    kd_stage_rows<double>(P, M, k, k == N - 1, w, rows);
+  }
+  if (tid >= 64 && tid < 64 + 48) {      // boundary rows (coordinate picks), by a wave that has no interval to evaluate
+    const int i = tid - 64, oU = 12 * (N + 1) + 12 * N;
+    double v;
+    if (i < 12) v = x[i];
+    else if (i < 24) v = x[oU + (i - 12)];
+    else { const int j = i - 24; v = j < 12 ? x[12 * N + (j % 6)] : x[12 * N + 6 + (j % 6)]; }
+    g[i] = v;
+  }
+  __syncthreads();
+}
 
 #define KD_BEGIN() __syncthreads(); if (threadIdx.x == 0) {
 #define KD_BEGIN_SYNCED() if (threadIdx.x == 0) {
