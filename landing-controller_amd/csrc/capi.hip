@@ -59,7 +59,7 @@ struct landing_ctx {
   // fenced by this event (recorded behind them, waited for before the next writer / reader touches the block) -- ADVICE r2
   hipEvent_t scratch_done = nullptr;
   double* d_kd_ws = nullptr; size_t kd_cap = 0; int* d_kd_active = nullptr; int* d_kd_done = nullptr; int kd_done_cap = 0;      // workspace of landing_kinodyn_solve_batch (kd_capi.inc), count of members still iterating
-  unsigned char* d_kd_pairs = nullptr; int kd_npair = 0;      // structurally non-zero pairs of a Hessian block of the kinodynamic NLP ([2][kd_npair]: i | j; solver_capi.inc, kd_ensure_pairs)
+  unsigned char* d_kd_pairs = nullptr; int kd_npair = 0; int rbd_std_base = 0;      // structurally non-zero pairs of a Hessian block of the kinodynamic NLP ([2][kd_npair]: i | j; solver_capi.inc, kd_ensure_pairs)
   const double* wb_skip = nullptr;      // landing_wb_skip_taken: consumed by the next landing_wb_rollout
   int wb_semi = 0;             // integrator of the whole-body loop: 0 explicit Euler, 1 semi-implicit Euler (landing_wb_set_integrator)
   bool rbd_arrow = false;      // the model set by landing_rbd_set_model is "six base joints + four 3-joint legs on the base": H is block-arrow (wb_kernels.hip)

@@ -594,7 +594,7 @@ __global__ void __launch_bounds__(64) landing_kinodyn_rows_kernel(KdArgs a) {
 // One stage function, templated on the scalar: double for g, Dual for one tangent direction -- the Jacobian block of a stage
 // (rows x 72 columns over w = [X_k, c_k, f_k, jpos_k, X_k+1, c_k+1]) is produced exactly, one thread per (member, interval, column),
 // the way the reference gets it from CasADi's algorithmic differentiation.
-struct KdNlpParams { double dt[64]; double mass, Ib[3], Ibi[3], mu; };
+struct KdNlpParams { double dt[64]; double mass, Ib[3], Ibi[3], mu; int std_base = 0; };      // std_base: the tree's base is Px Py Pz Rx Ry Rz with identity tree transforms (landing_rbd_set_model)
 constexpr int KD_NW = 72, KD_ROWS = 141, KD_ROWS_LAST = 117, KD_BND = 48;
 __host__ __device__ inline int kd_ng(int N) { return KD_BND + (N - 1) * KD_ROWS + KD_ROWS_LAST; }
 __host__ __device__ inline int kd_nx(int N) { return 12 * (N + 1) + 12 * N + 24 * N; }
@@ -726,7 +726,9 @@ __device__ __noinline__ void kd_leg_kin_d(const RbdModel& M, int l, const double
 template <class T> struct KdRowArray { T* p; __device__ __forceinline__ void put(const T& v) { *p++ = v; } };
 // w: the stage's 72 variables -- an array of T, or a view that forms them on access (KdSeedView: the hyper-dual kernel keeps 72 doubles and two seed
 // indices instead of 72 hyper-dual numbers)
-template <class T, class OUT, class WIN>
+// STDB: 1 / 0 = the base-transform form is decided at compile time (the derivative kernels exist in both forms: a run-time test keeps the chain's registers alive,
+// 0.348 against 0.335 s per batch), -1 = by P.std_base (the value paths)
+template <class T, class OUT, class WIN, int STDB = -1>
 __device__ void kd_stage_rows(const KdNlpParams& P, const RbdModel& M, int k, bool last, const WIN& w, OUT& out, int legmask = 15) {
   typedef typename KdVec<T>::type V;
   const T zero = lit(w[0], 0.0);
@@ -762,9 +764,17 @@ __device__ void kd_stage_rows(const KdNlpParams& P, const RbdModel& M, int k, bo
   for (int l = 0; l < 4; ++l) out.put(f[3 * l + 2]);                                                                       // :131
   // world -> base transform of the tree (the six base joints take pos, rpy), for the forward kinematics of :182
   T E0[9], r0[3], Ej[9], rj[3];
-  for (int j = 0; j < 9; ++j) E0[j] = lit(w[0], (j % 4 == 0) ? 1.0 : 0.0);
-  r0[0] = r0[1] = r0[2] = zero;
-  for (int i = 0; i < 6; ++i) { joint_xform(M.jtype[i], X[i], M.E[i], M.r[i], Ej, rj); kd_compose(Ej, rj, E0, r0); }
+  if (STDB == 1 || (STDB < 0 && P.std_base)) {      // (uniform: a template argument or a kernel argument)
+    // floating base Px Py Pz Rx Ry Rz with identity tree transforms (rbd.quad3d_model / landing_rbd_model_mc3d; checked by landing_rbd_set_model): the chain of the
+    // six base joints is rz(y) ry(p) rx(r) and the position -- the transpose of R and pos, which the rows above have formed already.  In the hyper-dual kernel the chain
+    // was six 3 x 3 products of hyper-dual numbers: 0.363 -> 0.334 s per batch of the refinement
+    for (int a = 0; a < 3; ++a) for (int b2 = 0; b2 < 3; ++b2) E0[3 * a + b2] = R[3 * b2 + a];
+    r0[0] = pos.x; r0[1] = pos.y; r0[2] = pos.z;
+  } else {
+    for (int j = 0; j < 9; ++j) E0[j] = lit(w[0], (j % 4 == 0) ? 1.0 : 0.0);
+    r0[0] = r0[1] = r0[2] = zero;
+    for (int i = 0; i < 6; ++i) { joint_xform(M.jtype[i], X[i], M.E[i], M.r[i], Ej, rj); kd_compose(Ej, rj, E0, r0); }
+  }
   T fkv[12];
   const double l14 = M.l1 + M.l4;
   for (int l = 0; l < 4; ++l) {
@@ -867,6 +877,7 @@ __global__ void __launch_bounds__(64) landing_kinodyn_nlp_g_kernel(KdNlpArgs a) 
 #endif
 constexpr int KD_JAC_STAGES = KD_JAC_STAGES_DEF, KD_JAC_THREADS = KD_JAC_STAGES * KD_NW;      // 576
 __host__ __device__ inline long long kd_jac_blocks(long long B, int N) { return B * ((N + KD_JAC_STAGES - 1) / KD_JAC_STAGES); }
+template <int STDB>
 __global__ void __launch_bounds__(KD_JAC_THREADS) landing_kinodyn_nlp_jac_kernel(KdNlpArgs a) {
   const int N = a.N, nblk = (N + KD_JAC_STAGES - 1) / KD_JAC_STAGES;
   const int b = (int)(blockIdx.x / nblk), k0 = (int)(blockIdx.x % nblk) * KD_JAC_STAGES;
@@ -889,7 +900,7 @@ __global__ void __launch_bounds__(KD_JAC_THREADS) landing_kinodyn_nlp_jac_kernel
   struct ColOut { double* J; bool zero; const double* y; double acc;
                   __device__ __forceinline__ void put(const Dual& v) { const double d = zero ? 0.0 : v.d; *J = d; J += KD_NW; if (y) { acc += d * *y; ++y; } } };
   ColOut out{a.jac + a.oj(b) + ((size_t)k * KD_ROWS) * KD_NW + col, last && col >= 60, (a.jty && a.lam) ? a.lam + a.og(b) + KD_BND + (size_t)k * KD_ROWS : nullptr, 0.0};
-  kd_stage_rows<Dual>(a.P, *a.model, k, last, w, out);
+  kd_stage_rows<Dual, ColOut, DualSeedView, STDB>(a.P, *a.model, k, last, w, out);
   if (a.jty && a.lam) a.jty[a.oj(b) + (size_t)k * KD_NW + col] = out.acc;
 }
 
@@ -941,6 +952,7 @@ __host__ __device__ inline long long kd_hess_blocks(long long B, int N, int npai
 #ifndef KD_HESS_WAVES
 #define KD_HESS_WAVES 1
 #endif
+template <int STDB>
 __global__ void __launch_bounds__(64, KD_HESS_WAVES) landing_kinodyn_nlp_hess_kernel(KdNlpArgs a, const unsigned char* __restrict__ pair_i, const unsigned char* __restrict__ pair_j, int npair) {
   const int nch = (KD_HESS_G * npair + 63) / 64, N = a.N, ngr = (N + KD_HESS_G - 1) / KD_HESS_G;
   const long long blk = blockIdx.x;
@@ -974,7 +986,7 @@ __global__ void __launch_bounds__(64, KD_HESS_WAVES) landing_kinodyn_nlp_hess_ke
   const int pl = kd_pair_leg(i, j);
   struct LamOut { const double* lam; double s; __device__ __forceinline__ void put(const HDual& v) { s += *lam++ * v.ab; } };      // lam' (second-order part), row after row
   LamOut out{lam, 0.0};
-  kd_stage_rows<HDual>(a.P, *a.model, k, last, w, out, pl < 0 ? 15 : (1 << pl));
+  kd_stage_rows<HDual, LamOut, KdSeedView, STDB>(a.P, *a.model, k, last, w, out, pl < 0 ? 15 : (1 << pl));
   const double s = out.s;
   Hk[i * KD_NW + j] = s; Hk[j * KD_NW + i] = s;
 }

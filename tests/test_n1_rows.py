@@ -243,6 +243,56 @@ def test_kinodyn_nlp_hessian_gpu():
     L.close()
 
 
+def _base_forms_check(L, dev, N, B):
+    """The derivative kernels exist in two forms (csrc/rbd_kernels.hip kd_stage_rows): with the base transform of the tree taken from R and pos -- the reference model's
+    floating base Px Py Pz Rx Ry Rz, what landing_rbd_set_model recognises -- and composed joint by joint.  A model that differs from the standard one by a tree offset of
+    1e-300 m takes the second form: g, the Jacobian blocks and the Hessian blocks of both agree to rounding; an offset of 0.25 m shows up in g (the second form runs)."""
+    import torch
+    mass, Ib, Ibi = lc("constants").robot_constants()
+    Ib, Ibi = np.asarray(Ib), np.asarray(Ibi)
+    R = lc("rbd").Rbd(L)
+    nx, ng = R.kinodyn_nlp_dims(N)
+    rng = np.random.default_rng(5)
+    dt = 0.02 + 0.03 * rng.random(N); mu = 0.75
+    xs = 0.3 * rng.normal(size=(B, nx)); xs[:, 2:12 * (N + 1):12] += 0.3
+    lam = rng.normal(size=(B, ng))
+    t = lambda a_: torch.tensor(np.ascontiguousarray(a_), dtype=torch.float64, device=dev)
+    st = torch.cuda.current_stream().cuda_stream if dev == "cuda" else 0
+    sync = (lambda: torch.cuda.synchronize()) if dev == "cuda" else (lambda: None)
+    dx, dl = t(xs), t(lam)
+    out = []
+    for offset in (0.0, 1e-300, 0.25):
+        R.model.r[0][0] = offset
+        L._check(L.lib.landing_rbd_set_model(L.ctx, __import__("ctypes").byref(R.model)), "landing_rbd_set_model")
+        g = torch.zeros(B, ng, dtype=torch.float64, device=dev); J = torch.zeros(B, N, 141, 72, dtype=torch.float64, device=dev); H = torch.zeros(B, N, 72, 72, dtype=torch.float64, device=dev)
+        R.kinodyn_nlp_eval(B, N, dx.data_ptr(), dt, mass, Ib, Ibi, mu, g.data_ptr(), J.data_ptr(), st)
+        R.kinodyn_nlp_hess(B, N, dx.data_ptr(), dt, mass, Ib, Ibi, mu, dl.data_ptr(), H.data_ptr(), st); sync()
+        out.append((g.cpu().numpy(), J.cpu().numpy(), H.cpu().numpy()))
+    for a, b, name in zip(out[0], out[1], ("g", "jac", "hess")):
+        assert np.isfinite(a).all() and np.abs(a).max() > 1e-3, name
+        assert np.abs(a - b).max() <= 1e-11 * max(1.0, np.abs(a).max()), (name, np.abs(a - b).max())
+    # a real offset of the tree's root moves every forward-kinematics row by a constant: only the joint-by-joint form can see it -- it is the form a non-standard model gets
+    assert np.abs(out[2][0] - out[0][0]).max() > 0.1
+    for a, b, name in zip(out[0][1:], out[2][1:], ("jac", "hess")):
+        assert np.abs(a - b).max() <= 1e-11 * max(1.0, np.abs(a).max()), (name, np.abs(a - b).max())
+    R.model.r[0][0] = 0.0
+    L._check(L.lib.landing_rbd_set_model(L.ctx, __import__("ctypes").byref(R.model)), "landing_rbd_set_model")
+
+
+def test_kinodyn_base_transform_forms_agree_emulated():
+    subprocess.run(["make", "-C", os.path.join(ROOT, "landing-controller_amd", "csrc"), "emu"], check=True, capture_output=True)
+    L = lc("capi").LandingLib(3, lib_path=os.path.join(ROOT, "tests", "emu", "liblanding_emu.so"))
+    _base_forms_check(L, "cpu", N=3, B=2)
+    L.close()
+
+
+@pytest.mark.gpu
+def test_kinodyn_base_transform_forms_agree_gpu():
+    L = lc("capi").LandingLib(20, device=0)
+    _base_forms_check(L, "cuda", N=20, B=64)
+    L.close()
+
+
 def test_kinodyn_bounds_hold_on_the_stored_solution():
     """host side (landing-controller_amd/kinodyn.py): lbg / ubg in the kernel's row order with the script's values -- the stored solution of the
     CURRENT formulation (prevSoln.mat: FK band 1e-2) lies inside them to the producing solver's tolerance, rows through the oracle"""
