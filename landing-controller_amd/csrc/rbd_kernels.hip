@@ -678,6 +678,35 @@ __device__ void kd_compose(const T* Eu, const T* ru, T* Ea, T* ra) {      // (Ea
   ra[0] = ra[0] + t.x; ra[1] = ra[1] + t.y; ra[2] = ra[2] + t.z;
 }
 
+// (Ea, ra) <- plux(rot_A(q) Et, rt) * plux(Ea, ra) for a revolute joint about axis A whose sine / cosine the caller holds (the leg rows need them for the torque
+// rows anyway): t = Ea' rt and G = Et Ea cost products with the model's constants only, then two rows of G are rotated -- 12 products of T numbers instead of the 27 of
+// the general composition of joint_xform's dense E (and no second sincos per joint)
+template <int A, class T>
+__device__ __forceinline__ void kd_rot_compose_t(const T& S, const T& Cc, const double* Et, const double* rt, T* Ea, T* ra) {
+  constexpr int b = (A + 1) % 3, d = (A + 2) % 3;
+  const T tx = Ea[0] * rt[0] + Ea[3] * rt[1] + Ea[6] * rt[2], ty = Ea[1] * rt[0] + Ea[4] * rt[1] + Ea[7] * rt[2], tz = Ea[2] * rt[0] + Ea[5] * rt[1] + Ea[8] * rt[2];
+  T G[9];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) G[3 * r + c] = Ea[c] * Et[3 * r] + Ea[3 + c] * Et[3 * r + 1] + Ea[6 + c] * Et[3 * r + 2];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    Ea[3 * A + c] = G[3 * A + c];
+    Ea[3 * b + c] = Cc * G[3 * b + c] + S * G[3 * d + c];
+    Ea[3 * d + c] = Cc * G[3 * d + c] - S * G[3 * b + c];
+  }
+  ra[0] = ra[0] + tx; ra[1] = ra[1] + ty; ra[2] = ra[2] + tz;
+}
+template <class T>
+__device__ __forceinline__ void kd_rot_compose(int jt, const T& S, const T& Cc, const double* Et, const double* rt, T* Ea, T* ra) {
+  switch (jt) {
+    case 0: kd_rot_compose_t<0>(S, Cc, Et, rt, Ea, ra); break;
+    case 1: kd_rot_compose_t<1>(S, Cc, Et, rt, Ea, ra); break;
+    default: kd_rot_compose_t<2>(S, Cc, Et, rt, Ea, ra); break;
+  }
+}
+
 // Kinematic rows of one leg of an interval (landing_optimization.m:148-171, 182): p_rel x y z, |p_rel|^2, the three leg torques -> o7[0..6];
 // foot position of the tree -> fk3.  Everything it needs comes through pointers (w = the interval's 72 variables, R body -> world, (E0, r0) the
 // world -> base transform of the tree).  For T = double the function is called out of line (kd_leg_kin_d): inlined four times into the row
@@ -710,8 +739,17 @@ __device__ __forceinline__ void kd_leg_kin(const RbdModel& M, int l, const T* w,
     for (int j = 0; j < 9; ++j) El[j] = E0[j];
     for (int j = 0; j < 3; ++j) rl[j] = r0[j];
     const int jb = M.b_foot[l] - 1;
-    for (int i = jb - 2; i <= jb; ++i) { joint_xform(M.jtype[i], jp[3 * l + (i - (jb - 2))], M.E[i], M.r[i], Ej, rj); kd_compose(Ej, rj, El, rl); }
-    const V pf = add3(mk3(rl[0], rl[1], rl[2]), mulT3(El, mk3(lit(w[0], M.foot_r[l][0]), lit(w[0], M.foot_r[l][1]), lit(w[0], M.foot_r[l][2]))));
+    {
+      const T* Sj[3] = {&s1, &s2, &s3}; const T* Cj[3] = {&c1, &c2, &c3};
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        const int i = jb - 2 + u, jt = M.jtype[i];
+        if (jt < 3) kd_rot_compose(jt, *Sj[u], *Cj[u], M.E[i], M.r[i], El, rl);      // (uniform: the model)
+        else { joint_xform(jt, jp[3 * l + u], M.E[i], M.r[i], Ej, rj); kd_compose(Ej, rj, El, rl); }
+      }
+    }
+    const double fr0 = M.foot_r[l][0], fr1 = M.foot_r[l][1], fr2 = M.foot_r[l][2];      // (El' foot_r with the model's constants as plain doubles)
+    const V pf = mk3(rl[0] + (El[0] * fr0 + El[3] * fr1 + El[6] * fr2), rl[1] + (El[1] * fr0 + El[4] * fr1 + El[7] * fr2), rl[2] + (El[2] * fr0 + El[5] * fr1 + El[8] * fr2));
   fk3[0] = pf.x; fk3[1] = pf.y; fk3[2] = pf.z;
 }
 __device__ __noinline__ void kd_leg_kin_d(const RbdModel& M, int l, const double* w, const double* R, const double* E0, const double* r0, double* o7, double* fk3) {
@@ -812,8 +850,17 @@ __device__ void kd_stage_rows(const KdNlpParams& P, const RbdModel& M, int k, bo
     for (int j = 0; j < 9; ++j) El[j] = E0[j];
     for (int j = 0; j < 3; ++j) rl[j] = r0[j];
     const int jb = M.b_foot[l] - 1;
-    for (int i = jb - 2; i <= jb; ++i) { joint_xform(M.jtype[i], jp[3 * l + (i - (jb - 2))], M.E[i], M.r[i], Ej, rj); kd_compose(Ej, rj, El, rl); }
-    const V pf = add3(mk3(rl[0], rl[1], rl[2]), mulT3(El, mk3(lit(w[0], M.foot_r[l][0]), lit(w[0], M.foot_r[l][1]), lit(w[0], M.foot_r[l][2]))));
+    {      // (kd_rot_compose: the joints' sines / cosines are those of the torque rows above)
+      const T* Sj[3] = {&s1, &s2, &s3}; const T* Cj[3] = {&c1, &c2, &c3};
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        const int i = jb - 2 + u, jt = M.jtype[i];
+        if (jt < 3) kd_rot_compose(jt, *Sj[u], *Cj[u], M.E[i], M.r[i], El, rl);      // (uniform: the model)
+        else { joint_xform(jt, jp[3 * l + u], M.E[i], M.r[i], Ej, rj); kd_compose(Ej, rj, El, rl); }
+      }
+    }
+    const double fr0 = M.foot_r[l][0], fr1 = M.foot_r[l][1], fr2 = M.foot_r[l][2];      // (El' foot_r with the model's constants as plain doubles)
+    const V pf = mk3(rl[0] + (El[0] * fr0 + El[3] * fr1 + El[6] * fr2), rl[1] + (El[1] * fr0 + El[4] * fr1 + El[7] * fr2), rl[2] + (El[2] * fr0 + El[5] * fr1 + El[8] * fr2));
     fkv[3 * l] = pf.x; fkv[3 * l + 1] = pf.y; fkv[3 * l + 2] = pf.z;
   }
   const double km = 0.71 * P.mu;
