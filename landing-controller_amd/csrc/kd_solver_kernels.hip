@@ -31,7 +31,10 @@ constexpr int KD_NSIG = 24, KD_NV = 60;          // state; stage variables v = (
 constexpr int KD_MS = 62;                        // LDS row stride of the stage array [M | m] (column 60 = right-hand side)
 constexpr int KD_PS = 25;                        // LDS row stride of the cost-to-go P (24 x 24)
 constexpr int KD_AS = 37;                        // LDS row stride of [A^ | b] (12 x 37)
-constexpr int KD_JC_ROWS = 36, KD_JC_S = 65;     // rows per chunk of the staged Jacobian (the 129 inequality rows of an interval = 4 chunks), LDS row stride (64 columns + pad)
+#ifndef KD_JC_ROWS_DEF
+#define KD_JC_ROWS_DEF 44
+#endif
+constexpr int KD_JC_ROWS = KD_JC_ROWS_DEF, KD_JC_S = 65;     // rows per chunk of the staged Jacobian (the 129 inequality rows of an interval = 3 chunks of 44; round 5: 4 of 36), LDS row stride (64 columns + pad)
 // per-interval record of the backward sweep (doubles): gains K (36 x 24) | kappa (36) | [A^ | b] (12 x 37) | state rows of the cost-to-go
 // P_k (12 x 24) | p_k (12)
 constexpr int KD_REC_K = 0, KD_REC_KAP = 864, KD_REC_AH = 900, KD_REC_PX = 1344, KD_REC_PV = 1632, KD_REC = 1648;
@@ -126,9 +129,11 @@ struct KdLds {
   double pv[KD_NSIG];
   double Ah[12 * KD_AS];               // [A^ | b]
   double Y[KD_NSIG * KD_AS];           // P [A^ | b] (+ p): rows of sigma+
-  double Jc[KD_JC_ROWS * KD_JC_S];     // chunk of the interval's inequality rows (v columns, zero padded to 64)
+  union {      // (the chunk buffer lives in the backward sweep, the knot steps in the forward sweep: one piece of LDS -- what pays for 44 instead of 36 rows per chunk)
+    double Jc[KD_JC_ROWS * KD_JC_S];     // chunk of the interval's inequality rows (v columns, zero padded to 64)
+    double dsg[KD_NSIG * 65];            // d sigma_k of every knot (N <= 64)
+  };
   double sgc[KD_JC_ROWS], rhc[KD_JC_ROWS];
-  double dsg[KD_NSIG * 65];            // d sigma_k of every knot (N <= 64)
   double dxw[KD_NW];
   double red[(KD_THREADS / 64) * 6];
   int hist[64];                        // clip_k > 4: histogram of the blocking slacks over half-octaves of |ds| / distance
