@@ -130,7 +130,7 @@ typedef struct {
                             iterations mean 34.1, p99 43; 1.8 / 80 -> 63.2; 1.5 / 120 -> 63.4; 1.8 / 120 -> 60.7 (60.4), mean 32.3, p99 40, slowest
                             batch 74 instead of 89 ms; 1.8 / 160 -> 60.6; 2.0 / 120 -> 64.6 and 1.9 / 140 -> 63.3 (p99.9 59..61: the tail grows);
                             kappa_mu 0.1 -> slower.  All 131 072 members converge in every variant.                                            */
-  int max_soc;           /* reserved                                               */
+  int max_soc;           /* reserved: second-order corrections proper are not implemented (slack_corr below repairs the same rejections without a solve) */
   int max_resets;        /* multiplier resets allowed per NLP (default 8), see reset_du.  (2 was tried in round 2: it stops the rare
                             locally infeasible member ~130 iterations earlier, but the N=41-script formulation -- kin-box
                             .05/.05/.27 with the running cost -- then loses 4 of its 17 stored reference cases.)            */
@@ -303,17 +303,49 @@ typedef struct {
                             0 in landing_solver_opts_default                                                              */
   int kd_clone_max;      /* families per wave (workspace: 4 waves x 3 variants x kd_clone_max member blocks behind the batch)          */
   int kd_clone_iter;     /* iteration limit of a clone (its feasibility phase included in the usual way: limit + limit); 0 = 200      */
+  /* ---- round 6: the feasibility phase the way IPOPT runs its restoration phase (fields appended: the layout of rounds 2-5 callers is a prefix).
+     Measured with the CPU port on the reference's production problem (N = 20, non-uniform grid, data-generation law, the 16 x 1024 drop states of
+     tools/soak.py; tools/dev/feas_lab.py; round 5 in brackets): 15 926 converged (15 858) + 438 certificates, every one a KKT point of the elastic problem
+     to tol (488 "certificates", 45 % of them stationary-violation exits) + 13 stalled + 7 undecided (38), slowest member of a batch 386 iterations on
+     average (424); GPU numbers: DESIGN.md 4.3 */
+  double feas_back;      /* an entry into the phase that is not the last one allowed RETURNS to the interior-point iteration as soon as the violation of the
+                            rows (1-norm, equality rows included) has fallen to feas_back times its value at the entry -- IPOPT leaves its restoration
+                            phase as soon as the violation has come down and the filter accepts (required_infeasibility_reduction 0.9).  Default 0.2;
+                            0 = the phase always runs to a feasible point / an elastic KKT point (rounds 3-5)                                      */
+  int feas_max;          /* entries into the phase per solve (default 3; rounds 3-5: 1).  The last one has no early return.  Everything together -- the
+                            interior-point iterations, the phases, what follows them -- ends after 3 max_iter iterations at the latest (as before) */
+  double feas_delta_dec; /* inside the phase the first regularisation tried is delta_last * feas_delta_dec instead of delta_last * delta_dec (default 0.1;
+                            0 = delta_dec).  The elastic problem has no objective: along its flat directions the step is gradient / delta_w, and the
+                            iterate reaches the vertex it is heading for only once delta_w has fallen to ~1e-10 -- 38 iterations of halving from the
+                            1e-3 the first barrier problems leave behind (traces: tools/dev/feas_trace.py), during which the equality rows are thrown
+                            off by orders of magnitude and come back ("wandering", DESIGN.md 4.3 of round 5)                                         */
+  double feas_ret_push;  /* the point a phase hands back is taken over WARM: slacks pushed only feas_ret_push off their bounds (bound_push and bound_frac
+                            of that re-initialisation), bound multipliers mu / distance with mu = feas_ret_mu, so that the feasibility the phase gained is
+                            kept (rounds 3-5 re-initialised as at the start: bound_push 1.0 and mu 0.5 threw the iterate back to a violation of the
+                            size it had entered with).  Defaults 0.01 / 0.01; feas_ret_push = 0: the re-initialisation of the start                  */
+  double feas_ret_mu;
+  int feas_resume;       /* 1 (default): a phase that ends at a stationary violation (feas_stat) which the polishing step below could not turn into a KKT
+                            point hands its point back to the interior-point iteration ONCE instead of ending the solve; if that does not lead anywhere
+                            either (line search jammed again, iteration limit, no factorisation) the solve ends as LANDING_STALLED.  0: LANDING_STALLED
+                            at once                                                                                                               */
+  double feas_polish;    /* at the first stationary violation of a phase the regularisation is dropped to this value (default 1e-8; 0 = off) and the
+                            stationarity count restarts: of 21 members per 4096 that round 5 reported "infeasible" from such a point, 19 are 5 Newton
+                            steps away from the KKT point of the elastic problem (an honest status 3), the others are not stationary at all          */
 } landing_solver_opts;
 
 /* status codes written per batch member by landing_solve_batch */
 #define LANDING_CONVERGED 0
 #define LANDING_MAX_ITER 1
 #define LANDING_NUMERICAL 2     /* NaN/Inf or regularisation blow-up; other members unaffected */
-#define LANDING_INFEASIBLE 3    /* the feasibility phase (landing_solver_opts::feas_phase) ended at a KKT point of the elastic problem with positive
-                                   violation, or with a violation that has been stationary for feas_stat iterations at mu <= 1e-4 (equality
-                                   rows within 1e-3 there): a
-                                   certificate of LOCAL infeasibility (what IPOPT reports as "converged to a point of local
-                                   infeasibility"); x is that point, kkt[0] its largest violation                                            */
+#define LANDING_INFEASIBLE 3    /* the feasibility phase (landing_solver_opts::feas_phase) ended at a KKT point of the elastic problem (stationarity,
+                                   equality rows and complementarity all within tol) with positive violation: a certificate of LOCAL
+                                   infeasibility (what IPOPT reports as "converged to a point of local infeasibility"); x is that point,
+                                   kkt[0] its largest violation.  Since round 6 nothing else is reported under this code                     */
+#define LANDING_STALLED 4       /* no certificate and no solution: the feasibility phase ended at a violation that had been stationary for feas_stat
+                                   iterations at mu <= 1e-4 (equality rows within 1e-3) without being a KKT point of the elastic problem, or the
+                                   line search jammed again with no entry into the phase left (feas_max).  x is the last iterate, kkt[0] its largest
+                                   violation.  Rounds 3-5 reported the first case as LANDING_INFEASIBLE; a caller may re-pose such a member with
+                                   other options -- the outcome says nothing about the problem                                                */
 
 void landing_form_default(landing_form* f);
 void landing_solver_opts_default(landing_solver_opts* o);

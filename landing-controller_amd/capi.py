@@ -30,7 +30,8 @@ class SolverOpts(C.Structure):
                 ("delta_init", C.c_double), ("delta_inc_first", C.c_double), ("delta_inc", C.c_double), ("delta_dec", C.c_double),
                 ("tau_min", C.c_double), ("alpha_fallback", C.c_double), ("reset_delta", C.c_double), ("clip_k", C.c_int), ("clip_until", C.c_double), ("theta_floor", C.c_double), ("fresh_restart", C.c_int), ("dual_step_cap", C.c_double), ("slack_corr", C.c_double), ("watchdog", C.c_int), ("barrier_smax", C.c_double), ("factor_fp32", C.c_int),
                 ("feas_phase", C.c_int), ("feas_rho", C.c_double), ("feas_cert", C.c_double), ("delta_floor", C.c_double), ("jam_clip", C.c_int), ("stag_relief", C.c_int), ("feas_jam", C.c_int), ("feas_stat", C.c_int),
-                ("kd_clone_after", C.c_int), ("kd_clone_max", C.c_int), ("kd_clone_iter", C.c_int)]
+                ("kd_clone_after", C.c_int), ("kd_clone_max", C.c_int), ("kd_clone_iter", C.c_int),
+                ("feas_back", C.c_double), ("feas_max", C.c_int), ("feas_delta_dec", C.c_double), ("feas_ret_push", C.c_double), ("feas_ret_mu", C.c_double), ("feas_resume", C.c_int), ("feas_polish", C.c_double)]
 
 
 ARGS21 = ["Xref", "Uref", "dt", "q_min", "q_max", "qd_min", "qd_max", "q_init", "qd_init", "q_term_min", "q_term_max",

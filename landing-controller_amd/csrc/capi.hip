@@ -95,6 +95,7 @@ void landing_solver_opts_default(landing_solver_opts* o) {
   o->kd_clone_after = 0; o->kd_clone_max = 0; o->kd_clone_iter = 0;
   o->feas_phase = 1; o->feas_rho = 1000.0; o->feas_cert = 1e-4;
   o->delta_floor = 3e-4;
+  o->feas_back = 0.2; o->feas_max = 3; o->feas_delta_dec = 0.1; o->feas_ret_push = 0.01; o->feas_ret_mu = 0.01; o->feas_resume = 1; o->feas_polish = 1e-8;
 }
 
 void landing_solver_opts_warm(landing_solver_opts* o) {

@@ -60,7 +60,7 @@ struct KdState {
   int stag, full_prev; double e_prev;      // stag_relief (landing_nlp.h): full steps of the last barrier problem that did not halve the error
   // feasibility (restoration) phase, round 5 -- the scheme of landing_ipm_kernel (solver_kernels.hip, landing_nlp.h feas_phase / feas_jam / feas_stat):
   // feas = 1 while the elastic problem is being solved, lim = iteration limit in force, fjam / fstat / v1_ref = the two rules' counters
-  int feas, feas_used, lim, fjam, fstat; double v1_ref, c_rn, f_vmax, f_v1;
+  int feas, feas_used, lim, fjam, fstat, polished; double v1_ref, c_rn, f_vmax, f_v1;
   double prof[8]; long long tp;      // development aid: wall_clock64 ticks (100 MHz) per phase, summed over the iterations: grad | mu | backward | forward | dual | line search | accept
 };
 
@@ -760,7 +760,7 @@ __global__ void __launch_bounds__(KD_THREADS) landing_kd_init_kernel(KdSolveArgs
     K.nfilt = 0; K.it = 0; K.status = LANDING_MAX_ITER; K.done = 0; K.need_reg_streak = 0; K.first_failed = 0; K.cutstreak = 0; K.force_step = 0;
     K.wd_count = 0; K.last_mu_it = 0; K.accepted = 0; K.armijo_step = 0; K.fact_ok = 0; K.skipped_zero = 0; K.attempt = 0; K.flag = 0; K.ls_done = 0;
     K.need_corr = 0; K.fallback = 0; K.nfact = 0; K.ntrial = 0; K.nreset = 0; K.last_reset_it = 0; K.ncrawl = 0; K.clip_k_cur = o.clip_k; K.fresh = 0; K.reg_it = -1000; K.pending = 0; K.stag = 0; K.full_prev = 0; K.e_prev = 1e300;
-    K.feas = 0; K.feas_used = 0; K.lim = o.max_iter; K.fjam = 0; K.fstat = 0; K.v1_ref = 0.0; K.c_rn = 0.0; K.f_vmax = 0.0; K.f_v1 = 0.0;
+    K.feas = 0; K.feas_used = 0; K.lim = o.max_iter; K.fjam = 0; K.fstat = 0; K.polished = 0; K.v1_ref = 0.0; K.c_rn = 0.0; K.f_vmax = 0.0; K.f_v1 = 0.0;
     for (int i = 0; i < 8; ++i) K.prof[i] = 0.0; K.tp = 0;
   }
   __syncthreads();
@@ -841,8 +841,8 @@ __global__ void __launch_bounds__(KD_THREADS, 2) landing_kd_iter_kernel(KdSolveA
         bool give_up = false;
         if (K.feas) {
           // feasibility phase (landing_nlp.h): a feasible point (or an elastic KKT point with negligible violation) restarts the solve from here, an elastic
-          // KKT point with positive violation -- or a violation that has been stationary for feas_stat iterations with the equality rows at 1e-3 -- is the
-          // certificate of local infeasibility
+          // KKT point with positive violation is the certificate of local infeasibility; a violation that has been stationary for feas_stat iterations with
+          // the equality rows at 1e-3 is not (LANDING_STALLED, round 6)
           const bool conv = fmax(du, fmax(pr, co)) <= o.tol;
           if (!(du < 1e300) || !(pr < 1e300) || !(co < 1e300)) { K.status = LANDING_NUMERICAL; K.flag = 1; }
           else if (K.f_vmax <= 1e-9 && pr <= o.tol) K.flag = 3;
@@ -851,7 +851,11 @@ __global__ void __launch_bounds__(KD_THREADS, 2) landing_kd_iter_kernel(KdSolveA
           else if (o.feas_stat > 0) {
             const double v1 = K.f_v1;
             if (K.fstat < 0 || !(fabs(v1 - K.v1_ref) <= 0.05 * K.v1_ref)) { K.v1_ref = v1; K.fstat = 0; } else K.fstat++;
-            if (K.fstat >= o.feas_stat && K.mu <= 1e-4 && pr <= 1e-3) { if (v1 > o.feas_cert) { K.status = LANDING_INFEASIBLE; K.flag = 1; } else K.flag = 3; }
+            if (K.fstat >= o.feas_stat && K.mu <= 1e-4 && pr <= 1e-3) {      // round 6 (landing_nlp.h): a stationary violation is not a certificate -- the regularisation is dropped once
+              if (v1 <= o.feas_cert) K.flag = 3;                             // (a stationary point is then a few Newton steps from the elastic KKT point, status 3 above); after that LANDING_STALLED
+              else if (o.feas_polish > 0.0 && !K.polished) { K.polished = 1; K.fstat = -1; K.delta_last = o.feas_polish / o.delta_dec; K.need_reg_streak = 2; }
+              else { K.status = LANDING_STALLED; K.flag = 1; }
+            }
           }
           if (K.flag == 0 && K.it >= K.lim) { K.status = LANDING_MAX_ITER; K.flag = 1; }
           if (K.flag == 3) {

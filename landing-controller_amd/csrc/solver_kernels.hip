@@ -197,6 +197,10 @@ struct IpmState {
   int feas, feas_used, lim, fact_failed;
   int fjam, fstat; double v1_ref;      // feas_jam / feas_stat (landing_nlp.h): leaky count of iterations with a tiny accepted step; iterations with a stationary violation, its reference value
   double c_rn, f_vmax, f_v1;      // |z + w - rho|_inf of the elastic rows; max-norm and 1-norm violation of the inequality rows at x
+  // round 6 (landing_nlp.h: feas_max, feas_back, feas_resume, feas_polish): entries into the phase so far; 1 once a stalled phase has handed its point back (or the
+  // line search jammed with no entry left); 1 once the regularisation was dropped at a stationary violation; violation at the entry point (1-norm, equality rows
+  // included) and 1-norm residual of the equality rows at x; iteration count nothing runs beyond; 1: the entry pass of the phase has to record th_entry
+  int n_feas, stalled, polished, hard_lim, want_entry; double th_entry, f_theq;
 };
 enum { ACT_GO = 0, ACT_STOP = 1, ACT_RESET = 2, ACT_FEAS = 3, ACT_BACK = 4 };
 
@@ -1158,6 +1162,27 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
     }
     __syncthreads();
   };
+  // ... at the point a feasibility phase hands back (landing_nlp.h, feas_ret_push): slacks pushed only feas_ret_push off their bounds, bound multipliers
+  // mu / distance -- what the phase gained in feasibility is kept
+  auto init_slacks_return = [&](double mu_) {
+    const double push = o.feas_ret_push;
+    for (int r = lane; r < ng; r += NT) {
+      const double lb = S.bnd_lb[bidx(r)], ub = S.bnd_ub[bidx(r)];
+      double sv = 0.0, zl = 0.0, zu = 0.0;
+      if (r >= 12 && lb != ub) {
+        const bool hL = lb > -INF, hU = ub < INF;
+        sv = M.g[r];
+        double pl, pu;
+        if (hL && hU) { pl = fmin(push * fmax(1.0, fabs(lb)), push * (ub - lb)); pu = fmin(push * fmax(1.0, fabs(ub)), push * (ub - lb)); }
+        else { pl = push * fmax(1.0, hL ? fabs(lb) : 0.0); pu = push * fmax(1.0, hU ? fabs(ub) : 0.0); }
+        if (hL) sv = fmax(sv, lb + pl);
+        if (hU) sv = fmin(sv, ub - pu);
+        zl = hL ? fmin(fmax(mu_ / (sv - lb), 1e-8), 1e3) : 0.0; zu = hU ? fmin(fmax(mu_ / (ub - sv), 1e-8), 1e3) : 0.0;
+      }
+      M.s[r] = sv; M.zL[r] = zl; M.zU[r] = zu; M.y[r] = zu - zl;
+    }
+    __syncthreads();
+  };
   init_slacks();
   // primal / complementarity errors, Sigma and rho of the CURRENT point for barrier parameter mu_ (one pass over the
   // rows; the accept pass below produces the same quantities for the next iterate, so this runs only at the start,
@@ -1181,14 +1206,14 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
   // inequality rows at x (max norm, 1-norm) and |z + w - rho_pen|_inf in K
   auto feas_point_pass = [&](double mu_) {
     const double frho = o.feas_rho;
-    double pr = 0.0, co = 0.0, cm = 0.0, rn = 0.0, ys = 0.0, zs = 0.0, nz = 0.0, vmax = 0.0, v1 = 0.0;
+    double pr = 0.0, co = 0.0, cm = 0.0, rn = 0.0, ys = 0.0, zs = 0.0, nz = 0.0, vmax = 0.0, v1 = 0.0, teq = 0.0;
     for (int r = lane; r < ng; r += NT) {
       const double lb = S.bnd_lb[bidx(r)], ub = S.bnd_ub[bidx(r)];
       double sg = 0.0, rh = 0.0;
       if (r >= 12) {
         const double g = r_g[r];
         ys += fabs(r_y[r]);
-        if (lb == ub) pr = fmax(pr, fabs(g - lb));
+        if (lb == ub) { pr = fmax(pr, fabs(g - lb)); teq += fabs(g - lb); }
         else {
           const double s = r_s[r], v = fmax(fmax(lb - g, g - ub), 0.0);
           pr = fmax(pr, fabs(g - s)); vmax = fmax(vmax, v); v1 += v;
@@ -1211,9 +1236,12 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
     }
     double v[6] = {pr, co, cm, ys, zs, nz}; const int op[6] = {RMAX, RMAX, RMAX, RSUM, RSUM, RSUM};
     block_reduce<6>(v, op, S.red);
-    double u[3] = {rn, vmax, v1}; const int op3[3] = {RMAX, RMAX, RSUM};
-    block_reduce<3>(u, op3, S.red);
-    KS_BEGIN_SYNCED() K.c_pr = v[0]; K.c_co = v[1]; K.c_cm = v[2]; K.c_ys = v[3]; K.c_zs = v[4]; K.c_nz = fmax(v[5], 1.0); K.c_rn = u[0]; K.f_vmax = u[1]; K.f_v1 = u[2]; KS_END();
+    double u[4] = {rn, vmax, v1, teq}; const int op4[4] = {RMAX, RMAX, RSUM, RSUM};
+    block_reduce<4>(u, op4, S.red);
+    KS_BEGIN_SYNCED()
+      K.c_pr = v[0]; K.c_co = v[1]; K.c_cm = v[2]; K.c_ys = v[3]; K.c_zs = v[4]; K.c_nz = fmax(v[5], 1.0); K.c_rn = u[0]; K.f_vmax = u[1]; K.f_v1 = u[2]; K.f_theq = u[3];
+      if (K.want_entry) { K.th_entry = u[2] + u[3]; K.want_entry = 0; }      // first pass of a phase: the violation it starts from
+    KS_END();
   };
   auto point_pass = [&](double mu_) {
     if (K.feas) { feas_point_pass(mu_); return; }
@@ -1257,6 +1285,7 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
     K.e_pr = 0; K.e_du = 0; K.e_co = 0;
     K.jamrun = 0; K.stag = 0; K.full_prev = 0; K.e_prev = 1e300;
     K.feas = 0; K.feas_used = 0; K.fact_failed = 0; K.lim = o.max_iter; K.fjam = 0; K.fstat = 0; K.v1_ref = 0.0; K.c_rn = 0.0; K.f_vmax = 0.0; K.f_v1 = 0.0;
+    K.n_feas = 0; K.stalled = 0; K.polished = 0; K.want_entry = 0; K.th_entry = 0.0; K.f_theq = 0.0; K.hard_lim = o.max_iter > 0 ? 3 * o.max_iter : 0;
   }
   __syncthreads();
   // the lane = stage phases are called by the lanes that have work only: the callee-saved registers an out-of-line function touches
@@ -1298,17 +1327,25 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
           const bool conv = fmax(du, fmax(pr, co)) <= o.tol;
           if (!(du < 1e300) || !(pr < 1e300) || !(co < 1e300)) { K.status = LANDING_NUMERICAL; act = ACT_STOP; }
           else if (K.f_vmax <= 1e-9 && pr <= o.tol) act = ACT_BACK;
-          else if (conv && K.f_v1 > o.feas_cert) { K.status = LANDING_INFEASIBLE; act = ACT_STOP; }
+          else if (conv && K.f_v1 > o.feas_cert) { K.status = LANDING_INFEASIBLE; act = ACT_STOP; }      // KKT point of the elastic problem with positive violation: the certificate
           else if (conv) act = ACT_BACK;
-          else if (o.feas_stat > 0) {      // stationary violation (landing_nlp.h)
+          else if (o.feas_back > 0.0 && !K.feas_used && K.f_v1 + K.f_theq <= o.feas_back * K.th_entry) act = ACT_BACK;      // the violation has come down: IPOPT leaves its restoration phase here
+          else if (o.feas_stat > 0) {      // stationary violation (landing_nlp.h): NOT a certificate
             const double v1 = K.f_v1;
             if (K.fstat < 0 || !(fabs(v1 - K.v1_ref) <= 0.05 * K.v1_ref)) { K.v1_ref = v1; K.fstat = 0; } else K.fstat++;
-            if (K.fstat >= o.feas_stat && mu <= 1e-4 && pr <= 1e-3) { if (v1 > o.feas_cert) { K.status = LANDING_INFEASIBLE; act = ACT_STOP; } else act = ACT_BACK; }
+            if (K.fstat >= o.feas_stat && mu <= 1e-4 && pr <= 1e-3) {
+              if (v1 <= o.feas_cert) act = ACT_BACK;
+              else if (o.feas_polish > 0.0 && !K.polished) {      // once: the regularisation drops -- a stationary point is then a few Newton steps from the elastic KKT point
+                K.polished = 1; K.fstat = -1; K.delta_last = o.feas_polish / (o.feas_delta_dec > 0.0 ? o.feas_delta_dec : o.delta_dec); K.need_reg_streak = 2;
+              }
+              else if (o.feas_resume && !K.stalled) { K.stalled = 1; K.feas_used = 1; act = ACT_BACK; }      // the interior-point iteration resumes from this point, once
+              else { K.status = LANDING_STALLED; act = ACT_STOP; }
+            }
           }
           if (act == ACT_GO && it >= K.lim) act = ACT_STOP;
           if (act == ACT_BACK) {
-            K.feas = 0; K.lim = it + (o.max_iter > 1 ? o.max_iter : 1); K.status = LANDING_MAX_ITER;
-            K.mu = o.mu_init; K.nfilt = 0; K.delta_last = 0.0; K.need_reg_streak = 0; K.wd_count = 0; K.th_max = 0.0; K.nreset = 0; K.last_reset_it = it; K.ncrawl = 0;
+            K.feas = 0; K.lim = it + (o.max_iter > 1 ? o.max_iter : 1); if (K.lim > K.hard_lim) K.lim = K.hard_lim; K.status = LANDING_MAX_ITER;
+            K.mu = (o.feas_ret_push > 0.0 && o.feas_ret_mu > 0.0) ? o.feas_ret_mu : o.mu_init; K.fjam = 0; K.nfilt = 0; K.delta_last = 0.0; K.need_reg_streak = 0; K.wd_count = 0; K.th_max = 0.0; K.nreset = 0; K.last_reset_it = it; K.ncrawl = 0;
             K.cutstreak = 0; K.force_step = 0;
             K.it = it + 1;
           }
@@ -1318,7 +1355,7 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
         else if (fmax(du, fmax(pr, co)) <= o.tol) { K.status = LANDING_CONVERGED; act = ACT_STOP; }
         else if (it >= K.lim) give_up = true;      // (>=: K.it runs ahead of a limit set from a max_iter < 1)
         else if (du > o.reset_du && nreset >= o.max_resets && o.max_resets > 0) { K.status = LANDING_NUMERICAL; give_up = true; }   // jammed again: give up
-        else if (o.feas_jam > 0 && K.fjam >= o.feas_jam && pr > 1e-3 && !K.feas_used && o.feas_phase) give_up = true;      // jammed line search: the feasibility phase starts now (landing_nlp.h)
+        else if (o.feas_jam > 0 && K.fjam >= o.feas_jam && pr > 1e-3 && o.feas_phase) { give_up = true; if (K.feas_used) K.stalled = 1; }      // jammed line search: the feasibility phase starts now (landing_nlp.h); no entry left: the solve ends here, status 4
         else {
           // crawling: still in the first barrier problem (mu never decreased) restart_period iterations after the last (re)start
           const bool stalled = o.restart_period > 0 && it - K.last_reset_it >= o.restart_period && mu >= o.mu_init && nreset < o.max_resets && K.ncrawl < ((o.fresh_restart & 4) ? 2 : 1);
@@ -1344,9 +1381,10 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
         }
         if (give_up) {
           // the solve would end here as NUMERICAL / MAX_ITER: enter the feasibility phase once (landing_solver_opts::feas_phase)
-          if (o.feas_phase && !K.feas_used && o.max_iter > 0) {      // (max_iter < 1: the caller asked for no iteration at all, the phase would get none either)
+          if (K.stalled) K.status = LANDING_STALLED;      // the point a stalled phase handed back did not lead anywhere either
+          if (o.feas_phase && !K.feas_used && o.max_iter > 0 && it < K.hard_lim) {      // (max_iter < 1: the caller asked for no iteration at all, the phase would get none either)
             act = ACT_FEAS;
-            K.feas = 1; K.feas_used = 1; K.status = LANDING_MAX_ITER; K.lim = it + o.max_iter; K.fstat = -1;
+            K.feas = 1; K.n_feas++; K.feas_used = K.n_feas >= o.feas_max ? 1 : 0; K.status = LANDING_MAX_ITER; K.lim = it + o.max_iter; if (K.lim > K.hard_lim) K.lim = K.hard_lim; K.fstat = -1; K.fjam = 0; K.want_entry = 1;
             K.mu = o.mu_init; K.nfilt = 0; K.th_max = 0.0; K.delta_last = 0.0; K.need_reg_streak = 0; K.cutstreak = 0; K.force_step = 0; K.wd_count = 0;
             K.it = it + 1;
           } else act = ACT_STOP;
@@ -1392,7 +1430,7 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
       if (L.run_cost) rc_init_hc();
       for (int r = lane + 12; r < ng; r += NT) if (S.bnd_lb[bidx(r)] == S.bnd_ub[bidx(r)]) M.y[r] = 0.0;
       __syncthreads();
-      init_slacks();
+      if (o.feas_ret_push > 0.0) init_slacks_return(K.mu); else init_slacks();
       point_pass(K.mu);
       continue;
     }
@@ -1444,7 +1482,8 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
     // (o.sticky_delta = 1: when the first trial of the previous iteration failed, start from delta_last itself)
     KS_BEGIN()
       const double dl = K.delta_last;
-      K.delta = (K.need_reg_streak >= 2 && dl > 0.0) ? fmax(1e-20, dl * ((o.sticky_delta && K.first_failed) ? 1.0 : o.delta_dec)) : 0.0;
+      const double ddec = (K.feas && o.feas_delta_dec > 0.0) ? o.feas_delta_dec : o.delta_dec;      // (the elastic problem has flat directions: its regularisation has to fall faster, landing_nlp.h)
+      K.delta = (K.need_reg_streak >= 2 && dl > 0.0) ? fmax(1e-20, dl * ((o.sticky_delta && K.first_failed) ? 1.0 : ddec)) : 0.0;
       if (!L.run_cost && !K.feas) {      // proximal term of the terminal-cost form (landing_nlp.h)
         double fl = o.delta_floor;
         if (o.stag_relief > 0 && K.stag >= o.stag_relief) {      // ... a tenth of it per stagnating iteration
@@ -1466,7 +1505,7 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
         K.flag = 0;
         if (!ok && K.attempt < 60) {      // next attempt with a larger regularisation
           double d = K.delta; const double dl = K.delta_last;
-          if (d == 0.0) d = (dl == 0.0) ? o.delta_init : fmax(1e-20, dl * o.delta_dec);
+          if (d == 0.0) d = (dl == 0.0) ? o.delta_init : fmax(1e-20, dl * ((K.feas && o.feas_delta_dec > 0.0) ? o.feas_delta_dec : o.delta_dec));
           else d *= (dl == 0.0 ? o.delta_inc_first : o.delta_inc);
           if (!(d > 1e40)) { K.delta = d; K.flag = 1; S.prof[PH_NFACT] += 1.0; }
         }
@@ -1474,7 +1513,7 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
       if (!K.flag) break;
     }
     if (!K.fact_ok) {      // the step cannot be computed: give up (status NUMERICAL), or -- once -- continue in the feasibility phase
-      KS_BEGIN() K.status = LANDING_NUMERICAL; K.fact_failed = (o.feas_phase && !K.feas_used && !K.feas) ? 1 : 0; KS_END();
+      KS_BEGIN() K.status = K.stalled ? LANDING_STALLED : LANDING_NUMERICAL; K.fact_failed = (o.feas_phase && !K.feas_used && !K.feas) ? 1 : 0; KS_END();
       if (K.fact_failed) continue;
       break;
     }

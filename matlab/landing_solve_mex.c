@@ -71,6 +71,7 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     OPT_I(max_resets); OPT_D(reset_du); OPT_I(restart_period); OPT_I(dispatch_order); OPT_D(delta_init); OPT_D(delta_inc_first); OPT_D(delta_inc);
     OPT_D(delta_dec); OPT_D(tau_min); OPT_D(alpha_fallback); OPT_D(reset_delta); OPT_I(clip_k); OPT_D(clip_until); OPT_D(theta_floor);
     OPT_I(fresh_restart); OPT_D(dual_step_cap); OPT_D(slack_corr); OPT_I(watchdog); OPT_D(barrier_smax); OPT_I(factor_fp32); OPT_I(feas_phase); OPT_D(feas_rho); OPT_D(feas_cert); OPT_D(delta_floor); OPT_I(jam_clip); OPT_I(stag_relief); OPT_I(feas_jam); OPT_I(feas_stat);
+    OPT_D(feas_back); OPT_I(feas_max); OPT_D(feas_delta_dec); OPT_D(feas_ret_push); OPT_D(feas_ret_mu); OPT_I(feas_resume); OPT_D(feas_polish);
     {
       const mxArray* dv = os ? mxGetField(os, 0, "devices") : NULL;
       if (dv && !mxIsEmpty(dv)) {

@@ -46,6 +46,7 @@ typedef struct {
   double delta_floor;    /* first regularisation tried in an iteration of the terminal-cost form (include/landing_nlp.h)                     */
   int jam_clip, stag_relief;      /* include/landing_nlp.h */
   int feas_jam, feas_stat;        /* include/landing_nlp.h (round 5) */
+  double feas_back; int feas_max; double feas_delta_dec, feas_ret_push, feas_ret_mu; int feas_resume; double feas_polish;      /* include/landing_nlp.h (round 6) */
 } lo_solver_opts;
 
 void lo_solver_opts_default(lo_solver_opts* o) {
@@ -55,6 +56,7 @@ void lo_solver_opts_default(lo_solver_opts* o) {
   o->barrier_smax = 1.0; o->watchdog = 3; o->slack_corr = 0.9; o->dual_step_cap = 1.0; o->fresh_restart = 9; o->theta_floor = 30.0; o->clip_k = 4; o->clip_until = 0.03;
   o->feas_phase = 1; o->feas_rho = 1000.0; o->feas_cert = 1e-4;
   o->delta_floor = 3e-4; o->jam_clip = 2; o->stag_relief = 3; o->feas_jam = 8; o->feas_stat = 25;
+  o->feas_back = 0.2; o->feas_max = 3; o->feas_delta_dec = 0.1; o->feas_ret_push = 0.01; o->feas_ret_mu = 0.01; o->feas_resume = 1; o->feas_polish = 1e-8;
 }
 
 #define NW 48
@@ -200,7 +202,22 @@ static double slack_step(double s0, double ds, double alpha, double lb, double u
   return s;
 }
 
-/* one NLP; returns status (0 converged, 1 max_iter, 2 numerical) */
+/* slacks and multipliers of the interior-point iteration at the point a feasibility phase hands back (include/landing_nlp.h, feas_ret_push):
+ * slacks pushed only feas_ret_push off their bounds, bound multipliers mu / distance -- what the phase gained in feasibility is kept */
+static void init_slacks_return(work_t* W, const lo_solver_opts* op, double mu) {
+  lo_solver_opts o2 = *op; lo_int r;
+  o2.bound_push = op->feas_ret_push; o2.bound_frac = op->feas_ret_push;
+  init_slacks(W, &o2);
+  for (r = 12; r < W->ng; ++r) {
+    const double lb = W->lb[r], ub = W->ub[r];
+    if (lb == ub) continue;
+    W->zL[r] = lb > -INFINITY ? fmin(fmax(mu / (W->s[r] - lb), 1e-8), 1e3) : 0.0;
+    W->zU[r] = ub < INFINITY ? fmin(fmax(mu / (ub - W->s[r]), 1e-8), 1e3) : 0.0;
+    W->y[r] = W->zU[r] - W->zL[r];
+  }
+}
+
+/* one NLP; returns status (0 converged, 1 max_iter, 2 numerical, 3 certified locally infeasible, 4 stalled: include/landing_nlp.h) */
 static int solve_one(const lo_form* F, const double* p, const double* x0, const lo_solver_opts* op, double* x_out,
                      double* lam_out, int* iters_out, double kkt_out[3], long long counters[2]) {
   const int N = F->N; const lo_int nx = lo_nx(N), ng = lo_ng(N);
@@ -209,6 +226,10 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
   double filt_th[64], filt_ph[64];
   double* gx;
   int feas = 0, feas_used = 0, fact_failed = 0, lim = op->max_iter; const double frho = op->feas_rho;
+  /* round 6 (include/landing_nlp.h): up to feas_max entries into the phase, an entry that is not the last one returns as soon as the violation has
+   * fallen to feas_back of its value at the entry; a phase that stalls hands its point back once (feas_resume); everything inside 3 max_iter iterations */
+  int n_feas = 0, stalled = 0, polished = 0; double th_entry = 0.0; const int hard_lim = op->max_iter > 0 ? 3 * op->max_iter : 0;
+  const double fdec = op->feas_delta_dec > 0.0 ? op->feas_delta_dec : op->delta_dec;
   lo_param_offsets_form(F, &o);
   W->N = N; W->nx = nx; W->ng = ng; W->feas = 0;
   W->en = dalloc(ng); W->ep = dalloc(ng); W->wn = dalloc(ng); W->wp = dalloc(ng); W->den = dalloc(ng); W->dep = dalloc(ng); W->dwn = dalloc(ng); W->dwp = dalloc(ng);
@@ -280,23 +301,34 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
     }
     if (getenv("LO_TRACE")) fprintf(stderr, "it %4d pr %9.2e du %9.2e co %9.2e mu %8.1e dlast %8.1e nreset %d nfilt %d\n", it, pr, du, co, mu, delta_last, nreset, nfilt);
     if (feas) {
-      double vmax = 0.0, v1 = 0.0; int back = 0;
+      double vmax = 0.0, v1 = 0.0, theq = 0.0; int back = 0;
       for (r = 12; r < ng; ++r) {
         const double lb = W->lb[r], ub = W->ub[r], g = W->g[r], v = fmax(fmax(lb - g, g - ub), 0.0);
-        if (lb == ub) continue;
+        if (lb == ub) { theq += fabs(g - lb); continue; }
         vmax = fmax(vmax, v); v1 += v;
       }
       if (getenv("LO_TRACE")) fprintf(stderr, "   feas: viol_inf %9.2e viol_1 %9.2e\n", vmax, v1);
       if (!(du < 1e300) || !(pr < 1e300) || !(co < 1e300)) { status = 2; break; }
       if (vmax <= 1e-9 && pr <= op->tol) back = 1;                       /* a feasible point: back to the interior-point solve from here */
-      else if (fmax(du, fmax(pr, co)) <= op->tol) { if (v1 > op->feas_cert) { status = 3; break; } back = 1; }
-      else if (op->feas_stat > 0) {      /* stationary violation (include/landing_nlp.h) */
+      else if (fmax(du, fmax(pr, co)) <= op->tol) { if (v1 > op->feas_cert) { status = 3; break; } back = 1; }      /* KKT point of the elastic problem: certificate, or negligible violation */
+      else if (op->feas_back > 0.0 && !feas_used && v1 + theq <= op->feas_back * th_entry) {      /* IPOPT leaves its restoration phase as soon as the violation has come down */
+        back = 1; if (getenv("LO_TRACE")) fprintf(stderr, "   early return at it %d: theta %9.2e <= %g x %9.2e\n", it, v1 + theq, op->feas_back, th_entry);
+      }
+      else if (op->feas_stat > 0) {      /* stationary violation (include/landing_nlp.h): NOT a certificate */
         if (fstat < 0 || !(fabs(v1 - v1_ref) <= 0.05 * v1_ref)) { v1_ref = v1; fstat = 0; } else fstat++;
-        if (fstat >= op->feas_stat && mu <= 1e-4 && pr <= 1e-3) { if (v1 > op->feas_cert) { status = 3; break; } back = 1; }
+        if (fstat >= op->feas_stat && mu <= 1e-4 && pr <= 1e-3) {
+          if (v1 <= op->feas_cert) back = 1;
+          else if (op->feas_polish > 0.0 && !polished) {      /* once: the regularisation drops to feas_polish -- a stationary point is then a few Newton steps from the KKT point (status 3) */
+            polished = 1; fstat = -1; delta_last = op->feas_polish / fdec; streak = 2; if (getenv("LO_TRACE")) fprintf(stderr, "   polish at it %d\n", it);
+          }
+          else if (op->feas_resume && !stalled) { stalled = 1; feas_used = 1; back = 1; if (getenv("LO_TRACE")) fprintf(stderr, "   stalled at it %d: the interior-point iteration resumes\n", it); }
+          else { status = 4; break; }
+        }
       }
       if (back) {
-        feas = 0; W->feas = 0; lim = it + (op->max_iter > 1 ? op->max_iter : 1);
-        init_slacks(W, op); mu = op->mu_init; nfilt = 0; delta_last = 0.0; streak = 0; wd_count = 0; th_max = 0.0; nreset = 0; last_reset_it = it; ncrawl = 0; cutstreak = 0; force_step = 0;
+        feas = 0; W->feas = 0; lim = it + (op->max_iter > 1 ? op->max_iter : 1); if (lim > hard_lim) lim = hard_lim;
+        if (op->feas_ret_push > 0.0) { mu = op->feas_ret_mu > 0.0 ? op->feas_ret_mu : op->mu_init; init_slacks_return(W, op, mu); } else { init_slacks(W, op); mu = op->mu_init; }
+        fjam = 0; nfilt = 0; delta_last = 0.0; streak = 0; wd_count = 0; th_max = 0.0; nreset = 0; last_reset_it = it; ncrawl = 0; cutstreak = 0; force_step = 0;
         for (r = 12; r < ng; ++r) if (W->lb[r] == W->ub[r]) W->y[r] = 0.0;
         continue;
       }
@@ -310,16 +342,20 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
       else if (fmax(du, fmax(pr, co)) <= op->tol) { status = 0; break; }
       else if (it >= lim) give_up = 1;
       else if (du > op->reset_du && nreset >= op->max_resets && op->max_resets > 0) { status = 2; give_up = 1; }
-      else if (op->feas_jam > 0 && fjam >= op->feas_jam && pr > 1e-3 && !feas_used && op->feas_phase) { give_up = 1; if (getenv("LO_TRACE")) fprintf(stderr, "   jammed line search -> feasibility phase at it %d\n", it); }
+      else if (op->feas_jam > 0 && fjam >= op->feas_jam && pr > 1e-3 && op->feas_phase) { give_up = 1; if (feas_used) stalled = 1;      /* (no entry left: the solve ends here, status 4) */ if (getenv("LO_TRACE")) fprintf(stderr, "   jammed line search at it %d\n", it); }
       if (give_up) {
-        if (!op->feas_phase || feas_used || op->max_iter < 1) break;
+        if (stalled) status = 4;      /* the point a stalled phase handed back did not lead anywhere either */
+        if (!op->feas_phase || feas_used || op->max_iter < 1 || it >= hard_lim) break;
         /* feasibility phase: from the current point (from the caller's initial guess when the iterate is not finite) */
         fstat = -1;
-        feas = 1; W->feas = 1; feas_used = 1; status = 1; nfilt = 0; th_max = 0.0; delta_last = 0.0; streak = 0; lim = it + op->max_iter; cutstreak = 0; force_step = 0; wd_count = 0;
+        feas = 1; W->feas = 1; feas_used = (++n_feas >= op->feas_max); status = 1; fjam = 0; nfilt = 0; th_max = 0.0; delta_last = 0.0; streak = 0; lim = it + op->max_iter; if (lim > hard_lim) lim = hard_lim; cutstreak = 0; force_step = 0; wd_count = 0;
         { int bad = 0; for (i = 0; i < nx; ++i) if (!(fabs(W->x[i]) < 1e6)) bad = 1;
           if (bad) { memcpy(W->x, x0, sizeof(double) * nx); for (i = 0; i < 6; ++i) { W->x[i] = p[o.q_init + i]; W->x[6 + i] = p[o.qd_init + i]; } }
           eval_g(F, W->x, p, W->g); }
         mu = op->mu_init;
+        th_entry = 0.0;      /* violation of the rows at the entry point (1-norm, equality rows included) */
+        for (r = 12; r < ng; ++r) { const double lb = W->lb[r], ub = W->ub[r], g = W->g[r]; th_entry += (lb == ub) ? fabs(g - lb) : fmax(fmax(lb - g, g - ub), 0.0); }
+        if (getenv("LO_TRACE")) fprintf(stderr, "   phase entry %d at it %d, theta %9.2e\n", n_feas, it, th_entry);
         for (r = 12; r < ng; ++r) {
           const double lb = W->lb[r], ub = W->ub[r], g = W->g[r];
           if (lb == ub) { W->y[r] = 0.0; continue; }
@@ -423,7 +459,7 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
       }
     }
     /* factorisation with inertia correction (same schedule as the HIP kernel) */
-    delta = (streak >= 2 && delta_last > 0.0) ? fmax(1e-20, delta_last * op->delta_dec) : 0.0;
+    delta = (streak >= 2 && delta_last > 0.0) ? fmax(1e-20, delta_last * (feas ? fdec : op->delta_dec)) : 0.0;
     if (!F->run_cost && !feas) {
       double fl = op->delta_floor;
       if (stag_k > 0 && stag >= stag_k) { int e; for (e = stag - stag_k; e >= 0; --e) fl *= 0.1; if (fl < 1e-12) fl = 0.0; }
@@ -431,14 +467,14 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
     }
     for (attempt = 0; attempt < 60 && !fact_ok; ++attempt) {
       if (attempt > 0) {
-        if (delta == 0.0) delta = (delta_last == 0.0) ? op->delta_init : fmax(1e-20, delta_last * op->delta_dec);
+        if (delta == 0.0) delta = (delta_last == 0.0) ? op->delta_init : fmax(1e-20, delta_last * (feas ? fdec : op->delta_dec));
         else delta *= (delta_last == 0.0 ? op->delta_inc_first : op->delta_inc);
         if (delta > 1e40) break;
       }
       counters[0]++;
       fact_ok = riccati_backward(F, p, W, delta, &o, sig);
     }
-    if (!fact_ok) { status = 2; if (op->feas_phase && !feas_used && !feas) { fact_failed = 1; continue; } break; }
+    if (!fact_ok) { status = stalled ? 4 : 2; if (op->feas_phase && !feas_used && !feas) { fact_failed = 1; continue; } break; }
     if (delta > 0.0) { delta_last = delta; streak++; } else streak = 0;
     if (streak > 8) streak = 0;
     /* forward sweep */

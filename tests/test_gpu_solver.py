@@ -280,17 +280,17 @@ def test_reference_bound_frac_is_a_supported_configuration(libs, oracle_mod):
     assert r["kkt"][ok].max() <= KKT_TOL * 1.0001
 
 
-@pytest.mark.parametrize("law,min_conv", [("main", 0.995), ("datagen", 0.955)])
+@pytest.mark.parametrize("law,min_conv", [("main", 0.995), ("datagen", 0.965)])
 def test_n20_production_problem_full_batch(libs, oracle_mod, law, min_conv):
     """BASELINE configs[0] as the reference's production callers pose it: N = 20 on the non-uniform grid
     dt = [0.05, 0.02 x 15, 0.05, 0.05, 0.1, 0.2] (landing_optimization.m:28, generate_training_data_automated.m:28, nn_warmstart.m:49), both
     sampling laws (problem.DROP_LAWS), each caller's own f_max, 1024 drop states per law, from the callers' linear references.
-    Converged members are KKT points <= 1e-6 by the kernel's report, re-certified under the oracle's (reference-pinned) functions on a
-    sample.  Every other member must end with a CERTIFICATE of local infeasibility from the feasibility phase (status 3: a KKT point of the
-    elastic problem with positive violation, or a point with a stationary violation whose equality rows hold to 1e-3: feas_stat, landing_nlp.h) --
-    at most 0.5 % may stay undecided.  Round 5 (feas_jam / feas_stat: the phase starts when the line search jams and ends when the violation is
-    stationary): 16 x 1024 drop states per law on the GPU, main 16 347 converged + 37 certified + 0 undecided, mean batch 42 ms (round 4: 129 ms);
-    datagen ~96.5 % converged, ~3.5 % certified, <= 0.1 % undecided, mean batch 120 ms (225 ms) -- profiles/r05_soak_n20_*.json."""
+    Converged members are KKT points <= 1e-6 by the kernel's report, EVERY one re-certified under the oracle's (reference-pinned) functions.
+    Round 6: status 3 means ONE thing again -- a KKT point of the elastic problem with positive violation, equality rows
+    <= 1e-6 under the oracle for EVERY certificate; a stationary violation that is not such a point is LANDING_STALLED (4), counted as undecided
+    here; no certified member may be one that the plain iteration (no phase) solves within 150 iterations (`lost == 0`); at most 0.5 % undecided.
+    The phase now works the way IPOPT's restoration phase does (landing_nlp.h: feas_back, feas_max, feas_ret_push, feas_delta_dec, feas_polish, feas_resume).
+    CPU port on these very batches: main 1020 converged + 4 certified, datagen 994 + 28 + 2 stalled; 16 x 1024 per law on the GPU: profiles/r06_soak_n20_*.json."""
     N, B = 20, 1024
     Pm = lc("problem")
     O = oracle_mod.Oracle(N)
@@ -301,24 +301,24 @@ def test_n20_production_problem_full_batch(libs, oracle_mod, law, min_conv):
     print("N=20 production grid, law %s: %d / %d converged, iterations mean %.1f p99 %.0f max %d; v_z of the others: %s" %
           (law, ok.sum(), B, r["iters"][ok].mean(), np.percentile(r["iters"][ok], 99), r["iters"][ok].max(), np.round(np.sort(qd[~ok, 5]), 2)[:12]))
     cert = r["status"] == 3
-    print("   certified locally infeasible: %d (largest violation %.1e .. %.1e), undecided: %d" % (cert.sum(), r["kkt"][cert, 0].min() if cert.any() else 0, r["kkt"][cert, 0].max() if cert.any() else 0, (~ok & ~cert).sum()))
+    print("   certified locally infeasible: %d (largest violation %.1e .. %.1e), stalled: %d, undecided otherwise: %d" % (
+        cert.sum(), r["kkt"][cert, 0].min() if cert.any() else 0, r["kkt"][cert, 0].max() if cert.any() else 0, (r["status"] == 4).sum(), np.isin(r["status"], (1, 2)).sum()))
     assert ok.mean() >= min_conv, f"{ok.sum()}/{B}"
     assert (ok | cert).mean() >= 0.995, np.bincount(r["status"])
     assert r["kkt"][ok].max() <= KKT_TOL * 1.0001
     for b in np.nonzero(ok)[0]:      # every converged member is re-certified
         assert O.kkt(r["x"][b], P[b], r["lam_g"][b]).max() <= KKT_TOL * 1.0001
-    lb, ub = O.bounds(P[0])
-    for b in np.nonzero(cert)[0][:8]:      # a certificate: dynamics and initial state hold, the violation of the inequality rows is what the kernel reports
+    for b in np.nonzero(cert)[0]:      # EVERY certificate: dynamics and initial state hold to 1e-6, the violation of the inequality rows is what the kernel reports
         g = O.g(r["x"][b], P[b]); lbb, ubb = O.bounds(P[b])
         eq = lbb == ubb
-        assert np.abs(g[eq] - lbb[eq]).max() <= 1e-3 * 1.0001      # (1e-6 at an elastic KKT point, 1e-3 at a point of stationary violation)
+        assert np.abs(g[eq] - lbb[eq]).max() <= 1e-6 * 1.0001
         viol = np.maximum(np.maximum(lbb - g, g - ubb), 0.0)
         assert abs(viol.max() - r["kkt"][b, 0]) <= 1e-9 and viol.sum() > 1e-4
     o.feas_phase = 0      # ... and without the phase the certified members end undecided (NUMERICAL / MAX_ITER) or converge only after hundreds of
     r0 = libs[N].solve_host(P, X0, o)      # iterations; whoever the jam rule (feas_jam) never touched converges to the same bits
     ok0 = r0["status"] == 0
-    lost = cert & ok0 & (r0["iters"] <= 150)      # sent into the phase by the jam rule although the plain iteration would have converged soon: a LOCAL certificate
-    assert lost.sum() <= max(1, 0.1 * cert.sum()) and ok0.sum() <= ok.sum() + 3, (lost.sum(), cert.sum(), ok0.sum(), ok.sum())
+    lost = cert & ok0 & (r0["iters"] <= 150)      # sent into the phase by the jam rule although the plain iteration would have converged soon
+    assert lost.sum() == 0 and ok0.sum() <= ok.sum() + 3, (lost.sum(), cert.sum(), ok0.sum(), ok.sum())
     same = ok0 & ok & (r0["iters"] == r["iters"])
     assert same.sum() >= 0.98 * ok0.sum() and np.array_equal(r0["x"][same], r["x"][same])
 

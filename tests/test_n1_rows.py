@@ -236,6 +236,38 @@ def test_kinodyn_nlp_hessian_emulated():
     _hess_check(L, "cpu", N=2, B=1, seed=3, oracle_cols=(4, 26, 38))      # a rotation angle, a vertical force, a hip joint
 
 
+def test_kinodyn_hessian_pair_table_does_not_depend_on_the_first_call_emulated():
+    """the table of structurally non-zero Hessian pairs is probed once per context; probed with the first call's parameter VALUES, a first call with
+    a symmetric inertia (omega x I omega = 0: 36 exact zeros) left every later call on that context with those entries missing.  Now the probe uses fixed generic
+    constants and landing_rbd_set_model invalidates the table: symmetric inertia first, the real one second == the real one on a fresh context, bit for bit."""
+    import torch
+    mass, Ib, Ibi = lc("constants").robot_constants()
+    Ib, Ibi = np.asarray(Ib), np.asarray(Ibi)
+    N, B = 2, 1
+    rng = np.random.default_rng(5)
+    emu = os.path.join(ROOT, "tests", "emu", "liblanding_emu.so")
+    def hess(L, R, Ib_, Ibi_):
+        nx, ng = R.kinodyn_nlp_dims(N)
+        r2 = np.random.default_rng(6)
+        xs = 0.3 * r2.normal(size=(B, nx)); xs[:, 2:12 * (N + 1):12] += 0.3
+        lam = r2.normal(size=(B, ng)); dt = np.array([0.03, 0.04])
+        dx, dl = torch.tensor(xs), torch.tensor(lam)
+        H = torch.zeros(B, N, 72, 72, dtype=torch.float64)
+        R.kinodyn_nlp_hess(B, N, dx.data_ptr(), dt, mass, Ib_, Ibi_, 0.75, dl.data_ptr(), H.data_ptr(), 0)
+        return H.numpy().copy()
+    L1 = lc("capi").LandingLib(20, lib_path=emu); R1 = lc("rbd").Rbd(L1)
+    sym = np.full(3, 0.03)
+    Hs = hess(L1, R1, sym, 1.0 / sym)
+    assert (Hs[0, :, 6:9, 6:9] == 0.0).all()                      # omega x (I omega) vanishes for a spherical inertia
+    H2 = hess(L1, R1, Ib, Ibi)                                    # ... same context, the real inertia
+    L2 = lc("capi").LandingLib(20, lib_path=emu); R2 = lc("rbd").Rbd(L2)
+    H3 = hess(L2, R2, Ib, Ibi)
+    assert np.abs(H3[0, :, 6:9, 6:9]).max() > 1e-3 and np.array_equal(H2, H3)
+    R1b = lc("rbd").Rbd(L1)                                       # landing_rbd_set_model again: the table is invalidated and rebuilt at the next call
+    assert np.array_equal(hess(L1, R1b, Ib, Ibi), H3)
+    L1.close(); L2.close()
+
+
 @pytest.mark.gpu
 def test_kinodyn_nlp_hessian_gpu():
     L = lc("capi").LandingLib(20, device=0)

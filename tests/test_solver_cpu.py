@@ -244,6 +244,40 @@ def test_feas_jam_and_stat_cut_the_production_tail(emu_lib, oracle_mod):
     L.close()
 
 
+def test_round6_phase_rules_kernel_follows_port(emu_lib, oracle_mod):
+    """Round 6 (landing_nlp.h: feas_back / feas_max / feas_delta_dec / feas_ret_push / feas_resume / feas_polish): the feasibility phase
+    the way IPOPT runs its restoration phase -- an early entry returns as soon as the violation has come down, up to three entries, the point handed
+    back is taken over warm, status 3 ONLY at a KKT point of the elastic problem (equality rows <= 1e-6), a stationary violation is polished once and
+    otherwise ends as LANDING_STALLED (4).  Three members of the reference's production problem (data-generation law), one per path, through the
+    emulated kernel and the CPU port: same status, same iteration count, same point.
+      * (100000, 145): jam at ~60, phase, early return, converges after 93 iterations (rounds 3-5 rules: 386);
+      * (100000, 592): ends at an elastic KKT point with positive violation: certificate, equality rows <= 1e-6 under the oracle;
+      * (7, 94): the third phase stalls, the polishing step does not make it a KKT point, the resumed iteration jams again: status 4."""
+    N = 20
+    Pm = lc("problem")
+    O = oracle_mod.Oracle(N)
+    L = lc("capi").LandingLib(N, lib_path=emu_lib)
+    o = L.default_opts(); o.max_iter = 300
+    assert (o.feas_back, o.feas_max, o.feas_delta_dec, o.feas_ret_push, o.feas_ret_mu, o.feas_resume, o.feas_polish) == (0.2, 3, 0.1, 0.01, 0.01, 1, 1e-8)
+    for seed, m, status in ((100000, 145, 0), (100000, 592, 3), (7, 94, 4)):
+        P, X0, _, _ = Pm.make_batch(1024, N, 0.6, seed=seed, consts=Pm.production_constants("datagen"), dt_grid="reference", law="datagen")
+        c = oracle_mod.cpu_solve_batch(O, P[m:m + 1], X0[m:m + 1], threads=1, max_iter=300)
+        g = L.solve_host(P[m:m + 1], X0[m:m + 1], o)
+        assert c["status"][0] == status and g["status"][0] == status and g["iters"][0] == c["iters"][0], (seed, m, c["status"], g["status"], c["iters"], g["iters"])
+        assert np.abs(g["x"][0] - c["x"][0]).max() <= 1e-3 and abs(g["kkt"][0, 0] - c["kkt"][0, 0]) <= 1e-7
+        gg = O.g(g["x"][0], P[m]); lb, ub = O.bounds(P[m]); eq = lb == ub
+        viol = np.maximum(np.maximum(lb - gg, gg - ub), 0.0)
+        if status == 0:
+            assert O.kkt(g["x"][0], P[m], g["lam_g"][0]).max() <= 1e-6 * 1.0001
+            old = oracle_mod.cpu_solve_batch(O, P[m:m + 1], X0[m:m + 1], threads=1, max_iter=300, feas_max=1, feas_back=0.0, feas_delta_dec=0.0, feas_ret_push=0.0, feas_resume=0, feas_polish=0.0, feas_jam=0, feas_stat=0)
+            assert old["iters"][0] >= 3 * c["iters"][0]
+        if status == 3:
+            assert np.abs(gg[eq] - lb[eq]).max() <= 1e-6 and abs(viol.max() - g["kkt"][0, 0]) <= 1e-9 and viol.sum() > 1e-4
+        if status == 4:
+            assert abs(viol.max() - g["kkt"][0, 0]) <= 1e-9
+    L.close()
+
+
 def test_stag_relief_shortens_the_known_slow_member(oracle_mod):
     """landing_solver_opts::stag_relief (round 4): member 304 of the bench batch (seed 20211) reaches pr ~ 1e-5 after 36 iterations and then takes 45 FULL
     Newton steps to 1e-6 -- the proximal term delta_floor against a curvature of ~1e-5.  With the rule (default 3) the floor shrinks once three such steps have

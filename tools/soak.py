@@ -40,7 +40,7 @@ its, sts, ms = np.concatenate(its), np.concatenate(sts), np.array(ms[1:] if len(
 worst = sorted(set(worst), reverse=True)[:16]
 print(json.dumps({"workload": "%d batches x %d drop states, N=%d, dt grid %s, sampling law %s, objective form %s, max_iter 300, KKT tol 1e-6" % (a.batches, a.B, a.N, a.grid, a.law, a.form), "options": a.opts,
                   "vz_of_unconverged_min_max": [min(vz_fail), max(vz_fail)] if vz_fail else None,
-                  "members": int(its.size), "converged": int((sts == 0).sum()), "max_iter_hit": int((sts == 1).sum()), "numerical": int((sts == 2).sum()), "certified_locally_infeasible": int((sts == 3).sum()),
+                  "members": int(its.size), "converged": int((sts == 0).sum()), "max_iter_hit": int((sts == 1).sum()), "numerical": int((sts == 2).sum()), "certified_locally_infeasible": int((sts == 3).sum()), "stalled": int((sts == 4).sum()),
                   "iters_mean": float(its.mean()), "iters_p50": float(np.median(its)), "iters_p99": float(np.percentile(its, 99)), "iters_p999": float(np.percentile(its, 99.9)), "iters_max": int(its.max()),
                   "batch_ms_mean": float(ms.mean()), "batch_ms_min": float(ms.min()), "batch_ms_max": float(ms.max()), "nlps_per_s_mean": float(a.B / ms.mean() * 1e3),
                   "worst_members_iters_seed_index_status": worst}))
