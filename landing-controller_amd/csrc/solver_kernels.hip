@@ -201,6 +201,8 @@ struct IpmState {
   // line search jammed with no entry left); 1 once the regularisation was dropped at a stationary violation; violation at the entry point (1-norm, equality rows
   // included) and 1-norm residual of the equality rows at x; iteration count nothing runs beyond; 1: the entry pass of the phase has to record th_entry
   int n_feas, stalled, polished, hard_lim, want_entry; double th_entry, f_theq;
+  double fdc;      // factor between the regularisation of the last iteration and the first one tried in this one inside the phase (feas_delta_dec, adapted: squared after an
+                   // iteration whose first factorisation succeeded, square root (<= 0.7) after one that needed more)
 };
 enum { ACT_GO = 0, ACT_STOP = 1, ACT_RESET = 2, ACT_FEAS = 3, ACT_BACK = 4 };
 
@@ -1285,7 +1287,7 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
     K.e_pr = 0; K.e_du = 0; K.e_co = 0;
     K.jamrun = 0; K.stag = 0; K.full_prev = 0; K.e_prev = 1e300;
     K.feas = 0; K.feas_used = 0; K.fact_failed = 0; K.lim = o.max_iter; K.fjam = 0; K.fstat = 0; K.v1_ref = 0.0; K.c_rn = 0.0; K.f_vmax = 0.0; K.f_v1 = 0.0;
-    K.n_feas = 0; K.stalled = 0; K.polished = 0; K.want_entry = 0; K.th_entry = 0.0; K.f_theq = 0.0; K.hard_lim = o.max_iter > 0 ? 3 * o.max_iter : 0;
+    K.n_feas = 0; K.stalled = 0; K.polished = 0; K.want_entry = 0; K.th_entry = 0.0; K.f_theq = 0.0; K.hard_lim = o.max_iter > 0 ? 3 * o.max_iter : 0; K.fdc = o.feas_delta_dec > 0.0 ? o.feas_delta_dec : o.delta_dec;
   }
   __syncthreads();
   // the lane = stage phases are called by the lanes that have work only: the callee-saved registers an out-of-line function touches
@@ -1314,6 +1316,9 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
         const int it = K.it, nreset = K.nreset;
         if (K.feas) du = fmax(du, K.c_rn);      // the elastic problem has the extra stationarity rows rho_pen - z - w = 0
         K.e_pr = pr; K.e_du = du; K.e_co = co;
+#if !defined(__HIP_DEVICE_COMPILE__) && defined(LANDING_EMU_TRACE)
+        if (getenv("LO_TRACE")) fprintf(stderr, "it %4d pr %9.2e du %9.2e co %9.2e mu %8.1e dlast %8.1e nreset %d nfilt %d feas %d fdc %.3f\n", it, pr, du, co, mu, K.delta_last, nreset, K.nfilt, K.feas, K.fdc);
+#endif
         if (o.stag_relief > 0) {      // full Newton steps in the last barrier problem that do not halve the error: the proximal term is what holds them back
           const double E = fmax(pr, du);
           K.stag = (!K.feas && mu <= o.tol / 10.0 * 1.0000001 && K.full_prev && E > 0.5 * K.e_prev) ? K.stag + 1 : 0;
@@ -1384,7 +1389,7 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
           if (K.stalled) K.status = LANDING_STALLED;      // the point a stalled phase handed back did not lead anywhere either
           if (o.feas_phase && !K.feas_used && o.max_iter > 0 && it < K.hard_lim) {      // (max_iter < 1: the caller asked for no iteration at all, the phase would get none either)
             act = ACT_FEAS;
-            K.feas = 1; K.n_feas++; K.feas_used = K.n_feas >= o.feas_max ? 1 : 0; K.status = LANDING_MAX_ITER; K.lim = it + o.max_iter; if (K.lim > K.hard_lim) K.lim = K.hard_lim; K.fstat = -1; K.fjam = 0; K.want_entry = 1;
+            K.feas = 1; K.n_feas++; K.feas_used = K.n_feas >= o.feas_max ? 1 : 0; K.status = LANDING_MAX_ITER; K.lim = it + o.max_iter; if (K.lim > K.hard_lim) K.lim = K.hard_lim; K.fstat = -1; K.fjam = 0; K.want_entry = 1; K.fdc = o.feas_delta_dec > 0.0 ? o.feas_delta_dec : o.delta_dec;
             K.mu = o.mu_init; K.nfilt = 0; K.th_max = 0.0; K.delta_last = 0.0; K.need_reg_streak = 0; K.cutstreak = 0; K.force_step = 0; K.wd_count = 0;
             K.it = it + 1;
           } else act = ACT_STOP;
@@ -1482,7 +1487,7 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
     // (o.sticky_delta = 1: when the first trial of the previous iteration failed, start from delta_last itself)
     KS_BEGIN()
       const double dl = K.delta_last;
-      const double ddec = (K.feas && o.feas_delta_dec > 0.0) ? o.feas_delta_dec : o.delta_dec;      // (the elastic problem has flat directions: its regularisation has to fall faster, landing_nlp.h)
+      const double ddec = (K.feas && o.feas_delta_dec > 0.0) ? K.fdc : o.delta_dec;      // (the elastic problem has flat directions: its regularisation has to fall faster, landing_nlp.h)
       K.delta = (K.need_reg_streak >= 2 && dl > 0.0) ? fmax(1e-20, dl * ((o.sticky_delta && K.first_failed) ? 1.0 : ddec)) : 0.0;
       if (!L.run_cost && !K.feas) {      // proximal term of the terminal-cost form (landing_nlp.h)
         double fl = o.delta_floor;
@@ -1505,7 +1510,8 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
         K.flag = 0;
         if (!ok && K.attempt < 60) {      // next attempt with a larger regularisation
           double d = K.delta; const double dl = K.delta_last;
-          if (d == 0.0) d = (dl == 0.0) ? o.delta_init : fmax(1e-20, dl * ((K.feas && o.feas_delta_dec > 0.0) ? o.feas_delta_dec : o.delta_dec));
+          if (d == 0.0) d = (dl == 0.0) ? o.delta_init : fmax(1e-20, dl * ((K.feas && o.feas_delta_dec > 0.0) ? K.fdc : o.delta_dec));
+          else if (K.feas && o.feas_delta_dec > 0.0 && K.attempt == 1 && d < dl) d = dl;      // the regularisation of the last iteration is the best guess of what this one needs
           else d *= (dl == 0.0 ? o.delta_inc_first : o.delta_inc);
           if (!(d > 1e40)) { K.delta = d; K.flag = 1; S.prof[PH_NFACT] += 1.0; }
         }
@@ -1518,8 +1524,10 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
       break;
     }
     KS_BEGIN()
+      const bool adapt = K.feas && o.feas_delta_dec > 0.0;
+      if (adapt) K.fdc = K.attempt <= 1 ? fmax(o.feas_delta_dec, K.fdc * K.fdc) : fmin(0.7, sqrt(K.fdc));      // (attempt counts the factorisations of this iteration)
       if (K.delta > 0.0) { K.delta_last = K.delta; K.need_reg_streak++; } else K.need_reg_streak = 0;
-      if (K.need_reg_streak > 8) K.need_reg_streak = 0;      // probe delta = 0 again from time to time
+      if (K.need_reg_streak > 8) K.need_reg_streak = adapt ? 2 : 0;      // probe delta = 0 again from time to time (not inside the phase: the elastic problem has no objective)
     KS_END();
     PROF_ADD(PH_BACK, K.tp);
 

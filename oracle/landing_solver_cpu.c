@@ -229,7 +229,8 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
   /* round 6 (include/landing_nlp.h): up to feas_max entries into the phase, an entry that is not the last one returns as soon as the violation has
    * fallen to feas_back of its value at the entry; a phase that stalls hands its point back once (feas_resume); everything inside 3 max_iter iterations */
   int n_feas = 0, stalled = 0, polished = 0; double th_entry = 0.0; const int hard_lim = op->max_iter > 0 ? 3 * op->max_iter : 0;
-  const double fdec = op->feas_delta_dec > 0.0 ? op->feas_delta_dec : op->delta_dec;
+  const double fdec = op->feas_delta_dec > 0.0 ? op->feas_delta_dec : op->delta_dec; const int adapt = op->feas_delta_dec > 0.0;
+  double fdc = fdec;      /* ... adapted inside a phase: squared after an iteration whose first factorisation succeeded, square root (<= 0.7) after one that needed more */
   lo_param_offsets_form(F, &o);
   W->N = N; W->nx = nx; W->ng = ng; W->feas = 0;
   W->en = dalloc(ng); W->ep = dalloc(ng); W->wn = dalloc(ng); W->wp = dalloc(ng); W->den = dalloc(ng); W->dep = dalloc(ng); W->dwn = dalloc(ng); W->dwp = dalloc(ng);
@@ -348,6 +349,7 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
         if (!op->feas_phase || feas_used || op->max_iter < 1 || it >= hard_lim) break;
         /* feasibility phase: from the current point (from the caller's initial guess when the iterate is not finite) */
         fstat = -1;
+        fdc = fdec;
         feas = 1; W->feas = 1; feas_used = (++n_feas >= op->feas_max); status = 1; fjam = 0; nfilt = 0; th_max = 0.0; delta_last = 0.0; streak = 0; lim = it + op->max_iter; if (lim > hard_lim) lim = hard_lim; cutstreak = 0; force_step = 0; wd_count = 0;
         { int bad = 0; for (i = 0; i < nx; ++i) if (!(fabs(W->x[i]) < 1e6)) bad = 1;
           if (bad) { memcpy(W->x, x0, sizeof(double) * nx); for (i = 0; i < 6; ++i) { W->x[i] = p[o.q_init + i]; W->x[6 + i] = p[o.qd_init + i]; } }
@@ -459,7 +461,7 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
       }
     }
     /* factorisation with inertia correction (same schedule as the HIP kernel) */
-    delta = (streak >= 2 && delta_last > 0.0) ? fmax(1e-20, delta_last * (feas ? fdec : op->delta_dec)) : 0.0;
+    delta = (streak >= 2 && delta_last > 0.0) ? fmax(1e-20, delta_last * (feas ? fdc : op->delta_dec)) : 0.0;
     if (!F->run_cost && !feas) {
       double fl = op->delta_floor;
       if (stag_k > 0 && stag >= stag_k) { int e; for (e = stag - stag_k; e >= 0; --e) fl *= 0.1; if (fl < 1e-12) fl = 0.0; }
@@ -467,7 +469,8 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
     }
     for (attempt = 0; attempt < 60 && !fact_ok; ++attempt) {
       if (attempt > 0) {
-        if (delta == 0.0) delta = (delta_last == 0.0) ? op->delta_init : fmax(1e-20, delta_last * (feas ? fdec : op->delta_dec));
+        if (delta == 0.0) delta = (delta_last == 0.0) ? op->delta_init : fmax(1e-20, delta_last * (feas ? fdc : op->delta_dec));
+        else if (feas && adapt && attempt == 1 && delta < delta_last) delta = delta_last;      /* the regularisation of the last iteration is the best guess of what this one needs */
         else delta *= (delta_last == 0.0 ? op->delta_inc_first : op->delta_inc);
         if (delta > 1e40) break;
       }
@@ -475,8 +478,9 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
       fact_ok = riccati_backward(F, p, W, delta, &o, sig);
     }
     if (!fact_ok) { status = stalled ? 4 : 2; if (op->feas_phase && !feas_used && !feas) { fact_failed = 1; continue; } break; }
+    if (feas && adapt) fdc = attempt <= 1 ? fmax(fdec, fdc * fdc) : fmin(0.7, sqrt(fdc));      /* (attempt counts the factorisations of this iteration) */
     if (delta > 0.0) { delta_last = delta; streak++; } else streak = 0;
-    if (streak > 8) streak = 0;
+    if (streak > 8) streak = (feas && adapt) ? 2 : 0;      /* (the elastic problem has no objective: delta_w = 0 is not probed again inside the phase) */
     /* forward sweep */
     for (k = 0; k < N; ++k) {
       const int last = (k == N - 1), nu = last ? 12 : 24, nr = lo_stage_rows(F, k), g0 = 36 + 104 * k; int q, a, t;

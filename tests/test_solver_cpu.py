@@ -233,8 +233,9 @@ def test_feas_jam_and_stat_cut_the_production_tail(emu_lib, oracle_mod):
     for b in np.nonzero(new["status"] == 3)[0]:
         g = O.g(new["x"][b], P[b]); lb, ub = O.bounds(P[b]); eq = lb == ub
         viol = np.maximum(np.maximum(lb - g, g - ub), 0.0)
-        assert np.abs(g[eq] - lb[eq]).max() <= 1e-3 * 1.0001 and abs(viol.max() - new["kkt"][b, 0]) <= 1e-9 and viol.sum() > 1e-4
-    m = int(np.nonzero((new["status"] == 3) & (new["iters"] < 200) & (old["iters"] > 300))[0][0])      # certified early by the new rules
+        assert np.abs(g[eq] - lb[eq]).max() <= 1e-6 * 1.0001 and abs(viol.max() - new["kkt"][b, 0]) <= 1e-9 and viol.sum() > 1e-4      # (round 6: status 3 = elastic KKT point, nothing else)
+    m = 131      # certified early by the new rules (416 iterations without them); member 40 is another one, but behind its first early return (round 6) it passes through a
+    assert new["status"][m] == 3 and new["iters"][m] < 200 and old["iters"][m] > 300      # region with pr ~ 50 where the kernel's and the port's roundings part ways
     L = lc("capi").LandingLib(N, lib_path=emu_lib)
     o = L.default_opts(); o.max_iter = 300
     assert (o.feas_jam, o.feas_stat) == (8, 25)
