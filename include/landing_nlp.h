@@ -473,6 +473,31 @@ int landing_solve_21_multi(const int* devices, int n_dev, int N, int B, const do
                            double* x_star, double* f_star, double* lam_g, int* status, int* iters, double* kkt);
 void landing_multi_release_cached(void);
 
+/* ---- streaming: consecutive batches through ONE context with the GPU kept busy across batch boundaries (round 6) --------------------
+ * Replaces the serial loop of generate_data/generate_training_data_automated.m:38,130-136 for a caller that produces its drop states batch by batch.
+ * One launch ends with its slowest member: a batch of 1024 takes 53 ms on the 512 resident slots of an MI355X while the slots are busy for 40 ms on
+ * average; with the next batch's launch in flight behind it the freed slots are refilled at once (19.2 k -> 24-25 k NLPs/s, bench.py `streamed`).
+ *   landing_stream_create   `lanes` launches may be in flight (0 = 2, 1..8); lane 0 is the context itself, every further lane a child context with the
+ *                           same formulation and its own solver workspace (1.1 MB per member at N = 40); each lane has its own non-blocking HIP stream
+ *   landing_stream_submit   = landing_solve_batch on the next lane (round robin), asynchronous: returns a ticket >= 0 (or a negative LANDING_E_*).
+ *                           `in_stream`: the stream on which d_p / d_x0 become ready (NULL = the default stream); the caller keeps inputs and outputs of
+ *                           a submission alive and untouched until it has waited for the ticket; outputs of submissions in flight must not overlap
+ *   landing_stream_wait     stream != NULL: that stream waits for the submission (no host synchronisation); NULL: the host waits
+ *   landing_stream_sync     ... for everything submitted so far
+ * Results are bit-identical to landing_solve_batch one call at a time (members are independent; a lane runs the very same launch).
+ *   landing_solve_stream_host   host arrays of ANY number of members cut into chunks (0 = 1024) that go through such a stream, uploads of chunk i + 1
+ *                           and downloads of chunk i - 1 under the solve of chunk i: what matlab/landing_solve_mex.c calls for batches above 2048 */
+typedef struct landing_stream landing_stream;
+landing_stream* landing_stream_create(landing_ctx* ctx, int lanes);
+void landing_stream_destroy(landing_stream* s);
+int landing_stream_lanes(const landing_stream* s);
+long long landing_stream_submit(landing_stream* s, int B, const double* d_p, const double* d_x0, const landing_solver_opts* opts,
+                                double* d_x, double* d_f, double* d_lam_g, int* d_status, int* d_iters, double* d_kkt, void* in_stream);
+int landing_stream_wait(landing_stream* s, long long ticket, void* stream);
+int landing_stream_sync(landing_stream* s, void* stream);
+int landing_solve_stream_host(landing_ctx* ctx, int B, int chunk, int lanes, const double* p, const double* x0, const landing_solver_opts* opts,
+                              double* x, double* f, double* lam_g, int* status, int* iters, double* kkt);
+
 /* ---- tracking-controller synthesis along solved trajectories -------------------------------------
  * SRBM variational linearisation A (24 x 24), B (24 x 12) (utilities_general/srbm-utilities/generateVariationalDynamics.m:29-62)
  * and the Riccati differential equation Pdot = A'P + PA - P B R^-1 B'P + Q integrated backward along the sampled

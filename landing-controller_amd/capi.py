@@ -62,7 +62,8 @@ EXPORTS = ["landing_last_error", "landing_form_default", "landing_solver_opts_de
            "landing_solve_21_multi", "landing_multi_release_cached",
            "landing_np_ccc", "landing_ctx_np", "landing_pack_args25", "landing_solve_args25", "landing_riccati_gains_batch", "landing_mpc_shift", "landing_solver_opts_warm", "landing_rbd_set_model", "landing_fb_dynamics_batch",
            "landing_kinodyn_rows_batch", "landing_kinodyn_nlp_dims", "landing_kinodyn_nlp_eval", "landing_kinodyn_nlp_hess", "landing_leg_ik_batch", "landing_nnz_hess_rc", "landing_pattern_hess_rc",
-           "landing_eval_hess_rc_batch", "landing_eval_hess_rc_batch_host"]
+           "landing_eval_hess_rc_batch", "landing_eval_hess_rc_batch_host",
+           "landing_stream_create", "landing_stream_destroy", "landing_stream_lanes", "landing_stream_submit", "landing_stream_wait", "landing_stream_sync", "landing_solve_stream_host"]
 
 
 def load(path=None):
@@ -114,7 +115,45 @@ def load(path=None):
         lib.landing_multi_solve_args21.argtypes = [vp, C.c_int, C.POINTER(Args21), C.POINTER(SolverOpts), _dp, _dp, _dp, _ip, _ip, _dp]
         lib.landing_solve_21_multi.argtypes = [C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int] + [_dp] * 21 + [C.POINTER(SolverOpts), _dp, _dp, _dp, _ip, _ip, _dp]
     lib.landing_solve_21.argtypes = [vp, C.c_int] + [_dp] * 21 + [C.POINTER(SolverOpts), _dp, _dp, _ip, _ip, _dp]
+    if hasattr(lib, "landing_stream_create"):      # streaming entry points (round 6)
+        lib.landing_stream_create.restype = C.c_void_p
+        lib.landing_stream_create.argtypes = [vp, C.c_int]
+        lib.landing_stream_destroy.argtypes = [vp]
+        lib.landing_stream_lanes.argtypes = [vp]
+        lib.landing_stream_submit.restype = C.c_longlong
+        lib.landing_stream_submit.argtypes = [vp, C.c_int, vp, vp, C.POINTER(SolverOpts), vp, vp, vp, vp, vp, vp, vp]
+        lib.landing_stream_wait.argtypes = [vp, C.c_longlong, vp]
+        lib.landing_stream_sync.argtypes = [vp, vp]
+        lib.landing_solve_stream_host.argtypes = [vp, C.c_int, C.c_int, C.c_int, _dp, _dp, C.POINTER(SolverOpts), _dp, _dp, _dp, _ip, _ip, _dp]
     return lib
+
+
+class SolveStream:
+    """landing_stream_* (include/landing_nlp.h): consecutive batches through one context with `lanes` launches in flight.  Device pointers; the caller keeps
+    the buffers of a submission alive until it has waited for its ticket."""
+
+    def __init__(self, lib, lanes=2):
+        self.L = lib
+        self.h = lib.lib.landing_stream_create(lib.ctx, lanes)
+        if not self.h:
+            raise RuntimeError("landing_stream_create: " + lib.lib.landing_last_error().decode())
+        self.lanes = lib.lib.landing_stream_lanes(self.h)
+
+    def submit(self, B, d_p, d_x0, opts, d_x, d_f=0, d_lam_g=0, d_status=0, d_iters=0, d_kkt=0, in_stream=0):
+        t = self.L.lib.landing_stream_submit(self.h, B, d_p, d_x0, C.byref(opts), d_x, d_f or None, d_lam_g or None, d_status or None, d_iters or None, d_kkt or None, in_stream or None)
+        if t < 0:
+            raise RuntimeError("landing_stream_submit: " + self.L.lib.landing_last_error().decode())
+        return t
+
+    def wait(self, ticket, stream=0):
+        self.L._check(self.L.lib.landing_stream_wait(self.h, ticket, stream or None), "landing_stream_wait")
+
+    def sync(self, stream=0):
+        self.L._check(self.L.lib.landing_stream_sync(self.h, stream or None), "landing_stream_sync")
+
+    def close(self):
+        if self.h:
+            self.L.lib.landing_stream_destroy(self.h); self.h = None
 
 
 def matlab_args25(N, args):
@@ -259,6 +298,22 @@ class LandingLib:
                                                status.ctypes.data_as(_ip), iters.ctypes.data_as(_ip), _p(kkt))
         self._check(rc, "landing_solve_batch_host")
         return dict(x=x, f=f, lam_g=lam, status=status, iters=iters, kkt=kkt)
+
+    def solve_stream_host(self, p, x0, opts=None, chunk=1024, lanes=2):
+        """landing_solve_stream_host: any number of members, cut into chunks that go through a stream of `lanes` launches in flight"""
+        p = np.ascontiguousarray(np.atleast_2d(p), float); x0 = np.ascontiguousarray(np.atleast_2d(x0), float)
+        B = p.shape[0]
+        opts = opts or self.default_opts()
+        x = np.zeros((B, self.nx)); f = np.zeros(B); lam = np.zeros((B, self.ng))
+        status = np.zeros(B, np.int32); iters = np.zeros(B, np.int32); kkt = np.zeros((B, 3))
+        rc = self.lib.landing_solve_stream_host(self.ctx, B, chunk, lanes, _p(p), _p(x0), C.byref(opts), _p(x), _p(f), _p(lam),
+                                                status.ctypes.data_as(_ip), iters.ctypes.data_as(_ip), _p(kkt))
+        self._check(rc, "landing_solve_stream_host")
+        return dict(x=x, f=f, lam_g=lam, status=status, iters=iters, kkt=kkt)
+
+    def stream(self, lanes=2):
+        """landing_stream_create on this context: SolveStream with submit / wait / sync / close"""
+        return SolveStream(self, lanes)
 
     def pack_args21(self, args):
         """p [B, np] from the 21 MATLAB-shaped arguments (landing_pack_args21; host only)"""

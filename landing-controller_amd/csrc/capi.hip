@@ -64,6 +64,7 @@ struct landing_ctx {
   int wb_semi = 0;             // integrator of the whole-body loop: 0 explicit Euler, 1 semi-implicit Euler (landing_wb_set_integrator)
   bool rbd_arrow = false;      // the model set by landing_rbd_set_model is "six base joints + four 3-joint legs on the base": H is block-arrow (wb_kernels.hip)
   std::mutex mu;      // serialises landing_solve_batch calls on one context (the workspace belongs to the context)
+  std::mutex hs_mu; landing_stream* hs_obj = nullptr; int hs_lanes = 0;      // stream of landing_solve_stream_host, one call at a time (child contexts and their workspaces are kept between calls)
 };
 // call with ctx->mu held: the stream waits for the previous user of the context's scratch blocks
 static hipError_t scratch_acquire(landing_ctx* ctx, hipStream_t s) {
@@ -283,6 +284,7 @@ landing_ctx* landing_create(int N, int device, const landing_form* form) {
 void landing_destroy(landing_ctx* ctx) {
   if (!ctx) return;
   hipSetDevice(ctx->device);
+  if (ctx->hs_obj) { landing_stream_destroy(ctx->hs_obj); ctx->hs_obj = nullptr; }
   ctx->ws.release();
   if (ctx->d_edge_map) (void)hipFree(ctx->d_edge_map);
   if (ctx->d_vbl) (void)hipFree(ctx->d_vbl);
@@ -473,4 +475,5 @@ int landing_bounds_batch(landing_ctx* ctx, int B, const double* d_p, double* d_l
 
 #include "solver_capi.inc"
 #include "multi_capi.inc"
+#include "stream_capi.inc"
 #include "kd_capi.inc"

@@ -153,3 +153,35 @@ def test_multi_device_rejects_the_25_argument_formulation_and_null_arguments(lib
     rc = L.lib.landing_multi_solve_args21(C.c_void_p(m), B, C.byref(a), C.byref(o), x.ctypes.data_as(C.POINTER(C.c_double)), None, None, None, None, None)
     L.lib.landing_multi_destroy(C.c_void_p(m))
     assert rc == -1 and b"NULL argument" in L.lib.landing_last_error()
+
+
+def test_stream_entry_points_are_the_single_calls_bit_for_bit(libs):
+    """landing_stream_* / landing_solve_stream_host (round 6): batches through one context with several launches in flight -- every lane runs the very
+    launch landing_solve_batch would, so the results are the single-call results bit for bit, whatever the number of lanes, ragged last chunk and a
+    running-cost formulation (the child contexts of the lanes inherit it) included.  Emulated kernels: streams and events are no-ops there, the
+    GPU test (tests/test_gpu_dataset.py) runs the same comparison with real concurrency."""
+    import torch
+    capi, P = lc("capi"), lc("problem")
+    N, B = 6, 5
+    for form in ({}, dict(run_cost=dict(QX=[0, 0, 10, 1, 1, 0, .1, .1, .1, .1, .1, .1], Qc=[1.0, 1.0, 0.5], Qf=[1e-4, 1e-4, 1e-3], f_ref=[0, 0, 20.0]))):
+        L = capi.LandingLib(N, lib_path=libs[1], **form)
+        Pb, X0, _, _ = P.make_batch(B, N, 0.6, seed=3)
+        o = L.default_opts(); o.max_iter = 4
+        ref = L.solve_host(Pb, X0, o)
+        for lanes, chunk in (((1, 2), (2, 2), (3, 1), (2, 8)) if not form else ((2, 2),)):
+            r = L.solve_stream_host(Pb, X0, o, chunk=chunk, lanes=lanes)
+            for k in ("x", "f", "lam_g", "status", "iters", "kkt"):
+                assert np.array_equal(r[k], ref[k]), (lanes, chunk, k)
+        # device-pointer form: three submissions on two lanes, waited for in another order
+        S = L.stream(2)
+        assert S.lanes == 2
+        dP, dX0 = torch.tensor(Pb), torch.tensor(X0)
+        outs = [(torch.zeros(B, L.nx, dtype=torch.float64), torch.zeros(B, dtype=torch.int32), torch.zeros(B, dtype=torch.int32)) for _ in range(3)]
+        tk = [S.submit(B, dP.data_ptr(), dX0.data_ptr(), o, x.data_ptr(), d_status=st.data_ptr(), d_iters=it.data_ptr()) for x, st, it in outs]
+        assert tk == [0, 1, 2]
+        S.wait(tk[2]); S.wait(tk[0]); S.sync()
+        for x, st, it in outs:
+            assert np.array_equal(x.numpy(), ref["x"]) and np.array_equal(st.numpy(), ref["status"]) and np.array_equal(it.numpy(), ref["iters"])
+        with pytest.raises(RuntimeError):
+            S.wait(7)
+        S.close(); L.close()

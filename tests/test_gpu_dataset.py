@@ -37,8 +37,9 @@ def test_batched_data_generation_roundtrip(tmp_path):
 
 
 def test_two_batches_in_flight_give_the_same_results():
-    """pipeline.BatchPipeline: batches streamed through two contexts / two streams return, in order, exactly what one solve
-    at a time returns (every member is solved independently; nothing is shared between the lanes)"""
+    """pipeline.BatchPipeline over the library's streaming entry points (landing_stream_create / _submit / _wait, round 6: ONE context, two launches in
+    flight on the library's own lanes): batches return, in order, exactly what one solve at a time returns, bit for bit (every member is solved
+    independently; a lane runs the very launch landing_solve_batch would)"""
     capi, P, pl = lc("capi"), lc("problem"), lc("pipeline")
     N, B = 40, 256
     batches = [P.make_batch(B, N, 0.6, seed=900 + i)[:2] for i in range(5)]
@@ -56,3 +57,30 @@ def test_two_batches_in_flight_give_the_same_results():
         ref = L.solve_host(Pb, X0)
         assert np.array_equal(ref["x"], g["x"]) and np.array_equal(ref["status"], g["status"]) and np.array_equal(ref["iters"], g["iters"])
     L.close()
+
+
+def test_stream_host_entry_point_chunks_a_large_batch_bit_for_bit():
+    """landing_solve_stream_host: 2500 drop states in chunks of 1024 through two lanes (uploads / downloads under the solves, ragged last chunk) == one
+    landing_solve_batch_host call; the device-pointer form with three submissions on two lanes, consumed through stream waits only (no host sync between)."""
+    import torch
+    capi, P = lc("capi"), lc("problem")
+    N, B = 40, 2500
+    L = capi.LandingLib(N, device=0)
+    Pb, X0, _, _ = P.make_batch(B, N, 0.6, seed=77)
+    o = L.default_opts(); o.max_iter = 300
+    ref = L.solve_host(Pb, X0, o)
+    r = L.solve_stream_host(Pb, X0, o, chunk=1024, lanes=2)
+    for k in ("x", "f", "lam_g", "status", "iters", "kkt"):
+        assert np.array_equal(r[k], ref[k]), k
+    assert (r["status"] == 0).all()
+    S = L.stream(2)
+    dP, dX0 = torch.tensor(Pb[:600], device="cuda"), torch.tensor(X0[:600], device="cuda")
+    outs = [(torch.zeros(200, L.nx, device="cuda", dtype=torch.float64), torch.zeros(200, device="cuda", dtype=torch.int32)) for _ in range(3)]
+    cur = torch.cuda.current_stream().cuda_stream
+    tk = [S.submit(200, dP[200 * i:].data_ptr(), dX0[200 * i:].data_ptr(), o, x.data_ptr(), d_status=st.data_ptr(), in_stream=cur) for i, (x, st) in enumerate(outs)]
+    for t in tk:
+        S.wait(t, stream=cur)                    # the current stream waits; the copies below are ordered behind it
+    got = [x.cpu().numpy() for x, _ in outs]
+    for i in range(3):
+        assert np.array_equal(got[i], ref["x"][200 * i:200 * (i + 1)])
+    S.close(); L.close()
