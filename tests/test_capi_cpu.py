@@ -153,7 +153,8 @@ def test_solver_opts_mirror_matches_the_header():
                 reset_du=1e9, stage_local_reg=0, sticky_delta=0, restart_period=75, dispatch_order=1, delta_init=1e-4, delta_inc_first=10.0, delta_inc=4.0,
                 delta_dec=0.5, tau_min=0.9, alpha_fallback=1e-2, reset_delta=1e5, clip_k=4, clip_until=0.03, theta_floor=30.0, fresh_restart=9,
                 dual_step_cap=1.0, slack_corr=0.9, watchdog=3, barrier_smax=1.0, factor_fp32=0, feas_phase=1, feas_rho=1000.0, feas_cert=1e-4, delta_floor=3e-4, jam_clip=2, stag_relief=3, feas_jam=8, feas_stat=25,
-                kd_clone_after=0, kd_clone_max=0, kd_clone_iter=0)
+                kd_clone_after=0, kd_clone_max=0, kd_clone_iter=0,
+                feas_back=0.2, feas_max=3, feas_delta_dec=0.1, feas_ret_push=0.01, feas_ret_mu=0.01, feas_resume=1, feas_polish=1e-8)
     assert {n: getattr(o, n) for n, _ in capi.SolverOpts._fields_} == want
     w = capi.SolverOpts(); lib.landing_solver_opts_warm(C.byref(w))
     assert (w.bound_push, w.bound_frac, w.mu_init, w.restart_period, w.max_iter, w.clip_k, w.fresh_restart, w.factor_fp32) == (1e-4, 1e-4, 1e-4, 0, 14, 0, 0, 0)
