@@ -378,8 +378,8 @@ def main():
         lanes[1][0].close()
 
     # ---- the same K steps through the library's own streaming entry points (round 6): ONE context, ONE caller stream, two launches in
-    # flight on the library's lanes (landing_stream_create / _submit / _wait); the count of converged members of submission i - 2 is taken on the caller's
-    # stream behind a stream-wait for its ticket, and submission i is ordered behind that count -- no host synchronisation inside the loop
+    # flight on the library's lanes (landing_stream_create / _submit / _wait); the host waits for the ticket of submission i - 2, counts its converged
+    # members and submits i while i - 1 runs (tools/dev/stream_probe.py: a stream-side wait on a third stream costs 12 % -- the HIP streams share hardware queues)
     streamed = None
     if not a.dry and a.steps >= 2 and not a.no_extras:
         S = lib.stream(2)
@@ -394,17 +394,17 @@ def main():
         tsr = time.perf_counter()
         for i in range(a.steps):
             if i >= 2:
-                S.wait(tk[i - 2], stream=stream); conv_s += (sl[i % 2][1] == 0).sum()
+                S.wait(tk[i - 2]); conv_s += (sl[i % 2][1] == 0).sum()      # the host waits for submission i - 2 (a data-generation caller reads its results here); i - 1 keeps the GPU busy
             tk.append(ssub(i))
         for i in range(max(0, a.steps - 2), a.steps):
-            S.wait(tk[i], stream=stream); conv_s += (sl[i % 2][1] == 0).sum()
+            S.wait(tk[i]); conv_s += (sl[i % 2][1] == 0).sum()
         sync()
         tsr = time.perf_counter() - tsr
         tse = torch.tensor([tsr], device=dev, dtype=torch.float64)
         if multi:
             dist.all_reduce(tse, op=dist.ReduceOp.MAX); dist.all_reduce(conv_s, op=dist.ReduceOp.SUM)
         streamed = {"value": float(conv_s.item()) / float(tse.item()), "unit": "NLPs/s", "lanes": 2, "ms_per_step": 1e3 * float(tse.item()) / a.steps,
-                    "note": "same K steps through landing_stream_submit / landing_stream_wait: one context, one caller stream, two launches in flight inside the library, no host synchronisation between steps"}
+                    "note": "same K steps through landing_stream_submit / landing_stream_wait: one context, one host thread, two launches in flight inside the library; the host waits for submission i - 2 before it submits i"}
         S.close()
 
     if rank == 0:
