@@ -582,11 +582,12 @@ int landing_kinodyn_nlp_hess(landing_ctx* ctx, int B, int N, const double* d_x, 
  * landing_solve_batch on this NLP's stage structure (state (X_k, c_k), controls (f_k, jpos_k, c_k+1): the joint angles are stage-local and are
  * eliminated inside the stage), exact first and second derivatives from landing_kinodyn_nlp_eval / _hess, B members per call.
  *   landing_kinodyn_form     the literals of the script's constraint set (:139-189)
- *   landing_kinodyn_bounds   lbg / ubg [ng x B] from the script's arguments (host arrays, trailing batch axis; Opti's canonicalisation, with ONE
- *                            caveat: the 8 friction rows of an interval, `f_xy >= -0.71 mu f_z` (:176,178), are emitted as g = f_xy + km f_z in [0, inf);
- *                            neither side of that inequality is parametric, so a CasADi-built Opti may hold them as -km f_z - f_xy in (-inf, 0] --
- *                            not checkable here (libcasadi is an absent blob): g, the jac_g rows and lam_g of those rows would then differ in SIGN from
- *                            a CasADi-built nlpsol; the feasible set and the solver are unaffected)
+ *   landing_kinodyn_bounds   lbg / ubg [ng x B] from the script's arguments (host arrays, trailing batch axis; Opti's canonicalisation,
+ *                            optistack_internal.cpp:742-856: a side without decision variables becomes a bound of g = the other side, an inequality with
+ *                            variables on both sides becomes g = lhs - rhs in (-inf, 0].  Round 6 settled the 8 friction rows of an interval written with
+ *                            `>=`, `f_xy >= -0.71 mu f_z` (:176,178): MATLAB's a >= b is CasADi's le(b, a), so Opti holds them as
+ *                            g = -0.71 mu f_z - f_xy in (-inf, 0] -- which is what the rows, jac_g and lam_g of this library now are (rounds 3-5 emitted
+ *                            f_xy + 0.71 mu f_z in [0, inf): same feasible set, opposite sign of g, of the Jacobian rows and of lam_g for those rows))
  *   landing_kinodyn_solve_batch   device pointers: d_lbg, d_ubg [B][ng]; d_cost [B][24] = QN (12) | Xref(:, end) (12) (terminal cost :83-86);
  *                            d_x0 [B][nx]; dt, mass, Ib, Ib_inv, mu shared by the batch (prm).  Outputs as landing_solve_batch: d_x [B][nx],
  *                            d_f [B], d_lam_g [B][ng] (CasADi sign), d_status [B] (LANDING_*), d_iters [B], d_kkt [B][3] (pr, du, compl unscaled)
@@ -613,6 +614,8 @@ void landing_kinodyn_form_default(landing_kinodyn_form* f);       /* the literal
 void landing_kinodyn_form_knitro(landing_kinodyn_form* f);        /* ... of generate_solver/generate_landingCtrller_KNITRO.m (kin_box_y = 0.125 + kin_box(2), :154): what
                                                                       landing_solve_kinodyn_24[_on] use when no form is passed -- they stand for the function that script builds */
 void landing_kinodyn_solver_opts_default(landing_solver_opts* o);
+void landing_kinodyn_solver_opts_warm(landing_solver_opts* o);     /* the `_ws` re-solve from a previous solution (landing_optimization.m:395-435, generate_landingCtrller_KNITRO_warmstart.m):
+                                                                      bound_push = bound_frac = mu_init = 1e-4, no cold-start rules, no portfolio, max_iter 100 */
 int landing_kinodyn_bounds(int N, int B, const landing_kinodyn_form* form, const double* q_init, const double* qd_init, const double* c_init,
                            const double* q_min, const double* q_term_min, const double* q_term_max, const double* qd_term_min, const double* qd_term_max,
                            const double* jpos_min, const double* jpos_max, const double* kin_box, const double* l_leg_max, double* lbg, double* ubg);
@@ -652,6 +655,23 @@ int landing_solve_kinodyn_24_on_form(int device, int N, int B, const landing_kin
 /* CCS patterns of this NLP in CasADi's compressed form, which = 0: jac_g_x (ng x nx), 1: upper triangle of hess_gamma_x_x; colind [nx + 1],
  * row [*nnz] (pass row = NULL to get the count first).  Derived from the derivative kernels themselves (device needed). */
 int landing_kinodyn_pattern(landing_ctx* ctx, int N, int which, long long* colind, long long* row, long long* nnz);
+
+/* ---- CasADi-external face of the kinodynamic refinement NLP (round 6) ------------------------------------------------------------------------
+ * What landingCtrller_KNITRO_mi355x.so (csrc/casadi_abi.cpp with -DLANDING_KD=1) forwards to: the seven nlp_* functions of the library the reference generates
+ * for this NLP (generate_solver/generate_landingCtrller_KNITRO.m:360-377; its own artefacts are missing blobs) for ONE problem on host arrays.
+ *   p   the ACTIVE Opti parameters in declaration order (:51-82): Xref 12(N+1) | dt N | q_init 6 | qd_init 6 | c_init 12 | jpos_min 12 | jpos_max 12 |
+ *       q_term_min 6 | q_term_max 6 | qd_term_min 6 | qd_term_max 6 | q_min 6 | QN 12 | mu | l_leg_max | mass | Ib 3 | Ib_inv 3 | kin_box 2, np = 13 N + 113
+ *       (Uref, q_max, qd_min, qd_max are declared and never used: inactive, dropped -- the rule SURVEY row a2 verified on landingCtrller_IPOPT.c)
+ *   g   rows of landing_kinodyn_nlp_eval = Opti's canonical forms; jac / hess: CCS nonzeros in the patterns of landing_kinodyn_casadi_pattern
+ *       (= landing_kinodyn_pattern, pointers stay valid while the context lives); lam_g in CasADi's sign; lbg / ubg from p: landing_kinodyn_casadi_bounds
+ *   any output may be NULL; lam_f NULL = 1; grad_gamma_p: exact for Xref / QN, central differences for dt, mass, Ib, Ib_inv, mu, 0 for parameters of the bounds */
+long long landing_kinodyn_casadi_np(int N);
+int landing_kinodyn_casadi_offsets(int N, long long off[19]);
+int landing_kinodyn_casadi_bounds(int N, const landing_kinodyn_form* form, const double* p, double* lbg, double* ubg);
+int landing_kinodyn_casadi_pattern(landing_ctx* ctx, int N, int which, const long long** colind, const long long** row, long long* nnz);
+int landing_kinodyn_casadi_eval_host(landing_ctx* ctx, int N, const double* x, const double* p, const double* lam_f, const double* lam_g,
+                                     double* f, double* g, double* grad_f, double* jac, double* hess, double* grad_gamma_x, double* grad_gamma_p);
+void landing_kinodyn_casadi_release(landing_ctx* ctx);
 
 /* ---- SQP (Gauss-Newton / iLQR) loop on the 18-DoF model (BASELINE configs[3]) --------------------------------
  * Trajectory-tracking problem per member: state x = [q; qd] (36), control u = the 12 joint torques (base unactuated), known foot

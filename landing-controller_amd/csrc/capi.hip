@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <array>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <set>
 #include <string>
@@ -477,3 +478,4 @@ int landing_bounds_batch(landing_ctx* ctx, int B, const double* d_p, double* d_l
 #include "multi_capi.inc"
 #include "stream_capi.inc"
 #include "kd_capi.inc"
+#include "kd_casadi_capi.inc"

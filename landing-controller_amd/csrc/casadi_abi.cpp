@@ -17,6 +17,12 @@
 #ifndef LANDING_CCC
 #define LANDING_CCC 0
 #endif
+// LANDING_KD = 1: the kinodynamic refinement NLP (generate_solver/generate_landingCtrller_KNITRO.m:360-377 generates and loads ./landingCtrller_KNITRO.so;
+// a missing blob of the reference tree): x = [X; jpos; U] (48 N + 12), p = the 13 N + 113 active Opti parameters, g in Opti's canonical form, patterns and
+// values from landing_kinodyn_casadi_* (include/landing_nlp.h); the context carries the reference's 'quad3D' / 'mc3D' model (landing_rbd_model_mc3d)
+#ifndef LANDING_KD
+#define LANDING_KD 0
+#endif
 
 namespace {
 const int N = LANDING_N;
@@ -30,6 +36,36 @@ void dense(std::vector<long long>& s, long long n) {
   s.clear(); s.push_back(n); s.push_back(1); s.push_back(0); s.push_back(n);
   for (long long i = 0; i < n; ++i) s.push_back(i);
 }
+#if LANDING_KD
+landing_ctx* g_kd_ctx = nullptr;
+landing_ctx* kd_ctx_locked() {      // (g_mu held) the kinodynamic patterns come from the derivative kernels themselves: the context is needed before the tables
+  if (!g_kd_ctx) {
+    const char* d = std::getenv("LANDING_DEVICE");
+    g_kd_ctx = landing_create(N, d ? std::atoi(d) : 0, nullptr);
+    if (g_kd_ctx) { landing_rbd_model m; landing_rbd_model_mc3d(&m); if (landing_rbd_set_model(g_kd_ctx, &m)) { landing_destroy(g_kd_ctx); g_kd_ctx = nullptr; } }
+  }
+  return g_kd_ctx;
+}
+void build_sparsity() {
+  if (!s_x.empty()) return;
+  long long nx = 0, ng = 0;
+  landing_kinodyn_nlp_dims(N, &nx, &ng);
+  const long long np = landing_kinodyn_casadi_np(N);
+  landing_ctx* c = kd_ctx_locked();
+  if (!c) return;
+  std::vector<long long> sj, sh;
+  for (int which = 0; which < 2; ++which) {
+    const long long *ci = nullptr, *r = nullptr; long long nnz = 0;
+    if (landing_kinodyn_casadi_pattern(c, N, which, &ci, &r, &nnz)) return;
+    std::vector<long long>& s = which ? sh : sj;
+    s.push_back(which ? nx : ng); s.push_back(nx);
+    s.insert(s.end(), ci, ci + nx + 1); s.insert(s.end(), r, r + nnz);
+  }
+  dense(s_x, nx); dense(s_p, np); dense(s_one, 1); dense(s_g, ng);
+  s_jac = sj; s_hess = sh;
+  zeros.assign((size_t)std::max(std::max(nx, ng), np), 0.0);
+}
+#else
 void build_sparsity() {
   if (!s_x.empty()) return;
   const long long nx = landing_nx(N), ng = landing_ng(N), np = LANDING_CCC ? landing_np_ccc(N) : landing_np(N);
@@ -44,9 +80,13 @@ void build_sparsity() {
   s_hess.insert(s_hess.end(), ci.begin(), ci.end()); s_hess.insert(s_hess.end(), r.begin(), r.end());
   zeros.assign((size_t)std::max(std::max(nx, ng), np), 0.0);
 }
+#endif
 landing_ctx* ctx() {
   std::lock_guard<std::mutex> lk(g_mu);
   build_sparsity();
+#if LANDING_KD
+  g_ctx = kd_ctx_locked();
+#endif
   if (!g_ctx) {
     const char* d = std::getenv("LANDING_DEVICE");
     landing_form form;
@@ -70,6 +110,9 @@ int eval(const double* x, const double* p, const double* lam_f, const double* la
   landing_ctx* c = ctx();
   if (!c) return 1;
   if (!f && !g && !grad_f && !jac && !hess && !ggx && !ggp) return 0;
+#if LANDING_KD
+  return landing_kinodyn_casadi_eval_host(c, N, x, p, lam_f, lam_g, f, g, grad_f, jac, hess, ggx, ggp) == 0 ? 0 : 1;
+#endif
   if (LANDING_CCC && hess) {      // the running cost adds diagonals casadi_s4 does not hold: extended pattern, own entry point
     if (landing_eval_hess_rc_batch_host(c, 1, x, p, lam_f, lam_g, hess) != 0) return 1;
     hess = nullptr;
@@ -80,7 +123,12 @@ int eval(const double* x, const double* p, const double* lam_f, const double* la
 void addref() { std::lock_guard<std::mutex> lk(g_mu); ++g_refs; }
 void dropref() {
   std::lock_guard<std::mutex> lk(g_mu);
-  if (--g_refs <= 0 && g_ctx) { landing_destroy(g_ctx); g_ctx = nullptr; g_refs = 0; }
+  if (--g_refs <= 0 && g_ctx) {
+#if LANDING_KD
+    landing_kinodyn_casadi_release(g_ctx); g_kd_ctx = nullptr; s_x.clear();      // (the pattern tables point into the context's cache)
+#endif
+    landing_destroy(g_ctx); g_ctx = nullptr; g_refs = 0;
+  }
 }
 const long long* sp(int which) {
   { std::lock_guard<std::mutex> lk(g_mu); build_sparsity(); }

@@ -865,9 +865,9 @@ __device__ void kd_stage_rows(const KdNlpParams& P, const RbdModel& M, int k, bo
   }
   const double km = 0.71 * P.mu;
   for (int l = 0; l < 4; ++l) out.put(f[3 * l] - f[3 * l + 2] * km);                                                         // :175
-  for (int l = 0; l < 4; ++l) out.put(f[3 * l] + f[3 * l + 2] * km);                                                         // :176
+  for (int l = 0; l < 4; ++l) out.put(f[3 * l + 2] * (-km) - f[3 * l]);      // :176  f_x >= -km f_z: neither side is parametric, so Opti holds it as  -km f_z - f_x <= 0  (optistack_internal.cpp:793-806: e = args[j] - args[j+1] of `(-km f_z) <= f_x`)
   for (int l = 0; l < 4; ++l) out.put(f[3 * l + 1] - f[3 * l + 2] * km);                                                     // :177
-  for (int l = 0; l < 4; ++l) out.put(f[3 * l + 1] + f[3 * l + 2] * km);                                                     // :178
+  for (int l = 0; l < 4; ++l) out.put(f[3 * l + 2] * (-km) - f[3 * l + 1]);  // :178  likewise
   out.put(X[2]);                                                                                                           // :181
   for (int j = 0; j < 12; ++j) out.put(c[j] - fkv[j]);                                                                     // :186
   for (int j = 0; j < 12; ++j) out.put(c[j] - fkv[j]);                                                                     // :187

@@ -74,9 +74,8 @@ def bounds(N, q_init, qd_init, c_init, kin_box, q_term_min=(-10, -10, 0.15, -0.1
             lb[r] = -0.4; ub[r] = -0.075; r += 1
             lb[r] = -INF; ub[r] = l_leg_max ** 2; r += 1
             lb[r:r + 3] = -np.asarray(tau_max); ub[r:r + 3] = tau_max; r += 3
-        for s in range(4):                                           # friction: <= 0, >= 0, <= 0, >= 0
-            if s % 2 == 0: lb[r:r + 4] = -INF; ub[r:r + 4] = 0.0
-            else: lb[r:r + 4] = 0.0; ub[r:r + 4] = INF
+        for s in range(4):                                           # friction: all four groups are `g1 - g2 <= 0` in Opti's canonical form (round 6)
+            lb[r:r + 4] = -INF; ub[r:r + 4] = 0.0
             r += 4
         lb[r] = z_min; ub[r] = INF; r += 1
         lb[r:r + 12] = -fk_band; ub[r:r + 12] = INF; r += 12
@@ -150,3 +149,26 @@ def make_args24(N, q_init, qd_init, x_srbm, dt, mass, Ib, Ib_inv, mu=0.75, l_leg
                 q_term_max=rep([10, 10, 5, 0.1, 0.1, 10]), qd_term_min=rep([-10, -10, -10, -.5, -.5, -.5]), qd_term_max=rep([10, 10, 10, .5, .5, .5]),
                 QN=rep(QN_DEFAULT), x0=x0, jpos_min=rep(JPOS_MIN), jpos_max=rep(JPOS_MAX), kin_box=kb, mu=rep([mu]), l_leg_max=rep([l_leg_max]),
                 mass=rep([mass]), Ib=rep(Ib), Ib_inv=rep(Ib_inv))
+
+
+KNITRO_PARAMS = ("Xref", "dt", "q_init", "qd_init", "c_init", "jpos_min", "jpos_max", "q_term_min", "q_term_max", "qd_term_min", "qd_term_max", "q_min", "QN", "mu", "l_leg_max",
+                 "mass", "Ib", "Ib_inv", "kin_box")
+
+
+def knitro_param_offsets(N):
+    """offsets of the ACTIVE Opti parameters of generate_landingCtrller_KNITRO.m (:51-82) inside p, declaration order (landing_kinodyn_casadi_offsets)"""
+    lens = (12 * (N + 1), N, 6, 6, 12, 12, 12, 6, 6, 6, 6, 6, 12, 1, 1, 1, 3, 3, 2)
+    off, o = {}, 0
+    for n, l in zip(KNITRO_PARAMS, lens):
+        off[n] = (o, o + l); o += l
+    return off, o
+
+
+def pack_params_knitro(N, **kw):
+    """p of the CasADi-external face (landingCtrller_KNITRO_mi355x.so) from the script's parameter values; Xref 12 x (N+1) column-major"""
+    off, n = knitro_param_offsets(N)
+    p = np.zeros(n)
+    for name, (a, b) in off.items():
+        v = np.asarray(kw[name], float)
+        p[a:b] = v.flatten(order="F") if v.ndim > 1 else v
+    return p

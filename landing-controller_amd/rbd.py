@@ -132,6 +132,13 @@ class Rbd:
         self.L.lib.landing_kinodyn_solver_opts_default(C.byref(o))
         return o
 
+    def kinodyn_warm_opts(self):
+        """landing_kinodyn_solver_opts_warm: the re-solve from a previous solution"""
+        from .capi import SolverOpts
+        o = SolverOpts()
+        self.L.lib.landing_kinodyn_solver_opts_warm(C.byref(o))
+        return o
+
     def kinodyn_solve_host(self, N, lbg, ubg, cost, x0, dt, mass, Ib, Ib_inv, mu, opts=None):
         """landing_kinodyn_solve_batch_host: B kinodynamic refinement NLPs (host arrays [B, ng], [B, ng], [B, 24], [B, nx]) -> dict"""
         lbg = np.ascontiguousarray(np.atleast_2d(lbg), float); ubg = np.ascontiguousarray(np.atleast_2d(ubg), float)
@@ -189,6 +196,49 @@ class Rbd:
         fn.argtypes = [C.c_int, C.c_int, C.c_void_p] + [dp] * 14
         self.L._check(fn(N, B, None, *[v.ctypes.data_as(dp) for v in a], lb.ctypes.data_as(dp), ub.ctypes.data_as(dp)), "landing_kinodyn_bounds")
         return lb, ub
+
+    # ---- CasADi-external face of the kinodynamic NLP (include/landing_nlp.h, round 6): what landingCtrller_KNITRO_mi355x.so forwards to
+    def kinodyn_casadi_np(self, N):
+        fn = self.L.lib.landing_kinodyn_casadi_np; fn.restype = C.c_longlong; fn.argtypes = [C.c_int]
+        return int(fn(N))
+
+    def kinodyn_casadi_pattern(self, N, which):
+        lp = C.POINTER(C.c_longlong)
+        ci, r, nnz = lp(), lp(), C.c_longlong()
+        fn = self.L.lib.landing_kinodyn_casadi_pattern
+        fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(lp), C.POINTER(lp), lp]
+        self.L._check(fn(self.L.ctx, N, which, C.byref(ci), C.byref(r), C.byref(nnz)), "landing_kinodyn_casadi_pattern")
+        nx = 48 * N + 12
+        return np.array(ci[:nx + 1], np.int64), np.array(r[:nnz.value], np.int64)
+
+    def kinodyn_casadi_bounds(self, N, p):
+        dp = C.POINTER(C.c_double)
+        p = np.ascontiguousarray(p, float); ng = 48 + 141 * (N - 1) + 117
+        lb, ub = np.zeros(ng), np.zeros(ng)
+        fn = self.L.lib.landing_kinodyn_casadi_bounds
+        fn.argtypes = [C.c_int, C.c_void_p, dp, dp, dp]
+        self.L._check(fn(N, None, p.ctypes.data_as(dp), lb.ctypes.data_as(dp), ub.ctypes.data_as(dp)), "landing_kinodyn_casadi_bounds")
+        return lb, ub
+
+    def kinodyn_casadi_eval(self, N, x, p, lam_f=1.0, lam_g=None, want=("f", "g", "grad_f", "jac", "hess", "ggx", "ggp")):
+        """landing_kinodyn_casadi_eval_host: one problem, host arrays; returns a dict of the requested outputs (jac / hess as CCS nonzeros)"""
+        dp = C.POINTER(C.c_double)
+        nx, ng, npar = 48 * N + 12, 48 + 141 * (N - 1) + 117, self.kinodyn_casadi_np(N)
+        x = np.ascontiguousarray(x, float); p = np.ascontiguousarray(p, float)
+        assert x.shape == (nx,) and p.shape == (npar,)
+        nj, nh = (len(self.kinodyn_casadi_pattern(N, w)[1]) for w in (0, 1))
+        size = dict(f=1, g=ng, grad_f=nx, jac=nj, hess=nh, ggx=nx, ggp=npar)
+        out = {k: np.zeros(size[k]) for k in want}
+        ptr = lambda k: out[k].ctypes.data_as(dp) if k in out else None
+        lf = C.c_double(lam_f)
+        lg = np.ascontiguousarray(lam_g, float) if lam_g is not None else None
+        fn = self.L.lib.landing_kinodyn_casadi_eval_host
+        fn.argtypes = [C.c_void_p, C.c_int, dp, dp, dp, dp] + [dp] * 7
+        self.L._check(fn(self.L.ctx, N, x.ctypes.data_as(dp), p.ctypes.data_as(dp), C.byref(lf), lg.ctypes.data_as(dp) if lg is not None else None,
+                         *[ptr(k) for k in ("f", "g", "grad_f", "jac", "hess", "ggx", "ggp")]), "landing_kinodyn_casadi_eval_host")
+        if "f" in out:
+            out["f"] = float(out["f"][0])
+        return out
 
     def kinodyn_pattern(self, N, which):
         """landing_kinodyn_pattern: CCS (colind, row) of jac_g_x (which = 0) or triu(hess_gamma_x_x) (which = 1)"""

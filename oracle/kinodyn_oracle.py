@@ -97,7 +97,8 @@ def stage_rows(w, dt, last, mass, Ib, Ib_inv, mu):
         pr = cf[l] - (pos + R @ HIP[l])
         out += [pr, [pr @ pr], tq[3 * l:3 * l + 3]]
     km = 0.71 * mu
-    out += [ff[:, 0] - km * ff[:, 2], ff[:, 0] + km * ff[:, 2], ff[:, 1] - km * ff[:, 2], ff[:, 1] + km * ff[:, 2], [pos[2]], fk_err, fk_err, jp, jp]
+    # (the two `>=` friction rows in Opti's canonical form: neither side of `f_xy >= -km f_z` is parametric, so the row is (-km f_z) - f_xy <= 0, optistack_internal.cpp:793-806)
+    out += [ff[:, 0] - km * ff[:, 2], -km * ff[:, 2] - ff[:, 0], ff[:, 1] - km * ff[:, 2], -km * ff[:, 2] - ff[:, 1], [pos[2]], fk_err, fk_err, jp, jp]
     return np.concatenate([np.atleast_1d(np.asarray(o, float)) for o in out])
 
 
@@ -265,7 +266,7 @@ def stage_rows_batch(W, dt, last, mass, Ib, Ib_inv, mu):
         fb = -(Rw2b @ ff[:, l, :, None])
         out.append((np.swapaxes(J, 1, 2) @ fb)[:, :, 0])
     km = 0.71 * mu
-    out += [ff[:, :, 0] - km * ff[:, :, 2], ff[:, :, 0] + km * ff[:, :, 2], ff[:, :, 1] - km * ff[:, :, 2], ff[:, :, 1] + km * ff[:, :, 2], pos[:, 2:3], fk_err, fk_err, jp, jp]
+    out += [ff[:, :, 0] - km * ff[:, :, 2], -km * ff[:, :, 2] - ff[:, :, 0], ff[:, :, 1] - km * ff[:, :, 2], -km * ff[:, :, 2] - ff[:, :, 1], pos[:, 2:3], fk_err, fk_err, jp, jp]
     return np.concatenate(out, axis=1)
 
 

@@ -36,7 +36,7 @@ def test_library_exports_every_declared_symbol(built):
         assert hasattr(lib, n), n
 
 
-@pytest.mark.parametrize("so", ["landingCtrller_IPOPT_mi355x.so", "landingCtrller_IPOPT_N40_mi355x.so", "nlp_quad_SRBM_mi355x.so"])
+@pytest.mark.parametrize("so", ["landingCtrller_IPOPT_mi355x.so", "landingCtrller_IPOPT_N40_mi355x.so", "nlp_quad_SRBM_mi355x.so", "landingCtrller_KNITRO_mi355x.so"])
 def test_casadi_dropin_exports_reference_symbol_set(built, so):
     lib = C.CDLL(os.path.join(PKG, so))
     suffixes = ["", "_alloc_mem", "_init_mem", "_free_mem", "_checkout", "_release", "_incref", "_decref", "_n_in",

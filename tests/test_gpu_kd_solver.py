@@ -235,3 +235,33 @@ def test_portfolio_takes_the_outlier_out_of_the_batch(ctx):
     kk = _certify(s["x"][ok], s["lam_g"][ok], lb[ok], ub[ok], cost[ok], dt, consts.mu)
     assert kk.max() <= KKT_TOL * 1.0001, kk.max()
     assert np.allclose(kk, s["kkt"][ok], rtol=1e-3, atol=1e-9)
+
+
+def test_warm_start_preset_resolves_from_the_previous_solution_in_a_few_iterations(ctx):
+    """landing_kinodyn_solver_opts_warm (round 6): every production caller solves the refinement NLP twice, the second time from the first solution
+    (`prevSoln`, main_scripts/landing_optimization.m:395-435; generate_solver/generate_landingCtrller_KNITRO_warmstart.m builds the `_ws` function for it).
+    256 drop states of law "main": cold solve, then the re-solve of every converged member from its x* under the preset -- all converge again, in at most
+    10 iterations each (cold: ~31 on average), to KKT points <= 1e-6 under the oracle; with the cold-start defaults the same re-solve needs several times as many."""
+    L, R = ctx
+    P, kd = lc("problem"), lc("kinodyn")
+    B = 256
+    consts = P.production_constants("main")
+    Pp, X0, q, qd = P.make_batch(B, N, 0.6, seed=12, consts=consts, dt_grid="reference", law="main")
+    srbm = L.solve_host(Pp, X0)
+    mass, Ib, Ibi, dt = _consts()
+    prob = [kd.member_problem(N, q[b], qd[b], srbm["x"][b]) for b in range(B)]
+    lb, ub, cost, x0 = (np.array([p[i] for p in prob]) for i in range(4))
+    cold = R.kinodyn_solve_host(N, lb, ub, cost, x0, dt, mass, Ib, Ibi, consts.mu, R.kinodyn_default_opts())
+    ok = cold["status"] == 0
+    assert ok.sum() >= 0.75 * B
+    w = R.kinodyn_warm_opts()
+    assert (w.bound_push, w.bound_frac, w.mu_init, w.kd_clone_after, w.max_iter) == (1e-4, 1e-4, 1e-4, 0, 100)
+    warm = R.kinodyn_solve_host(N, lb[ok], ub[ok], cost[ok], cold["x"][ok], dt, mass, Ib, Ibi, consts.mu, w)
+    again = R.kinodyn_solve_host(N, lb[ok], ub[ok], cost[ok], cold["x"][ok], dt, mass, Ib, Ibi, consts.mu, R.kinodyn_default_opts())
+    print("re-solve from x*: warm preset %d / %d converged, iterations mean %.1f max %d; cold-start defaults mean %.1f max %d; the cold solve itself mean %.1f" % (
+        (warm["status"] == 0).sum(), ok.sum(), warm["iters"].mean(), warm["iters"].max(), again["iters"].mean(), again["iters"].max(), cold["iters"][ok].mean()))
+    assert (warm["status"] == 0).all() and warm["iters"].max() <= 10
+    assert again["iters"].mean() >= 2.0 * warm["iters"].mean()
+    kk = _certify(warm["x"], warm["lam_g"], lb[ok], ub[ok], cost[ok], dt, consts.mu)
+    assert kk.max() <= KKT_TOL * 1.0001
+    assert np.abs(warm["x"] - cold["x"][ok]).max() <= 1e-2      # the same solution, polished

@@ -99,6 +99,76 @@ def test_casadi_dropin_on_gpu_matches_reference_golden():
     lib.nlp_decref()
 
 
+def test_knitro_dropin_on_gpu_matches_oracle():
+    """landingCtrller_KNITRO_mi355x.so (round 6): the CasADi-external face of the kinodynamic refinement NLP (generate_landingCtrller_KNITRO.m:360-377 generates and loads
+    ./landingCtrller_KNITRO.so; a missing blob of the reference) called exactly as CasADi's external() would -- metadata CasADi asserts on (external.cpp:325-363),
+    arg / res pointer arrays, NULL outputs skipped -- at the script's size (21 knots: x 972, p 373, g 2844) against the oracle (KD oracle: parity unpinned beyond row
+    feasibility of the reference's two stored solutions; derivatives of the oracle are complex-step / Richardson derivatives of itself)."""
+    from oracle import kinodyn_oracle as ko
+    kd = lc("kinodyn")
+    N, nx, ng, npar = 20, 972, 2844, 373
+    lib = C.CDLL(os.path.join(PKG, "landingCtrller_KNITRO_mi355x.so"))
+    dp = C.POINTER(C.c_double); llp = C.POINTER(C.c_longlong)
+    lib.nlp_incref()
+    for fn, i, want in (("nlp_jac_g_sparsity_in", 0, (nx, 1)), ("nlp_jac_g_sparsity_in", 1, (npar, 1)), ("nlp_jac_g_sparsity_out", 0, (ng, 1)), ("nlp_jac_g_sparsity_out", 1, (ng, nx)), ("nlp_hess_l_sparsity_out", 0, (nx, nx))):
+        f = getattr(lib, fn); f.restype = llp; f.argtypes = [C.c_longlong]
+        sp = f(i); assert (sp[0], sp[1]) == want, (fn, i, sp[0], sp[1])
+    spj = lib.nlp_jac_g_sparsity_out(1); nnz_j = spj[2 + nx]
+    sph = lib.nlp_hess_l_sparsity_out(0); nnz_h = sph[2 + nx]
+    assert (nnz_j, nnz_h) == (13536, 5720)      # the counts of landing_kinodyn_pattern (DESIGN 4.8)
+    lib.nlp_grad_name_out.restype = C.c_char_p; lib.nlp_grad_name_out.argtypes = [C.c_longlong]
+    assert [lib.nlp_grad_name_out(i) for i in range(4)] == [b"f", b"g", b"grad_gamma_x", b"grad_gamma_p"]
+    mass, Ib, Ibi = lc("constants").robot_constants()
+    Ib, Ibi = np.asarray(Ib), np.asarray(Ibi)
+    rng = np.random.default_rng(21)
+    dt = np.asarray(lc("problem").REFERENCE_DT_GRID, float); mu = 0.75
+    x = 0.3 * rng.normal(size=nx); x[2:12 * (N + 1):12] += 0.3
+    lam = rng.normal(size=ng); lf = np.array([0.6])
+    Xref = rng.normal(size=(12, N + 1)); QN = np.array(kd.QN_DEFAULT, float)
+    q_init = np.array([0, 0, 0.6, 0.1, -0.3, 0.05]); qd_init = np.array([0.1, -0.2, 0.3, 0.5, -0.4, -3.0])
+    p = kd.pack_params_knitro(N, Xref=Xref, dt=dt, q_init=q_init, qd_init=qd_init, c_init=kd.c_init_of(q_init), jpos_min=kd.JPOS_MIN, jpos_max=kd.JPOS_MAX,
+                              q_term_min=[-10, -10, 0.15, -0.1, -0.1, -10], q_term_max=[10, 10, 5, 0.1, 0.1, 10], qd_term_min=[-10, -10, -10, -.5, -.5, -.5], qd_term_max=[10, 10, 10, .5, .5, .5],
+                              q_min=[-10, -10, 0.075, -10, -10, -10], QN=QN, mu=mu, l_leg_max=0.4, mass=mass, Ib=Ib, Ib_inv=Ibi, kin_box=kd.kin_box_of(q_init[3:6], qd_init[3:6]))
+    ptr = lambda a: a.ctypes.data_as(dp)
+
+    def call(name, ins, outs):
+        arg = (dp * len(ins))(*[ptr(a) if a is not None else None for a in ins])
+        res = (dp * len(outs))(*[ptr(a) if a is not None else None for a in outs])
+        f = getattr(lib, name); f.restype = C.c_int
+        assert f(arg, res, None, None, 0) == 0
+    g = np.zeros(ng); jac = np.zeros(nnz_j)
+    call("nlp_jac_g", [x, p], [g, jac])
+    assert np.abs(g - ko.nlp_g(x, N, dt, mass, Ib, Ibi, mu)).max() <= 1e-11
+    f = np.zeros(1); gx = np.zeros(nx); gp = np.zeros(npar)
+    call("nlp_grad", [x, p, lf, lam], [f, None, gx, gp])      # res[1] == NULL is skipped
+    d = x[12 * N:12 * N + 12] - Xref[:, N]
+    assert abs(f[0] - QN @ d ** 2) <= 1e-12
+    gfx = np.zeros(nx); gfx[12 * N:12 * N + 12] = lf[0] * 2 * QN * d
+    ref = ko.grad_lagrangian_batch(x[None], lam[None], N, dt, mass, Ib, Ibi, mu, gfx[None])[0]
+    assert np.abs(gx - ref).max() <= 1e-9 * max(1.0, np.abs(ref).max())
+    # J' lam through the CCS values == grad_gamma_x - lam_f grad f
+    colind = np.array(spj[2:2 + nx + 1]); rows = np.array(spj[3 + nx:3 + nx + nnz_j])
+    jtl = np.array([jac[colind[c]:colind[c + 1]] @ lam[rows[colind[c]:colind[c + 1]]] for c in range(nx)])
+    assert np.abs(jtl - (gx - gfx)).max() <= 1e-10 * max(1.0, np.abs(gx).max())
+    # Hessian columns against central differences of the oracle's exact gradient
+    h = np.zeros(nnz_h)
+    call("nlp_hess_l", [x, p, lf, lam], [h])
+    hc = np.array(sph[2:2 + nx + 1]); hr = np.array(sph[3 + nx:3 + nx + nnz_h])
+    H = np.zeros((nx, nx))
+    for c in range(nx):
+        H[hr[hc[c]:hc[c + 1]], c] = h[hc[c]:hc[c + 1]]
+    H = H + np.triu(H, 1).T
+    def grad_gamma(xx):
+        gq = np.zeros(nx); gq[12 * N:12 * N + 12] = lf[0] * 2 * QN * (xx[12 * N:12 * N + 12] - Xref[:, N])
+        return ko.grad_lagrangian_batch(xx[None], lam[None], N, dt, mass, Ib, Ibi, mu, gq[None])[0]
+    for j in (4, 9, 12 * 7 + 3, 12 * N + 2, 12 * (N + 1) + 5, 12 * (N + 1) + 12 * N + 30, nx - 3):
+        e = np.zeros(nx); e[j] = 1e-5
+        col = (grad_gamma(x + e) - grad_gamma(x - e)) / 2e-5
+        assert np.abs(H[:, j] - col).max() <= 1e-6 * max(1.0, np.abs(col).max()), j
+    assert gp[252 + 3] != 0.0 and (gp[12 * (N + 1) + N:12 * (N + 1) + N + 60] == 0.0).all()      # dt enters g; q_init ... jpos_max sit in the bounds only
+    lib.nlp_decref()
+
+
 def test_ccc_dropin_on_gpu_matches_oracle(oracle_mod):
     """nlp_quad_SRBM_mi355x.so (the N=41 script's NLP: kin-box .05/.05/.27, running cost, QX / Qc / Qf / Uref in p) through the CasADi ABI
     against the oracle; no generated C of that script exists in the reference, so the oracle's restatement (finite-difference checked,
