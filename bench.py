@@ -48,7 +48,7 @@ FP64_PEAK_TFLOPS = 78.6      # MI355X fp64 vector = matrix peak (AMD datasheet; 
 HBM_PEAK_GBPS = 8000.0       # MI355X_MICROARCH.md
 SURVEY_8D_KKT_FLOPS = 4.4e6  # block-tridiagonal factor+solve per interior-point iteration at N=40
 SURVEY_8D_CALLBACK_FLOPS = 0.14e6
-PMC_FILE = os.path.join(ROOT, "profiles", "r05_pmc_ipm.json")      # default of --pmc-file
+PMC_FILE = os.path.join(ROOT, "profiles", "r06_pmc_ipm.json")      # default of --pmc-file
 
 
 def kernel_source_sha():
@@ -436,7 +436,7 @@ def main():
 def measure_kinodyn(np, torch, local, B=1024, N=20, seed=20211, reps=2):
     """SURVEY 8f row N1 beside the headline (rank 0, behind the timed region, never part of `value`): the production callers' pipeline on one batch --
     SRBM solve (N = 20, production grid, law "main") -> kinodynamic refinement of the same drop states through the device-pointer entry point.  The same
-    measurement as tools/bench_kd_solve.py (profiles/r05_kd_bench.json).  Any failure is reported as a string: this leg must not take the headline down."""
+    measurement as tools/bench_kd_solve.py (profiles/r06_kd_bench.json).  Any failure is reported as a string: this leg must not take the headline down."""
     try:
         P_ = importlib.import_module("landing-controller_amd.problem"); capi = importlib.import_module("landing-controller_amd.capi")
         rbd = importlib.import_module("landing-controller_amd.rbd"); kd = importlib.import_module("landing-controller_amd.kinodyn")

@@ -57,18 +57,19 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
   }
   if (os && !mxIsEmpty(os) && !mxIsStruct(os)) mexErrMsgTxt("landing_refine_mex: the 25th argument must be an options struct");
   if (os && mxIsEmpty(os)) os = NULL;
-  landing_kinodyn_solver_opts_default(&o);
+  if (opt_scalar(os, "warm", 0.0) != 0.0) { landing_kinodyn_solver_opts_warm(&o); own_opts = 1; }      /* the `_ws` re-solve from a previous solution (landing_optimization.m:395-435) */
+  else landing_kinodyn_solver_opts_default(&o);
 #define OPT_D(f) o.f = opt_scalar(os, #f, o.f)
 #define OPT_I(f) o.f = (int)opt_scalar(os, #f, (double)o.f)
   OPT_D(tol); OPT_I(max_iter); OPT_D(mu_init); OPT_D(bound_push); OPT_D(bound_frac); OPT_D(kappa_eps); OPT_D(kappa_mu); OPT_D(theta_mu); OPT_I(max_resets);
   OPT_D(reset_du); OPT_I(restart_period); OPT_D(delta_init); OPT_D(delta_inc_first); OPT_D(delta_inc); OPT_D(delta_dec); OPT_D(tau_min); OPT_D(alpha_fallback);
   OPT_D(reset_delta); OPT_I(clip_k); OPT_D(clip_until); OPT_D(theta_floor); OPT_I(fresh_restart); OPT_D(dual_step_cap); OPT_D(slack_corr); OPT_I(watchdog);
-  OPT_D(barrier_smax); OPT_D(delta_floor); OPT_I(jam_clip); OPT_I(stag_relief); OPT_I(feas_phase); OPT_I(feas_stat); OPT_I(kd_clone_after); OPT_I(kd_clone_max); OPT_I(kd_clone_iter);
+  OPT_D(barrier_smax); OPT_D(delta_floor); OPT_I(jam_clip); OPT_I(stag_relief); OPT_I(feas_phase); OPT_I(feas_stat); OPT_D(feas_polish); OPT_I(kd_clone_after); OPT_I(kd_clone_max); OPT_I(kd_clone_iter);
   device = (int)opt_scalar(os, "device", 0.0);
   {      /* the library's defaults (incl. its retry ladder for the members the first pass leaves undecided) unless the caller set a solver option */
     static const char* solver_fields[] = {"tol", "max_iter", "mu_init", "bound_push", "bound_frac", "kappa_eps", "kappa_mu", "theta_mu", "max_resets", "reset_du",
       "restart_period", "delta_init", "delta_inc_first", "delta_inc", "delta_dec", "tau_min", "alpha_fallback", "reset_delta", "clip_k", "clip_until", "theta_floor",
-      "fresh_restart", "dual_step_cap", "slack_corr", "watchdog", "barrier_smax", "delta_floor", "jam_clip", "stag_relief", "feas_phase", "feas_stat", "kd_clone_after", "kd_clone_max", "kd_clone_iter"};
+      "fresh_restart", "dual_step_cap", "slack_corr", "watchdog", "barrier_smax", "delta_floor", "jam_clip", "stag_relief", "feas_phase", "feas_stat", "feas_polish", "kd_clone_after", "kd_clone_max", "kd_clone_iter"};
     size_t q;
     for (q = 0; q < sizeof(solver_fields) / sizeof(solver_fields[0]); ++q) if (os && mxGetField(os, 0, solver_fields[q])) own_opts = 1;
   }

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Profiles of one round (run on the GPU box through gpurun): kernel-trace stats of bench.py + separate PMC passes
 # (never combined with tracing domains other than --kernel-trace).  Output: gpurun_out/prof_$1/*
-tag=${1:-r05}
+tag=${1:-r06}
 out=$PWD/gpurun_out/prof_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
