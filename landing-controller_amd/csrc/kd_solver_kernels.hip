@@ -61,6 +61,9 @@ struct KdState {
   // feasibility (restoration) phase, round 5 -- the scheme of landing_ipm_kernel (solver_kernels.hip, landing_nlp.h feas_phase / feas_jam / feas_stat):
   // feas = 1 while the elastic problem is being solved, lim = iteration limit in force, fjam / fstat / v1_ref = the two rules' counters
   int feas, feas_used, lim, fjam, fstat, polished; double v1_ref, c_rn, f_vmax, f_v1;
+  // round 6 (landing_nlp.h feas_max / feas_back / feas_ret_push / feas_delta_dec / feas_resume): entries into the phase, stalled flag, hard iteration limit, "record the
+  // entry violation" flag; violation at the entry (1-norm, equality rows included), 1-norm residual of the equality rows at x, adapted regularisation factor of the phase
+  int n_feas, stalled, hard_lim, want_entry; double th_entry, f_theq, fdc;
   double prof[8]; long long tp;      // development aid: wall_clock64 ticks (100 MHz) per phase, summed over the iterations: grad | mu | backward | forward | dual | line search | accept
 };
 
@@ -677,14 +680,14 @@ KD_PHASE void kd_feas_point_pass(const KdMem& M, int ng, const double* lbm, cons
   KdLds& S = KSH;
   const int tid = threadIdx.x, NT = blockDim.x;
   const double INF = INFINITY;
-  double pr = 0.0, co = 0.0, cm = 0.0, rn = 0.0, ys = 0.0, zs = 0.0, nz = 0.0, vmax = 0.0, v1 = 0.0;
+  double pr = 0.0, co = 0.0, cm = 0.0, rn = 0.0, ys = 0.0, zs = 0.0, nz = 0.0, vmax = 0.0, v1 = 0.0, teq = 0.0;
   for (int r = tid; r < ng; r += NT) {
     const double lb = lbm[r], ub = ubm[r];
     double sg = 0.0, rh = 0.0;
     if (r >= 24) {
       const double g = M.g[r];
       ys += fabs(M.y[r]);
-      if (lb == ub) pr = fmax(pr, fabs(g - lb));
+      if (lb == ub) { pr = fmax(pr, fabs(g - lb)); teq += fabs(g - lb); }
       else {
         const double s = M.s[r], v = fmax(fmax(lb - g, g - ub), 0.0);
         pr = fmax(pr, fabs(g - s)); vmax = fmax(vmax, v); v1 += v;
@@ -707,9 +710,12 @@ KD_PHASE void kd_feas_point_pass(const KdMem& M, int ng, const double* lbm, cons
   }
   double v[6] = {pr, co, cm, ys, zs, nz}; const int op[6] = {RMAX, RMAX, RMAX, RSUM, RSUM, RSUM};
   block_reduce<6>(v, op, S.red);
-  double u[3] = {rn, vmax, v1}; const int op3[3] = {RMAX, RMAX, RSUM};
-  block_reduce<3>(u, op3, S.red);
-  KD_BEGIN_SYNCED() S.ks.c_pr = v[0]; S.ks.c_co = v[1]; S.ks.c_cm = v[2]; S.ks.c_ys = v[3]; S.ks.c_zs = v[4]; S.ks.c_nz = fmax(v[5], 1.0); S.ks.c_rn = u[0]; S.ks.f_vmax = u[1]; S.ks.f_v1 = u[2]; KD_END();
+  double u[4] = {rn, vmax, v1, teq}; const int op4[4] = {RMAX, RMAX, RSUM, RSUM};
+  block_reduce<4>(u, op4, S.red);
+  KD_BEGIN_SYNCED()
+    S.ks.c_pr = v[0]; S.ks.c_co = v[1]; S.ks.c_cm = v[2]; S.ks.c_ys = v[3]; S.ks.c_zs = v[4]; S.ks.c_nz = fmax(v[5], 1.0); S.ks.c_rn = u[0]; S.ks.f_vmax = u[1]; S.ks.f_v1 = u[2]; S.ks.f_theq = u[3];
+    if (S.ks.want_entry) { S.ks.th_entry = u[2] + u[3]; S.ks.want_entry = 0; }      // first pass of a phase: the violation it starts from
+  KD_END();
 }
 
 KD_PHASE void kd_init_slacks(const KdMem& M, int ng, const double* lbm, const double* ubm, const landing_solver_opts& o) {
@@ -726,6 +732,27 @@ KD_PHASE void kd_init_slacks(const KdMem& M, int ng, const double* lbm, const do
       if (hL) sv = fmax(sv, lb + pl);
       if (hU) sv = fmin(sv, ub - pu);
       zl = hL ? 1.0 : 0.0; zu = hU ? 1.0 : 0.0;
+    }
+    M.s[r] = sv; M.zL[r] = zl; M.zU[r] = zu; M.y[r] = zu - zl;
+  }
+  __syncthreads();
+}
+
+// ... at the point a feasibility phase hands back (landing_nlp.h feas_ret_push, round 6): slacks pushed only feas_ret_push off their bounds, multipliers mu / distance
+KD_PHASE void kd_init_slacks_return(const KdMem& M, int ng, const double* lbm, const double* ubm, const landing_solver_opts& o, double mu_) {
+  const double INF = INFINITY, push = o.feas_ret_push;
+  for (int r = threadIdx.x; r < ng; r += blockDim.x) {
+    const double lb = lbm[r], ub = ubm[r];
+    double sv = 0.0, zl = 0.0, zu = 0.0;
+    if (r >= 24 && lb != ub) {
+      const bool hL = lb > -INF, hU = ub < INF;
+      sv = M.g[r];
+      double pl, pu;
+      if (hL && hU) { pl = fmin(push * fmax(1.0, fabs(lb)), push * (ub - lb)); pu = fmin(push * fmax(1.0, fabs(ub)), push * (ub - lb)); }
+      else { pl = push * fmax(1.0, hL ? fabs(lb) : 0.0); pu = push * fmax(1.0, hU ? fabs(ub) : 0.0); }
+      if (hL) sv = fmax(sv, lb + pl);
+      if (hU) sv = fmin(sv, ub - pu);
+      zl = hL ? fmin(fmax(mu_ / (sv - lb), 1e-8), 1e3) : 0.0; zu = hU ? fmin(fmax(mu_ / (ub - sv), 1e-8), 1e3) : 0.0;
     }
     M.s[r] = sv; M.zL[r] = zl; M.zU[r] = zu; M.y[r] = zu - zl;
   }
@@ -761,6 +788,7 @@ __global__ void __launch_bounds__(KD_THREADS) landing_kd_init_kernel(KdSolveArgs
     K.wd_count = 0; K.last_mu_it = 0; K.accepted = 0; K.armijo_step = 0; K.fact_ok = 0; K.skipped_zero = 0; K.attempt = 0; K.flag = 0; K.ls_done = 0;
     K.need_corr = 0; K.fallback = 0; K.nfact = 0; K.ntrial = 0; K.nreset = 0; K.last_reset_it = 0; K.ncrawl = 0; K.clip_k_cur = o.clip_k; K.fresh = 0; K.reg_it = -1000; K.pending = 0; K.stag = 0; K.full_prev = 0; K.e_prev = 1e300;
     K.feas = 0; K.feas_used = 0; K.lim = o.max_iter; K.fjam = 0; K.fstat = 0; K.polished = 0; K.v1_ref = 0.0; K.c_rn = 0.0; K.f_vmax = 0.0; K.f_v1 = 0.0;
+    K.n_feas = 0; K.stalled = 0; K.want_entry = 0; K.th_entry = 0.0; K.f_theq = 0.0; K.hard_lim = o.max_iter > 0 ? 3 * o.max_iter : 0; K.fdc = o.feas_delta_dec > 0.0 ? o.feas_delta_dec : o.delta_dec;
     for (int i = 0; i < 8; ++i) K.prof[i] = 0.0; K.tp = 0;
   }
   __syncthreads();
@@ -848,19 +876,21 @@ __global__ void __launch_bounds__(KD_THREADS, 2) landing_kd_iter_kernel(KdSolveA
           else if (K.f_vmax <= 1e-9 && pr <= o.tol) K.flag = 3;
           else if (conv && K.f_v1 > o.feas_cert) { K.status = LANDING_INFEASIBLE; K.flag = 1; }
           else if (conv) K.flag = 3;
+          else if (o.feas_back > 0.0 && !K.feas_used && K.f_v1 + K.f_theq <= o.feas_back * K.th_entry) K.flag = 3;      // the violation has come down: back to the interior-point iteration (IPOPT's restoration phase)
           else if (o.feas_stat > 0) {
             const double v1 = K.f_v1;
             if (K.fstat < 0 || !(fabs(v1 - K.v1_ref) <= 0.05 * K.v1_ref)) { K.v1_ref = v1; K.fstat = 0; } else K.fstat++;
             if (K.fstat >= o.feas_stat && K.mu <= 1e-4 && pr <= 1e-3) {      // round 6 (landing_nlp.h): a stationary violation is not a certificate -- the regularisation is dropped once
               if (v1 <= o.feas_cert) K.flag = 3;                             // (a stationary point is then a few Newton steps from the elastic KKT point, status 3 above); after that LANDING_STALLED
-              else if (o.feas_polish > 0.0 && !K.polished) { K.polished = 1; K.fstat = -1; K.delta_last = o.feas_polish / o.delta_dec; K.need_reg_streak = 2; }
+              else if (o.feas_polish > 0.0 && !K.polished) { K.polished = 1; K.fstat = -1; K.delta_last = o.feas_polish / (o.feas_delta_dec > 0.0 ? o.feas_delta_dec : o.delta_dec); K.need_reg_streak = 2; }
+              else if (o.feas_resume && !K.stalled) { K.stalled = 1; K.feas_used = 1; K.flag = 3; }      // the interior-point iteration resumes from this point, once
               else { K.status = LANDING_STALLED; K.flag = 1; }
             }
           }
-          if (K.flag == 0 && K.it >= K.lim) { K.status = LANDING_MAX_ITER; K.flag = 1; }
+          if (K.flag == 0 && K.it >= K.lim) { K.status = K.stalled ? LANDING_STALLED : LANDING_MAX_ITER; K.flag = 1; }
           if (K.flag == 3) {
-            K.feas = 0; K.lim = K.it + (o.max_iter > 1 ? o.max_iter : 1); K.status = LANDING_MAX_ITER;
-            K.mu = o.mu_init; K.nfilt = 0; K.delta_last = 0.0; K.need_reg_streak = 0; K.wd_count = 0; K.th_max = 0.0; K.nreset = 0; K.last_reset_it = K.it; K.ncrawl = 0;
+            K.feas = 0; K.lim = K.it + (o.max_iter > 1 ? o.max_iter : 1); if (K.lim > K.hard_lim) K.lim = K.hard_lim; K.status = LANDING_MAX_ITER;
+            K.mu = (o.feas_ret_push > 0.0 && o.feas_ret_mu > 0.0) ? o.feas_ret_mu : o.mu_init; K.fjam = 0; K.nfilt = 0; K.delta_last = 0.0; K.need_reg_streak = 0; K.wd_count = 0; K.th_max = 0.0; K.nreset = 0; K.last_reset_it = K.it; K.ncrawl = 0;
             K.cutstreak = 0; K.force_step = 0;
             K.it = K.it + 1;
           }
@@ -869,7 +899,7 @@ __global__ void __launch_bounds__(KD_THREADS, 2) landing_kd_iter_kernel(KdSolveA
         else if (fmax(du, fmax(pr, co)) <= o.tol) { K.status = LANDING_CONVERGED; K.flag = 1; }
         else if (K.it >= K.lim) { K.status = LANDING_MAX_ITER; give_up = true; }
         else if (du > o.reset_du && K.nreset >= o.max_resets && o.max_resets > 0) { K.status = LANDING_NUMERICAL; give_up = true; }      // jammed again: give up
-        else if (o.feas_jam > 0 && K.fjam >= o.feas_jam && pr > 1e-3 && !K.feas_used && o.feas_phase) { K.status = LANDING_MAX_ITER; give_up = true; }      // jammed line search (landing_nlp.h)
+        else if (o.feas_jam > 0 && K.fjam >= o.feas_jam && pr > 1e-3 && o.feas_phase) { K.status = LANDING_MAX_ITER; give_up = true; if (K.feas_used) K.stalled = 1; }      // jammed line search (landing_nlp.h); no entry left: status 4
         else {
           // restart rules of the SRBM solver (solver_kernels.hip, landing_nlp.h fresh_restart): a jammed iterate (multipliers blown up), a first
           // barrier problem that crawls, a later one that has wandered off -> slacks, multipliers, barrier parameter and filter are re-initialised,
@@ -892,9 +922,11 @@ __global__ void __launch_bounds__(KD_THREADS, 2) landing_kd_iter_kernel(KdSolveA
           }
         }
         if (give_up) {      // the solve would end here as NUMERICAL / MAX_ITER: enter the feasibility phase once
-          if (o.feas_phase && !K.feas_used && o.max_iter > 0) {
+          if (K.stalled) K.status = LANDING_STALLED;
+          if (o.feas_phase && !K.feas_used && o.max_iter > 0 && K.it < K.hard_lim) {
             K.flag = 4;
-            K.feas = 1; K.feas_used = 1; K.status = LANDING_MAX_ITER; K.lim = K.it + o.max_iter; K.fstat = -1;
+            K.feas = 1; K.n_feas++; K.feas_used = K.n_feas >= o.feas_max ? 1 : 0; K.status = LANDING_MAX_ITER; K.lim = K.it + o.max_iter; if (K.lim > K.hard_lim) K.lim = K.hard_lim; K.fstat = -1;
+            K.fjam = 0; K.want_entry = 1; K.fdc = o.feas_delta_dec > 0.0 ? o.feas_delta_dec : o.delta_dec;
             K.mu = o.mu_init; K.nfilt = 0; K.th_max = 0.0; K.delta_last = 0.0; K.need_reg_streak = 0; K.cutstreak = 0; K.force_step = 0; K.wd_count = 0;
             K.it = K.it + 1;
           } else K.flag = 1;
@@ -927,7 +959,7 @@ __global__ void __launch_bounds__(KD_THREADS, 2) landing_kd_iter_kernel(KdSolveA
     if (K.flag == 3) {      // a feasible point (or negligible violation): the interior-point solve restarts from it; derivatives at the new multipliers next round
       for (int r = tid + 24; r < ng; r += NT) if (lbm[r] == ubm[r]) M.y[r] = 0.0;
       __syncthreads();
-      kd_init_slacks(M, ng, lbm, ubm, o);
+      if (o.feas_ret_push > 0.0) kd_init_slacks_return(M, ng, lbm, ubm, o, K.mu); else kd_init_slacks(M, ng, lbm, ubm, o);
       kd_point_pass(M, ng, lbm, ubm, K.mu);
       if (tid == 0) { *M.st = K; A.done[m] = 0; atomicAdd(A.n_active, 1); }
       return;
@@ -985,7 +1017,7 @@ __global__ void __launch_bounds__(KD_THREADS, 2) landing_kd_iter_kernel(KdSolveA
     // ================================================================ Riccati factorisation with inertia correction (IPOPT's schedule)
     KD_BEGIN()
       const double dl = K.delta_last;
-      K.delta = (K.need_reg_streak >= 2 && dl > 0.0) ? fmax(1e-20, dl * o.delta_dec) : 0.0;
+      K.delta = (K.need_reg_streak >= 2 && dl > 0.0) ? fmax(1e-20, dl * ((K.feas && o.feas_delta_dec > 0.0) ? K.fdc : o.delta_dec)) : 0.0;      // (inside the phase the regularisation falls faster, adapted: landing_nlp.h feas_delta_dec)
       { double fl = K.feas ? 0.0 : o.delta_floor;    // proximal term (the cost is terminal only: landing_nlp.h delta_floor; off in the feasibility phase)
         if (o.stag_relief > 0 && K.stag >= o.stag_relief) { for (int e = K.stag - o.stag_relief; e >= 0 && fl >= 1e-12; --e) fl *= 0.1; if (fl < 1e-12) fl = 0.0; }
         K.delta = fmax(K.delta, fl); }
@@ -1002,7 +1034,9 @@ __global__ void __launch_bounds__(KD_THREADS, 2) landing_kd_iter_kernel(KdSolveA
       K.flag = 0;
       if (!ok && K.attempt < 60) {
         double d = K.delta; const double dl = K.delta_last;
-        if (d == 0.0) d = (dl == 0.0) ? o.delta_init : fmax(1e-20, dl * o.delta_dec);
+        const bool adapt = K.feas && o.feas_delta_dec > 0.0;
+        if (d == 0.0) d = (dl == 0.0) ? o.delta_init : fmax(1e-20, dl * (adapt ? K.fdc : o.delta_dec));
+        else if (adapt && K.attempt == 1 && d < dl) d = dl;      // inside the phase: the regularisation of the last iteration is the best guess of what this one needs
 #if KD_DELTA_JUMP > 0
         // the first failure at the proximal floor is IPOPT's failure at delta = 0: continue from the last successful regularisation (if that was at
         // most KD_DELTA_JUMP iterations ago), not fourfold from the floor -- a member that needs delta ~ 1e2 .. 1e4 in its first barrier problem
@@ -1025,12 +1059,14 @@ __global__ void __launch_bounds__(KD_THREADS, 2) landing_kd_iter_kernel(KdSolveA
       if (tid == 0) { K.c_pr = INFINITY; *M.st = K; A.done[m] = 0; atomicAdd(A.n_active, 1); }
       return;
     }
-    if (tid == 0) { K.status = LANDING_NUMERICAL; K.done = 1; *M.st = K; A.done[m] = 1; }
+    if (tid == 0) { K.status = K.stalled ? LANDING_STALLED : LANDING_NUMERICAL; K.done = 1; *M.st = K; A.done[m] = 1; }
     return;
   }
   KD_BEGIN()
+    const bool adapt = K.feas && o.feas_delta_dec > 0.0;
+    if (adapt) K.fdc = K.attempt <= 1 ? fmax(o.feas_delta_dec, K.fdc * K.fdc) : fmin(0.7, sqrt(K.fdc));      // (attempt counts the factorisations of this iteration)
     if (K.delta > (K.feas ? 0.0 : o.delta_floor)) { K.delta_last = K.delta; K.reg_it = K.it; K.need_reg_streak++; } else K.need_reg_streak = 0;
-    if (K.need_reg_streak > 8) K.need_reg_streak = 0;
+    if (K.need_reg_streak > 8) K.need_reg_streak = adapt ? 2 : 0;      // (no probe of delta_w = 0 inside the phase: the elastic problem has no objective)
   KD_END();
   KD_PROF(2);
   kd_forward(M, N, lbm);
