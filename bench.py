@@ -338,6 +338,36 @@ def main():
                 "bytes_per_step_per_gpu": int(8 * B * (P.shape[1] + 2 * nx) + 4 * B),
                 "note": "H2D of p, x0 (pinned) and D2H of x*, status inside the timed step"}
 
+    # ---- the same K steps through the library's own streaming entry points (round 6, VERDICT r5 item 5): ONE context, ONE caller stream, two launches in
+    # flight on the library's lanes (landing_stream_create / _submit / _wait); the host waits for the ticket of submission i - 2, counts its converged
+    # members and submits i while i - 1 runs (tools/dev/stream_probe.py: a stream-side wait on a third stream costs 12 % -- the HIP streams share hardware queues)
+    streamed = None
+    if not a.dry and a.steps >= 2 and not a.no_extras:
+        S = lib.stream(2)
+        sl = [(mk(B, nx), mk(B, dt=torch.int32), mk(B, dt=torch.int32)) for _ in range(2)]
+        conv_s = torch.zeros(1, device=dev, dtype=torch.float64)
+        def ssub(i):
+            xq, stq, itq = sl[i % 2]
+            dPq, dXq = dev_batches[i % n_batches]
+            return S.submit(B, dPq.data_ptr(), dXq.data_ptr(), opts, xq.data_ptr(), 0, 0, stq.data_ptr(), itq.data_ptr(), 0, in_stream=stream)
+        t_ = [ssub(0), ssub(1)]; S.sync(); sync()
+        tk = []
+        tsr = time.perf_counter()
+        for i in range(a.steps):
+            if i >= 2:
+                S.wait(tk[i - 2]); conv_s += (sl[i % 2][1] == 0).sum()      # the host waits for submission i - 2 (a data-generation caller reads its results here); i - 1 keeps the GPU busy
+            tk.append(ssub(i))
+        for i in range(max(0, a.steps - 2), a.steps):
+            S.wait(tk[i]); conv_s += (sl[i % 2][1] == 0).sum()
+        sync()
+        tsr = time.perf_counter() - tsr
+        tse = torch.tensor([tsr], device=dev, dtype=torch.float64)
+        if multi:
+            dist.all_reduce(tse, op=dist.ReduceOp.MAX); dist.all_reduce(conv_s, op=dist.ReduceOp.SUM)
+        streamed = {"value": float(conv_s.item()) / float(tse.item()), "unit": "NLPs/s", "lanes": 2, "ms_per_step": 1e3 * float(tse.item()) / a.steps,
+                    "note": "same K steps through landing_stream_submit / landing_stream_wait: one context, one host thread, two launches in flight inside the library; the host waits for submission i - 2 before it submits i"}
+        S.close()
+
     # ---- the same K steps with two batches in flight (two contexts on two streams): the tail of one batch -- a handful of
     # members that need 2-4x the mean iteration count while most CUs idle -- overlaps with the bulk of the next one.  What a
     # data-generation job streaming batches through the GPU does; reported beside the one-batch-at-a-time `value`.
@@ -376,36 +406,6 @@ def main():
         piped = {"value": float(conv_p.item()) / float(tqe.item()), "unit": "NLPs/s", "batches_in_flight": 2, "ms_per_step": 1e3 * float(tqe.item()) / a.steps,
                  "note": "same K steps, two contexts on two streams, no synchronisation between steps"}
         lanes[1][0].close()
-
-    # ---- the same K steps through the library's own streaming entry points (round 6, VERDICT r5 item 5): ONE context, ONE caller stream, two launches in
-    # flight on the library's lanes (landing_stream_create / _submit / _wait); the host waits for the ticket of submission i - 2, counts its converged
-    # members and submits i while i - 1 runs (tools/dev/stream_probe.py: a stream-side wait on a third stream costs 12 % -- the HIP streams share hardware queues)
-    streamed = None
-    if not a.dry and a.steps >= 2 and not a.no_extras:
-        S = lib.stream(2)
-        sl = [(mk(B, nx), mk(B, dt=torch.int32), mk(B, dt=torch.int32)) for _ in range(2)]
-        conv_s = torch.zeros(1, device=dev, dtype=torch.float64)
-        def ssub(i):
-            xq, stq, itq = sl[i % 2]
-            dPq, dXq = dev_batches[i % n_batches]
-            return S.submit(B, dPq.data_ptr(), dXq.data_ptr(), opts, xq.data_ptr(), 0, 0, stq.data_ptr(), itq.data_ptr(), 0, in_stream=stream)
-        t_ = [ssub(0), ssub(1)]; S.sync(); sync()
-        tk = []
-        tsr = time.perf_counter()
-        for i in range(a.steps):
-            if i >= 2:
-                S.wait(tk[i - 2]); conv_s += (sl[i % 2][1] == 0).sum()      # the host waits for submission i - 2 (a data-generation caller reads its results here); i - 1 keeps the GPU busy
-            tk.append(ssub(i))
-        for i in range(max(0, a.steps - 2), a.steps):
-            S.wait(tk[i]); conv_s += (sl[i % 2][1] == 0).sum()
-        sync()
-        tsr = time.perf_counter() - tsr
-        tse = torch.tensor([tsr], device=dev, dtype=torch.float64)
-        if multi:
-            dist.all_reduce(tse, op=dist.ReduceOp.MAX); dist.all_reduce(conv_s, op=dist.ReduceOp.SUM)
-        streamed = {"value": float(conv_s.item()) / float(tse.item()), "unit": "NLPs/s", "lanes": 2, "ms_per_step": 1e3 * float(tse.item()) / a.steps,
-                    "note": "same K steps through landing_stream_submit / landing_stream_wait: one context, one host thread, two launches in flight inside the library; the host waits for submission i - 2 before it submits i"}
-        S.close()
 
     if rank == 0:
         cfg = {"workload": "3D-SRBM landing NLP, N=40 intervals, batch=%d random drop heights/attitudes per GPU, fp64 (BASELINE configs[1]%s)" % (B, "; x%d GPUs = configs[2]" % world if world > 1 else ""),
