@@ -207,6 +207,9 @@ struct IpmState {
 enum { ACT_GO = 0, ACT_STOP = 1, ACT_RESET = 2, ACT_FEAS = 3, ACT_BACK = 4 };
 
 // LDS of one member
+#ifndef LANDING_FWD_WAVE
+#define LANDING_FWD_WAVE 0         // 1: the state recursion of the forward sweep by one wave (forward_pass; round-6 experiment)
+#endif
 #ifndef LANDING_PIVOT_2X2
 #define LANDING_PIVOT_2X2 1        // the 4 x 4 pivot block through its 2 x 2 partition (pivot_block_step; 0: LDL^T + two triangular solves, rounds 2-4)
 #endif
@@ -879,6 +882,67 @@ __device__ LANDING_INL_FWD void forward_pass() {
     for (int j = 0; j < 3; ++j) { const int e = tid + j * 256; if (k < N && e < RIC_FWDN) b[e] = r[j]; }
   };
   if (tid < 24) sg[tid] = S.sig[tid];
+#if LANDING_FWD_WAVE
+  // Round 6 experiment (profiles/r06_ab_experiments.txt): the recursion is a 24 x 24 product per stage -- ONE wave runs it (two lanes per row, the same association of the sums as the
+  // eight-lanes-per-row form below, so the same bits), with a wave-local ordering between the stages instead of a workgroup barrier; the other three waves stage the records of the next
+  // two stages into LDS meanwhile (loads issued two groups ahead).  One workgroup barrier per TWO stages.
+  {
+    constexpr int FW = RIC_FWDN;
+    static_assert(FW <= NZ_TOT + RUNC && FW <= 2 * 12 * YS && 2 * FW <= 24 * PS + 2 * XCH, "four stage slots: cx | A^ | [P | A1] (two)");
+    double* const slotp[4] = {S.jhl, S.Ah, S.P, S.P + FW};      // (P and A1 are adjacent members of Lds)
+    static_assert(offsetof(Lds, A1) == offsetof(Lds, P) + sizeof(double) * 24 * PS, "P and A1 adjacent");
+    const int wave = tid >> 6, l = tid & 63, lt = tid - 64;
+    auto gfetch = [&](int grp, double (&r)[7]) {      // stages 2 grp, 2 grp + 1: 2 x 612 doubles over the 192 loader threads
+#pragma unroll
+      for (int i = 0; i < 7; ++i) {
+        int e = lt + 192 * i; e = e < 2 * FW ? e : 2 * FW - 1;
+        const int st = e >= FW ? 1 : 0; int k = 2 * grp + st; k = k < N ? k : N - 1;
+        r[i] = ((landing_gptr)(M.ric + (size_t)k * RIC_STRIDE + RIC_FWD0))[e - st * FW];
+      }
+    };
+    auto gstash = [&](int grp, const double (&r)[7]) {
+      double* const b0 = slotp[2 * (grp & 1)]; double* const b1 = slotp[2 * (grp & 1) + 1];
+#pragma unroll
+      for (int i = 0; i < 7; ++i) {
+        const int e = lt + 192 * i, st = e >= FW ? 1 : 0;
+        if (e < 2 * FW && 2 * grp + st < N) (st ? b1 : b0)[e - st * FW] = r[i];
+      }
+    };
+    auto group = [&](int grp) {      // the compute wave: stages 2 grp, 2 grp + 1 from the slots of pair grp & 1
+      const int r = l & 31, h = l >> 5; const bool valid = r < 24; const int rr = valid ? r : 0;
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {
+        const int k = 2 * grp + st;
+        if (k < N) {      // (uniform)
+          const double* b = slotp[2 * (grp & 1) + st];
+          const bool lastk = (k == N - 1);
+          const double* row = (rr < 12) ? b + 312 + rr * 24 : b + (rr - 12) * 24;
+          const double* sk = sg + 24 * k;
+          double a[4];
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) { const int j = 4 * h + jj; a[jj] = row[3 * j] * sk[3 * j] + row[3 * j + 1] * sk[3 * j + 1] + row[3 * j + 2] * sk[3 * j + 2]; }
+          double acc = (a[0] + a[1]) + (a[2] + a[3]);
+          acc += __shfl_xor(acc, 32);
+          if (valid && h == 0) sg[24 * (k + 1) + r] = (r < 12) ? b[600 + r] + acc : (lastk ? 0.0 : -(b[300 + (r - 12)] + acc));
+        }
+#if defined(__HIP_DEVICE_COMPILE__)
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // sigma_{k+1} is read by the other lanes of this wave in the next stage (LDS is in order within a wave)
+#endif
+        __builtin_amdgcn_wave_barrier();
+      }
+    };
+    double rA[7], rB[7];
+    if (wave > 0) { gfetch(0, rA); gfetch(1, rB); gstash(0, rA); gfetch(2, rA); }
+    __syncthreads();
+    const int NG = (N + 1) / 2;
+    for (int g0 = 0; g0 < NG; g0 += 2) {
+      if (wave == 0) group(g0); else { gstash(g0 + 1, rB); gfetch(g0 + 3, rB); }
+      __syncthreads();
+      if (wave == 0) group(g0 + 1); else { gstash(g0 + 2, rA); gfetch(g0 + 4, rA); }
+      __syncthreads();
+    }
+  }
+#else
   double r0[3], r1[3], r2[3], r3[3];
   fetch(0, r0); fetch(1, r1); fetch(2, r2); fetch(3, r3);
   stash(0, r0); fetch(4, r0);
@@ -904,6 +968,7 @@ __device__ LANDING_INL_FWD void forward_pass() {
   for (int k0 = 0; k0 < N; k0 += 4) {
     stage(k0, r1); stage(k0 + 1, r2); stage(k0 + 2, r3); stage(k0 + 3, r0);
   }
+#endif
   // ---- everything that hangs off the states, all stages at once
   for (int e = tid; e < 24 * (N + 1); e += NT) {
     const int k = e / 24, i = e % 24;
@@ -1532,7 +1597,9 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
     PROF_ADD(PH_BACK, K.tp);
 
     forward_pass();
+#ifndef LANDING_DEV_SKIP_ROWP      // development probe (timing only: the results are garbage without it)
     row_products(A.rterm, A.rlen);
+#endif
 
     PROF_ADD(PH_FWD, K.tp);
     // ================================================================ dual steps, step bounds, merit data
