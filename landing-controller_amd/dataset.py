@@ -131,3 +131,38 @@ def write_member_log(path, status, iters, kkt, f=None, extra=None):
             if extra:
                 rec.update(extra)
             fh.write(json.dumps(rec) + "\n")
+
+
+def generate_streamed(N, n_batches, B, shard_path, seed0=0, T=0.6, dt_grid="uniform", law="main", opts=None, depth=2, device=0, log_path=None, **form):
+    """The data-generation loop of generate_data/generate_training_data_automated.m:38-219 as a STREAM of batches through one GPU (round 6): the drop states of batch i + 1 are sampled on
+    the host and queued (`pipeline.BatchPipeline` over the library's landing_stream_submit / _wait: one context, `depth` launches in flight) while batch i is solved; the converged members of
+    every batch that leaves the pipeline are appended to the shard in the reference's layout (training_pairs / append_shard), every member is logged (write_member_log).  Returns the
+    counts per status and the number of samples written.  Results per batch are bit-identical to one solve at a time (tests/test_gpu_dataset.py)."""
+    import importlib
+    problem = importlib.import_module(__package__ + ".problem"); pipeline = importlib.import_module(__package__ + ".pipeline")
+    consts = problem.production_constants(law) if dt_grid == "reference" else None
+    pipe = pipeline.BatchPipeline(N, depth=depth, device=device, opts=opts, **form)
+    meta, counts, written = {}, {}, 0
+
+    def take(res):
+        nonlocal written
+        q, qd = meta.pop(res["tag"])
+        inp, out = training_pairs(N, q, qd, res["x"], res["status"])
+        if inp.shape[1]:
+            written = append_shard(shard_path, inp, out)
+        if log_path:
+            write_member_log(log_path, res["status"], res["iters"], res["kkt"], res["f"], extra={"batch": int(res["tag"])})
+        for s in res["status"]:
+            counts[int(s)] = counts.get(int(s), 0) + 1
+    try:
+        for i in range(n_batches):
+            P, X0, q, qd = problem.make_batch(B, N, T, seed=seed0 + i, consts=consts, dt_grid=dt_grid, law=law)
+            meta[i] = (q, qd)
+            done = pipe.submit(P, X0, tag=i)
+            if done is not None:
+                take(done)
+        for done in pipe.drain():
+            take(done)
+    finally:
+        pipe.close()
+    return dict(status_counts=counts, samples_written=written, batches=n_batches)

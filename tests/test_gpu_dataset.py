@@ -84,3 +84,25 @@ def test_stream_host_entry_point_chunks_a_large_batch_bit_for_bit():
     for i in range(3):
         assert np.array_equal(got[i], ref["x"][200 * i:200 * (i + 1)])
     S.close(); L.close()
+
+
+def test_streamed_data_generation_writes_the_same_shard_as_one_batch_at_a_time(tmp_path):
+    """dataset.generate_streamed (round 6): four batches of 128 drop states streamed through ONE context with two launches in flight, converged members appended to the shard in the
+    reference's layout -- the shard equals the one assembled from one solve at a time, column for column"""
+    capi, P, ds = lc("capi"), lc("problem"), lc("dataset")
+    N, B, nb = 40, 128, 4
+    r = ds.generate_streamed(N, nb, B, tmp_path / "shard", seed0=4100, log_path=tmp_path / "members.jsonl")
+    assert r["batches"] == nb and sum(r["status_counts"].values()) == nb * B and r["status_counts"].get(0, 0) >= nb * B - 2
+    with np.load(str(tmp_path / "shard.npz")) as d:
+        inp, out = d["input"], d["output"]
+    assert inp.shape[1] == r["samples_written"] == r["status_counts"][0]
+    L = capi.LandingLib(N, device=0)
+    cols_i, cols_o = [], []
+    for i in range(nb):
+        Pb, X0, q, qd = P.make_batch(B, N, 0.6, seed=4100 + i)
+        s = L.solve_host(Pb, X0)
+        a, b = ds.training_pairs(N, q, qd, s["x"], s["status"])
+        cols_i.append(a); cols_o.append(b)
+    L.close()
+    assert np.array_equal(inp, np.concatenate(cols_i, axis=1)) and np.array_equal(out, np.concatenate(cols_o, axis=1))
+    assert len(open(tmp_path / "members.jsonl").read().splitlines()) == nb * B
