@@ -12,7 +12,8 @@
  *                         any scalar field of landing_solver_opts by name: tol, max_iter, mu_init, bound_push, bound_frac, ...
  * Outputs beyond the first are created only when asked for: F 1xB, STATUS / ITERS int32 1xB, KKT 3xB, LAM_G ng x B.
  * Build:  mex landing_solve_mex.c -I<repo>/include -L<repo>/landing-controller_amd -llanding_mi355x
- * All packing / sharding / solving lives in landing_solve_21_multi (include/landing_nlp.h).  * Round 6: batches above 2048 members are streamed inside the library (landing_solve_batch_host -> landing_solve_stream_host: chunks of 1024 on two lanes of ONE context, uploads and
+ * All packing / sharding / solving lives in landing_solve_21_multi (include/landing_nlp.h).
+ * Round 6: batches above 2048 members are streamed inside the library (landing_solve_batch_host -> landing_solve_stream_host: chunks of 1024 on two lanes of ONE context, uploads and
  * downloads under the solves; include/landing_nlp.h "streaming") -- the serial loop of generate_training_data_automated.m:38 becomes one call whatever the number of samples, with the
  * GPU kept busy across chunk boundaries (24.9 k instead of 19.3 k NLPs/s at N = 40) and a device workspace of 2 x 1024 members.  STATUS 4 = stalled (no certificate, no solution).
 */
