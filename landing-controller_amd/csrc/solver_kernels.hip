@@ -207,6 +207,7 @@ struct IpmState {
 enum { ACT_GO = 0, ACT_STOP = 1, ACT_RESET = 2, ACT_FEAS = 3, ACT_BACK = 4 };
 
 // LDS of one member
+constexpr int FWD_DXL_NMAX = 64;   // horizons up to this keep a copy of dx in LDS for row_products: 36 N + 12 doubles in [P | A1 | A^]
 #ifndef LANDING_FWD_WAVE
 #define LANDING_FWD_WAVE 0         // 1: the state recursion of the forward sweep by one wave (forward_pass; round-6 experiment)
 #endif
@@ -257,6 +258,8 @@ __shared__ Lds SH;
 // (the store of a term that closes nothing goes to a per-lane dump slot).  A piece is a whole destination -- an entry of G (upper
 // triangle), gamma or A^ -- or one of the partial sums that asm_combine adds up in slot order (pieces are cut where the 256 equal
 // chunks of rounds 1-4 were, so every sum keeps its association).
+static_assert(36 * FWD_DXL_NMAX + 12 <= 24 * PS + 2 * XCH + 2 * 12 * YS && offsetof(Lds, A1) == offsetof(Lds, P) + sizeof(double) * 24 * PS && offsetof(Lds, Ah) == offsetof(Lds, A1) + sizeof(double) * 2 * XCH,
+              "dx (x layout, N <= FWD_DXL_NMAX) fits the adjacent arrays [P | A1 | A^] (forward_pass / row_products)");
 static_assert(offsetof(Lds, atab_mid) <= 65528, "the assembly tables address G, A^, gamma, cx, the partial sums and the dump slots with 16-bit byte offsets");
 __host__ __device__ inline unsigned long long aterm_pack(int pa, int pb, int pc, int d, bool keep, bool ah) {
   const unsigned lo = (unsigned)pa | ((unsigned)pb << 16);
@@ -969,11 +972,14 @@ __device__ LANDING_INL_FWD void forward_pass() {
     stage(k0, r1); stage(k0 + 1, r2); stage(k0 + 2, r3); stage(k0 + 3, r0);
   }
 #endif
-  // ---- everything that hangs off the states, all stages at once
+  // ---- everything that hangs off the states, all stages at once.  Round 6: dx also goes to LDS in the x layout ([P | A1 | A^] are free from here to the next backward sweep) for
+  // row_products, whose gathers of dx were one of its two remaining global gathers per term (horizons up to FWD_DXL_NMAX; longer ones gather from the workspace as before)
+  double* const dxl = S.P;
+  const bool use_dxl = N <= FWD_DXL_NMAX;
   for (int e = tid; e < 24 * (N + 1); e += NT) {
     const int k = e / 24, i = e % 24;
-    if (i < 12) M.dx[L.x_X(k) + i] = sg[e];
-    else if (k < N) M.dx[L.x_U(k) + (i - 12)] = sg[e];
+    if (i < 12) { M.dx[L.x_X(k) + i] = sg[e]; if (use_dxl) dxl[L.x_X(k) + i] = sg[e]; }
+    else if (k < N) { M.dx[L.x_U(k) + (i - 12)] = sg[e]; if (use_dxl) dxl[L.x_U(k) + (i - 12)] = sg[e]; }
   }
   for (int e = tid; e < 24 * N; e += NT) {
     const int k = e / 24, h = e % 24, i = h % 12;
@@ -984,6 +990,7 @@ __device__ LANDING_INL_FWD void forward_pass() {
 #pragma unroll
       for (int t = 0; t < 24; ++t) acc += rec[RIC_K + i * 24 + t] * sk[t];
       M.dx[L.x_U(k) + 12 + i] = -acc;
+      if (use_dxl) dxl[L.x_U(k) + 12 + i] = -acc;
     } else {                 // multipliers of the dynamics rows of stage k (state order -> row order)
       landing_gptr recn = (landing_gptr)(M.ric + (size_t)(k + 1) * RIC_STRIDE);
       double acc = recn[RIC_PV + i];
@@ -1013,7 +1020,8 @@ __device__ LANDING_INL_ROWP void row_products(const unsigned long long* __restri
   const MemberMem& M = S.M;
   const int tid = threadIdx.x, NT = blockDim.x;
   const double* __restrict__ Jn = M.J; const double* __restrict__ dxv = M.dx;
-  const double* __restrict__ gv = M.g; const double* __restrict__ sv = M.s; double* __restrict__ dsv = M.ds;
+  const double* dxl = S.P; const bool use_dxl = S.L.N <= FWD_DXL_NMAX;      // dx in LDS, x layout (forward_pass)
+  double* __restrict__ dsv = M.ds;      // (round 6: the `+ (g - s)` of a row is added by the dual pass, which loads g and s of every row anyway -- two of the four gathers per term are gone)
   double acc = 0.0;
   constexpr int BW = 8;
   unsigned long long tn[BW];
@@ -1025,17 +1033,17 @@ __device__ LANDING_INL_ROWP void row_products(const unsigned long long* __restri
     for (int u = 0; u < BW; ++u) t[u] = tn[u];
 #pragma unroll
     for (int u = 0; u < BW; ++u) { const int j = j0 + BW + u; tn[u] = (j < rlen) ? rterm[(size_t)j * NT + tid] : 0ull; }
-    double a[BW], b[BW], c[BW];
+    double a[BW], b[BW];
 #pragma unroll
     for (int u = 0; u < BW; ++u) {
-      const int ij = (int)(t[u] & 0xffffu), ix = (int)((t[u] >> 16) & 0xffffu), ir = (int)((t[u] >> 32) & 0xffffu);
-      a[u] = Jn[ij]; b[u] = dxv[ix]; c[u] = gv[ir] - sv[ir];
+      const int ij = (int)(t[u] & 0xffffu), ix = (int)((t[u] >> 16) & 0xffffu);
+      a[u] = Jn[ij]; b[u] = use_dxl ? dxl[ix] : dxv[ix];
     }
 #pragma unroll
     for (int u = 0; u < BW; ++u) {
       const bool valid = (t[u] >> 49) & 1ull, closes = (t[u] >> 48) & 1ull;
       acc += valid ? a[u] * b[u] : 0.0;
-      if (closes) { dsv[(int)((t[u] >> 32) & 0xffffu)] = acc + c[u]; acc = 0.0; }
+      if (closes) { dsv[(int)((t[u] >> 32) & 0xffffu)] = acc; acc = 0.0; }
     }
   }
   __syncthreads();
@@ -1619,7 +1627,9 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
         for (int r = lane + 12; r < ng; r += NT) {
           const double lb = S.bnd_lb[bidx(r)], ub = S.bnd_ub[bidx(r)], g = r_g[r];
           if (lb == ub) { th0 += fabs(g - lb); continue; }
-          const double s = r_s[r], ds = r_ds[r];
+          const double s = r_s[r];
+          double ds = r_ds[r];
+          if (r >= 36) { ds = ds + (g - s); r_ds[r] = ds; }      // row_products left J_d dx: the row's `+ (g - s)` is added here (the terminal rows 12..35 are complete)
           th0 += fabs(g - s);
           if (lb > -INF) {
             const double n = M.en[r], a = s - lb + n, z = r_zL[r], w = M.wn[r];
@@ -1644,7 +1654,9 @@ __global__ void __launch_bounds__(SOLVER_THREADS, LANDING_MIN_WAVES) landing_ipm
           if (rb + j * NT >= ng) continue;
           const double lb = lbv[j], ub = ubv[j], g = gv[j];
           if (lb == ub) { th0 += fabs(g - lb); continue; }
-          const double s = sv[j], ds = dsv[j];
+          const double s = sv[j];
+          double ds = dsv[j];
+          { const int r = rb + j * NT; if (r >= 36) { ds = ds + (g - s); r_ds[r] = ds; } }      // row_products left J_d dx: the row's `+ (g - s)` is added here (the terminal rows 12..35 are complete)
           th0 += fabs(g - s);
           double dprod = 1.0;
           if (lb > -INF) {
