@@ -73,8 +73,13 @@ __device__ __forceinline__ void load_stage(const Layout& L, const double* x, con
 }
 
 struct RowStore { double* g; __device__ __forceinline__ void put(int r, double v) { g[r] = v; } };
+#ifdef LANDING_DEV_NOSTORE      // development probe (timing only, garbage results): the values are summed and ONE value per segment is stored -- what do the lane-strided stores of the solver's derivative tasks cost?
+struct SeqStoreJ { double* q; double acc = 0.0; __device__ __forceinline__ void col() {} __device__ __forceinline__ void end() { *q = acc; } __device__ __forceinline__ void put(int, double v) { acc += v; } };
+struct SeqStoreH { double* q; double acc = 0.0; __device__ __forceinline__ void end() { *q = acc; } __device__ __forceinline__ void put(double v) { acc += v; } };
+#else
 struct SeqStoreJ { double* q; __device__ __forceinline__ void col() {} __device__ __forceinline__ void end() {} __device__ __forceinline__ void put(int, double v) { *q++ = v; } };
 struct SeqStoreH { double* q; __device__ __forceinline__ void end() {} __device__ __forceinline__ void put(double v) { *q++ = v; } };
+#endif
 struct LamStage { const double* l; __device__ __forceinline__ double operator()(int r) const { return l[r]; } };
 // the multipliers of a stage addressed by the row numbers of a MIDDLE stage (104 rows); `last`: the lane holds the last stage (80 rows: the six
 // no-slip rows of every foot are absent -> 0, the rows behind them move up).  r is a compile-time constant at every call site.
