@@ -68,10 +68,12 @@ def test_stream_host_entry_point_chunks_a_large_batch_bit_for_bit():
     L = capi.LandingLib(N, device=0)
     Pb, X0, _, _ = P.make_batch(B, N, 0.6, seed=77)
     o = L.default_opts(); o.max_iter = 300
-    ref = L.solve_host(Pb, X0, o)
+    halves = [L.solve_host(Pb[i:i + 1250], X0[i:i + 1250], o) for i in (0, 1250)]      # (<= 2048 members: one launch each, no streaming)
+    ref = {k: np.concatenate([h[k] for h in halves]) for k in halves[0]}
     r = L.solve_stream_host(Pb, X0, o, chunk=1024, lanes=2)
+    auto = L.solve_host(Pb, X0, o)                                                       # above 2048 members landing_solve_batch_host streams by itself
     for k in ("x", "f", "lam_g", "status", "iters", "kkt"):
-        assert np.array_equal(r[k], ref[k]), k
+        assert np.array_equal(r[k], ref[k]) and np.array_equal(auto[k], ref[k]), k
     assert (r["status"] == 0).all()
     S = L.stream(2)
     dP, dX0 = torch.tensor(Pb[:600], device="cuda"), torch.tensor(X0[:600], device="cuda")
