@@ -484,7 +484,8 @@ void landing_multi_release_cached(void);
  *                           a submission alive and untouched until it has waited for the ticket; outputs of submissions in flight must not overlap
  *   landing_stream_wait     stream != NULL: that stream waits for the submission (no host synchronisation); NULL: the host waits
  *   landing_stream_sync     ... for everything submitted so far
- * Results are bit-identical to landing_solve_batch one call at a time (members are independent; a lane runs the very same launch).
+ * Results are bit-identical to landing_solve_batch one call at a time (members are independent; a lane runs the very same launch).  A stream object is
+ * driven by ONE host thread (several objects on one context, or one per context, may be driven by several); B = 0 is a valid (empty) submission.
  *   landing_solve_stream_host   host arrays of ANY number of members cut into chunks (0 = 1024) that go through such a stream, uploads of chunk i + 1
  *                           and downloads of chunk i - 1 under the solve of chunk i: what matlab/landing_solve_mex.c calls for batches above 2048 */
 typedef struct landing_stream landing_stream;
