@@ -225,7 +225,7 @@ typedef struct {
                             of the round (lab): mean 53.5 -> 48.5 iterations but 1 member in 1000 wandered off at mu = 1e-4; with the
                             watchdog, the slack correction and the later-barrier-problem restart in place it is safe: CPU port on two
                             batches mean 53.2 -> 50.3, median 52 -> 49, slowest 107 -> 95 (numbers at scale in DESIGN.md).  0 = unscaled */
-  int factor_fp32;       /* RETIRED in round 5 -- must be 0; landing_solve_batch rejects any other value (LANDING_E_ARG).  Rounds 2-4 had a
+  int factor_fp32;       /* RETIRED in round 5 -- ignored: a non-zero value runs the fp64 factor like 0 (one warning on stderr per process).  Rounds 2-4 had a
                             variant of the stage elimination in single precision on v_mfma_f32_16x16x4_f32 (BASELINE configs[4]'s "fp32
                             MFMA KKT factor"; everything outside the factor fp64).  It reached the same fp64 KKT tolerance but never
                             paid: a stage elimination was 11 % SLOWER than the fp64 one (0.325 vs 0.292 ms of backward sweep per

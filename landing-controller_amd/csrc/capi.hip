@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <array>
 #include <map>
+#include <atomic>
 #include <memory>
 #include <mutex>
 #include <set>

@@ -147,17 +147,19 @@ def test_emulated_kernel_follows_cpu_port_with_running_cost(emu_lib, oracle_mod)
     assert abs(g["f"][0] - O.f(g["x"][0], P[0])) < 1e-10 * max(1.0, abs(g["f"][0]))
 
 
-def test_fp32_factor_option_is_retired_loudly(emu_lib):
+def test_fp32_factor_option_is_retired_and_ignored(emu_lib, capfd):
     """landing_solver_opts::factor_fp32 (the single-precision stage elimination of rounds 2-4) was retired in round 5 -- slower than the
-    fp64 factor on every measurement (include/landing_nlp.h): the field stays in the struct, any non-zero value is rejected"""
+    fp64 factor on every measurement (include/landing_nlp.h): the field stays in the struct, callers that still set it get the fp64
+    factor (the very same iterates) and one warning on stderr"""
     N = 20
     P, X0, _, _ = lc("problem").make_batch(1, N, 0.6, seed=1)
     L = lc("capi").LandingLib(N, lib_path=emu_lib)
     o = L.default_opts(); o.max_iter = 2; o.feas_phase = 0; o.factor_fp32 = 1
-    with pytest.raises(RuntimeError, match="retired"):
-        L.solve_host(P, X0, o)
+    a = L.solve_host(P, X0, o)
+    assert "factor_fp32 is retired" in capfd.readouterr().err
     o.factor_fp32 = 0
-    assert L.solve_host(P, X0, o)["iters"][0] == 2
+    b = L.solve_host(P, X0, o)
+    assert a["iters"][0] == b["iters"][0] == 2 and np.array_equal(a["x"], b["x"])
 
 
 def test_clip_rule_changes_the_path_and_shortens_it(oracle_mod):
