@@ -130,7 +130,8 @@ typedef struct {
                             iterations mean 34.1, p99 43; 1.8 / 80 -> 63.2; 1.5 / 120 -> 63.4; 1.8 / 120 -> 60.7 (60.4), mean 32.3, p99 40, slowest
                             batch 74 instead of 89 ms; 1.8 / 160 -> 60.6; 2.0 / 120 -> 64.6 and 1.9 / 140 -> 63.3 (p99.9 59..61: the tail grows);
                             kappa_mu 0.1 -> slower.  All 131 072 members converge in every variant.                                            */
-  int max_soc;           /* reserved: second-order corrections proper are not implemented (slack_corr below repairs the same rejections without a solve) */
+  int max_soc;           /* reserved, ignored: second-order corrections proper were measured in the CPU port in round 6 (2-3 % of the iterations meet the case, iteration counts
+                            unchanged: DESIGN.md 4.3b, profiles/r06_ab_experiments.txt A14) and not built into the kernel; slack_corr below repairs the same rejections without a solve */
   int max_resets;        /* multiplier resets allowed per NLP (default 8), see reset_du.  (2 was tried in round 2: it stops the rare
                             locally infeasible member ~130 iterations earlier, but the N=41-script formulation -- kin-box
                             .05/.05/.27 with the running cost -- then loses 4 of its 17 stored reference cases.)            */

@@ -47,6 +47,7 @@ typedef struct {
   int jam_clip, stag_relief;      /* include/landing_nlp.h */
   int feas_jam, feas_stat;        /* include/landing_nlp.h (round 5) */
   double feas_back; int feas_max; double feas_delta_dec, feas_ret_push, feas_ret_mu; int feas_resume; double feas_polish;      /* include/landing_nlp.h (round 6) */
+  int max_soc;           /* LAB ONLY (the kernel has no counterpart; default 0 = the kernel's algorithm): second-order corrections in IPOPT's form (Waechter & Biegler 2006, A-5.5..5.9) */
 } lo_solver_opts;
 
 void lo_solver_opts_default(lo_solver_opts* o) {
@@ -57,8 +58,10 @@ void lo_solver_opts_default(lo_solver_opts* o) {
   o->feas_phase = 1; o->feas_rho = 1000.0; o->feas_cert = 1e-4;
   o->delta_floor = 3e-4; o->jam_clip = 2; o->stag_relief = 3; o->feas_jam = 8; o->feas_stat = 25;
   o->feas_back = 0.2; o->feas_max = 3; o->feas_delta_dec = 0.1; o->feas_ret_push = 0.01; o->feas_ret_mu = 0.01; o->feas_resume = 1; o->feas_polish = 1e-8;
+  o->max_soc = 0;
 }
 
+long long lo_soc_taken = 0, lo_soc_tried = 0;      /* LAB ONLY: corrected steps taken / correction solves, over the life of the process */
 #define NW 48
 static const int ROW2STATE[12] = {0, 1, 2, 3, 4, 5, 9, 10, 11, 6, 7, 8};
 /* local variable (lo_stage_eval order X_k,c_k,f_k,X+,c+) -> w index (X,c,f,c+) or -1 */
@@ -160,6 +163,57 @@ static int riccati_backward(const lo_form* F, const double* p, work_t* W, double
     }
     if (!spd_solve(Pcc, 12, 12, rhs, 1, 1)) return 0;
     for (i = 0; i < 12; ++i) sig0[12 + i] = -rhs[i];
+  }
+  return 1;
+}
+
+/* LAB ONLY (max_soc): the Newton step of the current iteration's KKT matrix (same Sigma, same delta: the sweep re-factorises the identical matrix, cost is of no
+ * interest here) for ANOTHER primal residual c (rows 12..ng: g - s of an inequality row, g - lb of an equality row): dx, ds and the multipliers of the equality
+ * rows.  Interior-point mode only.  Overwrites W->rho, W->mvec, W->bv, W->kap, W->pvx (none is read again in the iteration). */
+static int soc_solve(const lo_form* F, const double* p, work_t* W, const lo_poff* o, double mu, double delta, const double* c, double* dx, double* ds, double* yn) {
+  const int N = W->N; const lo_int ng = W->ng; lo_int r; int k, i; double sig[24], w[NW];
+  for (r = 0; r < ng; ++r) {
+    const double lb = W->lb[r], ub = W->ub[r]; double rh = 0;
+    if (r >= 12 && lb != ub) {
+      const double s = W->s[r];
+      if (lb > -INFINITY) rh -= mu / (s - lb);
+      if (ub < INFINITY) rh += mu / (ub - s);
+      rh += W->sig[r] * c[r];
+    }
+    W->rho[r] = rh;
+  }
+  for (k = 0; k < N; ++k) {
+    const int nr = lo_stage_rows(F, k), g0 = 36 + 104 * k; int q, a;
+    const double* J = W->Jst + (size_t)k * 104 * 60; double* mk = W->mvec + k * NW;
+    memset(mk, 0, sizeof(double) * NW);
+    for (q = 12; q < nr; ++q) { const double rh = W->rho[g0 + q]; for (a = 0; a < 60; ++a) if (J[q * 60 + a] != 0.0 && loc2w(a) >= 0) mk[loc2w(a)] += rh * J[q * 60 + a]; }
+    for (q = 0; q < 12; ++q) W->bv[k * 12 + ROW2STATE[q]] = -c[g0 + q];
+    if (F->run_cost) { double gr[36]; for (a = 0; a < 36; ++a) gr[a] = 0.0; (void)lo_run_cost_stage(F, W->x, p, k, gr, gr + 12, gr + 24); for (a = 0; a < 36; ++a) mk[a] += gr[a]; }
+  }
+  if (!riccati_backward(F, p, W, delta, o, sig)) return 0;
+  for (k = 0; k < N; ++k) {
+    const int last = (k == N - 1), nu = last ? 12 : 24, nr = lo_stage_rows(F, k), g0 = 36 + 104 * k; int q, a, t;
+    const double* J = W->Jst + (size_t)k * 104 * 60; double signext[24];
+    for (a = 0; a < 24; ++a) w[a] = sig[a];
+    for (a = 0; a < nu; ++a) { double v = W->kap[k * 24 + a]; for (t = 0; t < 24; ++t) v += W->K[(size_t)k * 576 + a * 24 + t] * sig[t]; w[24 + a] = -v; }
+    for (a = nu; a < 24; ++a) w[24 + a] = 0.0;
+    for (a = 0; a < 12; ++a) { dx[12 * k + a] = w[a]; dx[12 * (N + 1) + 24 * k + a] = w[12 + a]; dx[12 * (N + 1) + 24 * k + 12 + a] = w[24 + a]; }
+    for (q = 12; q < nr; ++q) {
+      double v = 0; for (a = 0; a < 60; ++a) { const int wa = loc2w(a); if (wa >= 0 && J[q * 60 + a] != 0.0) v += J[q * 60 + a] * w[wa]; }
+      ds[g0 + q] = v + c[g0 + q];
+    }
+    for (a = 0; a < 12; ++a) { double v = W->bv[k * 12 + a]; for (t = 0; t < 36; ++t) v += W->Ah[(size_t)k * 432 + a * 36 + t] * w[t]; signext[a] = v; }
+    for (a = 0; a < 12; ++a) signext[12 + a] = last ? 0.0 : w[36 + a];
+    for (a = 0; a < 12; ++a) {
+      double v = W->pvx[(k + 1) * 12 + a]; const int nn = last ? 12 : 24;
+      for (t = 0; t < nn; ++t) v += W->Px[(size_t)(k + 1) * 288 + a * 24 + t] * signext[t];
+      yn[g0 + (a < 6 ? a : (a < 9 ? a + 3 : a - 3))] = -v;
+    }
+    memcpy(sig, signext, sizeof(sig));
+  }
+  for (i = 0; i < 12; ++i) {
+    const int ra = i < 6 ? 12 + i : 24 + (i - 6), rb = i < 6 ? 18 + i : 30 + (i - 6);
+    dx[12 * N + i] = sig[i]; ds[ra] = sig[i] + c[ra]; ds[rb] = sig[i] + c[rb];
   }
   return 1;
 }
@@ -599,6 +653,72 @@ static int solve_one(const lo_form* F, const double* p, const double* x0, const 
       }
       if (force_step && ok_f) { accepted = 1; nfilt = 0; break; }      /* watchdog: the step to the boundary is taken without the sufficient-decrease / switching tests (it passed theta_max and the filter entries: ok_f) */
       if (accepted) break;
+      if (!feas && op->max_soc > 0 && alpha == a_pr && tht >= th0) {   /* LAB ONLY: second-order corrections (IPOPT A-5.5..5.9) at the rejected first trial point */
+        double* cs = dalloc(ng); double* dx2 = dalloc(nx); double* ds2 = dalloc(ng); double* yn2 = dalloc(ng); double* xt2 = dalloc(nx); double* gt2 = dalloc(ng);
+        double th_soc = th0; int ps, took = 0;
+        for (r = 12; r < ng; ++r) {
+          const double lb = W->lb[r], ub = W->ub[r];
+          if (lb == ub) cs[r] = alpha * (W->g[r] - lb) + (W->gt[r] - lb);
+          else cs[r] = alpha * (W->g[r] - W->s[r]) + (W->gt[r] - slack_step(W->s[r], W->ds[r], alpha, lb, ub, clip_now, tau));
+        }
+        for (ps = 0; ps < op->max_soc && !took; ++ps) {
+          double a2 = 1.0, tht2 = 0, bt2 = 0, ft2 = 0, pht2; int okf2;
+#pragma omp atomic
+          lo_soc_tried++;
+          counters[0]++;
+          if (!soc_solve(F, p, W, &o, mu, delta, cs, dx2, ds2, yn2)) break;
+          for (r = 12; r < ng; ++r) {
+            const double lb = W->lb[r], ub = W->ub[r];
+            if (lb == ub) continue;
+            if (lb > -INFINITY && ds2[r] < 0.0) a2 = fmin(a2, -tau * (W->s[r] - lb) / ds2[r]);
+            if (ub < INFINITY && ds2[r] > 0.0) a2 = fmin(a2, tau * (ub - W->s[r]) / ds2[r]);
+          }
+          counters[1]++;
+          for (i = 0; i < nx; ++i) xt2[i] = W->x[i] + a2 * dx2[i];
+          eval_g(F, xt2, p, gt2);
+          for (r = 12; r < ng; ++r) {
+            const double lb = W->lb[r], ub = W->ub[r], g = gt2[r]; double s2;
+            if (lb == ub) { tht2 += fabs(g - lb); continue; }
+            s2 = W->s[r] + a2 * ds2[r]; tht2 += fabs(g - s2);
+            if (lb > -INFINITY) bt2 -= log(s2 - lb);
+            if (ub < INFINITY) bt2 -= log(ub - s2);
+          }
+          for (i = 0; i < 12; ++i) { const double d = xt2[12 * N + i] - p[12 * N + i]; ft2 += p[o.QN + i] * d * d; }
+          if (F->run_cost) for (k = 0; k < N; ++k) ft2 += lo_run_cost_stage(F, xt2, p, k, NULL, NULL, NULL);
+          pht2 = ft2 + mu * bt2;
+          okf2 = (tht2 <= th_max) && (pht2 < 1e300) && (pht2 > -1e300) && (tht2 < 1e300);
+          for (e = 0; e < nfilt && okf2; ++e) if (tht2 >= fmax(filt_th[e], th_floor) && pht2 >= filt_ph[e]) okf2 = 0;
+          if (okf2) {
+            if (switching) { if (pht2 <= ph0 + 1e-8 * alpha * dphi) { took = 1; armijo = 1; } }
+            else if (tht2 <= fmax((1.0 - 1e-5) * th0, th_floor) || pht2 <= ph0 - 1e-8 * th0) took = 1;
+          }
+          if (took) {      /* the corrected step replaces the search direction: primal step, slack steps, multipliers of the equality rows; bound multipliers from the slack steps */
+            memcpy(W->dx, dx2, sizeof(double) * nx); memcpy(W->xt, xt2, sizeof(double) * nx); memcpy(W->gt, gt2, sizeof(double) * ng);
+            a_du = 1.0;
+            for (r = 12; r < ng; ++r) {
+              const double lb = W->lb[r], ub = W->ub[r]; double yv;
+              W->ds[r] = ds2[r];
+              if (lb == ub) { W->yn[r] = yn2[r]; continue; }
+              yv = W->sig[r] * ds2[r];
+              if (lb > -INFINITY) { const double d = W->s[r] - lb, zl = W->zL[r], dz = mu / d - zl - zl / d * ds2[r]; W->dzL[r] = dz; yv -= mu / d; if (dz < 0.0) a_du = fmin(a_du, -tau * zl / dz); }
+              if (ub < INFINITY) { const double d = ub - W->s[r], zu = W->zU[r], dz = mu / d - zu + zu / d * ds2[r]; W->dzU[r] = dz; yv += mu / d; if (dz < 0.0) a_du = fmin(a_du, -tau * zu / dz); }
+              W->yn[r] = yv;
+            }
+            alpha = a2; clip_now = 0;
+#pragma omp atomic
+            lo_soc_taken++;
+            break;
+          }
+          if (tht2 > 0.99 * th_soc) break;      /* kappa_soc: the correction did not reduce the violation */
+          th_soc = tht2;
+          for (r = 12; r < ng; ++r) {
+            const double lb = W->lb[r], ub = W->ub[r];
+            cs[r] = a2 * cs[r] + ((lb == ub) ? gt2[r] - lb : gt2[r] - (W->s[r] + a2 * ds2[r]));
+          }
+        }
+        free(cs); free(dx2); free(ds2); free(yn2); free(xt2); free(gt2);
+        if (took) { accepted = 1; break; }
+      }
       if (!feas && op->slack_corr > 0.0 && alpha == a_pr && tht >= th0) {   /* slack correction at the rejected first trial point (include/landing_nlp.h): no new solve */
         const double kk = op->slack_corr; double tht2 = 0, bt2 = 0, pht2; int okf2;
         for (r = 12; r < ng; ++r) {

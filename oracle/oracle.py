@@ -151,7 +151,7 @@ class _SolverOpts(C.Structure):
                 ("delta_inc", C.c_double), ("delta_dec", C.c_double), ("tau_min", C.c_double), ("alpha_fallback", C.c_double),
                 ("restart_period", C.c_int), ("reset_delta", C.c_double), ("barrier_smax", C.c_double), ("watchdog", C.c_int), ("slack_corr", C.c_double), ("dual_step_cap", C.c_double), ("fresh_restart", C.c_int), ("theta_floor", C.c_double), ("clip_k", C.c_int), ("clip_until", C.c_double),
                 ("feas_phase", C.c_int), ("feas_rho", C.c_double), ("feas_cert", C.c_double), ("delta_floor", C.c_double), ("jam_clip", C.c_int), ("stag_relief", C.c_int), ("feas_jam", C.c_int), ("feas_stat", C.c_int),
-                ("feas_back", C.c_double), ("feas_max", C.c_int), ("feas_delta_dec", C.c_double), ("feas_ret_push", C.c_double), ("feas_ret_mu", C.c_double), ("feas_resume", C.c_int), ("feas_polish", C.c_double)]
+                ("feas_back", C.c_double), ("feas_max", C.c_int), ("feas_delta_dec", C.c_double), ("feas_ret_push", C.c_double), ("feas_ret_mu", C.c_double), ("feas_resume", C.c_int), ("feas_polish", C.c_double), ("max_soc", C.c_int)]
 
 
 def cpu_solve_batch(O, P, X0, threads=0, max_iter=None, tol=None, **opts):
