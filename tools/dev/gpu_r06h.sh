@@ -8,6 +8,7 @@ python bench.py > $out/bench.json 2> $out/bench.err
 python tools/bench_solve.py > $out/bench_solve_sizes.jsonl 2>> $out/bench.err
 python tools/bench_kd_solve.py --inflight 2 > $out/kd_bench.json 2>> $out/bench.err
 python tools/bench_mpc.py > $out/mpc.json 2>> $out/bench.err
+python tools/dev/itdump.py r06 > $out/itdump.log 2>> $out/bench.err
 python - <<'PY'
 import json
 d=json.load(open("gpurun_out/r06h/bench.json"))

@@ -21,7 +21,11 @@ tot = ph[:, :8].sum(axis=0) / 1e5 / ph[:, 10].sum()     # ms per iteration (100 
 print('ms/iter under load by phase (eval err sigrho back fwd dual ls accept):', np.round(tot, 4), 'sum %.4f' % tot.sum())
 os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
 np.savez(os.path.join(ROOT, 'gpurun_out', 'itdump_%s.npz' % tag), iters=it, status=r['status'], prof=ph, kkt=r['kkt'])
-import json
+import json, heapq
+def _makespan(t, order, slots=512):      # list scheduling: the next member of `order` goes to the slot that frees first
+    h = [0.0] * slots; heapq.heapify(h)
+    for m in order: heapq.heappush(h, heapq.heappop(h) + t[m])
+    return float(max(h))
 hist, edges = np.histogram(it, bins=[0, 30, 40, 50, 60, 70, 80, 90, 100, 120, 140, 160, 200, 250, 301])
 busy_ms = ph[:, :8].sum(axis=1) / 1e5          # per member: time its workgroup spent in the timed phases (100 MHz ticks)
 json.dump({"what": "bench batch (seed 20211, B=%d, N=40, max_iter 300): iteration histogram and per-member busy time of the solver kernel" % B,
@@ -29,6 +33,9 @@ json.dump({"what": "bench batch (seed 20211, B=%d, N=40, max_iter 300): iteratio
            "iters_mean": float(it.mean()), "iters_p50": float(np.median(it)), "iters_p90": float(np.percentile(it, 90)), "iters_p99": float(np.percentile(it, 99)), "iters_max": int(it.max()),
            "member_busy_ms": {"mean": float(busy_ms.mean()), "p50": float(np.median(busy_ms)), "p99": float(np.percentile(busy_ms, 99)), "max": float(busy_ms.max()), "sum": float(busy_ms.sum())},
            "slots": 512, "balanced_bound_ms": float(busy_ms.sum() / 512), "host_path_batch_ms": 1e3 * dt,
+           "list_scheduling_of_the_busy_times_ms": {"note": "1024 members on 512 slots = two members per slot: what ANY dispatch order can reach is the best pairing of a long with a short member, not the balanced bound",
+                                                    "library_order_initial_height": _makespan(busy_ms, np.argsort(-P[:, problem.param_offsets(N)["q_init"] + 2], kind="stable")),
+                                                    "index_order": _makespan(busy_ms, np.arange(B)), "longest_first_with_hindsight": _makespan(busy_ms, np.argsort(-busy_ms, kind="stable"))},
            "phase_ms_per_iter_under_load": dict(zip(["eval", "err", "cond", "back", "fwd", "dual", "ls", "accept"], [float(v) for v in tot])),
            "sweeps_per_iter": float(ph[:, 8].sum() / ph[:, 10].sum()), "stage_elims_per_iter": float(ph[:, 13].sum() / ph[:, 10].sum()), "trials_per_iter": float(ph[:, 9].sum() / ph[:, 10].sum())},
           open(os.path.join(ROOT, 'gpurun_out', 'iter_hist_%s.json' % tag), 'w'), indent=1)
