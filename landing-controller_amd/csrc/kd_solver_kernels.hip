@@ -289,6 +289,10 @@ KD_PHASE void kd_condense_stage(const KdMem& M, int N, int k, double delta) {
   };
   fetch(12);
 #endif
+#ifdef KD_DEV_COND_REPS      // timing probe (tools/dev): the chunk loop KD_DEV_COND_REPS times, the last pass counts -- same results, the difference of two builds is the loop's cost
+  for (int rep_ = 0; rep_ < KD_DEV_COND_REPS; ++rep_) {
+  if (rep_ > 0) { for (int t = 0; t < 4; ++t) acc[t] = f64x4{0.0, 0.0, 0.0, 0.0}; macc = 0.0; __syncthreads(); fetch(12); }
+#endif
   for (int r0 = 12; r0 < nr; r0 += KD_JC_ROWS) {
 #pragma unroll
     for (int q = 0; q < NE; ++q) { const int e = tid + q * KD_THREADS, rr = e >> 6, c = e & 63; if (rr < KD_JC_ROWS) S.Jc[rr * KD_JC_S + c] = pre[q]; }
@@ -304,6 +308,12 @@ KD_PHASE void kd_condense_stage(const KdMem& M, int N, int k, double delta) {
     if (tid < nv) { for (int kk = 0; kk < KD_JC_ROWS; ++kk) macc += S.Jc[kk * KD_JC_S + tid] * S.rhc[kk]; }
     __syncthreads();
   }
+#ifdef KD_DEV_COND_REPS
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("" : "+v"(macc));
+#endif
+  }
+#endif
   for (int t = 0; t < 4; ++t)
     for (int r = 0; r < 4; ++r) {
       const int a = 16 * wave + lk + 4 * r, b = 16 * t + lj;
