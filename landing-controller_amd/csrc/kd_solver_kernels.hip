@@ -38,6 +38,7 @@ constexpr int KD_JC_ROWS = KD_JC_ROWS_DEF, KD_JC_S = 65;     // rows per chunk o
 // per-interval record of the backward sweep (doubles): gains K (36 x 24) | kappa (36) | [A^ | b] (12 x 37) | state rows of the cost-to-go
 // P_k (12 x 24) | p_k (12)
 constexpr int KD_REC_K = 0, KD_REC_KAP = 864, KD_REC_AH = 900, KD_REC_PX = 1344, KD_REC_PV = 1632, KD_REC = 1648;
+constexpr int KD_GC = KD_NV * KD_NV + KD_NV;      // per interval: the inequality rows' part of the stage array, J_I' Sigma J_I (row major, 60 x 60) | J_I' rho (60)
 constexpr int KD_FILT = 48;
 constexpr int KD_THREADS = 256;
 // row r (0..11) of the Euler defects (v, omega, pos, rpy -- the script's order :125-128) <-> entry of X_k+1 it is linear in
@@ -57,6 +58,8 @@ struct KdState {
   int accepted, armijo_step, fact_ok, skipped_zero, attempt, flag, ls_done, need_corr, fallback, nfact, ntrial, nreset;
   int last_reset_it, ncrawl, clip_k_cur, fresh, reg_it;
   int pending;      // the inertia correction of this iteration continues in the next launch (landing_kd_iter_kernel, KD_TRIES_PER_ROUND)
+  int stage;        // 1: landing_kd_head_kernel has prepared this iteration (error test passed, barrier parameter, delta_w of the first attempt): landing_kd_condense_kernel and
+                    // landing_kd_iter_kernel act on it; 0: nothing to do for them this round (finished, restarted, or resumed through `pending`)
   int stag, full_prev; double e_prev;      // stag_relief (landing_nlp.h): full steps of the last barrier problem that did not halve the error
   // feasibility (restoration) phase, round 5 -- the scheme of landing_ipm_kernel (solver_kernels.hip, landing_nlp.h feas_phase / feas_jam / feas_stat):
   // feas = 1 while the elastic problem is being solved, lim = iteration limit in force, fjam / fstat / v1_ref = the two rules' counters
@@ -73,11 +76,12 @@ struct KdMem {
   double *J, *H, *rec, *wbuf;      // wbuf [N][72]: gathered stage variables of the in-kernel row evaluation
   double* jty;                     // [N][72]: J_k' y_k per interval and block column, written by the Jacobian kernel (rbd_kernels.hip, KdNlpArgs::jty)
   double *en, *ep, *wn, *wp;       // feasibility phase: violation variables of the lower / upper side of every inequality row and their multipliers
+  double* gc;                      // [N][KD_GC]: J_I' Sigma J_I (60 x 60) and J_I' rho (60) of every interval, written by landing_kd_condense_kernel (round 6)
   KdState* st;
 };
 __host__ __device__ inline size_t kd_ws_stride(int N) {
   const size_t nx = (size_t)kd_nx(N), ng = (size_t)kd_ng(N);
-  return 4 * nx + 10 * ng + (size_t)N * KD_ROWS * KD_NW + (size_t)N * KD_NW * KD_NW + (size_t)(N + 1) * KD_REC + 2 * (size_t)N * KD_NW + 4 * ng + (sizeof(KdState) + 7) / 8 + 8;
+  return 4 * nx + 10 * ng + (size_t)N * KD_ROWS * KD_NW + (size_t)N * KD_NW * KD_NW + (size_t)(N + 1) * KD_REC + 2 * (size_t)N * KD_NW + 4 * ng + (size_t)N * KD_GC + (sizeof(KdState) + 7) / 8 + 8;
 }
 __device__ __forceinline__ KdMem kd_carve(int N, double* w) {
   const size_t nx = (size_t)kd_nx(N), ng = (size_t)kd_ng(N);
@@ -89,6 +93,7 @@ __device__ __forceinline__ KdMem kd_carve(int N, double* w) {
   M.wbuf = w; w += (size_t)N * KD_NW;
   M.jty = w; w += (size_t)N * KD_NW;
   M.en = w; w += ng; M.ep = w; w += ng; M.wn = w; w += ng; M.wp = w; w += ng;
+  M.gc = w; w += (size_t)N * KD_GC;
   M.st = reinterpret_cast<KdState*>(w);
   return M;
 }
@@ -101,6 +106,7 @@ struct KdSolveArgs {
   double* ws; size_t ws_stride;
   double* x_out; double* f_out; double* lam_out; int* status; int* iters; double* kkt;
   int* n_active;           // number of members still iterating (written by the iteration kernel)
+  int* n_cond; int* cond_list;      // members whose head kernel has prepared an iteration this round (count, list [B]: the work list of landing_kd_condense_kernel)
   int* done;               // [B] 1 = the member has finished (read by the function-layer kernels: finished members are skipped)
   // Portfolio (round 5, landing_nlp.h kd_clone_after): members B0 .. B-1 are CLONE slots -- workspace blocks without a problem of their own.  After
   // kd_clone_after rounds the members still iterating are posed again in KD_NVAR clone slots each, from the callers' guess under another option set
@@ -138,7 +144,6 @@ struct KdLds {
     double Jc[KD_JC_ROWS * KD_JC_S];     // chunk of the interval's inequality rows (v columns, zero padded to 64)
     double dsg[KD_NSIG * 65];            // d sigma_k of every knot (N <= 64)
   };
-  double sgc[KD_JC_ROWS], rhc[KD_JC_ROWS];
   double dxw[KD_NW];
   double red[(KD_THREADS / 64) * 6];
   int hist[64];                        // clip_k > 4: histogram of the blocking slacks over half-octaves of |ds| / distance
@@ -188,93 +193,44 @@ KD_PHASE void kd_member_eval_g(const KdNlpParams& P, const RbdModel& M, int N, c
 #define KD_END() } __syncthreads()
 #define KD_PROF(slot) do { if (threadIdx.x == 0) { const long long n_ = (long long)wall_clock64(); KSH.ks.prof[slot] += (double)(n_ - KSH.ks.tp); KSH.ks.tp = n_; } } while (0)
 
-#ifndef KD_EARLY_FETCH
-#define KD_EARLY_FETCH 1      // (same-box A/B: 0.4478 -> 0.4446 s per batch)
+// ---- condensation of interval k -------------------------------------------------------------------------------------------------
+// Round 6: split in two.  (a) kd_condense_rows -- the inequality rows' part J_I' Sigma J_I and J_I' rho of EVERY interval of every member that iterates this round,
+// one workgroup per (member, interval) in landing_kd_condense_kernel between the head and the iteration kernel: it does not depend on the Riccati recursion, and
+// inside the backward sweep its three chunks per stage (loads of 62 KB of J behind one chunk of matrix-core work) were 15 % of a batch of law main and 18 % of a round
+// of the lock-step tail, where one member's chain is all there is (tools/dev/gpu_r06p.sh: builds that run the loop 1 / 2 / 3 times).  (b) kd_assemble_stage -- inside the
+// sweep: M = (H + delta_w I) + [that part], m, [A^ | b], every load of a thread in flight together.  Same sums in the same order as the fused form of rounds 4-5:
+// bit-identical iterates.
+#ifndef KD_COND_UNROLL
+#define KD_COND_UNROLL 44
 #endif
-// ---- condensation of interval k into KSH.Ms (nv x nv + rhs), KSH.Ah ------------------------------------------------------------
-KD_PHASE void kd_condense_stage(const KdMem& M, int N, int k, double delta) {
-  KdLds& S = KSH;
-  const int tid = threadIdx.x, NT = blockDim.x;
+#ifndef KD_COND_WGS
+#define KD_COND_WGS 3      // (168 registers: at 4 the chunk loop spills -- 35 against 19 ms of kernel time per batch, tools/dev/gpu_r06t.sh)
+#endif
+#ifndef KD_COND_GRID
+#define KD_COND_GRID 2048
+#endif
+struct KdCondLds {
+  double Jc[KD_JC_ROWS * KD_JC_S];     // chunk of the interval's inequality rows (v columns, zero padded to 64)
+  double sgc[KD_JC_ROWS], rhc[KD_JC_ROWS];
+};
+__shared__ KdCondLds KCS;
+
+// (a) J_I' Sigma J_I and m = J_I' rho over the inequality rows 12 .. nr-1 of interval k, in chunks of KD_JC_ROWS rows staged in LDS; the product runs on the fp64
+// matrix cores: wave w owns row tile w of M (16 rows), four column tiles; the loads of the next chunk are in flight while the matrix cores work on this one
+__device__ __forceinline__ void kd_condense_rows(const KdMem& M, int N, int k) {
+  KdCondLds& S = KCS;
+  const int tid = threadIdx.x;
   const bool last = k == N - 1;
   const int nv = last ? 48 : KD_NV, nr = last ? KD_ROWS_LAST : KD_ROWS;
   // (global address space: global_load, not flat_load -- a flat load also counts on the LDS counter, so every wait for an LDS read would wait for the
   // prefetched rows as well: solver_kernels.hip landing_gptr)
   const landing_gptr Jk = (landing_gptr)(M.J + (size_t)k * KD_ROWS * KD_NW);
-  const landing_gptr Hk = (landing_gptr)(M.H + (size_t)k * KD_NW * KD_NW);
-  const landing_gptr Gsig = (landing_gptr)M.sig, Grho = (landing_gptr)M.rho, Gg = (landing_gptr)M.g;
+  const landing_gptr Gsig = (landing_gptr)M.sig, Grho = (landing_gptr)M.rho;
   const int g0 = KD_BND + k * KD_ROWS;
-#if KD_EARLY_FETCH
-  // + J_I' Sigma J_I and m = J_I' rho over the inequality rows 12 .. nr-1, in chunks of KD_JC_ROWS rows staged in LDS; the product runs on
-  // the fp64 matrix cores: wave w owns row tile w of M (16 rows), four column tiles
   const int wave = tid >> 6, l = tid & 63, lj = l & 15, lk = l >> 4;
   f64x4 acc[4];
   for (int t = 0; t < 4; ++t) acc[t] = f64x4{0.0, 0.0, 0.0, 0.0};
   double macc = 0.0;
-  // (round 5: the loads of the next chunk are in flight while the matrix cores work on this one -- they used to be exposed, 5 x ~2 us per stage)
-  constexpr int NE = (KD_JC_ROWS * 64 + KD_THREADS - 1) / KD_THREADS;
-  double pre[NE], pre_sg = 0.0, pre_rh = 0.0;
-  auto fetch = [&](int r0) {
-#pragma unroll
-    for (int q = 0; q < NE; ++q) {
-      const int e = tid + q * KD_THREADS, rr = e >> 6, c = e & 63, r = r0 + rr;
-      const bool in = rr < KD_JC_ROWS && r < nr && c < nv;
-      const double v = Jk[(in ? r : 12) * KD_NW + kd_v2w(in ? c : 0)];      // unconditional load (clamped): all NE loads are issued together
-      pre[q] = in ? v : 0.0;
-    }
-    { const int r = r0 + tid; const bool in = tid < KD_JC_ROWS && r < nr; const double a = Gsig[g0 + (in ? r : 12)], b = Grho[g0 + (in ? r : 12)]; pre_sg = in ? a : 0.0; pre_rh = in ? b : 0.0; }
-  };
-  fetch(12);      // (round 5, late: the first chunk's loads are in flight behind the Hessian block's)
-  // Hessian block of lam' g over v, delta_w on the diagonal, right-hand side cleared; [A^ | b] from the defect rows: X_k+1 = A^ (sigma_k, f_k) + b in
-  // step form (rows in the order of X).  All loads of a thread are issued together, unconditionally (clamped addresses), and only then stored: with the load under
-  // the bounds test each of the 15 rounds waited for its own load -- 13.8 of the 26 us a stage's condensation took under load (development timers)
-  {
-    constexpr int NH = (KD_NV * KD_MS + KD_THREADS - 1) / KD_THREADS, NA = (12 * KD_AS + KD_THREADS - 1) / KD_THREADS;
-    double hv[NH], av[NA];
-#pragma unroll
-    for (int q = 0; q < NH; ++q) {
-      const int e = tid + q * KD_THREADS, a = e / KD_MS, b = e % KD_MS;
-      const bool in = a < nv && b < nv;
-      hv[q] = Hk[kd_v2w(in ? a : 0) * KD_NW + kd_v2w(in ? b : 0)];
-    }
-#pragma unroll
-    for (int q = 0; q < NA; ++q) {
-      const int e = tid + q * KD_THREADS, ee = e < 12 * KD_AS ? e : 0, r = ee / KD_AS, c = ee % KD_AS;
-      const double vj = Jk[r * KD_NW + (c < 36 ? c : 0)], vg = Gg[g0 + r];
-      av[q] = c < 36 ? -vj : -vg;
-    }
-#pragma unroll
-    for (int q = 0; q < NH; ++q) {
-      const int e = tid + q * KD_THREADS, a = e / KD_MS, b = e % KD_MS;
-      if (e < KD_NV * KD_MS) S.Ms[e] = (a < nv && b < nv) ? hv[q] + (a == b ? delta : 0.0) : 0.0;
-    }
-#pragma unroll
-    for (int q = 0; q < NA; ++q) {
-      const int e = tid + q * KD_THREADS, ee = e < 12 * KD_AS ? e : 0, r = ee / KD_AS, c = ee % KD_AS;
-      if (e < 12 * KD_AS) S.Ah[KD_ROW2X[r] * KD_AS + c] = av[q];
-    }
-  }
-  __syncthreads();
-#else
-  // Hessian block of lam' g over v, delta_w on the diagonal, right-hand side cleared
-  for (int e = tid; e < KD_NV * KD_MS; e += NT) {
-    const int a = e / KD_MS, b = e % KD_MS;
-    double v = 0.0;
-    if (a < nv && b < nv) v = Hk[kd_v2w(a) * KD_NW + kd_v2w(b)] + (a == b ? delta : 0.0);
-    S.Ms[e] = v;
-  }
-  // [A^ | b] from the defect rows: X_k+1 = A^ (sigma_k, f_k) + b in step form  (rows in the order of X)
-  for (int e = tid; e < 12 * KD_AS; e += NT) {
-    const int r = e / KD_AS, c = e % KD_AS;
-    S.Ah[KD_ROW2X[r] * KD_AS + c] = c < 36 ? -Jk[r * KD_NW + c] : -Gg[g0 + r];
-  }
-  __syncthreads();
-  // + J_I' Sigma J_I and m = J_I' rho over the inequality rows 12 .. nr-1, in chunks of KD_JC_ROWS rows staged in LDS; the product runs on
-  // the fp64 matrix cores: wave w owns row tile w of M (16 rows), four column tiles
-  const int wave = tid >> 6, l = tid & 63, lj = l & 15, lk = l >> 4;
-  f64x4 acc[4];
-  for (int t = 0; t < 4; ++t) acc[t] = f64x4{0.0, 0.0, 0.0, 0.0};
-  double macc = 0.0;
-  // (round 5: the loads of the next chunk are in flight while the matrix cores work on this one -- they used to be exposed, 5 x ~2 us per stage)
   constexpr int NE = (KD_JC_ROWS * 64 + KD_THREADS - 1) / KD_THREADS;
   double pre[NE], pre_sg = 0.0, pre_rh = 0.0;
   auto fetch = [&](int r0) {
@@ -288,7 +244,6 @@ KD_PHASE void kd_condense_stage(const KdMem& M, int N, int k, double delta) {
     { const int r = r0 + tid; const bool in = tid < KD_JC_ROWS && r < nr; const double a = Gsig[g0 + (in ? r : 12)], b = Grho[g0 + (in ? r : 12)]; pre_sg = in ? a : 0.0; pre_rh = in ? b : 0.0; }
   };
   fetch(12);
-#endif
 #ifdef KD_DEV_COND_REPS      // timing probe (tools/dev): the chunk loop KD_DEV_COND_REPS times, the last pass counts -- same results, the difference of two builds is the loop's cost
   for (int rep_ = 0; rep_ < KD_DEV_COND_REPS; ++rep_) {
   if (rep_ > 0) { for (int t = 0; t < 4; ++t) acc[t] = f64x4{0.0, 0.0, 0.0, 0.0}; macc = 0.0; __syncthreads(); fetch(12); }
@@ -303,9 +258,12 @@ KD_PHASE void kd_condense_stage(const KdMem& M, int N, int k, double delta) {
       acc[t] = mfma_tile<KD_JC_ROWS / 4>(acc[t], [&](int i, int kk) { return S.Jc[kk * KD_JC_S + 16 * wave + i] * S.sgc[kk]; },
                                          [&](int kk, int j) { return S.Jc[kk * KD_JC_S + 16 * t + j]; });
 #if defined(__HIP_DEVICE_COMPILE__)
-    for (int t = 0; t < 4; ++t) asm volatile("" : "+v"(acc[t]));      // accumulators in VGPRs: AGPRs of this phase would add to the VGPR maximum of the
-#endif                                                                  // row-evaluation phase (253) and cost the kernel its second workgroup per CU
-    if (tid < nv) { for (int kk = 0; kk < KD_JC_ROWS; ++kk) macc += S.Jc[kk * KD_JC_S + tid] * S.rhc[kk]; }
+    for (int t = 0; t < 4; ++t) asm volatile("" : "+v"(acc[t]));
+#endif
+    if (tid < nv) {
+#pragma unroll KD_COND_UNROLL
+      for (int kk = 0; kk < KD_JC_ROWS; ++kk) macc += S.Jc[kk * KD_JC_S + tid] * S.rhc[kk];      // (one wave; unrolled: the 88 LDS reads are issued ahead of the chain of sums, whose order stays)
+    }
     __syncthreads();
   }
 #ifdef KD_DEV_COND_REPS
@@ -314,12 +272,55 @@ KD_PHASE void kd_condense_stage(const KdMem& M, int N, int k, double delta) {
 #endif
   }
 #endif
+  double* gk = M.gc + (size_t)k * KD_GC;
   for (int t = 0; t < 4; ++t)
     for (int r = 0; r < 4; ++r) {
       const int a = 16 * wave + lk + 4 * r, b = 16 * t + lj;
-      if (a < nv && b < nv) S.Ms[a * KD_MS + b] += acc[t][r];
+      if (a < nv && b < nv) gk[a * KD_NV + b] = acc[t][r];
     }
-  if (tid < nv) S.Ms[tid * KD_MS + 60] = macc;
+  if (tid < nv) gk[KD_NV * KD_NV + tid] = macc;
+}
+
+// (b) stage array of interval k into KSH.Ms (nv x nv + rhs), KSH.Ah
+KD_PHASE void kd_assemble_stage(const KdMem& M, int N, int k, double delta) {
+  KdLds& S = KSH;
+  const int tid = threadIdx.x;
+  const bool last = k == N - 1;
+  const int nv = last ? 48 : KD_NV;
+  const landing_gptr Jk = (landing_gptr)(M.J + (size_t)k * KD_ROWS * KD_NW);
+  const landing_gptr Hk = (landing_gptr)(M.H + (size_t)k * KD_NW * KD_NW);
+  const landing_gptr Ck = (landing_gptr)(M.gc + (size_t)k * KD_GC);
+  const landing_gptr Gg = (landing_gptr)M.g;
+  const int g0 = KD_BND + k * KD_ROWS;
+  // Hessian block of lam' g over v with delta_w on the diagonal + the condensed inequality rows; right-hand side J_I' rho; [A^ | b] from the defect rows:
+  // X_k+1 = A^ (sigma_k, f_k) + b in step form (rows in the order of X).  All loads of a thread are issued together, unconditionally (clamped addresses), and only then
+  // stored: with the load under the bounds test each round waited for its own load (round 5)
+  constexpr int NH = (KD_NV * KD_MS + KD_THREADS - 1) / KD_THREADS, NA = (12 * KD_AS + KD_THREADS - 1) / KD_THREADS;
+  double hv[NH], cv[NH], av[NA];
+#pragma unroll
+  for (int q = 0; q < NH; ++q) {
+    const int e = tid + q * KD_THREADS, a = e / KD_MS, b = e % KD_MS;
+    const bool in = a < nv && b < nv, rhs = a < nv && b == KD_NV;
+    hv[q] = Hk[kd_v2w(in ? a : 0) * KD_NW + kd_v2w(in ? b : 0)];
+    cv[q] = Ck[in ? a * KD_NV + b : (rhs ? KD_NV * KD_NV + a : 0)];
+  }
+#pragma unroll
+  for (int q = 0; q < NA; ++q) {
+    const int e = tid + q * KD_THREADS, ee = e < 12 * KD_AS ? e : 0, r = ee / KD_AS, c = ee % KD_AS;
+    const double vj = Jk[r * KD_NW + (c < 36 ? c : 0)], vg = Gg[g0 + r];
+    av[q] = c < 36 ? -vj : -vg;
+  }
+#pragma unroll
+  for (int q = 0; q < NH; ++q) {
+    const int e = tid + q * KD_THREADS, a = e / KD_MS, b = e % KD_MS;
+    const bool in = a < nv && b < nv, rhs = a < nv && b == KD_NV;
+    if (e < KD_NV * KD_MS) S.Ms[e] = in ? (hv[q] + (a == b ? delta : 0.0)) + cv[q] : (rhs ? cv[q] : 0.0);
+  }
+#pragma unroll
+  for (int q = 0; q < NA; ++q) {
+    const int e = tid + q * KD_THREADS, ee = e < 12 * KD_AS ? e : 0, r = ee / KD_AS, c = ee % KD_AS;
+    if (e < 12 * KD_AS) S.Ah[KD_ROW2X[r] * KD_AS + c] = av[q];
+  }
   __syncthreads();
 }
 
@@ -501,7 +502,7 @@ __device__ __forceinline__ void kd_terminal(const KdMem& M, int N, const double*
 KD_PHASE bool kd_backward(const KdMem& M, int N, const double* cost, double delta) {
   kd_terminal(M, N, cost, delta);
   for (int k = N - 1; k >= 0; --k) {
-    kd_condense_stage(M, N, k, delta);
+    kd_assemble_stage(M, N, k, delta);
     if (!kd_riccati_stage(M, N, k)) return false;
   }
   return true;
@@ -524,7 +525,7 @@ KD_PHASE void kd_forward(const KdMem& M, int N, const double* lbm) {
   static_assert(2 * NREC <= KD_NV * KD_MS, "two records fit the stage array");
   double nxt[NQ];
   auto fetch = [&](int k) {
-    const landing_gptr rec = (landing_gptr)(M.rec + (size_t)(k < N ? k : N - 1) * KD_REC);      // (global_load: see kd_condense_stage)
+    const landing_gptr rec = (landing_gptr)(M.rec + (size_t)(k < N ? k : N - 1) * KD_REC);      // (global_load: see kd_condense_rows)
 #pragma unroll
     for (int q = 0; q < NQ; ++q) { const int e = tid + q * KD_THREADS; nxt[q] = rec[e < NREC ? e : NREC - 1]; }
   };
@@ -798,7 +799,7 @@ __global__ void __launch_bounds__(KD_THREADS) landing_kd_init_kernel(KdSolveArgs
     K.e_pr = K.e_du = K.e_co = 0.0; K.tau = 0.0; K.a_pr = K.a_du = 0.0; K.th0 = K.ph0 = K.dphi = K.alpha = K.s_corr = K.delta = K.ft = K.fval = 0.0; K.omt = -1.0;
     K.nfilt = 0; K.it = 0; K.status = LANDING_MAX_ITER; K.done = 0; K.need_reg_streak = 0; K.first_failed = 0; K.cutstreak = 0; K.force_step = 0;
     K.wd_count = 0; K.last_mu_it = 0; K.accepted = 0; K.armijo_step = 0; K.fact_ok = 0; K.skipped_zero = 0; K.attempt = 0; K.flag = 0; K.ls_done = 0;
-    K.need_corr = 0; K.fallback = 0; K.nfact = 0; K.ntrial = 0; K.nreset = 0; K.last_reset_it = 0; K.ncrawl = 0; K.clip_k_cur = o.clip_k; K.fresh = 0; K.reg_it = -1000; K.pending = 0; K.stag = 0; K.full_prev = 0; K.e_prev = 1e300;
+    K.need_corr = 0; K.fallback = 0; K.nfact = 0; K.ntrial = 0; K.nreset = 0; K.last_reset_it = 0; K.ncrawl = 0; K.clip_k_cur = o.clip_k; K.fresh = 0; K.reg_it = -1000; K.pending = 0; K.stage = 0; K.stag = 0; K.full_prev = 0; K.e_prev = 1e300;
     K.feas = 0; K.feas_used = 0; K.lim = o.max_iter; K.fjam = 0; K.fstat = 0; K.polished = 0; K.v1_ref = 0.0; K.c_rn = 0.0; K.f_vmax = 0.0; K.f_v1 = 0.0;
     K.n_feas = 0; K.stalled = 0; K.want_entry = 0; K.th_entry = 0.0; K.f_theq = 0.0; K.hard_lim = o.max_iter > 0 ? 3 * o.max_iter : 0; K.fdc = o.feas_delta_dec > 0.0 ? o.feas_delta_dec : o.delta_dec;
     for (int i = 0; i < 8; ++i) K.prof[i] = 0.0; K.tp = 0;
@@ -833,7 +834,11 @@ __global__ void __launch_bounds__(KD_THREADS) landing_kd_init_kernel(KdSolveArgs
 #define KD_TRIES_PER_ROUND 2      // (round 5: 3 with the matrix-core elimination, 0.7 instead of 1.8 ms per attempt -- 1.23 -> 1.07 s per batch of 1024; round 4: 1.  With the
                                   // portfolio and the delta_w continuation 2: the tail rounds wait for their slowest member's attempts -- 0.408 -> 0.394 s, 1 attempt 0.411)
 #endif
-__global__ void __launch_bounds__(KD_THREADS, 2) landing_kd_iter_kernel(KdSolveArgs A) {
+// Round 6: three launches per round.  landing_kd_head_kernel -- error test, stop / restart / phase decisions, barrier parameter, delta_w of the first attempt (one
+// workgroup per member); landing_kd_condense_kernel -- J_I' Sigma J_I and J_I' rho of every interval (one workgroup per member and interval: sigma and rho are final
+// once the head has set the barrier parameter); landing_kd_iter_kernel -- Riccati sweeps with inertia correction, forward sweep, line search, acceptance.  The state
+// travels in the member's workspace (KdState::stage says whether the head has prepared an iteration).
+__global__ void __launch_bounds__(KD_THREADS, 2) landing_kd_head_kernel(KdSolveArgs A) {
   const int m = blockIdx.x;
   if (m >= A.B) return;
   const int N = A.N, nx = kd_nx(N), ng = kd_ng(N), tid = threadIdx.x, NT = blockDim.x;
@@ -858,9 +863,9 @@ __global__ void __launch_bounds__(KD_THREADS, 2) landing_kd_iter_kernel(KdSolveA
   // that needs five regularisation attempts (1.8 ms each) used to hold all others back -- at full batch the launch took 15 ms for 2 x 3.3 ms of work
   // per slot.  After KD_TRIES_PER_ROUND failed factorisations the member therefore saves its state and RETURNS (pending): the next launch resumes
   // its inertia correction where it stopped, the derivative kernels skip it meanwhile (A.done[m] = 2: x has not moved).
-  const bool resume = K.pending != 0;
-  if (resume) { KD_BEGIN() K.pending = 0; KD_END(); }
-  else {
+  if (K.pending != 0) return;      // (uniform) its inertia correction continues in landing_kd_iter_kernel; nothing of the member has moved
+  {
+    if (tid == 0) K.stage = 0;
     // ---------------------------------------------------------------- optimality error (unscaled), stop test
     kd_grad_lag(M, N, cost, K.feas ? 0.0 : 1.0);
     KD_PROF(0);
@@ -1034,8 +1039,43 @@ __global__ void __launch_bounds__(KD_THREADS, 2) landing_kd_iter_kernel(KdSolveA
         if (o.stag_relief > 0 && K.stag >= o.stag_relief) { for (int e = K.stag - o.stag_relief; e >= 0 && fl >= 1e-12; --e) fl *= 0.1; if (fl < 1e-12) fl = 0.0; }
         K.delta = fmax(K.delta, fl); }
       K.skipped_zero = K.delta > 0.0; K.fact_ok = 0; K.attempt = 0; K.flag = 1; K.nfact++;
+      K.stage = 1;
+      *M.st = K;
+      A.cond_list[atomicAdd(A.n_cond, 1)] = m;      // (the order of the list is the order the hardware ran the workgroups in: every entry is independent work)
     KD_END();
   }
+}
+
+// J_I' Sigma J_I and J_I' rho of every interval of the members whose head kernel has prepared an iteration this round: work item w = (entry w / N of the list, interval
+// w % N), a fixed grid of workgroups strides over the items (four workgroups per CU: 128 registers, 23.6 KB of LDS) -- in the lock-step tail a handful of members
+// iterate, and a launch of one workgroup per (member, interval) of the whole batch cost 0.3 ms of empty workgroups per round
+__global__ void __launch_bounds__(KD_THREADS, KD_COND_WGS) landing_kd_condense_kernel(KdSolveArgs A) {
+  const int N = A.N, total = *A.n_cond * N;                 // (uniform)
+  for (int w = blockIdx.x; w < total; w += gridDim.x) {
+    const int m = A.cond_list[w / N], k = w % N;
+    const KdMem M = kd_carve(N, A.ws + (size_t)m * A.ws_stride);
+    kd_condense_rows(M, N, k);
+    __syncthreads();
+  }
+}
+
+__global__ void __launch_bounds__(KD_THREADS, 2) landing_kd_iter_kernel(KdSolveArgs A) {
+  const int m = blockIdx.x;
+  if (m >= A.B) return;
+  const int N = A.N, nx = kd_nx(N), ng = kd_ng(N), tid = threadIdx.x, NT = blockDim.x;
+  const KdMem M = kd_carve(N, A.ws + (size_t)m * A.ws_stride);
+  const int pm = kd_problem_of(A, m);
+  if (pm < 0) return;                                       // unused clone slot
+  if (M.st->done) return;                                   // (uniform: one global word per member)
+  if (!M.st->pending && M.st->stage != 1) return;           // finished, restarted or sent into / out of the feasibility phase by the head kernel: the next round starts afresh
+  const landing_solver_opts& o = kd_opts_of(A, m);
+  const double* lbm = A.lb + (size_t)pm * ng; const double* ubm = A.ub + (size_t)pm * ng;
+  const double* cost = A.cost + (size_t)pm * 24;
+  const double INF = INFINITY;
+  KdLds& S = KSH;
+  KdState& K = S.ks;
+  if (tid == 0) { K = *M.st; K.tp = (long long)wall_clock64(); K.pending = 0; K.stage = 0; }
+  __syncthreads();
   int tries = 0;
   for (;;) {
     const bool ok = kd_backward(M, N, cost, K.delta);

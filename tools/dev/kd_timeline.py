@@ -15,7 +15,7 @@ def flush(lo, hi):
     print("rounds %3d-%3d: " % (lo, hi) + "  ".join("%s %.2f" % (k, v) for k, v in sorted(acc.items())) + "  (ms per round)")
 n = 10; start = 0
 for r in kd:
-    key = "iter" if "iter" in r[2] else "hess" if "hess" in r[2] else "jac" if "jac" in r[2] else "other"
+    key = "iter" if "iter" in r[2] else "hess" if "hess" in r[2] else "jac" if "jac" in r[2] else "head" if "kd_head" in r[2] else "cond" if "kd_condense" in r[2] else "other"
     acc[key] = acc.get(key, 0) + (r[1] - r[0]) / 1e6 / n
     acc["gap"] = acc.get("gap", 0) + max(0, r[0] - prev_end) / 1e6 / n
     prev_end = max(prev_end, r[1])
