@@ -16,9 +16,11 @@
 // Division of work per interior-point iteration (host loop in kd_capi.inc, all members of the batch in lock step, finished members skip):
 //   landing_kinodyn_nlp_jac_kernel / _hess_kernel   (rbd_kernels.hip, whole batch)   exact J blocks (141 x 72) and Hessian blocks of lam' g
 //                                                    (72 x 72) of every interval by forward-mode AD, as CasADi provides them to the reference
-//   landing_kd_iter_kernel                          (this file, ONE WORKGROUP = ONE NLP)   error test, barrier update, condensation
-//       Q_k = H_k + J_k' Sigma J_k on the fp64 matrix cores (v_mfma_f64_16x16x4), Riccati sweep with inertia correction, forward sweep,
-//       step bounds, filter line search with g evaluated in the kernel (kd_stage_rows<double>, one lane per interval), acceptance.
+//   landing_kd_head_kernel                          (this file, ONE WORKGROUP = ONE NLP)   error test, stop / restart / phase decisions, barrier update
+//   landing_kd_condense_kernel                      (one workgroup per member and interval, round 6)   J_I' Sigma J_I and J_I' rho of the inequality rows on the
+//       fp64 matrix cores (v_mfma_f64_16x16x4) -- independent of the Riccati recursion
+//   landing_kd_iter_kernel                          (ONE WORKGROUP = ONE NLP)   Q_k = (H_k + delta_w I) + that part per stage, Riccati sweep with inertia correction,
+//       forward sweep, step bounds, filter line search with g evaluated in the kernel (kd_stage_rows<double>, one lane per interval), acceptance.
 // The iteration state of a member (mu, delta_w, filter, counters) lives in its workspace between launches.
 #include <hip/hip_runtime.h>
 #include <math.h>
