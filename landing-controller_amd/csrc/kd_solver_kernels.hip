@@ -108,6 +108,8 @@ struct KdSolveArgs {
   double* ws; size_t ws_stride;
   double* x_out; double* f_out; double* lam_out; int* status; int* iters; double* kkt;
   int* n_active;           // number of members still iterating (written by the iteration kernel)
+  int* n_dnext; int* dlist_next;    // members that need their derivatives in the NEXT round of launches (count, list [B]): appended wherever a member ends a launch with a new point (round 6: the derivative
+                                    // kernels are gridded over this list -- in the lock-step tail the launches over the whole batch were mostly workgroups that leave at once)
   int* n_cond; int* cond_list;      // members whose head kernel has prepared an iteration this round (count, list [B]: the work list of landing_kd_condense_kernel)
   int* done;               // [B] 1 = the member has finished (read by the function-layer kernels: finished members are skipped)
   // Portfolio (round 5, landing_nlp.h kd_clone_after): members B0 .. B-1 are CLONE slots -- workspace blocks without a problem of their own.  After
@@ -825,6 +827,7 @@ __global__ void __launch_bounds__(KD_THREADS) landing_kd_init_kernel(KdSolveArgs
     if (viol > o.tol) { K.status = LANDING_INFEASIBLE; K.done = 1; K.e_pr = viol; }
     *M.st = K;
     A.done[m] = K.done;
+    if (!K.done) A.dlist_next[atomicAdd(A.n_dnext, 1)] = m;      // (the host passes the list the NEXT derivative launches read)
   }
 }
 
@@ -972,7 +975,7 @@ __global__ void __launch_bounds__(KD_THREADS, 2) landing_kd_head_kernel(KdSolveA
       }
       kd_init_slacks(M, ng, lbm, ubm, o);
       kd_point_pass(M, ng, lbm, ubm, K.mu);
-      if (tid == 0) { *M.st = K; atomicAdd(A.n_active, 1); }
+      if (tid == 0) { *M.st = K; atomicAdd(A.n_active, 1); A.dlist_next[atomicAdd(A.n_dnext, 1)] = m; }
       return;
     }
     if (K.flag == 3) {      // a feasible point (or negligible violation): the interior-point solve restarts from it; derivatives at the new multipliers next round
@@ -980,7 +983,7 @@ __global__ void __launch_bounds__(KD_THREADS, 2) landing_kd_head_kernel(KdSolveA
       __syncthreads();
       if (o.feas_ret_push > 0.0) kd_init_slacks_return(M, ng, lbm, ubm, o, K.mu); else kd_init_slacks(M, ng, lbm, ubm, o);
       kd_point_pass(M, ng, lbm, ubm, K.mu);
-      if (tid == 0) { *M.st = K; A.done[m] = 0; atomicAdd(A.n_active, 1); }
+      if (tid == 0) { *M.st = K; A.done[m] = 0; atomicAdd(A.n_active, 1); A.dlist_next[atomicAdd(A.n_dnext, 1)] = m; }
       return;
     }
     if (K.flag == 4) {      // into the feasibility phase from the current point (from the caller's initial guess when the iterate is not finite)
@@ -1011,7 +1014,7 @@ __global__ void __launch_bounds__(KD_THREADS, 2) landing_kd_head_kernel(KdSolveA
       }
       __syncthreads();
       kd_feas_point_pass(M, ng, lbm, ubm, K.mu, o.feas_rho);
-      if (tid == 0) { *M.st = K; A.done[m] = 0; atomicAdd(A.n_active, 1); }
+      if (tid == 0) { *M.st = K; A.done[m] = 0; atomicAdd(A.n_active, 1); A.dlist_next[atomicAdd(A.n_dnext, 1)] = m; }
       return;
     }
     // ---------------------------------------------------------------- barrier parameter (monotone)
@@ -1110,7 +1113,7 @@ __global__ void __launch_bounds__(KD_THREADS, 2) landing_kd_iter_kernel(KdSolveA
   if (!K.fact_ok) {      // no regularisation made the step computable: give up (status NUMERICAL) or -- once -- continue in the feasibility phase: the next
     // round's stop test sees a non-finite error and takes that path (the point itself is kept)
     if (o.feas_phase && !K.feas_used && !K.feas && o.max_iter > 0) {
-      if (tid == 0) { K.c_pr = INFINITY; *M.st = K; A.done[m] = 0; atomicAdd(A.n_active, 1); }
+      if (tid == 0) { K.c_pr = INFINITY; *M.st = K; A.done[m] = 0; atomicAdd(A.n_active, 1); A.dlist_next[atomicAdd(A.n_dnext, 1)] = m; }
       return;
     }
     if (tid == 0) { K.status = K.stalled ? LANDING_STALLED : LANDING_NUMERICAL; K.done = 1; *M.st = K; A.done[m] = 1; }
@@ -1352,7 +1355,7 @@ __global__ void __launch_bounds__(KD_THREADS, 2) landing_kd_iter_kernel(KdSolveA
       { const long long n_ = (long long)wall_clock64(); K.prof[6] += (double)(n_ - K.tp); K.tp = n_; }
       *M.st = K;
       A.done[m] = 0;
-      atomicAdd(A.n_active, 1);
+      atomicAdd(A.n_active, 1); A.dlist_next[atomicAdd(A.n_dnext, 1)] = m;
     KD_END();
   } else {
     const double alpha = K.alpha, a_du = K.a_du, mu = K.mu, s_corr = K.s_corr, omt = K.omt;
@@ -1394,7 +1397,7 @@ __global__ void __launch_bounds__(KD_THREADS, 2) landing_kd_iter_kernel(KdSolveA
       { const long long n_ = (long long)wall_clock64(); K.prof[6] += (double)(n_ - K.tp); K.tp = n_; }
       *M.st = K;
       A.done[m] = 0;      // (2 while the member was pending: the next launch of the derivative kernels must see its new x)
-      atomicAdd(A.n_active, 1);
+      atomicAdd(A.n_active, 1); A.dlist_next[atomicAdd(A.n_dnext, 1)] = m;
     KD_END();
   }
 }

@@ -880,6 +880,7 @@ struct KdNlpArgs {
   // member strides in doubles (0 = dense arrays [B][nx], [B][ng], [B][N][141][72], [B][N][72][72]) and an optional per-member skip flag: the
   // interior-point solver (kd_solver_kernels.hip) evaluates straight into its per-member workspace and skips members that have finished
   long long sx, sg, sj, sh; const int* skip;
+  const int* list = nullptr; const int* n_list = nullptr;      // optional work list (round 6): block index b stands for member list[b], b < *n_list (the solver's members that need derivatives this round)
   double* jty = nullptr;      // optional [member stride sj][N][72]: J_k' lam_k per interval and column, a by-product of the Jacobian kernel (the solver's grad f + J' y)
   __host__ __device__ size_t ox(int b) const { return (size_t)b * (sx ? (size_t)sx : (size_t)(12 * (N + 1) + 36 * N)); }
   __host__ __device__ size_t og(int b) const { return (size_t)b * (sg ? (size_t)sg : (size_t)(48 + (N - 1) * 141 + 117)); }
@@ -927,7 +928,8 @@ __host__ __device__ inline long long kd_jac_blocks(long long B, int N) { return 
 template <int STDB>
 __global__ void __launch_bounds__(KD_JAC_THREADS) landing_kinodyn_nlp_jac_kernel(KdNlpArgs a) {
   const int N = a.N, nblk = (N + KD_JAC_STAGES - 1) / KD_JAC_STAGES;
-  const int b = (int)(blockIdx.x / nblk), k0 = (int)(blockIdx.x % nblk) * KD_JAC_STAGES;
+  int b = (int)(blockIdx.x / nblk); const int k0 = (int)(blockIdx.x % nblk) * KD_JAC_STAGES;
+  if (a.list) { if (b >= *a.n_list) return; b = a.list[b]; }
   if (b >= a.B) return;
   if (a.skip && a.skip[b]) return;
   __shared__ double xs[KD_JAC_STAGES][KD_NW];
@@ -1003,7 +1005,8 @@ template <int STDB>
 __global__ void __launch_bounds__(64, KD_HESS_WAVES) landing_kinodyn_nlp_hess_kernel(KdNlpArgs a, const unsigned char* __restrict__ pair_i, const unsigned char* __restrict__ pair_j, int npair) {
   const int nch = (KD_HESS_G * npair + 63) / 64, N = a.N, ngr = (N + KD_HESS_G - 1) / KD_HESS_G;
   const long long blk = blockIdx.x;
-  const int ch = (int)(blk % nch); const int gr = (int)((blk / nch) % ngr); const int b = (int)(blk / ((long long)nch * ngr));
+  const int ch = (int)(blk % nch); const int gr = (int)((blk / nch) % ngr); int b = (int)(blk / ((long long)nch * ngr));
+  if (a.list) { if (b >= *a.n_list) return; b = a.list[b]; }
   if (b >= a.B) return;
   if (a.skip && a.skip[b]) return;
   __shared__ double xs[KD_HESS_G][KD_NW];
