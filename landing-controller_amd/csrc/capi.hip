@@ -61,6 +61,8 @@ struct landing_ctx {
   // fenced by this event (recorded behind them, waited for before the next writer / reader touches the block) -- ADVICE r2
   hipEvent_t scratch_done = nullptr;
   double* d_kd_ws = nullptr; size_t kd_cap = 0; int* d_kd_active = nullptr; int* d_kd_done = nullptr; int kd_done_cap = 0;      // workspace of landing_kinodyn_solve_batch (kd_capi.inc), count of members still iterating
+  int kd_jpat_nnz[2] = {0, 0};
+  void* d_kd_jpat = nullptr;      // landing::KdJPat: structural non-zeros of the kinodynamic NLP's Jacobian blocks (kd_ensure_jpat, solver_capi.inc)
   unsigned char* d_kd_pairs = nullptr; int kd_npair = 0; int rbd_std_base = 0;      // structurally non-zero pairs of a Hessian block of the kinodynamic NLP ([2][kd_npair]: i | j; solver_capi.inc, kd_ensure_pairs)
   const double* wb_skip = nullptr;      // landing_wb_skip_taken: consumed by the next landing_wb_rollout
   int wb_semi = 0;             // integrator of the whole-body loop: 0 explicit Euler, 1 semi-implicit Euler (landing_wb_set_integrator)
@@ -298,6 +300,7 @@ void landing_destroy(landing_ctx* ctx) {
   for (int i = 0; i < 3; ++i) { if (ctx->aux[i]) (void)hipStreamDestroy(ctx->aux[i]); if (ctx->ev_join[i]) (void)hipEventDestroy(ctx->ev_join[i]); }
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
   if (ctx->d_kd_pairs) (void)hipFree(ctx->d_kd_pairs);
+  if (ctx->d_kd_jpat) (void)hipFree(ctx->d_kd_jpat);
   if (ctx->d_kd_ws) (void)hipFree(ctx->d_kd_ws);
   if (ctx->d_kd_active) (void)hipFree(ctx->d_kd_active);
   if (ctx->d_kd_done) (void)hipFree(ctx->d_kd_done);

@@ -100,6 +100,14 @@ __device__ __forceinline__ KdMem kd_carve(int N, double* w) {
   return M;
 }
 
+// Structural non-zeros of the inequality rows (12 ..) of an interval's Jacobian block, [0] = every interval but the last, [1] = the last one: the rows in the order of
+// falling counts (perm: the lanes of a wavefront then run rows of the same length), their entries as ranges rp[j] .. rp[j + 1] of the column list cl.  Built once per
+// context by asking the Jacobian kernel itself (kd_ensure_jpat, solver_capi.inc: an entry of a forward-mode derivative is exactly 0.0 where the row does not depend on the
+// variable): 529 of the 129 x 72 entries of a middle interval, at most 9 in a row.
+constexpr int KD_JP_ROWS = 132, KD_JP_NNZ = 640, KD_JP_MAX = 12;
+struct KdJPat { unsigned short rp[2][KD_JP_ROWS]; unsigned char perm[2][KD_JP_ROWS]; unsigned char cl[2][KD_JP_NNZ]; };
+static_assert(sizeof(KdJPat) % 8 == 0, "copied in 8-byte words");
+
 struct KdSolveArgs {
   const RbdModel* model; KdNlpParams P; int B, N; landing_solver_opts o;
   const double* x0;        // [B][nx]
@@ -110,6 +118,7 @@ struct KdSolveArgs {
   int* n_active;           // number of members still iterating (written by the iteration kernel)
   int* n_dnext; int* dlist_next;    // members that need their derivatives in the NEXT round of launches (count, list [B]): appended wherever a member ends a launch with a new point (round 6: the derivative
                                     // kernels are gridded over this list -- in the lock-step tail the launches over the whole batch were mostly workgroups that leave at once)
+  const KdJPat* jpat;      // structural non-zeros of the Jacobian blocks' inequality rows (device copy, built once per context)
   int* n_cond; int* cond_list;      // members whose head kernel has prepared an iteration this round (count, list [B]: the work list of landing_kd_condense_kernel)
   int* done;               // [B] 1 = the member has finished (read by the function-layer kernels: finished members are skipped)
   // Portfolio (round 5, landing_nlp.h kd_clone_after): members B0 .. B-1 are CLONE slots -- workspace blocks without a problem of their own.  After
@@ -146,7 +155,8 @@ struct KdLds {
   double Y[KD_NSIG * KD_AS];           // P [A^ | b] (+ p): rows of sigma+
   union {      // (the chunk buffer lives in the backward sweep, the knot steps in the forward sweep: one piece of LDS -- what pays for 44 instead of 36 rows per chunk)
     double Jc[KD_JC_ROWS * KD_JC_S];     // chunk of the interval's inequality rows (v columns, zero padded to 64)
-    double dsg[KD_NSIG * 65];            // d sigma_k of every knot (N <= 64)
+    struct { double dsg[KD_NSIG * 65];   // d sigma_k of every knot (N <= 64)
+             KdJPat jp; };               // the Jacobian blocks' non-zeros (forward sweep: ds = J_I dx)
   };
   double dxw[KD_NW];
   double red[(KD_THREADS / 64) * 6];
@@ -516,7 +526,7 @@ KD_PHASE bool kd_backward(const KdMem& M, int N, const double* cost, double delt
 #ifndef KD_DS_U
 #define KD_DS_U 16
 #endif
-KD_PHASE void kd_forward(const KdMem& M, int N, const double* lbm) {
+KD_PHASE void kd_forward(const KdMem& M, int N, const double* lbm, const KdJPat* jpat) {
   KdLds& S = KSH;
   const int tid = threadIdx.x, NT = blockDim.x;
   const int oJ = 12 * (N + 1), oU = oJ + 12 * N;
@@ -580,55 +590,38 @@ KD_PHASE void kd_forward(const KdMem& M, int N, const double* lbm) {
     M.yn[KD_BND + k * KD_ROWS + r] = -a;
   }
   __syncthreads();
-  // ds = J_I dx + (g - s): one wave per row, lanes over the 72 columns of the interval's block, four rows of a wave in flight at a time.
-  // The steps of all intervals' block variables are gathered first (into the stage array, free here), so that no barrier separates the
-  // intervals and the loads of the J blocks (74 KB per interval) stream (round 4: one row after the other, a barrier pair per interval)
-  const int wave = tid >> 6, l = tid & 63;
+  // ds = J_I dx + (g - s).  The steps of all intervals' block variables are gathered first (into the stage array, free here), so that no barrier separates the intervals.
+  // Round 6: over the STRUCTURAL non-zeros of the rows (KdJPat: 4.1 entries per row on average, at most 9, of 72): one lane per row, its entries gathered from the dense
+  // block with all loads of the row in flight, summed in column order -- no cross-lane reduction.  Rounds 4-5 streamed the dense rows (one wave per row, lanes over the 72
+  // columns, a 6-level shuffle reduction per row): 9.5 % of a batch of law main, 0.18 ms per round of the lock-step tail (tools/dev/gpu_r06w.sh).
   static_assert(64 * KD_NW <= KD_NV * KD_MS + KD_NSIG * KD_PS + KD_NSIG + 12 * KD_AS + KD_NSIG * KD_AS, "the gathered steps of N <= 64 intervals fit the arrays in front of Jc");
   double* dxa = S.Ms;      // [N][72]  (runs on into Pm, pv, Ah, Y for long horizons: all free during the forward sweep)
   for (int e = tid; e < N * KD_NW; e += NT) { const int k = e / KD_NW, i = kd_w_index(N, k, e % KD_NW); dxa[e] = i >= 0 ? M.dx[i] : 0.0; }
+  { const unsigned long long* src = reinterpret_cast<const unsigned long long*>(jpat); unsigned long long* dst = reinterpret_cast<unsigned long long*>(&S.jp);
+    for (int e = tid; e < (int)(sizeof(KdJPat) / 8); e += NT) dst[e] = src[e]; }
   __syncthreads();
+#ifdef KD_DEV_DS_REPS      // timing probe (tools/dev): the pass KD_DEV_DS_REPS times, same results
+  for (int rep_ = 0; rep_ < KD_DEV_DS_REPS; ++rep_)
+#endif
   {
-    const int nrows = (N - 1) * (KD_ROWS - 12) + (KD_ROWS_LAST - 12);      // inequality rows of all intervals, interval-major
-    // software pipeline: the loads of the next KD_DS_U rows of this wave are issued before the shuffle chains of the current ones (round 5: 4 rows; late round 5: 16 -- same box 0.378 -> 0.370 s per batch, 8 rows 0.372 --
-    // 160 steps of a wave each waited about one load latency: the pass was most of the forward sweep's 0.37 ms)
-    constexpr int U = KD_DS_U;
-    double j0[U], j1[U], gs = 0.0; int kk[U], gr[U];
-    auto issue = [&](int q0) {
-      int gl = KD_BND + 12;
+    constexpr int RM = KD_ROWS - 12, RL = KD_ROWS_LAST - 12;      // inequality rows of a middle / of the last interval
+    const int nmid = (N - 1) * RM, ntot = nmid + RL;
+    const landing_gptr Gg = (landing_gptr)M.g, Gs = (landing_gptr)M.s;
+    for (int i0 = 0; i0 < ntot; i0 += NT) {
+      const int idx = i0 + tid; const bool on = idx < ntot; const int ii = on ? idx : 0;
+      const int lp = ii >= nmid ? 1 : 0, k = lp ? N - 1 : ii / RM, j = lp ? ii - nmid : ii % RM;
+      const int r = S.jp.perm[lp][j], t0 = S.jp.rp[lp][j], cnt = S.jp.rp[lp][j + 1] - t0;
+      const landing_gptr Jr = (landing_gptr)(M.J + ((size_t)k * KD_ROWS + r) * KD_NW);      // (global_load: the LDS reads below wait on the LDS counter only)
+      const double* dk = dxa + k * KD_NW;
+      const int g = KD_BND + k * KD_ROWS + r;
+      double v[KD_JP_MAX]; int c[KD_JP_MAX];
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int q = q0 + u < nrows ? q0 + u : nrows - 1;
-        const int k = q / (KD_ROWS - 12), r = 12 + q % (KD_ROWS - 12);
-        const landing_gptr Jr = (landing_gptr)(M.J + ((size_t)k * KD_ROWS + r) * KD_NW);      // (global_load: the dk reads below wait on the LDS counter only)
-        j0[u] = Jr[l]; j1[u] = Jr[64 + (l < KD_NW - 64 ? l : 0)];
-        kk[u] = k; gr[u] = KD_BND + k * KD_ROWS + r;
-        gl = l == u ? gr[u] : gl;
-      }
-      if (l < U) gs = ((landing_gptr)M.g)[gl] - ((landing_gptr)M.s)[gl];
-    };
-    issue(U * wave);
-    for (int q0 = U * wave; q0 < nrows; q0 += 4 * U) {
-      double a[U]; int gc[U]; const double gsc = gs;
+      for (int u = 0; u < KD_JP_MAX; ++u) { c[u] = S.jp.cl[lp][t0 + (u < cnt ? u : 0)]; v[u] = Jr[c[u]]; }      // (clamped: every load is issued, unconditionally)
+      const double gs = Gg[g] - Gs[g];
+      double acc = 0.0;
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const double* dk = dxa + kk[u] * KD_NW;
-        a[u] = j0[u] * dk[l];
-        if (l < KD_NW - 64) a[u] += j1[u] * dk[64 + l];
-        gc[u] = gr[u];
-      }
-      if (q0 + 4 * U < nrows) issue(q0 + 4 * U);      // (uniform per wave)
-#pragma unroll
-      for (int mask = 32; mask >= 1; mask >>= 1) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) a[u] += __shfl_xor(a[u], mask);
-      }
-      if (l < U && q0 + l < nrows) {
-        double v = a[0]; int g = gc[0];
-#pragma unroll
-        for (int u = 1; u < U; ++u) { v = l == u ? a[u] : v; g = l == u ? gc[u] : g; }
-        M.ds[g] = v + gsc;
-      }
+      for (int u = 0; u < KD_JP_MAX; ++u) acc += u < cnt ? v[u] * dk[c[u]] : 0.0;
+      if (on) M.ds[g] = acc + gs;
     }
   }
   __syncthreads();
@@ -1126,7 +1119,7 @@ __global__ void __launch_bounds__(KD_THREADS, 2) landing_kd_iter_kernel(KdSolveA
     if (K.need_reg_streak > 8) K.need_reg_streak = adapt ? 2 : 0;      // (no probe of delta_w = 0 inside the phase: the elastic problem has no objective)
   KD_END();
   KD_PROF(2);
-  kd_forward(M, N, lbm);
+  kd_forward(M, N, lbm, A.jpat);
   KD_PROF(3);
   // ================================================================ dual steps, step bounds, merit data
   {
