@@ -657,6 +657,11 @@ int landing_solve_kinodyn_24_on_form(int device, int N, int B, const landing_kin
 /* CCS patterns of this NLP in CasADi's compressed form, which = 0: jac_g_x (ng x nx), 1: upper triangle of hess_gamma_x_x; colind [nx + 1],
  * row [*nnz] (pass row = NULL to get the count first).  Derived from the derivative kernels themselves (device needed). */
 int landing_kinodyn_pattern(landing_ctx* ctx, int N, int which, long long* colind, long long* row, long long* nnz);
+/* Diagnostic: the solver's own table of the structural non-zeros of a Jacobian block's inequality rows (rows 12.. of the 141 x 72 block of an interval; the forward
+ * sweep forms ds = J dx over these entries only, round 6): counts for an interval that is not the last / for the last one (529 / 457 with the Mini-Cheetah model), and,
+ * when `entries` is not NULL, the table itself as (row, column) byte pairs, the first *nnz_mid pairs for a middle interval, then *nnz_last for the last
+ * (room for 2 x 1280 bytes).  Built once per context by asking the Jacobian kernel (device needed); it must agree with landing_kinodyn_pattern. */
+int landing_kinodyn_block_nonzeros(landing_ctx* ctx, int* nnz_mid, int* nnz_last, unsigned char* entries);
 
 /* ---- CasADi-external face of the kinodynamic refinement NLP (round 6) ------------------------------------------------------------------------
  * What landingCtrller_KNITRO_mi355x.so (csrc/casadi_abi.cpp with -DLANDING_KD=1) forwards to: the seven nlp_* functions of the library the reference generates

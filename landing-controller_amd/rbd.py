@@ -252,6 +252,16 @@ class Rbd:
         self.L._check(fn(self.L.ctx, N, which, colind.ctypes.data_as(lp), row.ctypes.data_as(lp), C.byref(nnz)), "landing_kinodyn_pattern")
         return colind, row
 
+    def kinodyn_block_nonzeros(self):
+        """landing_kinodyn_block_nonzeros: the solver's table of the structural non-zeros of a Jacobian block's inequality rows -> ((rows, cols) of a middle interval,
+        (rows, cols) of the last one); rows count from the top of the 141 x 72 block"""
+        n0, n1 = C.c_int(), C.c_int(); buf = np.zeros(2 * 1280, np.uint8)
+        fn = self.L.lib.landing_kinodyn_block_nonzeros
+        fn.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_ubyte)]
+        self.L._check(fn(self.L.ctx, C.byref(n0), C.byref(n1), buf.ctypes.data_as(C.POINTER(C.c_ubyte))), "landing_kinodyn_block_nonzeros")
+        e = buf[:2 * (n0.value + n1.value)].reshape(-1, 2).astype(int)
+        return (e[:n0.value, 0], e[:n0.value, 1]), (e[n0.value:, 0], e[n0.value:, 1])
+
     def leg_ik(self, npts, d_q6, d_c, d_jpos, d_res=0, iters=12, jmin=None, jmax=None, stream=0):
         jmin = np.ascontiguousarray(JPOS_MIN[:3] if jmin is None else jmin, float); jmax = np.ascontiguousarray(JPOS_MAX[:3] if jmax is None else jmax, float)
         dp = C.POINTER(C.c_double)

@@ -166,6 +166,28 @@ def test_presolve_certificate_and_patterns(emu):
     assert cj.shape == (nx + 1,) and cj[-1] == rj.size and rj.max() < ng and np.all(np.diff(cj) >= 1)
     assert ch[-1] == rh.size and all(rh[ch[c]:ch[c + 1]].max(initial=-1) <= c for c in range(nx))      # upper triangle
     assert (rj.size, rh.size) == (NNZ_JAC, NNZ_HESS)
+    # round 6: the solver's own table of a block's non-zeros (the forward sweep forms ds = J dx over these entries only) against the CCS pattern above -- two probes with
+    # different random points and constants: per interval exactly the entries of the inequality rows 12.. of jac_g_x
+    (rm, cm), (rl, cl) = R.kinodyn_block_nonzeros()
+    assert (rm.size, rl.size) == (529, 457) and np.bincount(np.bincount(rm)[12:]).max() >= 1 and np.bincount(rm).max() <= 12
+    from_ccs = {k: set() for k in range(N)}
+    oJ, oU, BND, NR = 12 * (N + 1), 12 * (N + 1) + 12 * N, 48, 141
+    def widx(k, j):
+        if j < 12: return 12 * k + j
+        if j < 36: return oU + 24 * k + (j - 12)
+        if j < 48: return oJ + 12 * k + (j - 36)
+        if j < 60: return 12 * (k + 1) + (j - 48)
+        return oU + 24 * (k + 1) + (j - 60) if k + 1 < N else -1
+    col_of = {}
+    for k in range(N):
+        for j in range(72):
+            if widx(k, j) >= 0: col_of[(k, widx(k, j))] = j
+    for c in range(nx):
+        for r in rj[cj[c]:cj[c + 1]]:
+            if r >= BND and (r - BND) % NR >= 12:
+                k = (r - BND) // NR
+                from_ccs[k].add(((r - BND) % NR, col_of[(k, c)]))
+    assert from_ccs[3] == set(zip(rm.tolist(), cm.tolist())) and from_ccs[N - 1] == set(zip(rl.tolist(), cl.tolist()))
 
 
 NNZ_JAC, NNZ_HESS = 13536, 5720      # N = 20 (three random points agree; the reference ships no generated code of this NLP to compare with)
