@@ -61,7 +61,7 @@ struct landing_ctx {
   // fenced by this event (recorded behind them, waited for before the next writer / reader touches the block) -- ADVICE r2
   hipEvent_t scratch_done = nullptr;
   double* d_kd_ws = nullptr; size_t kd_cap = 0; int* d_kd_active = nullptr; int* d_kd_done = nullptr; int kd_done_cap = 0;      // workspace of landing_kinodyn_solve_batch (kd_capi.inc), count of members still iterating
-  int kd_jpat_nnz[2] = {0, 0};
+  int kd_jpat_nnz[2] = {0, 0}; size_t kd_cpat_off = 0;
   void* d_kd_jpat = nullptr;      // landing::KdJPat: structural non-zeros of the kinodynamic NLP's Jacobian blocks (kd_ensure_jpat, solver_capi.inc)
   unsigned char* d_kd_pairs = nullptr; int kd_npair = 0; int rbd_std_base = 0;      // structurally non-zero pairs of a Hessian block of the kinodynamic NLP ([2][kd_npair]: i | j; solver_capi.inc, kd_ensure_pairs)
   const double* wb_skip = nullptr;      // landing_wb_skip_taken: consumed by the next landing_wb_rollout

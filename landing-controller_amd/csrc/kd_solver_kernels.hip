@@ -107,6 +107,18 @@ __device__ __forceinline__ KdMem kd_carve(int N, double* w) {
 constexpr int KD_JP_ROWS = 132, KD_JP_NNZ = 640, KD_JP_MAX = 12;
 struct KdJPat { unsigned short rp[2][KD_JP_ROWS]; unsigned char perm[2][KD_JP_ROWS]; unsigned char cl[2][KD_JP_NNZ]; };
 static_assert(sizeof(KdJPat) % 8 == 0, "copied in 8-byte words");
+// The condensation J_I' Sigma J_I, J_I' rho of an interval over those non-zeros (landing_kd_condense_kernel): entry t of the block's non-zero list sits in row position
+// erow[t]; destination d = (va <= vb) of the 60 x 60 array (v = stage variable: block column w < 48, or w - 12 for w >= 60) sums the terms dterm[drp[d] .. drp[d + 1]),
+// each (ta | tb << 10 | row position << 20): (J[ta] sigma_row) J[tb], rows ascending; the right-hand side of variable va sums rterm[rrp[va] .. rrp[va + 1]), each
+// (ta | row position << 10): J[ta] rho_row.  3 305 products per middle interval instead of 129 x 60 x 60.  Built with KdJPat (kd_ensure_jpat).
+constexpr int KD_CP_ND = 1024, KD_CP_NT = 3072;
+struct KdCPat {
+  int nd[2], nt[2];
+  unsigned char erow[2][KD_JP_NNZ];
+  unsigned short drp[2][KD_CP_ND + 1]; unsigned short dab[2][KD_CP_ND];      // dab = va | vb << 8
+  unsigned int dterm[2][KD_CP_NT];
+  unsigned short rrp[2][KD_NV + 4]; unsigned int rterm[2][KD_JP_NNZ];
+};
 
 struct KdSolveArgs {
   const RbdModel* model; KdNlpParams P; int B, N; landing_solver_opts o;
@@ -118,6 +130,7 @@ struct KdSolveArgs {
   int* n_active;           // number of members still iterating (written by the iteration kernel)
   int* n_dnext; int* dlist_next;    // members that need their derivatives in the NEXT round of launches (count, list [B]): appended wherever a member ends a launch with a new point (round 6: the derivative
                                     // kernels are gridded over this list -- in the lock-step tail the launches over the whole batch were mostly workgroups that leave at once)
+  const KdCPat* cpat;      // the condensation over those non-zeros (device copy)
   const KdJPat* jpat;      // structural non-zeros of the Jacobian blocks' inequality rows (device copy, built once per context)
   int* n_cond; int* cond_list;      // members whose head kernel has prepared an iteration this round (count, list [B]: the work list of landing_kd_condense_kernel)
   int* done;               // [B] 1 = the member has finished (read by the function-layer kernels: finished members are skipped)
@@ -220,6 +233,9 @@ KD_PHASE void kd_member_eval_g(const KdNlpParams& P, const RbdModel& M, int N, c
 #ifndef KD_COND_WGS
 #define KD_COND_WGS 3      // (168 registers: at 4 the chunk loop spills -- 35 against 19 ms of kernel time per batch, tools/dev/gpu_r06t.sh)
 #endif
+#ifndef KD_COND_DENSE
+#define KD_COND_DENSE 0      // 1: the matrix-core form (kd_condense_rows); 0: over the structural non-zeros (kd_condense_rows_sparse)
+#endif
 #ifndef KD_COND_GRID
 #define KD_COND_GRID 2048
 #endif
@@ -293,6 +309,36 @@ __device__ __forceinline__ void kd_condense_rows(const KdMem& M, int N, int k) {
       if (a < nv && b < nv) gk[a * KD_NV + b] = acc[t][r];
     }
   if (tid < nv) gk[KD_NV * KD_NV + tid] = macc;
+}
+
+// (a') the same over the structural non-zeros of the block (KdJPat / KdCPat): the entries of the block into LDS (529 gathers), then one lane per destination of the
+// 60 x 60 array (upper triangle, mirrored on the way out) and per right-hand side.  Entries of the array that no row couples are never written: the workspace starts
+// cleared.  (The dense form above on the matrix cores: 0.51 ms per round of the full batch, this one: see DESIGN.md 4.8b.)
+struct KdCondSparseLds { double val[KD_JP_NNZ]; double sg[KD_JP_ROWS], rh[KD_JP_ROWS]; };
+__shared__ KdCondSparseLds KCP;
+__device__ __forceinline__ void kd_condense_rows_sparse(const KdMem& M, int N, int k, const KdJPat* __restrict__ jp, const KdCPat* __restrict__ cp) {
+  KdCondSparseLds& S = KCP;
+  const int tid = threadIdx.x, NT = blockDim.x;
+  const int lp = k == N - 1 ? 1 : 0, nrow = (lp ? KD_ROWS_LAST : KD_ROWS) - 12, nnz = jp->rp[lp][nrow];
+  const landing_gptr Jk = (landing_gptr)(M.J + (size_t)k * KD_ROWS * KD_NW);
+  const landing_gptr Gsig = (landing_gptr)M.sig, Grho = (landing_gptr)M.rho;
+  const int g0 = KD_BND + k * KD_ROWS;
+  for (int t = tid; t < nnz; t += NT) S.val[t] = Jk[(int)jp->perm[lp][cp->erow[lp][t]] * KD_NW + jp->cl[lp][t]];
+  for (int j = tid; j < nrow; j += NT) { const int r = jp->perm[lp][j]; S.sg[j] = Gsig[g0 + r]; S.rh[j] = Grho[g0 + r]; }
+  __syncthreads();
+  double* gk = M.gc + (size_t)k * KD_GC;
+  const int nd = cp->nd[lp];
+  for (int d = tid; d < nd; d += NT) {
+    const int t0 = cp->drp[lp][d], t1 = cp->drp[lp][d + 1], ab = cp->dab[lp][d], va = ab & 255, vb = ab >> 8;
+    double acc = 0.0;
+    for (int t = t0; t < t1; ++t) { const unsigned w = cp->dterm[lp][t]; acc += (S.val[w & 1023u] * S.sg[w >> 20]) * S.val[(w >> 10) & 1023u]; }
+    gk[va * KD_NV + vb] = acc; gk[vb * KD_NV + va] = acc;
+  }
+  if (tid < KD_NV) {
+    double acc = 0.0;
+    for (int t = cp->rrp[lp][tid]; t < cp->rrp[lp][tid + 1]; ++t) { const unsigned w = cp->rterm[lp][t]; acc += S.val[w & 1023u] * S.rh[w >> 10]; }
+    gk[KD_NV * KD_NV + tid] = acc;
+  }
 }
 
 // (b) stage array of interval k into KSH.Ms (nv x nv + rhs), KSH.Ah
@@ -1052,7 +1098,11 @@ __global__ void __launch_bounds__(KD_THREADS, KD_COND_WGS) landing_kd_condense_k
   for (int w = blockIdx.x; w < total; w += gridDim.x) {
     const int m = A.cond_list[w / N], k = w % N;
     const KdMem M = kd_carve(N, A.ws + (size_t)m * A.ws_stride);
+#if KD_COND_DENSE
     kd_condense_rows(M, N, k);
+#else
+    kd_condense_rows_sparse(M, N, k, A.jpat, A.cpat);
+#endif
     __syncthreads();
   }
 }
