@@ -469,6 +469,9 @@ KD_PHASE bool kd_riccati_stage(const KdMem& M, int N, int k) {
   const int tid = threadIdx.x, NT = blockDim.x;
   const bool last = k == N - 1;
   const int nv = last ? 48 : KD_NV, nu = nv - KD_NSIG, nsn = last ? 12 : 24;
+#ifdef LANDING_KD_DEV
+  const long long t_in_ = (long long)wall_clock64();
+#endif
   // Y = P+(:, X) [A^ | b] (+ p+ in the last column)
   for (int e = tid; e < nsn * KD_AS; e += NT) {
     const int i = e / KD_AS, c = e % KD_AS;
@@ -493,6 +496,9 @@ KD_PHASE bool kd_riccati_stage(const KdMem& M, int N, int k) {
     if (tid < 12) S.Ms[(48 + tid) * KD_MS + 60] += S.Y[(12 + tid) * KD_AS + 36];
   }
   __syncthreads();
+#ifdef LANDING_KD_DEV      // development timer: the products with the cost-to-go of the next stage (prof[7], part of the backward sweep's slot)
+  if (tid == 0) S.ks.prof[7] += (double)((long long)wall_clock64() - t_in_);
+#endif
   // Gauss-Jordan on the control rows / columns 24 .. nv-1 of [M | m] on the fp64 matrix cores (round 5): the 64 x 64 array lives in
   // v_mfma_f64_16x16x4 accumulator tiles (wave w owns column tile w, four row tiles), pivot blocks of 4 x 4 -- kd_pivot_block_step, the
   // scheme of the SRBM solver's block_eliminate (solver_kernels.hip): 9 exchange + barrier rounds per stage instead of 36.  (Round 4: scalar
