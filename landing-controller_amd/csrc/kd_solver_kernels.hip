@@ -468,36 +468,9 @@ KD_PHASE bool kd_riccati_stage(const KdMem& M, int N, int k) {
   KdLds& S = KSH;
   const int tid = threadIdx.x, NT = blockDim.x;
   const bool last = k == N - 1;
-  const int nv = last ? 48 : KD_NV, nu = nv - KD_NSIG, nsn = last ? 12 : 24;
+  const int nv = last ? 48 : KD_NV, nu = nv - KD_NSIG;
 #ifdef LANDING_KD_DEV
   const long long t_in_ = (long long)wall_clock64();
-#endif
-  // Y = P+(:, X) [A^ | b] (+ p+ in the last column)
-  for (int e = tid; e < nsn * KD_AS; e += NT) {
-    const int i = e / KD_AS, c = e % KD_AS;
-    double a = c == 36 ? S.pv[i] : 0.0;
-    for (int t = 0; t < 12; ++t) a += S.Pm[i * KD_PS + t] * S.Ah[t * KD_AS + c];
-    S.Y[e] = a;
-  }
-  __syncthreads();
-  for (int e = tid; e < 36 * 37; e += NT) {
-    const int a = e / 37, b = e % 37;
-    double v = 0.0;
-    for (int t = 0; t < 12; ++t) v += S.Ah[t * KD_AS + a] * S.Y[t * KD_AS + b];
-    S.Ms[a * KD_MS + (b < 36 ? b : 60)] += v;
-  }
-  if (!last) {
-    for (int e = tid; e < 12 * 36; e += NT) {
-      const int i = e / 36, b = e % 36;
-      const double v = S.Y[(12 + i) * KD_AS + b];
-      S.Ms[(48 + i) * KD_MS + b] += v; S.Ms[b * KD_MS + 48 + i] += v;
-    }
-    for (int e = tid; e < 144; e += NT) { const int i = e / 12, j = e % 12; S.Ms[(48 + i) * KD_MS + 48 + j] += S.Pm[(12 + i) * KD_PS + 12 + j]; }
-    if (tid < 12) S.Ms[(48 + tid) * KD_MS + 60] += S.Y[(12 + tid) * KD_AS + 36];
-  }
-  __syncthreads();
-#ifdef LANDING_KD_DEV      // development timer: the products with the cost-to-go of the next stage (prof[7], part of the backward sweep's slot)
-  if (tid == 0) S.ks.prof[7] += (double)((long long)wall_clock64() - t_in_);
 #endif
   // Gauss-Jordan on the control rows / columns 24 .. nv-1 of [M | m] on the fp64 matrix cores (round 5): the 64 x 64 array lives in
   // v_mfma_f64_16x16x4 accumulator tiles (wave w owns column tile w, four row tiles), pivot blocks of 4 x 4 -- kd_pivot_block_step, the
@@ -511,6 +484,48 @@ KD_PHASE bool kd_riccati_stage(const KdMem& M, int N, int k) {
     for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) { const int row = 16 * rt + lk + 4 * r; T[rt][r] = (row < KD_NV && c < KD_MS) ? S.Ms[row * KD_MS + c] : 0.0; }
+    {   // + the cost-to-go of the next stage, sigma+ = (X+, c+) with X+ = A^ (sigma, f) + b:  E' P E and E' (P e + p), formed on the matrix cores where it is consumed (round 6,
+        // the scheme of the SRBM solver's block_eliminate).  The own column of Y = P(:, X) [A^ | b] comes out of the matrix cores in accumulator layout, which IS the
+        // B-operand layout of the next product; columns of c+ and the p-part of the right-hand side enter P directly.  Rounds 4-5 formed Y and A^' Y in scalar loops through
+        // LDS with two barriers: 88 of the 349 us of a backward sweep per member-iteration under load (development timer).
+      const bool isg = c == KD_NV, sf = c < 36, cpl = c >= 48 && c < KD_NV;
+      const int cj = cpl ? 12 + (c - 48) : 0;
+      double be[3], pa1[3], pa2[3], add1[3], add2[3], av[3][3];
+#pragma unroll
+      for (int kt = 0; kt < 3; ++kt) {
+        const double v = S.Ah[(4 * kt + lk) * KD_AS + (sf ? c : 36)];
+        be[kt] = (sf || isg) ? v : 0.0;
+        pa1[kt] = S.Pm[lj * KD_PS + 4 * kt + lk];
+        const double q = S.Pm[(12 + (lj < 12 ? lj : 0)) * KD_PS + 4 * kt + lk];
+        pa2[kt] = lj < 12 ? q : 0.0;
+      }
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const int row = 4 * r + lk;
+        const double a1 = S.Pm[row * KD_PS + cj], a2 = S.Pm[(12 + row) * KD_PS + cj], g1 = S.pv[row], g2 = S.pv[12 + row];
+        add1[r] = cpl ? a1 : (isg ? g1 : 0.0);
+        add2[r] = cpl ? a2 : (isg ? g2 : 0.0);
+      }
+#pragma unroll
+      for (int rt = 0; rt < 3; ++rt) {
+        const int a = 16 * rt + lj;
+#pragma unroll
+        for (int kt = 0; kt < 3; ++kt) { const double v = S.Ah[(4 * kt + lk) * KD_AS + (a < 36 ? a : 0)]; av[rt][kt] = a < 36 ? v : 0.0; }
+      }
+      f64x4 Y1 = {0.0, 0.0, 0.0, 0.0}, Y2 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int kt = 0; kt < 3; ++kt) { Y1 = __builtin_amdgcn_mfma_f64_16x16x4f64(pa1[kt], be[kt], Y1, 0, 0, 0); Y2 = __builtin_amdgcn_mfma_f64_16x16x4f64(pa2[kt], be[kt], Y2, 0, 0, 0); }
+#pragma unroll
+      for (int r = 0; r < 3; ++r) { Y1[r] += add1[r]; Y2[r] += add2[r]; }
+#pragma unroll
+      for (int rt = 0; rt < 3; ++rt)
+#pragma unroll
+        for (int kt = 0; kt < 3; ++kt) T[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[rt][kt], Y1[kt], T[rt], 0, 0, 0);
+      T[3][0] += Y2[0]; T[3][1] += Y2[1]; T[3][2] += Y2[2];      // rows of c+ (48..59): + rows 12..23 of P E
+    }
+#ifdef LANDING_KD_DEV      // development timer: the products with the cost-to-go of the next stage (prof[7], part of the backward sweep's slot)
+    if (tid == 0) S.ks.prof[7] += (double)((long long)wall_clock64() - t_in_);
+#endif
     ok &= kd_pivot_block_step<24, 0>(T, ct, lj, lk, c);
     ok &= kd_pivot_block_step<28, 1>(T, ct, lj, lk, c);
     ok &= kd_pivot_block_step<32, 2>(T, ct, lj, lk, c);
