@@ -537,25 +537,28 @@ KD_PHASE bool kd_riccati_stage(const KdMem& M, int N, int k) {
       ok &= kd_pivot_block_step<52, 7>(T, ct, lj, lk, c);
       ok &= kd_pivot_block_step<56, 8>(T, ct, lj, lk, c);
     }
-    __syncthreads();
+    if (!ok) { __syncthreads(); return false; }      // (identical in every lane)
+    // gains and kappa to the interval's record, cost-to-go of this stage to LDS (+ its state rows to the record) -- straight from the accumulator tiles (round 6: rounds
+    // 4-5 stored the array back to LDS behind a barrier and read it again)
+    double* rec = M.rec + (size_t)k * KD_REC;
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { const int row = 16 * rt + lk + 4 * r; if (row < KD_NV && c < KD_MS) S.Ms[row * KD_MS + c] = T[rt][r]; }
-    __syncthreads();
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * rt + lk + 4 * r;
+        const double v = T[rt][r];
+        if (row >= KD_NV) continue;
+        if (row >= KD_NSIG) {      // control rows: [I | K | kappa]
+          const int a = row - KD_NSIG;
+          if (c < KD_NSIG) rec[KD_REC_K + a * 24 + c] = a < nu ? v : 0.0;
+          else if (c == KD_NV) rec[KD_REC_KAP + a] = a < nu ? v : 0.0;
+        } else {                   // state rows: the Schur complement [P_k | p_k]
+          if (c < KD_NSIG) { S.Pm[row * KD_PS + c] = v; if (row < 12) rec[KD_REC_PX + row * 24 + c] = v; }
+          else if (c == KD_NV) { S.pv[row] = v; if (row < 12) rec[KD_REC_PV + row] = v; }
+        }
+      }
+    for (int e = tid; e < 12 * KD_AS; e += NT) rec[KD_REC_AH + e] = S.Ah[e];
   }
-  if (!ok) { __syncthreads(); return false; }
-  double* rec = M.rec + (size_t)k * KD_REC;
-  for (int e = tid; e < 36 * 24; e += NT) { const int a = e / 24, b = e % 24; rec[KD_REC_K + e] = a < nu ? S.Ms[(24 + a) * KD_MS + b] : 0.0; }
-  if (tid < 36) rec[KD_REC_KAP + tid] = tid < nu ? S.Ms[(24 + tid) * KD_MS + 60] : 0.0;
-  for (int e = tid; e < 12 * KD_AS; e += NT) rec[KD_REC_AH + e] = S.Ah[e];
-  for (int e = tid; e < 24 * 24; e += NT) {
-    const int i = e / 24, j = e % 24;
-    const double v = S.Ms[i * KD_MS + j];
-    S.Pm[i * KD_PS + j] = v;
-    if (i < 12) rec[KD_REC_PX + e] = v;
-  }
-  if (tid < 24) { const double v = S.Ms[tid * KD_MS + 60]; S.pv[tid] = v; if (tid < 12) rec[KD_REC_PV + tid] = v; }
   __syncthreads();
   return true;
 }
