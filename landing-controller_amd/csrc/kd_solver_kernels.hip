@@ -128,6 +128,7 @@ struct KdSolveArgs {
   double* ws; size_t ws_stride;
   double* x_out; double* f_out; double* lam_out; int* status; int* iters; double* kkt;
   int* n_active;           // number of members still iterating (written by the iteration kernel)
+  const int* n_dcur; const int* dlist_cur;      // ... and the list of THIS round (the head kernel is gridded over it; pending members are on it too: the derivative kernels skip them by their flag)
   int* n_dnext; int* dlist_next;    // members that need their derivatives in the NEXT round of launches (count, list [B]): appended wherever a member ends a launch with a new point (round 6: the derivative
                                     // kernels are gridded over this list -- in the lock-step tail the launches over the whole batch were mostly workgroups that leave at once)
   const KdCPat* cpat;      // the condensation over those non-zeros (device copy)
@@ -907,7 +908,8 @@ __global__ void __launch_bounds__(KD_THREADS) landing_kd_init_kernel(KdSolveArgs
 // once the head has set the barrier parameter); landing_kd_iter_kernel -- Riccati sweeps with inertia correction, forward sweep, line search, acceptance.  The state
 // travels in the member's workspace (KdState::stage says whether the head has prepared an iteration).
 __global__ void __launch_bounds__(KD_THREADS, 2) landing_kd_head_kernel(KdSolveArgs A) {
-  const int m = blockIdx.x;
+  if ((int)blockIdx.x >= *A.n_dcur) return;
+  const int m = A.dlist_cur[blockIdx.x];
   if (m >= A.B) return;
   const int N = A.N, nx = kd_nx(N), ng = kd_ng(N), tid = threadIdx.x, NT = blockDim.x;
   const KdMem M = kd_carve(N, A.ws + (size_t)m * A.ws_stride);
@@ -931,7 +933,10 @@ __global__ void __launch_bounds__(KD_THREADS, 2) landing_kd_head_kernel(KdSolveA
   // that needs five regularisation attempts (1.8 ms each) used to hold all others back -- at full batch the launch took 15 ms for 2 x 3.3 ms of work
   // per slot.  After KD_TRIES_PER_ROUND failed factorisations the member therefore saves its state and RETURNS (pending): the next launch resumes
   // its inertia correction where it stopped, the derivative kernels skip it meanwhile (A.done[m] = 2: x has not moved).
-  if (K.pending != 0) return;      // (uniform) its inertia correction continues in landing_kd_iter_kernel; nothing of the member has moved
+  if (K.pending != 0) {            // (uniform) its inertia correction continues in landing_kd_iter_kernel; nothing of the member has moved (the condensation repeats itself: same J, sigma, rho)
+    if (tid == 0) A.cond_list[atomicAdd(A.n_cond, 1)] = m;
+    return;
+  }
   {
     if (tid == 0) K.stage = 0;
     // ---------------------------------------------------------------- optimality error (unscaled), stop test
@@ -1132,7 +1137,8 @@ __global__ void __launch_bounds__(KD_THREADS, KD_COND_WGS) landing_kd_condense_k
 }
 
 __global__ void __launch_bounds__(KD_THREADS, 2) landing_kd_iter_kernel(KdSolveArgs A) {
-  const int m = blockIdx.x;
+  if ((int)blockIdx.x >= *A.n_cond) return;      // the members the head kernel has passed on: prepared iterations and pending inertia corrections
+  const int m = A.cond_list[blockIdx.x];
   if (m >= A.B) return;
   const int N = A.N, nx = kd_nx(N), ng = kd_ng(N), tid = threadIdx.x, NT = blockDim.x;
   const KdMem M = kd_carve(N, A.ws + (size_t)m * A.ws_stride);
@@ -1173,7 +1179,7 @@ __global__ void __launch_bounds__(KD_THREADS, 2) landing_kd_iter_kernel(KdSolveA
     KD_END();
     if (!K.flag) break;
     if (++tries >= KD_TRIES_PER_ROUND) {
-      if (tid == 0) { K.pending = 1; *M.st = K; A.done[m] = 2; atomicAdd(A.n_active, 1); }
+      if (tid == 0) { K.pending = 1; *M.st = K; A.done[m] = 2; atomicAdd(A.n_active, 1); A.dlist_next[atomicAdd(A.n_dnext, 1)] = m; }      // (on the list for the head kernel; the derivative kernels skip it)
       return;
     }
   }
