@@ -1499,7 +1499,21 @@ __global__ void __launch_bounds__(KD_THREADS) landing_kd_finish_kernel(KdSolveAr
   const int m = blockIdx.x;
   if (m >= A.B0) return;
   const int N = A.N, nx = kd_nx(N), ng = kd_ng(N), tid = threadIdx.x, NT = blockDim.x;
-  const int wm = (A.win && A.win[m] != KD_NOWIN) ? A.win[m] : m;      // portfolio: the member of the family that converged first (else the original)
+  int wm = (A.win && A.win[m] != KD_NOWIN) ? A.win[m] : m;      // portfolio: the member of the family that converged first (else the original)
+  if (A.win && wm == m && A.cloned[m]) {      // no member of the family converged and the original ends undecided: a clone's certificate of local infeasibility (an elastic KKT point reached on
+    const KdState* s0 = kd_carve(N, A.ws + (size_t)m * A.ws_stride).st;      // another path) decides it -- the lowest slot, whatever order the hardware ran things in (it used to be discarded)
+    int best = KD_NOWIN;
+    if (!(s0->done && (s0->status == LANDING_CONVERGED || s0->status == LANDING_INFEASIBLE))) {
+      for (int c = tid; c < A.B - A.B0; c += NT)
+        if (A.src[c] == m) { const KdState* sc = kd_carve(N, A.ws + (size_t)(A.B0 + c) * A.ws_stride).st; if (sc->done && sc->status == LANDING_INFEASIBLE) best = best < A.B0 + c ? best : A.B0 + c; }
+    }
+    KSH.hist[tid & 63] = KD_NOWIN;
+    __syncthreads();
+    if (best != KD_NOWIN) atomicMin(&KSH.hist[0], best);
+    __syncthreads();
+    if (KSH.hist[0] != KD_NOWIN) wm = KSH.hist[0];
+    __syncthreads();
+  }
   const KdMem M = kd_carve(N, A.ws + (size_t)wm * A.ws_stride);
   const double* lbm = A.lb + (size_t)m * ng; const double* ubm = A.ub + (size_t)m * ng;
   const double* cost = A.cost + (size_t)m * 24;
