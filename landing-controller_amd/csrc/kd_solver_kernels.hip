@@ -198,12 +198,28 @@ KD_PHASE void kd_member_eval_g(const KdNlpParams& P, const RbdModel& M, int N, c
     for (int q = 0; q < NB; ++q) { const int e = e0 + tid + q * NT; if (e < tot) ws[e] = ix[q] >= 0 ? t[q] : 0.0; }
   }
   __syncthreads();
+  // Round 6: two passes.  (1) One lane per interval: every row but the legs' kinematics (legmask 0: zeros in those rows, c - fkv = 0).  (2) One lane per (interval, leg): the
+  // leg's hip-relative foot position, its torques and its forward kinematics -- the expensive part, which one lane used to run for its four legs one after the other (the
+  // line search's 0.07 ms per member-iteration was mostly that) -- into the seven rows of the leg and its six rows c - fkv.  Same functions on the same operands: the same bits.
   for (int k = tid; k < N; k += NT) {
     const double* w = ws + (size_t)k * KD_NW;
     // the rows go straight to the member's g array (a local out[141] is promoted to registers by the unrolled row code: 255 VGPRs + AGPR spills,
     // one workgroup per CU); the last interval writes its 117 rows only
     KdRowArray<double> rows{g + KD_BND + k * KD_ROWS};
-    kd_stage_rows<double>(P, M, k, k == N - 1, w, rows);
+    kd_stage_rows<double>(P, M, k, k == N - 1, w, rows, 0);
+  }
+  __syncthreads();
+  for (int e = tid; e < 4 * N; e += NT) {
+    const int k = e >> 2, l = e & 3;
+    const bool last = k == N - 1;
+    const double* w = ws + (size_t)k * KD_NW;
+    double R[9], E0[9], r0[3], o7[7], fk[3];
+    kd_base_frames_d(P, M, w, R, E0, r0);
+    kd_leg_kin_d(M, l, w, R, E0, r0, o7, fk);
+    double* gk = g + KD_BND + k * KD_ROWS;
+    const int lb = last ? 9 : 15, o1 = 16 + l * lb + (last ? 2 : 8), o2 = 16 + 4 * lb + 17 + 3 * l;
+    for (int a = 0; a < 7; ++a) gk[o1 + a] = o7[a];
+    for (int j = 0; j < 3; ++j) { const double v = w[12 + 3 * l + j] - fk[j]; gk[o2 + j] = v; gk[o2 + 12 + j] = v; }
   }
   if (tid >= 64 && tid < 64 + 48) {      // boundary rows (coordinate picks), by a wave that has no interval to evaluate
     const int i = tid - 64, oU = 12 * (N + 1) + 12 * N;

@@ -756,6 +756,28 @@ __device__ __noinline__ void kd_leg_kin_d(const RbdModel& M, int l, const double
   kd_leg_kin<double>(M, l, w, R, E0, r0, o7, fk3);
 }
 
+// The frames kd_stage_rows<double> hands to kd_leg_kin_d -- R_body_to_world and the world -> base transform of the tree -- for callers that evaluate one leg of an interval
+// on its own lane (kd_solver_kernels.hip kd_member_eval_g): the same expressions in the same order.
+__device__ __noinline__ void kd_base_frames_d(const KdNlpParams& P, const RbdModel& M, const double* w, double* R, double* E0, double* r0) {
+  const double* X = w;
+  double sr, cr, sp, cp, sy, cy;
+  sincos_t(X[3], sr, cr); sincos_t(X[4], sp, cp); sincos_t(X[5], sy, cy);
+  const double zero = 0.0;
+  const double Rr[9] = {cp * cy, zero - cp * sy, sp,
+                        cr * sy + sr * sp * cy, cr * cy - sr * sp * sy, zero - sr * cp,
+                        sr * sy - cr * sp * cy, sr * cy + cr * sp * sy, cr * cp};
+  for (int j = 0; j < 9; ++j) R[j] = Rr[j];
+  if (P.std_base) {
+    for (int a = 0; a < 3; ++a) for (int b2 = 0; b2 < 3; ++b2) E0[3 * a + b2] = R[3 * b2 + a];
+    r0[0] = X[0]; r0[1] = X[1]; r0[2] = X[2];
+  } else {
+    double Ej[9], rj[3];
+    for (int j = 0; j < 9; ++j) E0[j] = (j % 4 == 0) ? 1.0 : 0.0;
+    r0[0] = r0[1] = r0[2] = 0.0;
+    for (int i = 0; i < 6; ++i) { joint_xform(M.jtype[i], X[i], M.E[i], M.r[i], Ej, rj); kd_compose(Ej, rj, E0, r0); }
+  }
+}
+
 // legmask: bit l set = the rows of leg l that need the leg's kinematics (hip-relative position, leg torques, forward kinematics: the
 // expensive part of the function) are evaluated; a cleared bit writes zeros there.  The value / Jacobian kernels pass 15; the Hessian kernel
 // passes the one leg a pair of directions belongs to (second derivatives of the other legs' rows vanish for that pair).
