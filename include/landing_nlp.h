@@ -295,7 +295,9 @@ typedef struct {
                             mu_init = 1; everything else as the caller set it, iteration limit kd_clone_iter); three more waves
                             follow after 2, 3 and 4 times as many rounds for members that had no slot before.  The first member of such
                             a family (the original included) that converges ends the others and is reported under the original's
-                            index (x, lam_g, kkt, iters = that member's own count).  0 = off.  Why: which member of a batch is
+                            index (x, lam_g, kkt, iters = that member's own count); when nobody converged and the original ends without a
+                            decision, a clone's certificate of local infeasibility (status 3) is reported (round 6; it does not end the
+                            family early).  0 = off.  Why: which member of a batch is
                             slow depends on the path, not on the problem -- of 5 bench batches of 1024 (law "main") three hold a
                             member that needs 400 .. 1000 iterations (batch 1.1 .. 2.0 s instead of 0.72 s: the loop runs as long
                             as its slowest member), and each of these members converges in 28 .. 73 iterations under at least one
