@@ -945,7 +945,11 @@ __global__ void __launch_bounds__(64) landing_kinodyn_nlp_g_kernel(KdNlpArgs a) 
 #ifndef KD_JAC_STAGES_DEF
 #define KD_JAC_STAGES_DEF 4
 #endif
-constexpr int KD_JAC_STAGES = KD_JAC_STAGES_DEF, KD_JAC_THREADS = KD_JAC_STAGES * KD_NW;      // 576
+// Round 6: wavefront-pure columns, as in the Hessian kernel.  A column of leg l (c_l, f_l, jpos_l, c_l of the next interval) only moves that leg's kinematic rows -- the expensive part of
+// kd_stage_rows -- so wave l (0..3) takes the 12 columns of leg l of the block's four intervals (48 lanes, legmask 1 << l), wave 4 the 12 columns of X (every leg: pos and rpy move them all),
+// wave 5 the 12 columns of X_k+1 (no leg: the defect rows only).  4.5 waves x 4 legs of kinematics became 4 x 1 + 1 x 4: 0.95 -> see DESIGN.md 4.8b ms per round of the full batch.
+constexpr int KD_JAC_STAGES = KD_JAC_STAGES_DEF, KD_JAC_THREADS = 6 * 64;
+static_assert(KD_JAC_STAGES == 4, "the lane map of landing_kinodyn_nlp_jac_kernel: 4 intervals x 12 columns = 48 lanes of a wavefront");
 __host__ __device__ inline long long kd_jac_blocks(long long B, int N) { return B * ((N + KD_JAC_STAGES - 1) / KD_JAC_STAGES); }
 template <int STDB>
 __global__ void __launch_bounds__(KD_JAC_THREADS) landing_kinodyn_nlp_jac_kernel(KdNlpArgs a) {
@@ -956,9 +960,16 @@ __global__ void __launch_bounds__(KD_JAC_THREADS) landing_kinodyn_nlp_jac_kernel
   if (a.skip && a.skip[b]) return;
   __shared__ double xs[KD_JAC_STAGES][KD_NW];
   const double* x = a.x + a.ox(b);
-  const int ks = (int)threadIdx.x / KD_NW, col = (int)threadIdx.x % KD_NW, k = k0 + ks;
-  if (k < N) { const int i = kd_w_index(N, k, col); xs[ks][col] = i >= 0 ? x[i] : 0.0; }
+  for (int e = (int)threadIdx.x; e < KD_JAC_STAGES * KD_NW; e += KD_JAC_THREADS) {
+    const int kk = k0 + e / KD_NW, i = kk < N ? kd_w_index(N, kk, e % KD_NW) : -1;
+    xs[e / KD_NW][e % KD_NW] = i >= 0 ? x[i] : 0.0;
+  }
   __syncthreads();
+  const int wv = (int)threadIdx.x >> 6, ln = (int)threadIdx.x & 63;
+  if (ln >= 48) return;
+  const int ks = ln / 12, q = ln % 12, k = k0 + ks;
+  const int col = wv == 4 ? q : (wv == 5 ? 48 + q : (q < 9 ? 12 + 12 * (q / 3) + 3 * wv + q % 3 : 60 + 3 * wv + (q - 9)));
+  const int legmask = wv < 4 ? (1 << wv) : (wv == 4 ? 15 : 0);
   if (k >= N) return;
   struct DualSeedView {      // w[q] = x_q + eps [q == col], formed on access
     const double* xv; int col, off;
@@ -971,7 +982,7 @@ __global__ void __launch_bounds__(KD_JAC_THREADS) landing_kinodyn_nlp_jac_kernel
   struct ColOut { double* J; bool zero; const double* y; double acc;
                   __device__ __forceinline__ void put(const Dual& v) { const double d = zero ? 0.0 : v.d; *J = d; J += KD_NW; if (y) { acc += d * *y; ++y; } } };
   ColOut out{a.jac + a.oj(b) + ((size_t)k * KD_ROWS) * KD_NW + col, last && col >= 60, (a.jty && a.lam) ? a.lam + a.og(b) + KD_BND + (size_t)k * KD_ROWS : nullptr, 0.0};
-  kd_stage_rows<Dual, ColOut, DualSeedView, STDB>(a.P, *a.model, k, last, w, out);
+  kd_stage_rows<Dual, ColOut, DualSeedView, STDB>(a.P, *a.model, k, last, w, out, legmask);
   if (a.jty && a.lam) a.jty[a.oj(b) + (size_t)k * KD_NW + col] = out.acc;
 }
 
