@@ -83,7 +83,7 @@ struct KdMem {
 };
 __host__ __device__ inline size_t kd_ws_stride(int N) {
   const size_t nx = (size_t)kd_nx(N), ng = (size_t)kd_ng(N);
-  return 4 * nx + 10 * ng + (size_t)N * KD_ROWS * KD_NW + (size_t)N * KD_NW * KD_NW + (size_t)(N + 1) * KD_REC + 2 * (size_t)N * KD_NW + 4 * ng + (size_t)N * KD_GC + (sizeof(KdState) + 7) / 8 + 8;
+  return 4 * nx + 10 * ng + (size_t)N * KD_JCS + (size_t)N * KD_NW * KD_NW + (size_t)(N + 1) * KD_REC + 2 * (size_t)N * KD_NW + 4 * ng + (size_t)N * KD_GC + (sizeof(KdState) + 7) / 8 + 8;
 }
 __device__ __forceinline__ KdMem kd_carve(int N, double* w) {
   const size_t nx = (size_t)kd_nx(N), ng = (size_t)kd_ng(N);
@@ -91,7 +91,7 @@ __device__ __forceinline__ KdMem kd_carve(int N, double* w) {
   M.x = w; w += nx; M.xt = w; w += nx; M.dx = w; w += nx; M.gx = w; w += nx;
   M.g = w; w += ng; M.gt = w; w += ng; M.s = w; w += ng; M.ds = w; w += ng; M.zL = w; w += ng; M.zU = w; w += ng;
   M.y = w; w += ng; M.yn = w; w += ng; M.sig = w; w += ng; M.rho = w; w += ng;
-  M.J = w; w += (size_t)N * KD_ROWS * KD_NW; M.H = w; w += (size_t)N * KD_NW * KD_NW; M.rec = w; w += (size_t)(N + 1) * KD_REC;
+  M.J = w; w += (size_t)N * KD_JCS; M.H = w; w += (size_t)N * KD_NW * KD_NW; M.rec = w; w += (size_t)(N + 1) * KD_REC;      // (J: compact Jacobian blocks, rbd_kernels.hip KD_JCS)
   M.wbuf = w; w += (size_t)N * KD_NW;
   M.jty = w; w += (size_t)N * KD_NW;
   M.en = w; w += ng; M.ep = w; w += ng; M.wn = w; w += ng; M.wp = w; w += ng;
@@ -118,7 +118,9 @@ struct KdCPat {
   unsigned short drp[2][KD_CP_ND + 1]; unsigned short dab[2][KD_CP_ND];      // dab = va | vb << 8
   unsigned int dterm[2][KD_CP_NT];
   unsigned short rrp[2][KD_NV + 4]; unsigned int rterm[2][KD_JP_NNZ];
+  short jpos[2][KD_ROWS * KD_NW];      // place of (row, column) of a block in its compact form (KdNlpArgs::jpos)
 };
+static_assert(KD_JP_NNZ == KD_JC_NNZ, "one capacity");
 
 struct KdSolveArgs {
   const RbdModel* model; KdNlpParams P; int B, N; landing_solver_opts o;
@@ -264,6 +266,9 @@ __shared__ KdCondLds KCS;
 
 // (a) J_I' Sigma J_I and m = J_I' rho over the inequality rows 12 .. nr-1 of interval k, in chunks of KD_JC_ROWS rows staged in LDS; the product runs on the fp64
 // matrix cores: wave w owns row tile w of M (16 rows), four column tiles; the loads of the next chunk are in flight while the matrix cores work on this one
+#if KD_COND_DENSE
+#error "the matrix-core form of the condensation reads dense Jacobian blocks: the solver keeps them in compact form since round 6 (rbd_kernels.hip KD_JCS)"
+#endif
 __device__ __forceinline__ void kd_condense_rows(const KdMem& M, int N, int k) {
   KdCondLds& S = KCS;
   const int tid = threadIdx.x;
@@ -337,10 +342,10 @@ __device__ __forceinline__ void kd_condense_rows_sparse(const KdMem& M, int N, i
   KdCondSparseLds& S = KCP;
   const int tid = threadIdx.x, NT = blockDim.x;
   const int lp = k == N - 1 ? 1 : 0, nrow = (lp ? KD_ROWS_LAST : KD_ROWS) - 12, nnz = jp->rp[lp][nrow];
-  const landing_gptr Jk = (landing_gptr)(M.J + (size_t)k * KD_ROWS * KD_NW);
+  const landing_gptr Jk = (landing_gptr)(M.J + (size_t)k * KD_JCS + KD_JC_DEF);      // the block's non-zeros in table order (compact form)
   const landing_gptr Gsig = (landing_gptr)M.sig, Grho = (landing_gptr)M.rho;
   const int g0 = KD_BND + k * KD_ROWS;
-  for (int t = tid; t < nnz; t += NT) S.val[t] = Jk[(int)jp->perm[lp][cp->erow[lp][t]] * KD_NW + jp->cl[lp][t]];
+  for (int t = tid; t < nnz; t += NT) S.val[t] = Jk[t];
   for (int j = tid; j < nrow; j += NT) { const int r = jp->perm[lp][j]; S.sg[j] = Gsig[g0 + r]; S.rh[j] = Grho[g0 + r]; }
   __syncthreads();
   double* gk = M.gc + (size_t)k * KD_GC;
@@ -364,7 +369,7 @@ KD_PHASE void kd_assemble_stage(const KdMem& M, int N, int k, double delta) {
   const int tid = threadIdx.x;
   const bool last = k == N - 1;
   const int nv = last ? 48 : KD_NV;
-  const landing_gptr Jk = (landing_gptr)(M.J + (size_t)k * KD_ROWS * KD_NW);
+  const landing_gptr Jk = (landing_gptr)(M.J + (size_t)k * KD_JCS);      // (the 12 defect rows are the dense head of the compact block)
   const landing_gptr Hk = (landing_gptr)(M.H + (size_t)k * KD_NW * KD_NW);
   const landing_gptr Ck = (landing_gptr)(M.gc + (size_t)k * KD_GC);
   const landing_gptr Gg = (landing_gptr)M.g;
@@ -698,12 +703,12 @@ KD_PHASE void kd_forward(const KdMem& M, int N, const double* lbm, const KdJPat*
       const int idx = i0 + tid; const bool on = idx < ntot; const int ii = on ? idx : 0;
       const int lp = ii >= nmid ? 1 : 0, k = lp ? N - 1 : ii / RM, j = lp ? ii - nmid : ii % RM;
       const int r = S.jp.perm[lp][j], t0 = S.jp.rp[lp][j], cnt = S.jp.rp[lp][j + 1] - t0;
-      const landing_gptr Jr = (landing_gptr)(M.J + ((size_t)k * KD_ROWS + r) * KD_NW);      // (global_load: the LDS reads below wait on the LDS counter only)
+      const landing_gptr Jr = (landing_gptr)(M.J + (size_t)k * KD_JCS + KD_JC_DEF + t0);      // the row's entries, contiguous in the compact block (global_load: the LDS reads below wait on the LDS counter only)
       const double* dk = dxa + k * KD_NW;
       const int g = KD_BND + k * KD_ROWS + r;
       double v[KD_JP_MAX]; int c[KD_JP_MAX];
 #pragma unroll
-      for (int u = 0; u < KD_JP_MAX; ++u) { c[u] = S.jp.cl[lp][t0 + (u < cnt ? u : 0)]; v[u] = Jr[c[u]]; }      // (clamped: every load is issued, unconditionally)
+      for (int u = 0; u < KD_JP_MAX; ++u) { const int uu = u < cnt ? u : 0; c[u] = S.jp.cl[lp][t0 + uu]; v[u] = Jr[uu]; }      // (clamped: every load is issued, unconditionally)
       const double gs = Gg[g] - Gs[g];
       double acc = 0.0;
 #pragma unroll
