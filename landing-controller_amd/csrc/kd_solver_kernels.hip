@@ -118,7 +118,7 @@ struct KdCPat {
   unsigned short drp[2][KD_CP_ND + 1]; unsigned short dab[2][KD_CP_ND];      // dab = va | vb << 8
   unsigned int dterm[2][KD_CP_NT];
   unsigned short rrp[2][KD_NV + 4]; unsigned int rterm[2][KD_JP_NNZ];
-  short jpos[2][KD_ROWS * KD_NW];      // place of (row, column) of a block in its compact form (KdNlpArgs::jpos)
+  unsigned jcol[2][KD_NW][KD_JCOL];    // per column the stored rows of a block and their places in its compact form (KdNlpArgs::jcol)
 };
 static_assert(KD_JP_NNZ == KD_JC_NNZ, "one capacity");
 

@@ -898,15 +898,16 @@ __device__ void kd_stage_rows(const KdNlpParams& P, const RbdModel& M, int k, bo
 }
 
 // Compact form of an interval's Jacobian block for the solver (round 6): the 12 defect rows dense (12 x 72), then the structural non-zeros of the inequality rows in the order of
-// the solver's table (kd_solver_kernels.hip KdJPat: 529 / 457 entries); KdNlpArgs::jpos maps (row, column) of the 141 x 72 block to its place there (-1: structurally zero, not stored).
+// the solver's table (kd_solver_kernels.hip KdJPat: 529 / 457 entries); KdNlpArgs::jcol lists, per column of the 141 x 72 block, the rows that are stored and their places there.
 // The dense block is 93 % zeros and the Jacobian kernel was bound by storing them (1.37 GB per round of the full batch).
-constexpr int KD_JC_DEF = 12 * KD_NW, KD_JC_NNZ = 640, KD_JCS = KD_JC_DEF + KD_JC_NNZ;
+constexpr int KD_JC_DEF = 12 * KD_NW, KD_JC_NNZ = 640, KD_JCS = KD_JC_DEF + KD_JC_NNZ, KD_JCOL = 96;
 struct KdNlpArgs {
   const RbdModel* model; KdNlpParams P; int B, N; const double* x; double* g; double* jac; const double* lam; double* hess;
   // member strides in doubles (0 = dense arrays [B][nx], [B][ng], [B][N][141][72], [B][N][72][72]) and an optional per-member skip flag: the
   // interior-point solver (kd_solver_kernels.hip) evaluates straight into its per-member workspace and skips members that have finished
   long long sx, sg, sj, sh; const int* skip;
-  const short* jpos = nullptr;      // optional [2][141 * 72] (middle intervals | last interval): the Jacobian kernel writes the compact form, KD_JCS doubles per interval, instead of dense blocks
+  const unsigned* jcol = nullptr;   // optional [2][72][KD_JCOL]: per column of a block (middle intervals | last interval) its stored rows in rising order, (row << 16) | place in the compact form, closed by row 0xffff:
+                                    // the Jacobian kernel writes compact blocks of KD_JCS doubles per interval instead of dense ones
   const int* list = nullptr; const int* n_list = nullptr;      // optional work list (round 6): block index b stands for member list[b], b < *n_list (the solver's members that need derivatives this round)
   double* jty = nullptr;      // optional [member stride sj][N][72]: J_k' lam_k per interval and column, a by-product of the Jacobian kernel (the solver's grad f + J' y)
   __host__ __device__ size_t ox(int b) const { return (size_t)b * (sx ? (size_t)sx : (size_t)(12 * (N + 1) + 36 * N)); }
@@ -984,13 +985,14 @@ __global__ void __launch_bounds__(KD_JAC_THREADS) landing_kinodyn_nlp_jac_kernel
   const DualSeedView w{xs[ks], col, 0};
   const bool last = k == N - 1;
   // row after row of column col; with lam given the column's product with the multipliers of the interval's rows comes along (rows in order)
-  struct ColOut { double* J; bool zero; const double* y; double acc; const short* pos;      // pos: the column's entries of the place table (compact form), stride 72 like J
+  struct ColOut { double* J; bool zero; const double* y; double acc; const unsigned* lst; unsigned nxt; int row;      // lst: the column's stored rows (compact form); nxt = the next of them
                   __device__ __forceinline__ void put(const Dual& v) {
                     const double d = zero ? 0.0 : v.d;
-                    if (pos) { const int q = *pos; pos += KD_NW; if (q >= 0) J[q] = d; } else { *J = d; J += KD_NW; }
+                    if (lst) { if (row == (int)(nxt >> 16)) { J[nxt & 0xffffu] = d; nxt = *++lst; } ++row; } else { *J = d; J += KD_NW; }
                     if (y) { acc += d * *y; ++y; } } };
-  ColOut out{a.jpos ? a.jac + a.oj(b) + (size_t)k * KD_JCS : a.jac + a.oj(b) + ((size_t)k * KD_ROWS) * KD_NW + col, last && col >= 60,
-             (a.jty && a.lam) ? a.lam + a.og(b) + KD_BND + (size_t)k * KD_ROWS : nullptr, 0.0, a.jpos ? a.jpos + (last ? KD_ROWS * KD_NW : 0) + col : nullptr};
+  const unsigned* lst0 = a.jcol ? a.jcol + ((size_t)(last ? KD_NW : 0) + col) * KD_JCOL : nullptr;
+  ColOut out{a.jcol ? a.jac + a.oj(b) + (size_t)k * KD_JCS : a.jac + a.oj(b) + ((size_t)k * KD_ROWS) * KD_NW + col, last && col >= 60,
+             (a.jty && a.lam) ? a.lam + a.og(b) + KD_BND + (size_t)k * KD_ROWS : nullptr, 0.0, lst0, lst0 ? *lst0 : 0u, 0};
   kd_stage_rows<Dual, ColOut, DualSeedView, STDB>(a.P, *a.model, k, last, w, out, legmask);
   if (a.jty && a.lam) a.jty[a.oj(b) + (size_t)k * KD_NW + col] = out.acc;
 }
